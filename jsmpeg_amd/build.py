@@ -1,0 +1,106 @@
+"""In-tree native builds (no setup.py, no JIT cache): every shared object lands
+next to its sources under jsmpeg_amd/ or oracle/ so that it travels to the GPU
+box with the gpurun snapshot.  `python -m jsmpeg_amd.build [target...]`."""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+ORACLE = os.path.join(ROOT, "oracle")
+REFERENCE = os.environ.get("JSMPEG_REFERENCE", "/root/reference")
+NODE_INCLUDE = "/usr/include/node"
+
+LIB_SYNTH = os.path.join(PKG, "libjsmpeg_synth.so")
+LIB_HIP = os.path.join(PKG, "libjsmpeg_hip.so")
+ADDON_NODE = os.path.join(PKG, "js", "jsmpeg_hip.node")
+LIB_ORACLE = os.path.join(ORACLE, "libmpeg1_oracle.so")
+REF_DIR = os.path.join(ORACLE, "_ref")
+LIB_REF = os.path.join(REF_DIR, "libjsmpeg_ref.so")
+WASM_REF = os.path.join(REF_DIR, "jsmpeg_ref.wasm")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _csrc_headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
+           [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+
+
+def build_synth(force=False):
+    src = [os.path.join(CSRC, "synth_es.c")]
+    if force or _newer(LIB_SYNTH, src + _csrc_headers()):
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", LIB_SYNTH] + src)
+    return LIB_SYNTH
+
+
+def hip_sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build_hip(force=False):
+    """The product: HIP kernels + C-ABI runtime for gfx950 (cross-compiles
+    without a GPU)."""
+    src = hip_sources()
+    if force or _newer(LIB_HIP, src + _csrc_headers()):
+        _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+              "-o", LIB_HIP] + src)
+    return LIB_HIP
+
+
+def build_addon(force=False):
+    """N-API addon: thin glue from the Node host side to the C ABI."""
+    src = [os.path.join(CSRC, "napi_addon.c")]
+    if not os.path.exists(src[0]) or not os.path.isdir(NODE_INCLUDE):
+        return None
+    build_hip(force)
+    if force or _newer(ADDON_NODE, src + _csrc_headers() + [LIB_HIP]):
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-I", NODE_INCLUDE,
+              "-I", os.path.join(ROOT, "include"), "-o", ADDON_NODE] + src +
+             ["-L", PKG, "-ljsmpeg_hip", "-Wl,-rpath,$ORIGIN/.."])
+    return ADDON_NODE
+
+
+def build_oracle(force=False):
+    """CPU restatement (test infrastructure only)."""
+    src = [os.path.join(ORACLE, "mpeg1_oracle.c")]
+    if force or _newer(LIB_ORACLE, src + [os.path.join(ORACLE, "mpeg1_oracle.h")]):
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", LIB_ORACLE] + src)
+    return LIB_ORACLE
+
+
+def build_ref(force=False):
+    """oracle/_ref: the reference's own C decoder compiled from where it lies
+    (container only; the GPU box uses the prebuilt files).  Delegates to the
+    committed recipe oracle/Makefile."""
+    if not os.path.isdir(REFERENCE):
+        return LIB_REF if os.path.exists(LIB_REF) else None
+    _run(["make", "-s", "-C", ORACLE, "ref", "REFERENCE=" + REFERENCE] + (["-B"] if force else []))
+    return LIB_REF
+
+
+def build_all(force=False):
+    out = {"synth": build_synth(force), "oracle": build_oracle(force), "ref": build_ref(force)}
+    if shutil.which("hipcc"):
+        out["hip"] = build_hip(force)
+        out["addon"] = build_addon(force)
+    return out
+
+
+if __name__ == "__main__":
+    targets = sys.argv[1:] or ["all"]
+    for t in targets:
+        print(t, "->", globals()["build_" + t]())

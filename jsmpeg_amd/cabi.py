@@ -1,0 +1,150 @@
+"""ctypes view of the 15-function decoder C ABI (reference src/wasm/mpeg1.h:10-25).
+
+The same wrapper drives three libraries that export that ABI:
+  * jsmpeg_amd/libjsmpeg_hip.so  - the product (HIP, gfx950)
+  * oracle/libmpeg1_oracle.so    - CPU restatement (tests only)
+  * oracle/_ref/libjsmpeg_ref.so - the reference's own C (tests / cpu_baseline only)
+This module never picks a library itself: callers pass the path."""
+import ctypes
+
+import numpy as np
+
+MODE_EVICT = 1
+MODE_EXPAND = 2
+
+_SIGS = {
+    "mpeg1_decoder_create": (ctypes.c_void_p, [ctypes.c_uint, ctypes.c_int]),
+    "mpeg1_decoder_destroy": (None, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_write_ptr": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint]),
+    "mpeg1_decoder_get_index": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpeg1_decoder_set_index": (None, [ctypes.c_void_p, ctypes.c_uint]),
+    "mpeg1_decoder_did_write": (None, [ctypes.c_void_p, ctypes.c_uint]),
+    "mpeg1_decoder_has_sequence_header": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_frame_rate": (ctypes.c_float, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_coded_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_width": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_height": (ctypes.c_int, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_y_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_cr_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mpeg1_decoder_get_cb_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mpeg1_decoder_decode": (ctypes.c_bool, [ctypes.c_void_p]),
+}
+ABI_SYMBOLS = tuple(_SIGS)
+
+_libs = {}
+
+
+def load(path):
+    lib = _libs.get(path)
+    if lib is None:
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _libs[path] = lib
+    return lib
+
+
+class Mpeg1Decoder:
+    """One decoder handle of whichever library `path` names."""
+
+    def __init__(self, path, buffer_size=512 * 1024, mode=MODE_EXPAND):
+        self.lib = load(path)
+        self.h = self.lib.mpeg1_decoder_create(buffer_size, mode)
+        if not self.h:
+            raise RuntimeError("mpeg1_decoder_create failed (%s)" % path)
+
+    def close(self):
+        if self.h:
+            self.lib.mpeg1_decoder_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def write(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = int(data.size)
+        ptr = self.lib.mpeg1_decoder_get_write_ptr(self.h, n)
+        ctypes.memmove(ptr, data.ctypes.data, n)
+        self.lib.mpeg1_decoder_did_write(self.h, n)
+
+    def decode(self):
+        return bool(self.lib.mpeg1_decoder_decode(self.h))
+
+    @property
+    def index(self):
+        return self.lib.mpeg1_decoder_get_index(self.h)
+
+    @index.setter
+    def index(self, v):
+        self.lib.mpeg1_decoder_set_index(self.h, v)
+
+    @property
+    def has_sequence_header(self):
+        return bool(self.lib.mpeg1_decoder_has_sequence_header(self.h))
+
+    @property
+    def frame_rate(self):
+        return self.lib.mpeg1_decoder_get_frame_rate(self.h)
+
+    @property
+    def coded_size(self):
+        return self.lib.mpeg1_decoder_get_coded_size(self.h)
+
+    @property
+    def width(self):
+        return self.lib.mpeg1_decoder_get_width(self.h)
+
+    @property
+    def height(self):
+        return self.lib.mpeg1_decoder_get_height(self.h)
+
+    def planes(self):
+        """Copies of the most recently decoded (Y, Cr, Cb) coded-size planes."""
+        n = self.coded_size
+        out = []
+        for getter, size in ((self.lib.mpeg1_decoder_get_y_ptr, n), (self.lib.mpeg1_decoder_get_cr_ptr, n >> 2),
+                             (self.lib.mpeg1_decoder_get_cb_ptr, n >> 2)):
+            ptr = getter(self.h)
+            out.append(np.ctypeslib.as_array((ctypes.c_uint8 * size).from_address(ptr)).copy())
+        return tuple(out)
+
+
+def decode_stream(path, es, pic_offsets=None, buffer_size=None, mode=MODE_EXPAND, keep="hash", max_frames=None):
+    """Feeds `es` the way ts.js feeds the decoder (one write per picture when
+    `pic_offsets` is given, reference src/ts.js:205-210, else one write) and
+    pulls every picture.  Returns a list of per-frame md5 hex digests over
+    Y|Cr|Cb (keep="hash") or of (Y, Cr, Cb) arrays (keep="planes"), plus the
+    list of bit indices observed after each decode()."""
+    import hashlib
+    es = np.ascontiguousarray(es, dtype=np.uint8)
+    frames, indices = [], []
+    with Mpeg1Decoder(path, buffer_size or (len(es) + 1024), mode) as dec:
+        def pull():
+            while (max_frames is None or len(frames) < max_frames) and dec.decode():
+                indices.append(dec.index)
+                y, cr, cb = dec.planes()
+                if keep == "hash":
+                    h = hashlib.md5()
+                    h.update(y.tobytes()); h.update(cr.tobytes()); h.update(cb.tobytes())
+                    frames.append(h.hexdigest())
+                else:
+                    frames.append((y, cr, cb))
+        if pic_offsets is None:
+            dec.write(es)
+            pull()
+        else:
+            # streaming-style: write picture k, decode what is complete
+            # (a picture is only complete once the next start code is in)
+            n = len(pic_offsets) - 1
+            for k in range(n):
+                end = len(es) if k == n - 1 else int(pic_offsets[k + 1])
+                dec.write(es[int(pic_offsets[k]):end])
+            pull()
+        info = dict(width=dec.width, height=dec.height, coded_size=dec.coded_size, frame_rate=dec.frame_rate)
+    return frames, indices, info

@@ -1,0 +1,88 @@
+"""ctypes front-end of the synthetic MPEG-1 ES generator / TS muxer
+(csrc/synth_es.c).  Configs follow SURVEY.md section 8d."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+
+class SynthParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("width", "height", "n_frames", "gop")] + \
+               [("seed", ctypes.c_uint32)] + \
+               [(n, ctypes.c_int32) for n in ("ac_max", "qscale_lo", "qscale_hi", "escape_permille",
+                                               "custom_quant", "quirk_levels", "dc_size_max",
+                                               "coded_permille", "f_code_max")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.LIB_SYNTH
+        if not os.path.exists(path):
+            _build.build_synth()
+        _lib = ctypes.CDLL(path)
+        _lib.synth_es_generate.restype = ctypes.c_size_t
+        _lib.synth_es_generate.argtypes = [ctypes.POINTER(SynthParams), ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]
+        _lib.synth_ts_mux.restype = ctypes.c_size_t
+        _lib.synth_ts_mux.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                      ctypes.c_void_p, ctypes.c_size_t]
+    return _lib
+
+
+BASE_SEED = 0x4A534D50  # 'JSMP'
+
+# name -> generator parameters.  `streams`/`frames` are the
+# full-size figures; tests pass smaller n_frames.
+CONFIGS = {
+    "cfg0_240p_intra": dict(width=320, height=240, gop=1, frames=300, ac_max=6, qscale_lo=4, qscale_hi=11,
+                            escape_permille=20, dc_size_max=3, coded_permille=500, f_code_max=1, cfg=0),
+    "cfg1_720p": dict(width=1280, height=720, gop=12, frames=360, ac_max=3, qscale_lo=4, qscale_hi=11,
+                      escape_permille=20, dc_size_max=3, coded_permille=400, f_code_max=3, cfg=1),
+    "cfg2_1080p": dict(width=1920, height=1080, gop=12, frames=120, ac_max=3, qscale_lo=4, qscale_hi=11,
+                       escape_permille=20, dc_size_max=3, coded_permille=400, f_code_max=3, cfg=2),
+    "cfg4_2160p": dict(width=3840, height=2160, gop=12, frames=24, ac_max=8, qscale_lo=2, qscale_hi=6,
+                       escape_permille=20, dc_size_max=5, coded_permille=600, f_code_max=3, cfg=4),
+}
+
+
+def generate_es(width, height, n_frames, gop=12, seed=BASE_SEED, ac_max=4, qscale_lo=4, qscale_hi=11,
+                escape_permille=20, custom_quant=0, quirk_levels=0, dc_size_max=3, coded_permille=400,
+                f_code_max=3):
+    """Returns (es_bytes: np.uint8[n], pic_offsets: np.uint32[n_frames+1])."""
+    p = SynthParams(width, height, n_frames, gop, seed & 0xFFFFFFFF, ac_max, qscale_lo, qscale_hi,
+                    escape_permille, custom_quant, quirk_levels, dc_size_max, coded_permille, f_code_max)
+    mbs = ((width + 15) // 16) * ((height + 15) // 16)
+    cap = 4096 + n_frames * (mbs * (64 + 40 * max(ac_max, 1)) + 4096)
+    buf = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n_frames + 1, dtype=np.uint32)
+    n = lib().synth_es_generate(ctypes.byref(p), buf.ctypes.data, cap, offs.ctypes.data)
+    if n == 0:
+        raise RuntimeError("synthetic ES generation overflowed its buffer")
+    return buf[:n].copy(), offs
+
+
+def generate_config(name, n_frames=None, stream=0, **overrides):
+    c = dict(CONFIGS[name])
+    cfg = c.pop("cfg")
+    frames = c.pop("frames")
+    c.update(overrides)
+    seed = (BASE_SEED + cfg + 7919 * stream) & 0xFFFFFFFF
+    return generate_es(n_frames=n_frames or frames, seed=seed, **c)
+
+
+def mux_ts(es, pic_offsets, fps=30.0):
+    n_pics = len(pic_offsets) - 1
+    cap = (len(es) // 170 + 2 * n_pics + 16) * 188
+    out = np.empty(cap, dtype=np.uint8)
+    es = np.ascontiguousarray(es)
+    offs = np.ascontiguousarray(pic_offsets, dtype=np.uint32)
+    n = lib().synth_ts_mux(es.ctypes.data, offs.ctypes.data, n_pics, float(fps), out.ctypes.data, cap)
+    if n == 0:
+        raise RuntimeError("TS mux overflowed its buffer")
+    return out[:n].copy()

@@ -1,0 +1,83 @@
+"""Regenerates tests/golden/frames_*.json (container only: needs /root/reference).
+
+For each case the synthetic stream is produced by the committed generator
+(jsmpeg_amd/csrc/synth_es.c, deterministic in its parameters), muxed into TS and
+decoded by FOUR independent runs of the reference algorithm:
+  1. reference src/mpeg1.js under Node              (oracle/ref_node_decode.js js)
+  2. reference wasm build inlined in jsmpeg.min.js  (oracle/ref_node_decode.js wasm)
+  3. reference src/wasm/*.c compiled natively       (oracle/_ref/libjsmpeg_ref.so)
+  4. this repo's restatement                        (oracle/libmpeg1_oracle.so)
+The fixture is written only if all four agree on every frame.  It stores the
+generator parameters, md5 of the ES, and md5(Y|Cr|Cb) per frame, so the GPU box
+(which has no /root/reference) can regenerate the input and check the output.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from jsmpeg_amd import build, cabi, synth  # noqa: E402
+
+CASES = {
+    # name: (config, n_frames, overrides)
+    "cfg0_240p_intra": ("cfg0_240p_intra", 30, {}),
+    "cfg1_720p": ("cfg1_720p", 26, {}),
+    "cfg2_1080p": ("cfg2_1080p", 25, {}),
+    "cfg4_2160p": ("cfg4_2160p", 5, {}),
+    "custom_quant_escapes": ("cfg1_720p", 14, dict(width=352, height=288, custom_quant=1, escape_permille=200,
+                                                   dc_size_max=8, ac_max=12)),
+    "quirk_levels": ("cfg1_720p", 14, dict(width=176, height=144, quirk_levels=1, escape_permille=300, ac_max=20)),
+    "odd_size_17x33": ("cfg1_720p", 14, dict(width=17, height=33)),
+    "wide_2048x64": ("cfg1_720p", 8, dict(width=2048, height=64, f_code_max=3)),
+    "dense_high_rate": ("cfg1_720p", 7, dict(width=640, height=368, ac_max=40, coded_permille=950, qscale_lo=1,
+                                             qscale_hi=31, dc_size_max=8)),
+    "long_gop_p_chain": ("cfg1_720p", 40, dict(width=320, height=192, gop=40)),
+}
+
+
+def node_hashes(ts_path, impl):
+    out = subprocess.check_output(["node", os.path.join(ROOT, "oracle", "ref_node_decode.js"), ts_path, impl])
+    return json.loads(out)["hashes"]
+
+
+def main():
+    build.build_synth(); build.build_oracle(); build.build_ref()
+    for name, (cfg, n, ov) in CASES.items():
+        es, offs = synth.generate_config(cfg, n_frames=n, **ov)
+        ts = synth.mux_ts(es, offs)
+        with tempfile.NamedTemporaryFile(suffix=".ts", delete=False) as f:
+            f.write(ts.tobytes())
+        try:
+            runs = {
+                "ref_js": node_hashes(f.name, "js"),
+                "ref_wasm": node_hashes(f.name, "wasm"),
+                "ref_native": cabi.decode_stream(build.LIB_REF, es, offs)[0],
+                "oracle": cabi.decode_stream(build.LIB_ORACLE, es, offs)[0],
+            }
+        finally:
+            os.unlink(f.name)
+        first = runs["ref_js"]
+        for k, v in runs.items():
+            if v != first:
+                raise SystemExit("%s: %s disagrees with ref_js - not writing a fixture" % (name, k))
+        if len(first) != n:
+            raise SystemExit("%s: decoded %d of %d frames" % (name, len(first), n))
+        _, idx, info = cabi.decode_stream(build.LIB_REF, es)
+        fixture = dict(case=name, config=cfg, n_frames=n, overrides=ov, es_bytes=int(len(es)),
+                       es_md5=hashlib.md5(es.tobytes()).hexdigest(), agreed_by=sorted(runs), info=info,
+                       bit_index_after_decode=idx, frame_md5=first)
+        with open(os.path.join(HERE, "frames_%s.json" % name), "w") as fo:
+            json.dump(fixture, fo, indent=1)
+        print("%-22s %3d frames  %9d ES bytes  all four agree" % (name, n, len(es)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""Pins the oracle (oracle/mpeg1_oracle.c): against the committed golden
+fixtures everywhere, and against live runs of the reference (native C, JS and
+wasm under Node) where /root/reference exists."""
+import glob
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, have_reference
+from jsmpeg_amd import cabi, synth
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "frames_*.json")))
+
+
+def load_case(path):
+    fx = json.load(open(path))
+    es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"], "generator drifted from the fixture"
+    return fx, es, offs
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-5] for p in FIXTURES])
+def test_oracle_matches_golden(path, libs):
+    fx, es, offs = load_case(path)
+    frames, idx, info = cabi.decode_stream(libs["oracle"], es)
+    assert frames == fx["frame_md5"]
+    assert idx == fx["bit_index_after_decode"]
+    assert info["coded_size"] == fx["info"]["coded_size"] and info["width"] == fx["info"]["width"]
+    # streaming-style feed (one write per picture, ts.js:205-210) must give the same pictures
+    frames2, _, _ = cabi.decode_stream(libs["oracle"], es, offs)
+    assert frames2 == fx["frame_md5"]
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-5] for p in FIXTURES])
+def test_reference_native_matches_golden(path, libs):
+    if not libs["ref"] or not os.path.exists(libs["ref"]):
+        pytest.skip("oracle/_ref not built (needs /root/reference once)")
+    fx, es, offs = load_case(path)
+    frames, idx, _ = cabi.decode_stream(libs["ref"], es)
+    assert frames == fx["frame_md5"]
+    assert idx == fx["bit_index_after_decode"]
+
+
+def test_oracle_evict_mode_streaming(libs):
+    """EVICT (streaming) store: small buffer, write a picture / decode a picture
+    (buffer.c:167-190).  Same pictures as the one-shot EXPAND decode."""
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_cfg0_240p_intra.json"))
+    for lib in [libs["oracle"]] + ([libs["ref"]] if libs["ref"] and os.path.exists(libs["ref"]) else []):
+        got = []
+        with cabi.Mpeg1Decoder(lib, 24 * 1024, cabi.MODE_EVICT) as dec:
+            n = len(offs) - 1
+            for k in range(n):
+                end = len(es) if k == n - 1 else int(offs[k + 1])
+                dec.write(es[int(offs[k]):end])
+                while dec.decode():
+                    h = hashlib.md5()
+                    for p in dec.planes():
+                        h.update(p.tobytes())
+                    got.append(h.hexdigest())
+        assert got == fx["frame_md5"], lib
+
+
+def test_oracle_unit_idct_dc_only(libs):
+    import ctypes
+    lib = ctypes.CDLL(libs["oracle"])
+    blk = (ctypes.c_int32 * 64)()
+    for dc in (-2048 * 32, -1000, -129, -128, 0, 127, 128, 255 * 256, 2047 * 32):
+        for i in range(64):
+            blk[i] = 0
+        blk[0] = dc
+        lib.oracle_idct(blk)
+        assert list(blk) == [(dc + 128) >> 8] * 64  # the reference's n == 1 shortcut, mpeg1.c:1578-1581
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference")
+@pytest.mark.parametrize("impl", ["js", "wasm"])
+def test_reference_under_node_matches_golden(impl, libs):
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_custom_quant_escapes.json"))
+    ts = synth.mux_ts(es, offs)
+    with tempfile.NamedTemporaryFile(suffix=".ts", delete=False) as f:
+        f.write(ts.tobytes())
+    try:
+        out = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "oracle", "ref_node_decode.js"),
+                                                  f.name, impl]))
+    finally:
+        os.unlink(f.name)
+    assert out["hashes"] == fx["frame_md5"]
+    assert out["sizes"] == [[fx["info"]["width"], fx["info"]["height"]]]
