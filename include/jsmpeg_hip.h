@@ -1,0 +1,149 @@
+/*
+ * jsmpeg_hip -- C ABI of the MI355X (gfx950) MPEG-1 video decode path.
+ *
+ * Drop-in boundary.  Part 1 is, symbol for symbol, the C ABI the reference
+ * already defines for this path and that its JS wrapper binds through
+ * WebAssembly exports (reference src/wasm/mpeg1.h:10-25, export list
+ * build.sh:49-77, binding src/mpeg1-wasm.js:21-119).  A maintainer swaps
+ * `module.instance.exports._mpeg1_decoder_*` for these (through the N-API
+ * addon jsmpeg_amd/js/jsmpeg_hip.node) and nothing above
+ * changes.  Part 2 is the additive batch interface (many streams x many
+ * pictures per call, frames left in HBM) that the throughput numbers are
+ * measured on; it has no reference counterpart.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature
+ * (streams are passed as void*).  All functions are synchronous unless stated.
+ * Nothing here falls back to a CPU decoder: without a usable HIP device
+ * mpeg1_decoder_create / jsmpeg_hip_batch_create return NULL and
+ * jsmpeg_hip_last_error() says why.
+ */
+#ifndef JSMPEG_HIP_H
+#define JSMPEG_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ part 1
+ * The reference's decoder ABI (src/wasm/mpeg1.h:10-25).                    */
+
+typedef struct mpeg1_decoder_t mpeg1_decoder_t;
+
+/* reference src/wasm/buffer.h:8-11 */
+typedef enum {
+	BIT_BUFFER_MODE_EVICT = 1,
+	BIT_BUFFER_MODE_EXPAND = 2
+} bit_buffer_mode_t;
+
+/* mpeg1.h:12 -- buffer_size = initial byte capacity of the compressed-data
+ * store (JS option videoBufferSize), mode = streaming ? EVICT : EXPAND. */
+mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_buffer_mode_t buffer_mode);
+/* mpeg1.h:13 */
+void mpeg1_decoder_destroy(mpeg1_decoder_t *self);
+/* mpeg1.h:14 -- host pointer to copy `byte_size` compressed bytes to; may
+ * evict or grow the store first (buffer.c:48-65). */
+void *mpeg1_decoder_get_write_ptr(mpeg1_decoder_t *self, unsigned int byte_size);
+/* mpeg1.h:15-16 -- read cursor, in BITS from the start of the store. */
+int mpeg1_decoder_get_index(mpeg1_decoder_t *self);
+void mpeg1_decoder_set_index(mpeg1_decoder_t *self, unsigned int index);
+/* mpeg1.h:17 -- commit bytes copied to the write pointer; parses the first
+ * sequence header when it arrives (mpeg1.c:812-819). */
+void mpeg1_decoder_did_write(mpeg1_decoder_t *self, unsigned int byte_size);
+/* mpeg1.h:19-23 */
+int mpeg1_decoder_has_sequence_header(mpeg1_decoder_t *self);
+float mpeg1_decoder_get_frame_rate(mpeg1_decoder_t *self);
+int mpeg1_decoder_get_coded_size(mpeg1_decoder_t *self);
+int mpeg1_decoder_get_width(mpeg1_decoder_t *self);
+int mpeg1_decoder_get_height(mpeg1_decoder_t *self);
+/* mpeg1.h:24-26 -- HOST pointers to the most recently decoded picture's
+ * coded-size planes (coded_size, coded_size/4, coded_size/4 bytes); valid
+ * until the next decode (mpeg1.c:841-851). */
+void *mpeg1_decoder_get_y_ptr(mpeg1_decoder_t *self);
+void *mpeg1_decoder_get_cr_ptr(mpeg1_decoder_t *self);
+void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *self);
+/* mpeg1.h:27 -- decode exactly one picture; false = no complete picture
+ * start code buffered (mpeg1.c:853-864).  Never reports errors. */
+bool mpeg1_decoder_decode(mpeg1_decoder_t *self);
+
+/* Additive: DEVICE pointer to the most recently decoded frame (Y | Cr | Cb
+ * contiguous, 1.5 * coded_size bytes), for consumers that stay on the GPU. */
+void *jsmpeg_hip_decoder_get_device_frame(mpeg1_decoder_t *self);
+
+/* ------------------------------------------------------------------ part 2
+ * Batch decode: N elementary streams, every picture, planes stay in HBM.   */
+
+typedef struct jsmpeg_hip_batch_t jsmpeg_hip_batch_t;
+
+typedef struct jsmpeg_hip_batch_config_t {
+	int32_t width, height;      /* display size every stream's sequence header must carry */
+	uint32_t max_streams;
+	uint32_t max_pictures;      /* frame pool = max_pictures frames of 1.5 * coded_size   */
+	uint64_t max_es_bytes;      /* total compressed bytes per batch                        */
+	int32_t device;             /* HIP device ordinal, -1 = current                        */
+} jsmpeg_hip_batch_config_t;
+
+typedef struct jsmpeg_hip_picture_info_t {
+	uint32_t stream;            /* index of the stream in the batch           */
+	uint32_t es_offset;         /* byte offset of the picture start code in that stream */
+	int32_t type;               /* picture_coding_type: 1 = I, 2 = P          */
+	int32_t decoded;            /* 0: skipped exactly where the reference skips (B/D, f_code 0, before the header) */
+	int32_t level;              /* dependency depth inside its chain           */
+	int32_t forward;            /* picture index of its forward reference, -1  */
+	uint32_t n_slices;
+} jsmpeg_hip_picture_info_t;
+
+jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_config_t *config);
+void jsmpeg_hip_batch_destroy(jsmpeg_hip_batch_t *b);
+
+/* Copies n_streams host elementary streams into the batch's HBM buffer
+ * (streams are laid out back to back with a small gap).  Returns 0 or < 0. */
+int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *es,
+                            const uint64_t *es_bytes);
+/* Same, from ONE packed DEVICE buffer (`begin[i]`, `end[i]` byte ranges; ranges
+ * must not touch: leave >= 8 bytes between streams).  The bytes are copied
+ * device-to-device on `hip_stream` (void* hipStream_t, NULL = default). */
+int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,
+                                   uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
+                                   void *hip_stream);
+
+/* The hot path over the resident batch: start-code index -> tables -> slice
+ * parse -> reconstruct, level by level.  Work is enqueued on `hip_stream`; the
+ * call returns once everything is enqueued (it synchronises once internally,
+ * after the index, to size the launches).  Returns the number of pictures
+ * found or < 0. */
+int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream);
+/* Waits for the last decode; returns 0 or < 0. */
+int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b);
+
+uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b);
+int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t picture, jsmpeg_hip_picture_info_t *out);
+/* Geometry of a frame in the pool: Y at 0, Cr at luma_bytes, Cb at
+ * luma_bytes + chroma_bytes; frame p at pool + p * frame_stride. */
+int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *coded_width, int32_t *coded_height,
+                              uint32_t *luma_bytes, uint32_t *chroma_bytes, uint64_t *frame_stride);
+void *jsmpeg_hip_batch_frame_pool(jsmpeg_hip_batch_t *b);              /* device pointer */
+/* Device-to-host copy of one picture's planes (any of y/cr/cb may be NULL). */
+int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t picture, void *y, void *cr, void *cb);
+/* 64-bit content hash of every picture's planes, computed on the device
+ * (jsmpeg_amd/hashing.py gives the same value for host planes). out[picture_count]. */
+int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *out);
+/* hipEvent timings of the last decode, milliseconds: [0] start-code index +
+ * tables, [1] host table turn-around, [2] slice parse, [3] reconstruct,
+ * [4] total.  Valid after jsmpeg_hip_batch_sync. */
+int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
+/* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
+ * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture. */
+int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[6]);
+
+/* Last error of the calling thread ("" if none). */
+const char *jsmpeg_hip_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int jsmpeg_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

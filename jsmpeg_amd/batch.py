@@ -1,0 +1,170 @@
+"""ctypes front-end of the batch interface of include/jsmpeg_hip.h (part 2).
+Host-side plumbing only; every byte of decode work happens in libjsmpeg_hip.so
+on the GPU.  Loading fails loudly when the library is missing."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+
+class BatchConfig(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("max_streams", ctypes.c_uint32),
+                ("max_pictures", ctypes.c_uint32), ("max_es_bytes", ctypes.c_uint64), ("device", ctypes.c_int32)]
+
+
+class PictureInfo(ctypes.Structure):
+    _fields_ = [("stream", ctypes.c_uint32), ("es_offset", ctypes.c_uint32), ("type", ctypes.c_int32),
+                ("decoded", ctypes.c_int32), ("level", ctypes.c_int32), ("forward", ctypes.c_int32),
+                ("n_slices", ctypes.c_uint32)]
+
+
+BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_hip_batch_upload",
+                 "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
+                 "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
+                 "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
+                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_last_error",
+                 "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.LIB_HIP
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: build it with `python -m jsmpeg_amd.build hip` "
+                               "(there is no CPU fallback for the decode path)" % path)
+        L = ctypes.CDLL(path)
+        vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
+        L.jsmpeg_hip_batch_create.restype = vp
+        L.jsmpeg_hip_batch_create.argtypes = [ctypes.POINTER(BatchConfig)]
+        L.jsmpeg_hip_batch_destroy.restype = None
+        L.jsmpeg_hip_batch_destroy.argtypes = [vp]
+        L.jsmpeg_hip_batch_upload.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_upload.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+        L.jsmpeg_hip_batch_upload_device.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_upload_device.argtypes = [vp, vp, u64, u32, vp, vp, vp]
+        L.jsmpeg_hip_batch_decode.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_decode.argtypes = [vp, vp]
+        L.jsmpeg_hip_batch_sync.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_sync.argtypes = [vp]
+        L.jsmpeg_hip_batch_picture_count.restype = u32
+        L.jsmpeg_hip_batch_picture_count.argtypes = [vp]
+        L.jsmpeg_hip_batch_picture_info.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_picture_info.argtypes = [vp, u32, ctypes.POINTER(PictureInfo)]
+        L.jsmpeg_hip_batch_geometry.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_geometry.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(u32),
+                                                ctypes.POINTER(u32), ctypes.POINTER(u64)]
+        L.jsmpeg_hip_batch_frame_pool.restype = vp
+        L.jsmpeg_hip_batch_frame_pool.argtypes = [vp]
+        L.jsmpeg_hip_batch_read_frame.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_read_frame.argtypes = [vp, u32, vp, vp, vp]
+        L.jsmpeg_hip_batch_frame_hashes.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_frame_hashes.argtypes = [vp, vp]
+        L.jsmpeg_hip_batch_timings.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.jsmpeg_hip_batch_counters.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_counters.argtypes = [vp, ctypes.POINTER(u64)]
+        L.jsmpeg_hip_last_error.restype = ctypes.c_char_p
+        L.jsmpeg_hip_device_count.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().jsmpeg_hip_last_error().decode()
+
+
+class Batch:
+    """Many elementary streams -> every picture's Y/Cr/Cb planes in HBM."""
+
+    def __init__(self, width, height, max_streams, max_pictures, max_es_bytes, device=-1):
+        self.L = lib()
+        cfg = BatchConfig(width, height, max_streams, max_pictures, max_es_bytes, device)
+        self.h = self.L.jsmpeg_hip_batch_create(ctypes.byref(cfg))
+        if not self.h:
+            raise RuntimeError("jsmpeg_hip_batch_create: " + last_error())
+        cw, ch, lu, chb, fs = (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint32(), ctypes.c_uint32(),
+                               ctypes.c_uint64())
+        self._ok(self.L.jsmpeg_hip_batch_geometry(self.h, cw, ch, lu, chb, fs))
+        self.coded_width, self.coded_height = cw.value, ch.value
+        self.luma_bytes, self.chroma_bytes, self.frame_stride = lu.value, chb.value, fs.value
+
+    def _ok(self, rc):
+        if rc < 0:
+            raise RuntimeError(last_error())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.jsmpeg_hip_batch_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload(self, streams):
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(arrs)
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
+        self._ok(self.L.jsmpeg_hip_batch_upload(self.h, n, ptrs, lens))
+
+    def upload_device(self, dev_ptr, total_bytes, begin, end, stream=None):
+        begin = np.ascontiguousarray(begin, dtype=np.uint32)
+        end = np.ascontiguousarray(end, dtype=np.uint32)
+        self._ok(self.L.jsmpeg_hip_batch_upload_device(self.h, dev_ptr, total_bytes, len(begin), begin.ctypes.data,
+                                                       end.ctypes.data, stream))
+
+    def decode(self, stream=None, sync=True):
+        n = self._ok(self.L.jsmpeg_hip_batch_decode(self.h, stream))
+        if sync:
+            self.sync()
+        return n
+
+    def sync(self):
+        self._ok(self.L.jsmpeg_hip_batch_sync(self.h))
+
+    @property
+    def picture_count(self):
+        return self.L.jsmpeg_hip_batch_picture_count(self.h)
+
+    def picture_info(self, p):
+        info = PictureInfo()
+        self._ok(self.L.jsmpeg_hip_batch_picture_info(self.h, p, ctypes.byref(info)))
+        return info
+
+    def pictures(self):
+        return [self.picture_info(p) for p in range(self.picture_count)]
+
+    def read_frame(self, p):
+        y = np.empty(self.luma_bytes, dtype=np.uint8)
+        cr = np.empty(self.chroma_bytes, dtype=np.uint8)
+        cb = np.empty(self.chroma_bytes, dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_batch_read_frame(self.h, p, y.ctypes.data, cr.ctypes.data, cb.ctypes.data))
+        return y, cr, cb
+
+    def frame_hashes(self):
+        out = np.zeros(max(1, self.picture_count), dtype=np.uint64)
+        self._ok(self.L.jsmpeg_hip_batch_frame_hashes(self.h, out.ctypes.data))
+        return out[:self.picture_count]
+
+    def timings(self):
+        ms = (ctypes.c_float * 5)()
+        self._ok(self.L.jsmpeg_hip_batch_timings(self.h, ms))
+        return dict(index_ms=ms[0], host_ms=ms[1], parse_ms=ms[2], recon_ms=ms[3], total_ms=ms[4])
+
+    def counters(self):
+        c = (ctypes.c_uint64 * 6)()
+        self._ok(self.L.jsmpeg_hip_batch_counters(self.h, c))
+        return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5])
+
+    @property
+    def frame_pool_ptr(self):
+        return self.L.jsmpeg_hip_batch_frame_pool(self.h)

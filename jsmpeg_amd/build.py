@@ -56,7 +56,7 @@ def build_hip(force=False):
     src = hip_sources()
     if force or _newer(LIB_HIP, src + _csrc_headers()):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+              "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
               "-o", LIB_HIP] + src)
     return LIB_HIP
 

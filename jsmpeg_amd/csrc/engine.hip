@@ -1,0 +1,789 @@
+/*
+ * Host runtime behind include/jsmpeg_hip.h: HBM buffers, launch sequencing and
+ * the two front ends (batch engine; the reference's one-picture-per-call
+ * decoder ABI).  No pixel, coefficient or VLC work happens on the host: the
+ * host only moves bytes, walks the (device-produced) start-code list to apply
+ * the reference's decode() control flow, and sizes launches.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "index_tables.h"
+#include "jsmpeg_hip.h"
+#include "kernels.h"
+
+/* ------------------------------------------------------------------ errors */
+
+static thread_local char g_err[512] = "";
+static int fail(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return -1;
+}
+#define HIP_TRY(expr)                                                                        \
+	do {                                                                                     \
+		hipError_t e_ = (expr);                                                              \
+		if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+extern "C" const char *jsmpeg_hip_last_error(void) { return g_err; }
+extern "C" int jsmpeg_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+/* ------------------------------------------------------------ shared state */
+
+static JmVlcLuts *g_luts_dev[16] = { nullptr };
+static int luts_for_device(int dev, JmVlcLuts **out) {
+	if (dev < 0 || dev >= 16) return fail("device ordinal %d out of range", dev);
+	if (!g_luts_dev[dev]) {
+		JmVlcLuts host;
+		jm_build_luts(&host);
+		JmVlcLuts *d = nullptr;
+		HIP_TRY(hipMalloc(&d, sizeof(JmVlcLuts)));
+		HIP_TRY(hipMemcpy(d, &host, sizeof(host), hipMemcpyHostToDevice));
+		g_luts_dev[dev] = d;
+	}
+	*out = g_luts_dev[dev];
+	return 0;
+}
+
+static void geom_init(JmGeom &g, int width, int height) {
+	g.mb_width = (width + 15) >> 4;
+	g.mb_height = (height + 15) >> 4;
+	g.mb_size = g.mb_width * g.mb_height;
+	g.coded_width = g.mb_width << 4;
+	g.coded_height = g.mb_height << 4;
+	g.luma_bytes = (uint32_t)(g.coded_width * g.coded_height);
+	g.chroma_bytes = g.luma_bytes >> 2;
+	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 255) & ~255ull;
+}
+
+#define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
+
+/* =========================================================================
+ * Batch engine
+ * ========================================================================= */
+
+struct jsmpeg_hip_batch_t {
+	jsmpeg_hip_batch_config_t cfg;
+	int device;
+	JmGeom g;
+	JmVlcLuts *d_luts;
+	hipStream_t stream;          /* stream of the last decode */
+
+	uint8_t *d_es; uint64_t es_cap; uint32_t es_bytes;
+	uint32_t n_streams;
+	std::vector<JmStream> h_streams;
+	JmStream *d_streams;
+
+	uint32_t sc_cap, scan_blocks_cap;
+	uint64_t *d_block_counts;
+	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_counters;
+	JmPic *d_pics; std::vector<JmPic> h_pics;
+	uint32_t *d_order; std::vector<uint32_t> h_order, level_off;
+	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
+	uint64_t *d_hashes;
+	uint32_t *d_dbg;
+	uint8_t epoch;
+
+	uint32_t n_sc, n_pics, n_levels, n_decoded, n_slices;
+	hipEvent_t ev[5];
+	bool timed;
+	uint32_t *h_counters; /* pinned */
+};
+
+static void batch_free(jsmpeg_hip_batch_t *b) {
+	if (!b) return;
+	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
+	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
+	hipFree(b->d_pics); hipFree(b->d_order); hipFree(b->d_mb); hipFree(b->d_tokens);
+	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg);
+	if (b->h_counters) hipHostFree(b->h_counters);
+	for (auto &e : b->ev) if (e) hipEventDestroy(e);
+	delete b;
+}
+
+static int batch_alloc(jsmpeg_hip_batch_t *b) {
+	const jsmpeg_hip_batch_config_t &c = b->cfg;
+	if (c.max_es_bytes + (uint64_t)JM_STREAM_GAP * c.max_streams + JM_ES_PAD >= (1ull << 32))
+		return fail("max_es_bytes too large: batch ES positions are 32-bit");
+	b->es_cap = c.max_es_bytes + (uint64_t)JM_STREAM_GAP * (c.max_streams + 1) + JM_ES_PAD + 64;
+	b->sc_cap = (uint32_t)(b->es_cap / 16 + 4096);
+	b->scan_blocks_cap = (uint32_t)(b->es_cap / JM_SCAN_BLOCK_BYTES + 2);
+	HIP_TRY(hipMalloc(&b->d_es, b->es_cap));
+	HIP_TRY(hipMemset(b->d_es, 0xff, b->es_cap));
+	HIP_TRY(hipMalloc(&b->d_streams, sizeof(JmStream) * std::max(1u, c.max_streams)));
+	HIP_TRY(hipMalloc(&b->d_block_counts, sizeof(uint64_t) * (b->scan_blocks_cap + 1)));
+	HIP_TRY(hipMalloc(&b->d_sc_pos, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(hipMalloc(&b->d_sc_code, b->sc_cap));
+	HIP_TRY(hipMalloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(hipMalloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(hipMalloc(&b->d_counters, 4 * sizeof(uint32_t)));
+	HIP_TRY(hipMalloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
+	HIP_TRY(hipMalloc(&b->d_order, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
+	HIP_TRY(hipMalloc(&b->d_mb, mb_bytes));
+	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
+	HIP_TRY(hipMalloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
+	size_t pool_bytes = (size_t)b->g.frame_bytes * std::max(1u, c.max_pictures) + 2 * POOL_GUARD;
+	HIP_TRY(hipMalloc(&b->d_pool_alloc, pool_bytes));
+	b->d_pool = b->d_pool_alloc + POOL_GUARD;
+	HIP_TRY(hipMalloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(hipHostMalloc(&b->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault));
+	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+	return 0;
+}
+
+extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_config_t *config) {
+	g_err[0] = 0;
+	if (!config || config->width <= 0 || config->height <= 0 || config->width > 4095 || config->height > 4095) {
+		fail("bad batch config");
+		return nullptr;
+	}
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+		fail("no HIP device available: the MPEG-1 decode path has no CPU fallback");
+		return nullptr;
+	}
+	jsmpeg_hip_batch_t *b = new jsmpeg_hip_batch_t();
+	b->cfg = *config;
+	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
+	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
+	b->d_pics = nullptr; b->d_order = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
+	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr;
+	for (auto &e : b->ev) e = nullptr;
+	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
+	b->timed = false; b->stream = nullptr;
+	if (config->device >= 0) {
+		if (hipSetDevice(config->device) != hipSuccess) { fail("hipSetDevice(%d) failed", config->device); delete b; return nullptr; }
+	}
+	if (hipGetDevice(&b->device) != hipSuccess) { fail("hipGetDevice failed"); delete b; return nullptr; }
+	geom_init(b->g, config->width, config->height);
+	if (luts_for_device(b->device, &b->d_luts) != 0 || batch_alloc(b) != 0) { batch_free(b); return nullptr; }
+	return b;
+}
+
+extern "C" void jsmpeg_hip_batch_destroy(jsmpeg_hip_batch_t *b) {
+	if (b) { hipDeviceSynchronize(); batch_free(b); }
+}
+
+static int batch_layout(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint64_t *lens) {
+	if (n_streams > b->cfg.max_streams) return fail("%u streams > max_streams %u", n_streams, b->cfg.max_streams);
+	uint64_t total = 0;
+	for (uint32_t i = 0; i < n_streams; i++) total += lens[i];
+	if (total > b->cfg.max_es_bytes) return fail("batch of %llu ES bytes > max_es_bytes %llu",
+	                                             (unsigned long long)total, (unsigned long long)b->cfg.max_es_bytes);
+	b->h_streams.assign(n_streams, JmStream());
+	uint64_t off = JM_STREAM_GAP;
+	for (uint32_t i = 0; i < n_streams; i++) {
+		off = (off + 15) & ~15ull;
+		JmStream &s = b->h_streams[i];
+		memset(&s, 0, sizeof(s));
+		s.es_begin = (uint32_t)off;
+		s.es_end = (uint32_t)(off + lens[i]);
+		s.seq_sc = JM_NONE;
+		off += lens[i] + JM_STREAM_GAP;
+	}
+	if (off + JM_ES_PAD > b->es_cap) return fail("batch layout exceeds the ES buffer");
+	b->es_bytes = (uint32_t)off;
+	b->n_streams = n_streams;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *es,
+                                       const uint64_t *es_bytes) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	if (batch_layout(b, n_streams, es_bytes) != 0) return -1;
+	/* gaps (and everything else) 0xff: can never complete a 00 00 01 */
+	HIP_TRY(hipMemset(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD));
+	for (uint32_t i = 0; i < n_streams; i++)
+		HIP_TRY(hipMemcpy(b->d_es + b->h_streams[i].es_begin, es[i], es_bytes[i], hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,
+                                              uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
+                                              void *hip_stream) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	std::vector<uint64_t> lens(n_streams);
+	for (uint32_t i = 0; i < n_streams; i++) {
+		if (end[i] < begin[i] || end[i] > total_bytes) return fail("stream %u: bad byte range", i);
+		lens[i] = end[i] - begin[i];
+	}
+	if (batch_layout(b, n_streams, lens.data()) != 0) return -1;
+	HIP_TRY(hipMemsetAsync(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD, st));
+	for (uint32_t i = 0; i < n_streams; i++)
+		HIP_TRY(hipMemcpyAsync(b->d_es + b->h_streams[i].es_begin, (const uint8_t *)dev_es + begin[i], lens[i],
+		                       hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	b->stream = st;
+	b->timed = false;
+	b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
+	if (b->n_streams == 0) return 0;
+
+	/* ---- 1. start-code index + tables (device) ---- */
+	HIP_TRY(hipEventRecord(b->ev[0], st));
+	HIP_TRY(hipMemsetAsync(b->d_counters, 0, 4 * sizeof(uint32_t), st));
+	JmScanBufs sb;
+	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.block_counts = b->d_block_counts;
+	sb.sc_pos = b->d_sc_pos; sb.sc_code = b->d_sc_code; sb.pic_sc = b->d_pic_sc; sb.counters = b->d_counters;
+	sb.sc_cap = b->sc_cap; sb.pic_cap = b->cfg.max_pictures; sb.pos_bias = 0;
+	HIP_TRY(jm_launch_scan(sb, st));
+	JmIndexBufs ib;
+	ib.es = b->d_es; ib.sc_pos = b->d_sc_pos; ib.sc_code = b->d_sc_code; ib.sc_owner = b->d_sc_owner;
+	ib.pic_sc = b->d_pic_sc; ib.counters = b->d_counters; ib.streams = b->d_streams; ib.pics = b->d_pics;
+	ib.counters_rw = b->d_counters; ib.n_streams = b->n_streams; ib.sc_cap = b->sc_cap;
+	ib.width = b->cfg.width; ib.height = b->cfg.height;
+	HIP_TRY(jm_launch_index(ib, st));
+	HIP_TRY(hipEventRecord(b->ev[1], st));
+
+	/* ---- 2. the one host turn-around: sizes + level order ---- */
+	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (b->h_counters[2]) return fail("start-code / picture table overflow: %u start codes, %u pictures (max_pictures %u)",
+	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
+	b->n_sc = b->h_counters[0]; b->n_pics = b->h_counters[1]; b->n_levels = b->h_counters[3];
+	b->h_pics.resize(b->n_pics);
+	if (b->n_pics) HIP_TRY(hipMemcpy(b->h_pics.data(), b->d_pics, sizeof(JmPic) * b->n_pics, hipMemcpyDeviceToHost));
+	b->level_off.assign(b->n_levels + 1, 0);
+	for (const JmPic &p : b->h_pics) if (p.decoded) { b->level_off[p.level + 1]++; b->n_decoded++; b->n_slices += p.n_slices; }
+	for (uint32_t l = 0; l < b->n_levels; l++) b->level_off[l + 1] += b->level_off[l];
+	b->h_order.resize(std::max<size_t>(1, b->n_decoded));
+	{
+		std::vector<uint32_t> cur(b->level_off.begin(), b->level_off.end());
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) b->h_order[cur[b->h_pics[p].level]++] = p;
+	}
+	if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_order, b->h_order.data(), sizeof(uint32_t) * b->n_decoded,
+	                                         hipMemcpyHostToDevice, st));
+	if (++b->epoch == 0) {
+		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
+		b->epoch = 1;
+	}
+	HIP_TRY(hipEventRecord(b->ev[2], st));
+
+	/* ---- 3. slice parse: every slice of the batch at once ---- */
+	JmParseBufs pb;
+	pb.es = b->d_es; pb.sc_pos = b->d_sc_pos; pb.sc_code = b->d_sc_code; pb.sc_owner = b->d_sc_owner;
+	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
+	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch;
+	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
+	pb.dbg = nullptr;
+	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */
+		if (!b->d_dbg) { HIP_TRY(hipMalloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
+		HIP_TRY(hipMemsetAsync(b->d_dbg, 0xee, (size_t)b->sc_cap * 16, st));
+		pb.dbg = b->d_dbg;
+	}
+	HIP_TRY(jm_launch_parse(pb, st));
+	HIP_TRY(hipEventRecord(b->ev[3], st));
+
+	/* ---- 4. reconstruct, one launch per dependency level ---- */
+	JmReconBufs rb;
+	rb.g = b->g; rb.pics = b->d_pics; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens;
+	rb.pool = b->d_pool; rb.dst_off = nullptr; rb.fwd_off = nullptr; rb.epoch = b->epoch; rb.zero_uncovered = 1;
+	for (uint32_t l = 0; l < b->n_levels; l++) {
+		rb.order = b->d_order + b->level_off[l];
+		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
+		HIP_TRY(jm_launch_recon(rb, st));
+	}
+	HIP_TRY(hipEventRecord(b->ev[4], st));
+	b->timed = true;
+	return (int)b->n_pics;
+}
+
+extern "C" int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+extern "C" uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b) { return b ? b->n_pics : 0; }
+
+extern "C" int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t picture, jsmpeg_hip_picture_info_t *out) {
+	if (!b || !out || picture >= b->n_pics) return fail("bad picture index");
+	const JmPic &p = b->h_pics[picture];
+	out->stream = p.stream;
+	out->es_offset = p.pos - b->h_streams[p.stream].es_begin;
+	out->type = p.type; out->decoded = p.decoded; out->level = p.level; out->forward = p.fwd; out->n_slices = p.n_slices;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *cw, int32_t *ch, uint32_t *luma,
+                                         uint32_t *chroma, uint64_t *stride) {
+	if (!b) return fail("null batch");
+	if (cw) *cw = b->g.coded_width;
+	if (ch) *ch = b->g.coded_height;
+	if (luma) *luma = b->g.luma_bytes;
+	if (chroma) *chroma = b->g.chroma_bytes;
+	if (stride) *stride = b->g.frame_bytes;
+	return 0;
+}
+
+extern "C" void *jsmpeg_hip_batch_frame_pool(jsmpeg_hip_batch_t *b) { return b ? b->d_pool : nullptr; }
+
+extern "C" int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t picture, void *y, void *cr, void *cb) {
+	g_err[0] = 0;
+	if (!b || picture >= b->n_pics) return fail("bad picture index");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const uint8_t *f = b->d_pool + (uint64_t)picture * b->g.frame_bytes;
+	if (y) HIP_TRY(hipMemcpy(y, f, b->g.luma_bytes, hipMemcpyDeviceToHost));
+	if (cr) HIP_TRY(hipMemcpy(cr, f + b->g.luma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
+	if (cb) HIP_TRY(hipMemcpy(cb, f + b->g.luma_bytes + b->g.chroma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *out) {
+	g_err[0] = 0;
+	if (!b || !out) return fail("null argument");
+	HIP_TRY(hipSetDevice(b->device));
+	if (!b->n_pics) return 0;
+	HIP_TRY(jm_launch_hash(b->d_pool, b->g.frame_bytes, b->g.luma_bytes + 2 * b->g.chroma_bytes, b->n_pics,
+	                       b->d_hashes, b->stream));
+	HIP_TRY(hipMemcpyAsync(out, b->d_hashes, sizeof(uint64_t) * b->n_pics, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]) {
+	g_err[0] = 0;
+	if (!b || !b->timed) return fail("no timed decode");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipEventSynchronize(b->ev[4]));
+	for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], b->ev[i], b->ev[i + 1]));
+	HIP_TRY(hipEventElapsedTime(&out_ms[4], b->ev[0], b->ev[4]));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[6]) {
+	if (!b) return fail("null batch");
+	out[0] = b->n_sc; out[1] = b->n_pics; out[2] = b->n_decoded; out[3] = b->n_levels; out[4] = b->n_slices;
+	out[5] = (uint64_t)b->g.mb_size;
+	return 0;
+}
+
+/* Debug/diagnostic read-back of the intermediate tables of the last decode
+ * (used by tests/tools that compare them with the simulator's). */
+extern "C" int jsmpeg_hip_batch_debug_read(jsmpeg_hip_batch_t *b, int what, void *dst, uint64_t offset, uint64_t bytes) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const uint8_t *src = nullptr;
+	switch (what) {
+	case 0: src = (const uint8_t *)b->d_sc_pos; break;
+	case 1: src = (const uint8_t *)b->d_sc_code; break;
+	case 2: src = (const uint8_t *)b->d_sc_owner; break;
+	case 3: src = (const uint8_t *)b->d_pics; break;
+	case 4: src = (const uint8_t *)b->d_mb; break;
+	case 5: src = (const uint8_t *)b->d_tokens; break;
+	case 6: src = (const uint8_t *)b->d_streams; break;
+	case 7: src = (const uint8_t *)b->d_es; break;
+	case 8: src = (const uint8_t *)b->d_dbg; break;
+	default: return fail("bad debug selector");
+	}
+	HIP_TRY(hipMemcpy(dst, src + offset, bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+/* =========================================================================
+ * The reference's one-picture-per-call decoder ABI (src/wasm/mpeg1.h:10-25)
+ * ========================================================================= */
+
+struct StartCode { uint32_t pos; uint8_t code; };
+
+struct mpeg1_decoder_t {
+	int device;
+	hipStream_t stream;
+	JmVlcLuts *d_luts;
+
+	/* compressed-data store (host mirror of bit_buffer_t, buffer.c:7-13) */
+	uint8_t *bytes;              /* pinned */
+	unsigned capacity, length, index /* bits */;
+	int mode;
+	std::vector<StartCode> codes; /* device-produced start-code list of bytes[0, length) */
+
+	/* device mirror of the store + scan scratch */
+	uint8_t *d_es; unsigned d_es_cap; unsigned mirrored; /* bytes [0, mirrored) are in d_es */
+	uint64_t *d_block_counts; uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner, *d_pic_sc, *d_counters;
+	unsigned scan_cap;
+	uint32_t *h_scan_pos; uint8_t *h_scan_code; uint32_t *h_counters; /* pinned */
+
+	/* sequence (mpeg1.c:701-713) */
+	int has_sequence_header;
+	float frame_rate;
+	int width, height;
+	JmGeom g;
+	JmStream h_stream;           /* quant matrices etc. */
+
+	/* per-picture device state */
+	JmStream *d_stream; JmPic *d_pic; uint32_t *d_order;
+	JmMbRec *d_mb; uint16_t *d_tokens; size_t tokens_cap;
+	uint8_t *d_pool_alloc, *d_pool;  /* two frames */
+	uint64_t *d_offs;                /* [0] dst offset, [1] fwd offset (as int64) */
+	int cur;                         /* frame index being written next (planes_current) */
+	uint8_t *h_frame;                /* pinned: last decoded Y | Cr | Cb */
+	uint8_t epoch;
+	std::vector<uint32_t> stage_pos; std::vector<uint8_t> stage_code;
+};
+
+static int dec_fail_cleanup(mpeg1_decoder_t *d);
+
+extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_buffer_mode_t buffer_mode) {
+	g_err[0] = 0;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+		fail("no HIP device available: the MPEG-1 decode path has no CPU fallback");
+		return nullptr;
+	}
+	mpeg1_decoder_t *d = new mpeg1_decoder_t();
+	d->bytes = nullptr; d->d_es = nullptr; d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr;
+	d->d_sc_owner = nullptr; d->d_pic_sc = nullptr; d->d_counters = nullptr; d->h_scan_pos = nullptr;
+	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_order = nullptr;
+	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr; d->d_offs = nullptr;
+	d->h_frame = nullptr; d->stream = nullptr;
+	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
+	d->d_es_cap = 0; d->mirrored = 0; d->scan_cap = 0; d->tokens_cap = 0;
+	d->has_sequence_header = 0; d->frame_rate = 0; d->width = d->height = 0; d->cur = 0; d->epoch = 0;
+	memset(&d->g, 0, sizeof(d->g)); memset(&d->h_stream, 0, sizeof(d->h_stream));
+	bool ok = hipGetDevice(&d->device) == hipSuccess && luts_for_device(d->device, &d->d_luts) == 0 &&
+	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipHostMalloc(&d->bytes, d->capacity + JM_ES_PAD, hipHostMallocDefault) == hipSuccess &&
+	          hipHostMalloc(&d->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+	          hipMalloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && hipMalloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
+	          hipMalloc(&d->d_order, sizeof(uint32_t)) == hipSuccess && hipMalloc(&d->d_offs, 2 * sizeof(uint64_t)) == hipSuccess;
+	if (ok) { uint32_t zero = 0; ok = hipMemcpy(d->d_order, &zero, 4, hipMemcpyHostToDevice) == hipSuccess; }
+	if (!ok) {
+		if (!g_err[0]) fail("decoder allocation failed: %s", hipGetErrorString(hipGetLastError()));
+		dec_fail_cleanup(d);
+		return nullptr;
+	}
+	return d;
+}
+
+static int dec_fail_cleanup(mpeg1_decoder_t *d) {
+	if (!d) return -1;
+	if (d->stream) hipStreamSynchronize(d->stream);
+	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
+	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
+	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_order);
+	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_offs); hipHostFree(d->h_frame);
+	if (d->stream) hipStreamDestroy(d->stream);
+	delete d;
+	return -1;
+}
+
+extern "C" void mpeg1_decoder_destroy(mpeg1_decoder_t *d) { dec_fail_cleanup(d); }
+
+/* buffer.c:167-190 */
+static void store_evict(mpeg1_decoder_t *d, unsigned needed) {
+	unsigned byte_pos = d->index >> 3, available = d->capacity - d->length;
+	if (byte_pos == d->length || needed > available + byte_pos) {
+		d->length = 0; d->index = 0; d->codes.clear(); d->mirrored = 0;
+		return;
+	}
+	if (byte_pos == 0) return;
+	memmove(d->bytes, d->bytes + byte_pos, d->length - byte_pos);
+	d->length -= byte_pos;
+	d->index -= byte_pos << 3;
+	size_t k = 0;
+	for (const StartCode &c : d->codes) if (c.pos >= byte_pos) d->codes[k++] = StartCode{ c.pos - byte_pos, c.code };
+	d->codes.resize(k);
+	d->mirrored = 0; /* device mirror is re-sent on the next did_write */
+}
+
+/* buffer.c:48-65 */
+extern "C" void *mpeg1_decoder_get_write_ptr(mpeg1_decoder_t *d, unsigned int n) {
+	if (!d) return nullptr;
+	if (n > d->capacity - d->length) {
+		if (d->mode == BIT_BUFFER_MODE_EVICT) store_evict(d, n);
+		if (n > d->capacity - d->length) {
+			/* EXPAND.  The reference's growth formula can under-allocate
+			 * (SURVEY.md 8a a2); grow to fit instead. */
+			unsigned cap = d->capacity * 2;
+			if (cap < d->length + n) cap = d->length + n;
+			uint8_t *nb = nullptr;
+			if (hipHostMalloc(&nb, (size_t)cap + JM_ES_PAD, hipHostMallocDefault) != hipSuccess) {
+				fail("cannot grow the compressed-data store to %u bytes", cap);
+				return nullptr;
+			}
+			memcpy(nb, d->bytes, d->length);
+			hipHostFree(d->bytes);
+			d->bytes = nb;
+			d->capacity = cap;
+			if (d->index > d->length << 3) d->index = d->length << 3;
+		}
+	}
+	return d->bytes + d->length;
+}
+
+extern "C" int mpeg1_decoder_get_index(mpeg1_decoder_t *d) { return d ? (int)d->index : 0; }
+extern "C" void mpeg1_decoder_set_index(mpeg1_decoder_t *d, unsigned int index) { if (d) d->index = index; }
+
+static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
+	unsigned need_es = d->capacity + JM_ES_PAD + 64;
+	if (d->d_es_cap < need_es) {
+		hipFree(d->d_es); d->d_es = nullptr;
+		HIP_TRY(hipMalloc(&d->d_es, need_es));
+		HIP_TRY(hipMemset(d->d_es, 0xff, need_es));
+		d->d_es_cap = need_es; d->mirrored = 0;
+	}
+	unsigned need = bytes / 4 + 64; /* at most one start code per 4 bytes */
+	if (d->scan_cap < need) {
+		hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code); hipFree(d->d_sc_owner); hipFree(d->d_pic_sc);
+		hipHostFree(d->h_scan_pos); hipHostFree(d->h_scan_code);
+		d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr; d->d_sc_owner = nullptr;
+		d->d_pic_sc = nullptr; d->h_scan_pos = nullptr; d->h_scan_code = nullptr; d->scan_cap = 0;
+		need = std::max(need * 2, 4096u);
+		HIP_TRY(hipMalloc(&d->d_block_counts, sizeof(uint64_t) * ((size_t)need * 4 / JM_SCAN_BLOCK_BYTES + 4)));
+		HIP_TRY(hipMalloc(&d->d_sc_pos, sizeof(uint32_t) * need));
+		HIP_TRY(hipMalloc(&d->d_sc_code, need));
+		HIP_TRY(hipMalloc(&d->d_sc_owner, sizeof(uint32_t) * need));
+		HIP_TRY(hipMalloc(&d->d_pic_sc, sizeof(uint32_t) * need));
+		HIP_TRY(hipHostMalloc(&d->h_scan_pos, sizeof(uint32_t) * need, hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc(&d->h_scan_code, need, hipHostMallocDefault));
+		d->scan_cap = need;
+	}
+	return 0;
+}
+
+/* Mirrors bytes [mirrored, length) to HBM and extends the start-code list with
+ * the device scan of the new tail (the reference finds start codes with a
+ * serial byte loop each time it needs one, buffer.c:73-110). */
+static int dec_scan_new_bytes(mpeg1_decoder_t *d, unsigned old_length) {
+	if (d->mirrored > old_length) d->mirrored = old_length;
+	unsigned from_copy = d->mirrored;
+	unsigned scan_from = d->mirrored == old_length ? (old_length >= 3 ? old_length - 3 : 0) : 0;
+	if (d->mirrored != old_length) { d->codes.clear(); from_copy = 0; } /* full re-send after an evict */
+	scan_from &= ~15u;
+	unsigned n = d->length - scan_from;
+	if (dec_ensure_scan(d, n) != 0) return -1;
+	HIP_TRY(hipMemcpyAsync(d->d_es + from_copy, d->bytes + from_copy, d->length - from_copy, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(hipMemsetAsync(d->d_es + d->length, 0xff, JM_ES_PAD, d->stream));
+	d->mirrored = d->length;
+	HIP_TRY(hipMemsetAsync(d->d_counters, 0, 4 * sizeof(uint32_t), d->stream));
+	JmScanBufs sb;
+	sb.es = d->d_es + scan_from; sb.n_bytes = n; sb.block_counts = d->d_block_counts; sb.sc_pos = d->d_sc_pos;
+	sb.sc_code = d->d_sc_code; sb.pic_sc = d->d_pic_sc; sb.counters = d->d_counters; sb.sc_cap = d->scan_cap;
+	sb.pic_cap = d->scan_cap; sb.pos_bias = scan_from;
+	HIP_TRY(jm_launch_scan(sb, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	unsigned found = std::min(d->h_counters[0], d->scan_cap);
+	if (found) {
+		HIP_TRY(hipMemcpyAsync(d->h_scan_pos, d->d_sc_pos, sizeof(uint32_t) * found, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipMemcpyAsync(d->h_scan_code, d->d_sc_code, found, hipMemcpyDeviceToHost, d->stream));
+		HIP_TRY(hipStreamSynchronize(d->stream));
+	}
+	unsigned last = d->codes.empty() ? 0 : d->codes.back().pos + 1;
+	for (unsigned i = 0; i < found; i++) {
+		unsigned pos = d->h_scan_pos[i];
+		if (pos < last && !d->codes.empty()) continue; /* already listed by an earlier scan */
+		d->codes.push_back(StartCode{ pos, d->h_scan_code[i] });
+	}
+	return 0;
+}
+
+static uint32_t host_bits(const mpeg1_decoder_t *d, uint64_t bitpos, int n) { return jm_bits_at(d->bytes, d->length, bitpos, n); }
+
+/* index of the first listed start code at or after byte `from` */
+static size_t first_code_from(const mpeg1_decoder_t *d, unsigned from) {
+	size_t lo = 0, hi = d->codes.size();
+	while (lo < hi) { size_t mid = (lo + hi) >> 1; if (d->codes[mid].pos < from) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+/* mpeg1.c:872-944 */
+static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
+	JmStream &s = d->h_stream;
+	uint64_t bit = ((uint64_t)pos + 4) * 8;
+	d->width = (int)host_bits(d, bit, 12); bit += 12;
+	d->height = (int)host_bits(d, bit, 12); bit += 12;
+	bit += 4;
+	static const float rates[16] = MPEG1_PICTURE_RATE_INIT;
+	d->frame_rate = rates[host_bits(d, bit, 4)]; bit += 4;
+	bit += 18 + 1 + 10 + 1;
+	static const uint8_t zz[64] = MPEG1_ZIGZAG_INIT;
+	static const uint8_t dq[64] = MPEG1_DEFAULT_INTRA_QUANT_INIT;
+	if (host_bits(d, bit++, 1)) { for (int i = 0; i < 64; i++, bit += 8) s.intra_q[zz[i]] = (uint8_t)host_bits(d, bit, 8); }
+	else memcpy(s.intra_q, dq, 64);
+	if (host_bits(d, bit++, 1)) { for (int i = 0; i < 64; i++, bit += 8) s.nonintra_q[zz[i]] = (uint8_t)host_bits(d, bit, 8); }
+	else memset(s.nonintra_q, 16, 64);
+	d->index = (unsigned)bit;
+	geom_init(d->g, d->width, d->height);
+	s.width = d->width; s.height = d->height; s.mb_width = d->g.mb_width; s.mb_height = d->g.mb_height;
+	s.mb_size = d->g.mb_size; s.valid = 1; s.seq_sc = 0;
+	if (d->g.mb_size <= 0) return fail("sequence header with empty picture");
+	size_t mb_bytes = sizeof(JmMbRec) * (size_t)d->g.mb_size;
+	HIP_TRY(hipMalloc(&d->d_mb, mb_bytes));
+	HIP_TRY(hipMemset(d->d_mb, 0, mb_bytes));
+	size_t pool = 2 * (size_t)d->g.frame_bytes + 2 * POOL_GUARD;
+	HIP_TRY(hipMalloc(&d->d_pool_alloc, pool));
+	HIP_TRY(hipMemset(d->d_pool_alloc, 0, pool));   /* zero planes like the JS typed arrays (mpeg1.js:131-152) */
+	d->d_pool = d->d_pool_alloc + POOL_GUARD;
+	HIP_TRY(hipHostMalloc(&d->h_frame, d->g.frame_bytes, hipHostMallocDefault));
+	memset(d->h_frame, 0, d->g.frame_bytes);
+	d->has_sequence_header = 1;
+	return 0;
+}
+
+/* mpeg1.c:812-819 */
+extern "C" void mpeg1_decoder_did_write(mpeg1_decoder_t *d, unsigned int n) {
+	if (!d) return;
+	g_err[0] = 0;
+	if (hipSetDevice(d->device) != hipSuccess) { fail("hipSetDevice failed"); return; }
+	unsigned old_length = d->length;
+	d->length += n;
+	if (dec_scan_new_bytes(d, old_length) != 0) return;
+	if (!d->has_sequence_header) {
+		/* find_start_code(START_SEQUENCE) from the cursor (buffer.c:96-105) */
+		size_t k = first_code_from(d, (d->index + 7) >> 3);
+		while (k < d->codes.size() && d->codes[k].code != JM_CODE_SEQUENCE) k++;
+		if (k == d->codes.size()) { d->index = d->length << 3; return; }
+		dec_sequence_header(d, d->codes[k].pos);
+	}
+}
+
+extern "C" int mpeg1_decoder_has_sequence_header(mpeg1_decoder_t *d) { return d ? d->has_sequence_header : 0; }
+extern "C" float mpeg1_decoder_get_frame_rate(mpeg1_decoder_t *d) { return d ? d->frame_rate : 0.f; }
+extern "C" int mpeg1_decoder_get_coded_size(mpeg1_decoder_t *d) { return d ? (int)d->g.luma_bytes : 0; }
+extern "C" int mpeg1_decoder_get_width(mpeg1_decoder_t *d) { return d ? d->width : 0; }
+extern "C" int mpeg1_decoder_get_height(mpeg1_decoder_t *d) { return d ? d->height : 0; }
+extern "C" void *mpeg1_decoder_get_y_ptr(mpeg1_decoder_t *d) { return d ? d->h_frame : nullptr; }
+extern "C" void *mpeg1_decoder_get_cr_ptr(mpeg1_decoder_t *d) { return d && d->h_frame ? d->h_frame + d->g.luma_bytes : nullptr; }
+extern "C" void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *d) {
+	return d && d->h_frame ? d->h_frame + d->g.luma_bytes + d->g.chroma_bytes : nullptr;
+}
+extern "C" void *jsmpeg_hip_decoder_get_device_frame(mpeg1_decoder_t *d) {
+	return d && d->d_pool ? d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes : nullptr;
+}
+
+/* One picture on the GPU: slices [first, end) of d->codes. */
+static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_t end, int type, int full_pel, int f_code) {
+	const unsigned pic_pos = d->codes[pic_k].pos;
+	const size_t n_slices = end - first;
+	const unsigned data_end = end < d->codes.size() ? d->codes[end].pos : d->length;
+	/* token slots: 4 per ES byte of the picture (tok_off = 0, slots relative to the picture) */
+	size_t tok_need = ((size_t)(data_end - pic_pos) + 16) * JM_TOKENS_PER_BYTE;
+	if (d->tokens_cap < tok_need) {
+		hipFree(d->d_tokens); d->d_tokens = nullptr; d->tokens_cap = 0;
+		tok_need = std::max(tok_need * 2, (size_t)1 << 20);
+		HIP_TRY(hipMalloc(&d->d_tokens, tok_need * sizeof(uint16_t)));
+		d->tokens_cap = tok_need;
+	}
+	/* tables: entries [0, n) = the slices, entry n = what ends the last slice */
+	const size_t n_entries = n_slices + 1;
+	d->stage_pos.resize(n_entries); d->stage_code.resize(n_entries);
+	if (d->scan_cap < n_entries) return fail("internal: staging smaller than slice count");
+	for (size_t i = 0; i < n_slices; i++) { d->stage_pos[i] = d->codes[first + i].pos; d->stage_code[i] = d->codes[first + i].code; }
+	d->stage_pos[n_slices] = data_end; d->stage_code[n_slices] = 0xB7;
+	std::vector<uint32_t> owner(n_entries, 0u);
+	owner[n_slices] = JM_NONE;
+
+	JmStream s = d->h_stream;
+	s.es_begin = 0; s.es_end = d->length; s.sc_lo = 0; s.sc_hi = (uint32_t)n_entries; s.pic_lo = 0; s.pic_hi = 1;
+	JmPic p;
+	memset(&p, 0, sizeof(p));
+	p.sc = JM_NONE; p.stream = 0; p.first_slice_sc = 0; p.n_slices = (uint32_t)n_slices;
+	p.type = (uint8_t)type; p.full_pel = (uint8_t)full_pel; p.f_code = (uint8_t)f_code; p.decoded = 1;
+	p.level = 0; p.fwd = -1; p.end_sc = (uint32_t)n_slices; p.pos = pic_pos; p.tok_off = 0;
+	int64_t offs[2] = { (int64_t)((uint64_t)d->cur * d->g.frame_bytes), (int64_t)((uint64_t)(d->cur ^ 1) * d->g.frame_bytes) };
+
+	hipStream_t st = d->stream;
+	HIP_TRY(hipMemcpyAsync(d->d_sc_pos, d->stage_pos.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_sc_code, d->stage_code.data(), n_entries, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_sc_owner, owner.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_stream, &s, sizeof(s), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_pic, &p, sizeof(p), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_offs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st)); /* the staged host vectors are pageable */
+	if (++d->epoch == 0) {
+		HIP_TRY(hipMemsetAsync(d->d_mb, 0, sizeof(JmMbRec) * (size_t)d->g.mb_size, st));
+		d->epoch = 1;
+	}
+	JmParseBufs pb;
+	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
+	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
+	pb.n_sc = (uint32_t)n_entries; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr;
+	HIP_TRY(jm_launch_parse(pb, st));
+	JmReconBufs rb;
+	rb.g = d->g; rb.pics = d->d_pic; rb.streams = d->d_stream; rb.order = d->d_order; rb.n_level_pics = 1;
+	rb.mb = d->d_mb; rb.tokens = d->d_tokens; rb.pool = d->d_pool;
+	rb.dst_off = d->d_offs; rb.fwd_off = reinterpret_cast<const int64_t *>(d->d_offs + 1);
+	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
+	HIP_TRY(jm_launch_recon(rb, st));
+	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
+	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	d->cur ^= 1;                                    /* plane rotation, mpeg1.c:986-994 */
+	return 0;
+}
+
+/* mpeg1.c:853-864 + decode_picture's control flow, mpeg1.c:947-995 */
+extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
+	if (!d || !d->has_sequence_header) return false;
+	g_err[0] = 0;
+	if (hipSetDevice(d->device) != hipSuccess) return false;
+	size_t k = first_code_from(d, (d->index + 7) >> 3);
+	while (k < d->codes.size() && d->codes[k].code != JM_CODE_PICTURE) k++;
+	if (k == d->codes.size()) { d->index = d->length << 3; return false; }
+	uint64_t bit = ((uint64_t)d->codes[k].pos + 4) * 8 + 10;
+	int type = (int)host_bits(d, bit, 3); bit += 3 + 16;
+	d->index = (unsigned)bit;
+	if (type <= 0 || type >= 3) return true;                       /* B, D, unknown: skipped */
+	int full_pel = 0, f_code = 0;
+	if (type == JM_PIC_PREDICTIVE) {
+		full_pel = (int)host_bits(d, bit, 1);
+		f_code = (int)host_bits(d, bit + 1, 3);
+		bit += 4;
+		d->index = (unsigned)bit;
+		if (f_code == 0) return true;
+	}
+	/* next start code from the cursor; skip extension / user data; take the run of slices */
+	size_t j = first_code_from(d, (d->index + 7) >> 3);
+	while (j < d->codes.size() && (d->codes[j].code == JM_CODE_EXTENSION || d->codes[j].code == JM_CODE_USER_DATA)) j++;
+	size_t first = j;
+	while (j < d->codes.size() && d->codes[j].code >= JM_CODE_SLICE_FIRST && d->codes[j].code <= JM_CODE_SLICE_LAST) j++;
+	if (j > first) {
+		if (dec_picture_gpu(d, k, first, j, type, full_pel, f_code) != 0) {
+			fprintf(stderr, "jsmpeg_hip: decode failed: %s\n", g_err);
+			abort(); /* never silently hand back a stale picture */
+		}
+	} else d->cur ^= 1; /* a picture without slices still rotates the planes (mpeg1.c:986-994) */
+	/* cursor: rewound onto the code that ended the picture, or end of data (mpeg1.c:980-984) */
+	d->index = j < d->codes.size() ? d->codes[j].pos << 3 : d->length << 3;
+	if (j == first) {
+		/* planes rotated without a decode: the "most recent" picture is now the other buffer */
+		hipMemcpy(d->h_frame, d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes,
+		          (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost);
+	}
+	return true;
+}

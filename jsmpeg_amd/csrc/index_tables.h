@@ -1,0 +1,114 @@
+/*
+ * Picture / stream tables built from the start-code list (one workgroup per
+ * stream; the three phases below are the per-thread bodies).
+ *
+ * Restates the control flow the reference runs one picture at a time:
+ *   - first sequence header only           mpeg1.c:812-819, 872-944 (mpeg1.js:29-36, 78-117)
+ *   - decode(): next picture start code    mpeg1.c:853-864
+ *   - picture header, skip B5/B2, take the run of slice codes 01..AF,
+ *     stop at the first other code         mpeg1.c:947-984
+ *   - plane rotation => forward reference  mpeg1.c:986-994
+ */
+#ifndef JSMPEG_AMD_INDEX_TABLES_H
+#define JSMPEG_AMD_INDEX_TABLES_H
+
+#include "mpeg1_dev.h"
+#include "mpeg1_vlc_codes.h"
+
+/* n (<= 25) bits at absolute bit position; bytes at or past `end` read as 0
+ * (what the JS typed array gives, buffer.js:152-175) */
+JM_HD uint32_t jm_bits_at(const uint8_t *es, uint32_t end, uint64_t bitpos, int n) {
+	uint32_t b = (uint32_t)(bitpos >> 3);
+	uint32_t w = 0;
+	for (int i = 0; i < 4; i++) w = (w << 8) | (b + (uint32_t)i < end ? es[b + i] : 0u);
+	return (w >> (32 - (int)(bitpos & 7) - n)) & ((1u << n) - 1u);
+}
+
+JM_HD uint32_t jm_lower_bound(const uint32_t *a, uint32_t n, uint32_t key) { /* first i with a[i] >= key */
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+/* Phase A (one thread per stream): ranges + the first sequence header. */
+JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
+                           uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h) {
+	st.sc_lo = jm_lower_bound(sc_pos, n_sc, st.es_begin);
+	st.sc_hi = jm_lower_bound(sc_pos, n_sc, st.es_end);
+	st.pic_lo = jm_lower_bound(pic_sc, n_pics, st.sc_lo);
+	st.pic_hi = jm_lower_bound(pic_sc, n_pics, st.sc_hi);
+	st.seq_sc = JM_NONE;
+	st.valid = 0;
+	for (uint32_t i = st.sc_lo; i < st.sc_hi; i++)
+		if (sc_code[i] == JM_CODE_SEQUENCE) { st.seq_sc = i; break; }
+	if (st.seq_sc == JM_NONE) return;
+	uint64_t bit = ((uint64_t)sc_pos[st.seq_sc] + 4) * 8;
+	st.width = (int32_t)jm_bits_at(es, st.es_end, bit, 12); bit += 12;
+	st.height = (int32_t)jm_bits_at(es, st.es_end, bit, 12); bit += 12;
+	bit += 4;
+	st.rate_code = (int32_t)jm_bits_at(es, st.es_end, bit, 4); bit += 4;
+	bit += 18 + 1 + 10 + 1;
+	const uint8_t zz[64] = MPEG1_ZIGZAG_INIT;
+	const uint8_t dq[64] = MPEG1_DEFAULT_INTRA_QUANT_INIT;
+	if (jm_bits_at(es, st.es_end, bit++, 1)) {
+		for (int i = 0; i < 64; i++, bit += 8) st.intra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, bit, 8);
+	} else for (int i = 0; i < 64; i++) st.intra_q[i] = dq[i];
+	if (jm_bits_at(es, st.es_end, bit++, 1)) {
+		for (int i = 0; i < 64; i++, bit += 8) st.nonintra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, bit, 8);
+	} else for (int i = 0; i < 64; i++) st.nonintra_q[i] = 16;
+	st.mb_width = (st.width + 15) >> 4;
+	st.mb_height = (st.height + 15) >> 4;
+	st.mb_size = st.mb_width * st.mb_height;
+	st.valid = (st.width == want_w && st.height == want_h) ? 1 : 0;
+}
+
+/* Phase B (one thread per picture of the stream): header + slice ownership. */
+JM_HD void jm_index_picture(JmPic &pic, uint32_t p, uint32_t stream_idx, const JmStream &st, const uint8_t *es,
+                            const uint32_t *sc_pos, const uint8_t *sc_code, const uint32_t *pic_sc,
+                            uint32_t *sc_owner, uint32_t es_origin, int tokens_relative) {
+	uint32_t sc = pic_sc[p];
+	pic.sc = sc;
+	pic.stream = stream_idx;
+	pic.pos = sc_pos[sc];
+	pic.tok_off = tokens_relative ? 0 : (uint64_t)(pic.pos - es_origin) * JM_TOKENS_PER_BYTE;
+	uint64_t bit = ((uint64_t)pic.pos + 4) * 8 + 10;                    /* temporal_reference */
+	pic.type = (uint8_t)jm_bits_at(es, st.es_end, bit, 3); bit += 3 + 16;  /* + vbv_delay */
+	pic.full_pel = 0; pic.f_code = 0;
+	bool ok = st.valid && st.seq_sc != JM_NONE && sc > st.seq_sc &&
+	          (pic.type == JM_PIC_INTRA || pic.type == JM_PIC_PREDICTIVE);
+	if (pic.type == JM_PIC_PREDICTIVE) {
+		pic.full_pel = (uint8_t)jm_bits_at(es, st.es_end, bit, 1);
+		pic.f_code = (uint8_t)jm_bits_at(es, st.es_end, bit + 1, 3);
+		if (pic.f_code == 0) ok = false;
+	}
+	pic.decoded = ok ? 1 : 0;
+	pic.first_slice_sc = JM_NONE; pic.n_slices = 0; pic.end_sc = sc + 1;
+	pic.level = 0; pic.fwd = -1;
+	if (!ok) return;
+	uint32_t j = sc + 1;
+	while (j < st.sc_hi && (sc_code[j] == JM_CODE_EXTENSION || sc_code[j] == JM_CODE_USER_DATA)) j++;
+	pic.first_slice_sc = j;
+	while (j < st.sc_hi && sc_code[j] >= JM_CODE_SLICE_FIRST && sc_code[j] <= JM_CODE_SLICE_LAST) {
+		sc_owner[j] = p;
+		j++;
+	}
+	pic.n_slices = j - pic.first_slice_sc;
+	pic.end_sc = j;
+}
+
+/* Phase C (one thread per stream): forward references and dependency levels.
+ * Returns the deepest level of the stream. */
+JM_HD int jm_index_chain(const JmStream &st, JmPic *pics) {
+	int last = -1, last_level = -1, deepest = -1;
+	for (uint32_t p = st.pic_lo; p < st.pic_hi; p++) {
+		JmPic &pic = pics[p];
+		if (!pic.decoded) continue;
+		if (pic.type == JM_PIC_PREDICTIVE && last >= 0) { pic.fwd = last; pic.level = last_level + 1; }
+		else { pic.fwd = -1; pic.level = 0; }
+		last = (int)p; last_level = pic.level;
+		if (pic.level > deepest) deepest = pic.level;
+	}
+	return deepest;
+}
+
+#endif

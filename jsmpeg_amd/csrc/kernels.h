@@ -1,0 +1,79 @@
+/* Launch wrappers of the gfx950 kernels (kernels.hip), called by the engine. */
+#ifndef JSMPEG_AMD_KERNELS_H
+#define JSMPEG_AMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "mpeg1_dev.h"
+#include "vlc_lut.h"
+
+/* bytes per workgroup of the start-code scan */
+#define JM_SCAN_BLOCK_BYTES 4096
+
+struct JmScanBufs {
+	const uint8_t *es;       /* batch ES buffer (readable JM_ES_PAD bytes past n_bytes) */
+	uint32_t n_bytes;
+	uint64_t *block_counts;  /* [n_blocks + 1]: low 32 = start codes, high 32 = picture codes */
+	uint32_t *sc_pos;        /* out [sc_cap] */
+	uint8_t *sc_code;        /* out [sc_cap] */
+	uint32_t *pic_sc;        /* out [pic_cap]: start-code index of every picture code */
+	uint32_t *counters;      /* [0] n_sc, [1] n_pics, [2] overflow flag, [3] deepest level + 1 */
+	uint32_t sc_cap, pic_cap;
+	uint32_t pos_bias;       /* added to every position (sequential mode scans a sub-range) */
+};
+hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st);
+
+struct JmIndexBufs {
+	const uint8_t *es;
+	const uint32_t *sc_pos;
+	const uint8_t *sc_code;
+	uint32_t *sc_owner;          /* [sc_cap], preset to JM_NONE by the launch */
+	const uint32_t *pic_sc;
+	const uint32_t *counters;
+	JmStream *streams;
+	JmPic *pics;
+	uint32_t *counters_rw;
+	uint32_t n_streams, sc_cap;
+	int width, height;
+};
+hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st);
+
+struct JmParseBufs {
+	const uint8_t *es;
+	const uint32_t *sc_pos;
+	const uint8_t *sc_code;
+	const uint32_t *sc_owner;
+	const JmPic *pics;
+	const JmStream *streams;
+	const JmVlcLuts *luts;       /* device global copy */
+	JmMbRec *mb;                 /* [n_pics * mb_size] */
+	uint16_t *tokens;
+	uint32_t n_sc;
+	int mb_size;
+	uint8_t epoch;
+	int debug_flags;             /* diagnostics only: 1 = LUTs from global memory, 2 = 64-lane workgroups */
+	uint32_t *dbg;               /* diagnostics only: 4 words per start-code entry, or null */
+};
+hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);
+
+struct JmReconBufs {
+	JmGeom g;
+	const JmPic *pics;
+	const JmStream *streams;
+	const uint32_t *order;       /* picture indices of this level */
+	uint32_t n_level_pics;
+	const JmMbRec *mb;
+	const uint16_t *tokens;
+	uint8_t *pool;               /* frame p at pool + p * g.frame_bytes ... */
+	const uint64_t *dst_off;     /* ... unless non-null: explicit byte offsets per order entry */
+	const int64_t *fwd_off;      /*     and forward offsets (-1 = none)                          */
+	uint8_t epoch;
+	int zero_uncovered;
+};
+hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
+
+/* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */
+hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,
+                          uint64_t *out, hipStream_t st);
+
+#endif

@@ -1,0 +1,306 @@
+/*
+ * gfx950 kernels of the MPEG-1 decode path.  The per-lane bodies live in
+ * slice_parse.h / recon_block.h / index_tables.h; this file holds what is
+ * GPU-shaped: the byte-parallel start-code scan (ballot-free two-pass
+ * compaction with wave prefix sums), LDS staging of the VLC tables and of the
+ * coefficient tiles, and the XCD-aware workgroup -> picture mapping.
+ *
+ * No MFMA anywhere: the path is integer byte work bounded by HBM traffic
+ * (DESIGN.md section 4).
+ */
+#include "kernels.h"
+
+#include "index_tables.h"
+#include "recon_block.h"
+#include "slice_parse.h"
+
+#define JM_WG 256
+
+/* ------------------------------------------------------------------------
+ * Start-code scan (reference buffer.c:73-110 is a serial byte loop).
+ * Each lane tests the 16 byte positions of one 16-byte chunk for 00 00 01 xx.
+ * Pass 1 counts per workgroup, pass 2 is a single-workgroup exclusive scan of
+ * the counts, pass 3 recomputes the matches and writes them in stream order.
+ * ---------------------------------------------------------------------- */
+
+struct ChunkMatch { uint32_t mask; uint32_t picmask; uint8_t code[16]; };
+
+static __device__ __forceinline__ ChunkMatch scan_chunk(const uint8_t *es, uint32_t off, uint32_t n_bytes) {
+	ChunkMatch m;
+	m.mask = 0; m.picmask = 0;
+	if (off >= n_bytes) return m;
+	const uint4 v = *reinterpret_cast<const uint4 *>(es + off);
+	const uint32_t nx = *reinterpret_cast<const uint32_t *>(es + off + 16);
+	uint32_t w[5] = { v.x, v.y, v.z, v.w, nx };
+#pragma unroll
+	for (int j = 0; j < 16; j++) {
+		/* bytes j .. j+3 as one little-endian word: 00 00 01 cc == 0xcc010000 */
+		uint32_t lo = w[j >> 2], hi = w[(j >> 2) + 1];
+		uint32_t q = (j & 3) ? (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (j & 3))) : lo;
+		bool hit = ((q & 0x00ffffffu) == 0x00010000u) && (off + j + 3 < n_bytes);
+		uint8_t code = (uint8_t)(q >> 24);
+		m.code[j] = code;
+		if (hit) { m.mask |= 1u << j; if (code == JM_CODE_PICTURE) m.picmask |= 1u << j; }
+	}
+	return m;
+}
+
+/* inclusive scan over the 256 lanes of a workgroup (4 waves) */
+static __device__ __forceinline__ uint32_t wg_inclusive_scan(uint32_t v, uint32_t *wave_tot /* LDS [4] */) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t t = __shfl_up(v, d, 64);
+		if (lane >= d) v += t;
+	}
+	if (lane == 63) wave_tot[wave] = v;
+	__syncthreads();
+	uint32_t add = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++) if (i < wave) add += wave_tot[i];
+	return v + add;
+}
+
+__global__ __launch_bounds__(JM_WG) void k_scan_count(JmScanBufs b) {
+	__shared__ uint32_t wave_tot[4];
+	uint32_t off = blockIdx.x * JM_SCAN_BLOCK_BYTES + threadIdx.x * 16;
+	ChunkMatch m = scan_chunk(b.es, off, b.n_bytes);
+	uint32_t packed = (uint32_t)__popc(m.mask) | ((uint32_t)__popc(m.picmask) << 16);
+	uint32_t incl = wg_inclusive_scan(packed, wave_tot);
+	if (threadIdx.x == JM_WG - 1)
+		b.block_counts[blockIdx.x] = (uint64_t)(incl & 0xffffu) | ((uint64_t)(incl >> 16) << 32);
+}
+
+__global__ __launch_bounds__(1024) void k_scan_prefix(uint64_t *counts, uint32_t n_blocks, uint32_t *counters) {
+	__shared__ uint64_t wave_tot[16];
+	__shared__ uint64_t carry_s;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry_s = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < n_blocks; base += 1024) {
+		uint32_t i = base + threadIdx.x;
+		uint64_t v = i < n_blocks ? counts[i] : 0, x = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			uint32_t lo = __shfl_up((uint32_t)x, d, 64), hi = __shfl_up((uint32_t)(x >> 32), d, 64);
+			if (lane >= d) x += ((uint64_t)hi << 32) | lo;   /* the two 32-bit halves never carry into each other */
+		}
+		if (lane == 63) wave_tot[wave] = x;
+		__syncthreads();
+		uint64_t add = carry_s;
+		for (int k = 0; k < wave; k++) add += wave_tot[k];
+		if (i < n_blocks) counts[i] = add + x - v;           /* exclusive */
+		__syncthreads();
+		if (threadIdx.x == 1023) carry_s = add + x;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		counts[n_blocks] = carry_s;
+		counters[0] = (uint32_t)carry_s;
+		counters[1] = (uint32_t)(carry_s >> 32);
+	}
+}
+
+__global__ __launch_bounds__(JM_WG) void k_scan_write(JmScanBufs b) {
+	__shared__ uint32_t wave_tot[4];
+	uint32_t off = blockIdx.x * JM_SCAN_BLOCK_BYTES + threadIdx.x * 16;
+	ChunkMatch m = scan_chunk(b.es, off, b.n_bytes);
+	uint32_t packed = (uint32_t)__popc(m.mask) | ((uint32_t)__popc(m.picmask) << 16);
+	uint32_t incl = wg_inclusive_scan(packed, wave_tot);
+	uint32_t excl = incl - packed;
+	uint64_t base = b.block_counts[blockIdx.x];
+	uint32_t sc_i = (uint32_t)base + (excl & 0xffffu), pic_i = (uint32_t)(base >> 32) + (excl >> 16);
+	uint32_t mask = m.mask;
+	while (mask) {
+		int j = __ffs(mask) - 1;
+		mask &= mask - 1;
+		if (sc_i < b.sc_cap) {
+			b.sc_pos[sc_i] = off + j + b.pos_bias;
+			b.sc_code[sc_i] = m.code[j];
+		} else b.counters[2] = 1;
+		if (m.picmask & (1u << j)) {
+			if (pic_i < b.pic_cap) b.pic_sc[pic_i] = sc_i; else b.counters[2] = 1;
+			pic_i++;
+		}
+		sc_i++;
+	}
+}
+
+hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st) {
+	uint32_t n_blocks = (b.n_bytes + JM_SCAN_BLOCK_BYTES - 1) / JM_SCAN_BLOCK_BYTES;
+	if (n_blocks == 0) n_blocks = 1;
+	hipLaunchKernelGGL(k_scan_count, dim3(n_blocks), dim3(JM_WG), 0, st, b);
+	hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(1024), 0, st, b.block_counts, n_blocks, b.counters);
+	hipLaunchKernelGGL(k_scan_write, dim3(n_blocks), dim3(JM_WG), 0, st, b);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
+ * Tables: one workgroup per stream.
+ * ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {
+	__shared__ JmStream st;
+	const uint32_t s = blockIdx.x;
+	uint32_t n_sc = b.counters[0], n_pics = b.counters[1];
+	if (n_sc > b.sc_cap) n_sc = b.sc_cap;
+	if (threadIdx.x == 0) {
+		st = b.streams[s];
+		jm_index_stream(st, b.es, b.sc_pos, b.sc_code, n_sc, b.pic_sc, n_pics, b.width, b.height);
+	}
+	__syncthreads();
+	for (uint32_t p = st.pic_lo + threadIdx.x; p < st.pic_hi; p += JM_WG) {
+		JmPic pic;
+		jm_index_picture(pic, p, s, st, b.es, b.sc_pos, b.sc_code, b.pic_sc, b.sc_owner, 0, 0);
+		b.pics[p] = pic;
+	}
+	__threadfence_block();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int deepest = jm_index_chain(st, b.pics);
+		if (deepest >= 0) atomicMax(&b.counters_rw[3], (uint32_t)(deepest + 1));
+		b.streams[s] = st;
+	}
+}
+
+hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
+	hipError_t e = hipMemsetAsync(b.sc_owner, 0xff, (size_t)b.sc_cap * sizeof(uint32_t), st);
+	if (e != hipSuccess) return e;
+	if (b.n_streams) hipLaunchKernelGGL(k_index, dim3(b.n_streams), dim3(JM_WG), 0, st, b);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
+ * Slice parse: one lane per start-code entry that a picture owns.
+ * ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(JM_WG) void k_parse(JmParseBufs b) {
+	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(b.luts);
+		uint4 *dst = reinterpret_cast<uint4 *>(&lut);
+		for (uint32_t i = threadIdx.x; i < sizeof(JmVlcLuts) / 16; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.n_sc) return;
+	const uint32_t p = b.sc_owner[i];
+	if (p == JM_NONE) return;
+	const JmPic pic = b.pics[p];
+	const JmStream *sp = b.streams + pic.stream;
+	const uint32_t pos = b.sc_pos[i];
+	uint32_t end = sp->es_end;
+	if (i + 1 < b.n_sc) { uint32_t nx = b.sc_pos[i + 1]; if (nx < end) end = nx; }
+	JmSliceCtx c;
+	c.lut = (b.debug_flags & 1) ? b.luts : &lut;
+	c.pic_type = pic.type; c.full_pel = pic.full_pel; c.f_code = pic.f_code;
+	c.mb_width = sp->mb_width; c.mb_size = sp->mb_size;
+	c.limit_bytes = end > pos + 4 ? end - (pos + 4) : 0;
+	c.epoch = b.epoch;
+	c.dbg = b.dbg ? b.dbg + 4 * (size_t)i : nullptr;
+	if (c.limit_bytes == 0 || c.mb_size != b.mb_size) return;
+	jm_parse_slice(b.es + pos + 4, b.sc_code[i], c, b.mb + (size_t)p * b.mb_size, b.tokens + pic.tok_off,
+	               (pos - pic.pos) * JM_TOKENS_PER_BYTE);
+}
+
+hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
+	if (b.n_sc == 0) return hipSuccess;
+	uint32_t wg = (b.debug_flags & 2) ? 64 : JM_WG;
+	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + wg - 1) / wg), dim3(wg), 0, st, b);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
+ * Reconstruct: one lane per 8x8 block; all workgroups of a picture are
+ * dispatched to the same XCD (workgroup b runs on XCD b % 8) so the forward
+ * frame's prediction reads hit one L2.
+ * ---------------------------------------------------------------------- */
+struct LdsColumn {
+	int16_t *base;
+	__device__ __forceinline__ int16_t &operator()(int k) { return base[k * JM_WG]; }
+};
+
+__global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
+	__shared__ __attribute__((aligned(16))) int16_t coef[64 * JM_WG];
+	__shared__ __attribute__((aligned(16))) uint8_t qm[128];
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
+	if (k >= b.n_level_pics) return;
+	const uint32_t p = b.order[k];
+	const JmPic pic = b.pics[p];
+	{
+		uint4 z = make_uint4(0, 0, 0, 0);
+		uint4 *c4 = reinterpret_cast<uint4 *>(coef);
+		for (uint32_t i = threadIdx.x; i < 64 * JM_WG * 2 / 16; i += JM_WG) c4[i] = z;
+		if (threadIdx.x < 128) {
+			const JmStream *sp = b.streams + pic.stream;
+			qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
+		}
+	}
+	__syncthreads();
+	const int g = (int)(blk * JM_WG + threadIdx.x);
+	if (g >= 6 * b.g.mb_size) return;
+	JmReconCtx c;
+	c.g = b.g;
+	c.mb = b.mb + (size_t)p * b.g.mb_size;
+	c.tok = b.tokens + pic.tok_off;
+	if (b.dst_off) {
+		c.dst = b.pool + b.dst_off[k];
+		c.fwd = b.fwd_off[k] < 0 ? nullptr : b.pool + b.fwd_off[k];
+	} else {
+		c.dst = b.pool + (uint64_t)p * b.g.frame_bytes;
+		c.fwd = pic.fwd < 0 ? nullptr : b.pool + (uint64_t)pic.fwd * b.g.frame_bytes;
+	}
+	c.intra_q = qm; c.nonintra_q = qm + 64;
+	c.epoch = b.epoch;
+	c.zero_uncovered = b.zero_uncovered;
+	LdsColumn col = { coef + threadIdx.x };
+	jm_recon_block(c, g, col);
+}
+
+hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
+	if (b.n_level_pics == 0) return hipSuccess;
+	uint32_t bpp = (uint32_t)(6 * b.g.mb_size + JM_WG - 1) / JM_WG;
+	uint32_t groups = (b.n_level_pics + 7) / 8;
+	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * bpp), dim3(JM_WG), 0, st, b, bpp);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
+ * Per-frame content hash (parity at full scale without copying planes back):
+ * h = sum_i mix(word_i, i) mod 2^64 over the little-endian 64-bit words of
+ * Y | Cr | Cb.  Mirrored in numpy by jsmpeg_amd/hashing.py.
+ * ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(JM_WG) void k_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t n_words,
+                                               uint32_t blocks_per_frame, uint64_t *out) {
+	__shared__ uint64_t part[4];
+	const uint32_t f = blockIdx.x / blocks_per_frame, blk = blockIdx.x % blocks_per_frame;
+	const uint64_t *w = reinterpret_cast<const uint64_t *>(pool + (uint64_t)f * frame_bytes);
+	uint64_t h = 0;
+	for (uint32_t i = blk * JM_WG + threadIdx.x; i < n_words; i += blocks_per_frame * JM_WG) {
+		uint64_t t = w[i] ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull);
+		t *= 0xD6E8FEB86659FD93ull;
+		t ^= t >> 32;
+		t *= 0xD6E8FEB86659FD93ull;
+		h += t;
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		uint32_t lo = __shfl_down((uint32_t)h, d, 64), hi = __shfl_down((uint32_t)(h >> 32), d, 64);
+		h += ((uint64_t)hi << 32) | lo;
+	}
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(out + f),
+	                                (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
+}
+
+hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,
+                          uint64_t *out, hipStream_t st) {
+	if (n_frames == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(out, 0, (size_t)n_frames * 8, st);
+	if (e != hipSuccess) return e;
+	uint32_t n_words = hashed_bytes / 8;
+	uint32_t bpf = (n_words + JM_WG * 16 - 1) / (JM_WG * 16);
+	if (bpf == 0) bpf = 1;
+	hipLaunchKernelGGL(k_hash, dim3(n_frames * bpf), dim3(JM_WG), 0, st, pool, frame_bytes, n_words, bpf, out);
+	return hipGetLastError();
+}

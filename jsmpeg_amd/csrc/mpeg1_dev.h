@@ -1,0 +1,115 @@
+/*
+ * Shared device-side data layout of the MI355X MPEG-1 decode path.
+ *
+ * Pipeline:
+ *   ES bytes in HBM
+ *     -> start-code index            (index_kernels.hip; reference buffer.c:73-110)
+ *     -> picture / stream tables     (index_tables.h;   reference mpeg1.c:872-995 headers)
+ *     -> slice parse, one lane per slice: VLC -> MbRec + 16-bit coefficient tokens
+ *                                    (slice_parse.h;    reference mpeg1.c:1000-1205, 1442-1552)
+ *     -> reconstruct, one lane per 8x8 block, one launch per dependency level:
+ *        dequantise -> IDCT -> half-pel prediction -> clamp -> coalesced plane rows
+ *                                    (recon_block.h;    reference mpeg1.c:1208-1437, 1535-1740)
+ *
+ * Everything here is plain C++ that hipcc compiles for gfx950; JM_HD lets the
+ * test-only simulator (tests/sim/) compile the very same per-lane functions
+ * with g++ so they can be debugged where there is no GPU.  The product never
+ * runs them on the CPU.
+ */
+#ifndef JSMPEG_AMD_MPEG1_DEV_H
+#define JSMPEG_AMD_MPEG1_DEV_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define JM_HD __host__ __device__ __forceinline__
+#define JM_D __device__ __forceinline__
+#else
+#define JM_HD inline
+#define JM_D inline
+#endif
+
+/* start codes (reference mpeg1.c:686-691) */
+enum {
+	JM_CODE_PICTURE = 0x00,
+	JM_CODE_SLICE_FIRST = 0x01,
+	JM_CODE_SLICE_LAST = 0xAF,
+	JM_CODE_USER_DATA = 0xB2,
+	JM_CODE_SEQUENCE = 0xB3,
+	JM_CODE_EXTENSION = 0xB5,
+};
+enum { JM_PIC_INTRA = 1, JM_PIC_PREDICTIVE = 2 };
+
+#define JM_NONE 0xffffffffu
+
+/* Slack the host keeps after the last ES byte so that window refills and the
+ * 16-byte scan loads never leave the allocation. */
+#define JM_ES_PAD 64
+/* Bytes written between two streams of a batch so no start code can straddle. */
+#define JM_STREAM_GAP 8
+/* Worst case is one token per 3 bits (an intra block of (0,+-1) pairs, "11s");
+ * 4 token slots per ES byte gives every slice a private, statically addressed
+ * token region: slot(slice) = 4 * slice_start_byte. */
+#define JM_TOKENS_PER_BYTE 4
+
+/* One stream of a batch. */
+struct JmStream {
+	uint32_t es_begin, es_end;     /* byte range in the batch ES buffer           */
+	uint32_t seq_sc;               /* start-code index of the first sequence header, JM_NONE if none */
+	uint32_t sc_lo, sc_hi;         /* this stream's range in the start-code list  */
+	uint32_t pic_lo, pic_hi;       /* this stream's range in the picture list     */
+	int32_t valid;                 /* header found and dimensions match the batch */
+	int32_t width, height;
+	int32_t mb_width, mb_height, mb_size;
+	int32_t rate_code;
+	uint8_t intra_q[64];           /* raster order (de-zig-zagged, mpeg1.c:887-904) */
+	uint8_t nonintra_q[64];
+};
+
+/* One picture start code of a batch. */
+struct JmPic {
+	uint32_t sc;                   /* index of its start code in the start-code list */
+	uint32_t stream;
+	uint32_t first_slice_sc;       /* start-code index of its first slice, JM_NONE if none */
+	uint32_t n_slices;
+	uint8_t type;                  /* picture_coding_type (3 bits)  */
+	uint8_t full_pel;
+	uint8_t f_code;
+	uint8_t decoded;               /* 1: I or P with f_code != 0, after the sequence header */
+	int32_t level;                 /* dependency depth: 0 for I, fwd level + 1 for P */
+	int32_t fwd;                   /* picture index whose planes are the forward reference, -1 if none */
+	uint32_t end_sc;               /* start-code index that ended the picture (first non-slice code), or the stream's sc_hi */
+	uint32_t pos;                  /* byte position of the picture start code in the ES buffer */
+	uint64_t tok_off;              /* first token slot of the picture in the token buffer */
+};
+
+struct alignas(16) uint4_like_t { uint32_t x, y, z, w; };
+
+/* One macroblock of one picture: what reconstruction needs, 16 bytes. */
+struct alignas(16) JmMbRec {
+	uint32_t tok;                  /* first token, relative to the picture's token base */
+	int16_t mvh, mvv;              /* half-pel units, after the full_pel shift (mpeg1.c:1169-1172) */
+	uint8_t cnt[6];                /* tokens per block (intra: DC token + AC tokens) */
+	uint8_t qf;                    /* quantizer_scale | intra << 5 | predicted << 6  */
+	uint8_t epoch;                 /* == batch epoch when written this batch          */
+};
+#define JM_MB_INTRA 0x20
+#define JM_MB_PRED 0x40
+
+/* 16-bit coefficient token: raster position << 10 | level (10-bit two's
+ * complement, -256..255: the full range of the escape forms, mpeg1.js:767-780).
+ * The first token of an intra block is the raw DC value (int16). */
+JM_HD uint16_t jm_token(int pos, int level) { return (uint16_t)((pos << 10) | (level & 1023)); }
+JM_HD int jm_token_pos(uint16_t t) { return t >> 10; }
+JM_HD int jm_token_level(uint16_t t) { return ((int)(t & 1023) ^ 512) - 512; }
+
+/* Geometry of the planes of one frame in the frame pool: Y | Cr | Cb. */
+struct JmGeom {
+	int32_t mb_width, mb_height, mb_size;
+	int32_t coded_width, coded_height;
+	uint32_t luma_bytes, chroma_bytes; /* per plane */
+	uint64_t frame_bytes;              /* luma + 2 chroma, rounded up to 256 */
+};
+
+#endif

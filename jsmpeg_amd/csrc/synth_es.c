@@ -188,11 +188,12 @@ static int draw_level(rng_t *r, const synth_params_t *p) {
 
 /* AC coefficients (and the DC for non-intra blocks) followed by end_of_block.
  * `n` is the scan position already consumed (1 for intra, 0 for non-intra). */
-static void put_coeffs(bitw_t *w, rng_t *r, const synth_params_t *p, int n, int min_count) {
+static int put_coeffs(bitw_t *w, rng_t *r, const synth_params_t *p, int n, int min_count) {
 	int count = rng_range(r, 0, p->ac_max);
 	if (count < min_count) count = min_count;
 	int first = (n == 0);
-	for (int k = 0; k < count && n <= 63; k++) {
+	int written = 0;
+	for (int k = 0; k < count && n <= 63; k++, written++) {
 		uint32_t u = rng_next(r) % 100u;
 		int run = u < 55 ? 0 : u < 75 ? 1 : u < 85 ? 2 : u < 97 ? 3 + (int)(rng_next(r) % 6u)
 		                                                         : 9 + (int)(rng_next(r) % 23u);
@@ -202,11 +203,12 @@ static void put_coeffs(bitw_t *w, rng_t *r, const synth_params_t *p, int n, int 
 		n += run + 1;
 	}
 	bw_put_str(w, "10"); /* end_of_block */
+	return written;
 }
 
 typedef struct { int y, cr, cb; } dcpred_t;
 
-static void put_intra_block(bitw_t *w, rng_t *r, const synth_params_t *p, int block, dcpred_t *dc) {
+static int put_intra_block(bitw_t *w, rng_t *r, const synth_params_t *p, int block, dcpred_t *dc) {
 	int *pred = block < 4 ? &dc->y : (block == 4 ? &dc->cr : &dc->cb);
 	int size = rng_range(r, 0, p->dc_size_max);
 	int diff = 0;
@@ -220,7 +222,7 @@ static void put_intra_block(bitw_t *w, rng_t *r, const synth_params_t *p, int bl
 	bw_put_code(w, block < 4 ? N_DCL[size] : N_DCC[size]);
 	if (size > 0) bw_put(w, (uint32_t)(diff > 0 ? diff : diff + (1 << size) - 1), size);
 	*pred += diff;
-	put_coeffs(w, r, p, 1, 0);
+	return put_coeffs(w, r, p, 1, 0);
 }
 
 /* --------------------------------------------------------- motion vectors */
@@ -252,11 +254,21 @@ static void put_motion_component(bitw_t *w, int d, int r_size) {
 
 /* ------------------------------------------------------------- pictures */
 
+/* what the roofline accounting needs to know about a generated stream */
+typedef struct synth_stats_t {
+	uint64_t macroblocks;        /* all pictures                                        */
+	uint64_t predicted;          /* macroblocks reconstructed from the forward frame:
+	                                non-intra or skipped, P pictures                    */
+	uint64_t coded_blocks;
+	uint64_t coefficients;       /* run/level pairs + intra DC terms                    */
+} synth_stats_t;
+
 typedef struct {
 	const synth_params_t *p;
 	geom_t g;
 	rng_t r;
 	bitw_t w;
+	synth_stats_t st;
 } gen_t;
 
 static void put_sequence_header(gen_t *G, int custom) {
@@ -312,8 +324,8 @@ static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
 	const synth_params_t *p = G->p;
 	bitw_t *w = &G->w;
 	for (int attempt = 0; attempt < 64; attempt++) {
-		size_t begin = w->pos;
 		bitw_t save_w = *w;
+		synth_stats_t save_st = G->st;
 		bw_start_code(w, row + 1);
 		size_t payload = w->pos;
 		int qscale = rng_range(&G->r, p->qscale_lo, p->qscale_hi);
@@ -333,6 +345,8 @@ static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
 				kind = u < 2 ? 0 : u < 12 ? 1 : u < 14 ? 2 : u < 15 ? 3 : 4;
 				if (kind == 4 && (firstmb || last)) kind = 1;
 			}
+			G->st.macroblocks++;
+			if (kind != 0) G->st.predicted++;
 			if (kind == 4) { pending_skip++; continue; }
 			put_mba_increment(w, pending_skip + 1);
 			if (pending_skip) {
@@ -388,8 +402,9 @@ static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
 			} else cbp = (mbtype & 0x01) ? 0x3f : 0;
 			for (int b = 0; b < 6; b++) {
 				if (!(cbp & (0x20 >> b))) continue;
-				if (mbtype & 0x01) put_intra_block(w, &G->r, p, b, &dc);
-				else put_coeffs(w, &G->r, p, 0, 1);
+				G->st.coded_blocks++;
+				if (mbtype & 0x01) { G->st.coefficients++; G->st.coefficients += (uint64_t)put_intra_block(w, &G->r, p, b, &dc); }
+				else G->st.coefficients += (uint64_t)put_coeffs(w, &G->r, p, 0, 1);
 			}
 		}
 		bw_align(w);
@@ -399,14 +414,15 @@ static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
 		    !(w->pos >= 2 && w->buf[w->pos - 1] == 0 && w->buf[w->pos - 2] == 0)) return;
 		/* start-code emulation: roll back and redraw (rng keeps advancing) */
 		*w = save_w;
-		(void)begin;
+		G->st = save_st;
 	}
 }
 
 /* Generates one elementary stream.  Returns its length in bytes (0 on
  * overflow).  pic_offsets[i] = byte offset where picture i's access unit
  * begins (including a preceding sequence/GOP header), pic_offsets[n] = end. */
-size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint32_t *pic_offsets) {
+size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint32_t *pic_offsets,
+                         synth_stats_t *stats) {
 	gen_t G;
 	init_numeric_codes();
 	memset(&G, 0, sizeof(G));
@@ -441,6 +457,7 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 	}
 	bw_start_code(&G.w, 0xB7); /* sequence_end */
 	if (pic_offsets) pic_offsets[p->n_frames] = (uint32_t)(G.w.pos - 4);
+	if (stats) *stats = G.st;
 	return G.w.overflow ? 0 : G.w.pos;
 }
 

@@ -16,6 +16,10 @@ class SynthParams(ctypes.Structure):
                                                "coded_permille", "f_code_max")]
 
 
+class SynthStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("macroblocks", "predicted", "coded_blocks", "coefficients")]
+
+
 _lib = None
 
 
@@ -28,7 +32,7 @@ def lib():
         _lib = ctypes.CDLL(path)
         _lib.synth_es_generate.restype = ctypes.c_size_t
         _lib.synth_es_generate.argtypes = [ctypes.POINTER(SynthParams), ctypes.c_void_p, ctypes.c_size_t,
-                                           ctypes.c_void_p]
+                                           ctypes.c_void_p, ctypes.POINTER(SynthStats)]
         _lib.synth_ts_mux.restype = ctypes.c_size_t
         _lib.synth_ts_mux.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_void_p, ctypes.c_size_t]
@@ -53,17 +57,20 @@ CONFIGS = {
 
 def generate_es(width, height, n_frames, gop=12, seed=BASE_SEED, ac_max=4, qscale_lo=4, qscale_hi=11,
                 escape_permille=20, custom_quant=0, quirk_levels=0, dc_size_max=3, coded_permille=400,
-                f_code_max=3):
-    """Returns (es_bytes: np.uint8[n], pic_offsets: np.uint32[n_frames+1])."""
+                f_code_max=3, with_stats=False):
+    """Returns (es_bytes: np.uint8[n], pic_offsets: np.uint32[n_frames+1]) [+ stats dict]."""
     p = SynthParams(width, height, n_frames, gop, seed & 0xFFFFFFFF, ac_max, qscale_lo, qscale_hi,
                     escape_permille, custom_quant, quirk_levels, dc_size_max, coded_permille, f_code_max)
     mbs = ((width + 15) // 16) * ((height + 15) // 16)
     cap = 4096 + n_frames * (mbs * (64 + 40 * max(ac_max, 1)) + 4096)
     buf = np.empty(cap, dtype=np.uint8)
     offs = np.zeros(n_frames + 1, dtype=np.uint32)
-    n = lib().synth_es_generate(ctypes.byref(p), buf.ctypes.data, cap, offs.ctypes.data)
+    st = SynthStats()
+    n = lib().synth_es_generate(ctypes.byref(p), buf.ctypes.data, cap, offs.ctypes.data, ctypes.byref(st))
     if n == 0:
         raise RuntimeError("synthetic ES generation overflowed its buffer")
+    if with_stats:
+        return buf[:n].copy(), offs, {k: int(getattr(st, k)) for k, _ in SynthStats._fields_}
     return buf[:n].copy(), offs
 
 

@@ -1,0 +1,107 @@
+"""Parity tests proper: the HIP path (through the C ABI in libjsmpeg_hip.so)
+against the committed golden fixtures and against the oracle on the same
+seeded inputs.  Bit-exact: the path is integer/byte work.  Needs an MI355X."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from jsmpeg_amd import batch as jb
+from jsmpeg_amd import cabi, hashing, synth
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "frames_*.json")))
+IDS = [os.path.basename(p)[7:-5] for p in FIXTURES]
+
+
+def load_case(path):
+    fx = json.load(open(path))
+    es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"]
+    return fx, es, offs
+
+
+def md5_planes(planes):
+    h = hashlib.md5()
+    for p in planes:
+        h.update(p.tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_batch_matches_golden(path, hip_lib):
+    fx, es, _ = load_case(path)
+    with jb.Batch(fx["info"]["width"], fx["info"]["height"], 1, fx["n_frames"] + 2, len(es) + 1024) as b:
+        b.upload([es])
+        n = b.decode()
+        assert n == fx["n_frames"]
+        pics = b.pictures()
+        assert all(p.decoded for p in pics)
+        got = [md5_planes(b.read_frame(p)) for p in range(n)]
+        assert got == fx["frame_md5"]
+        # device-side hash agrees with the host mirror on the copied-back planes
+        dev = b.frame_hashes()
+        for p in (0, n // 2, n - 1):
+            assert int(dev[p]) == hashing.frame_hash(*b.read_frame(p))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_decoder_abi_matches_golden(path, hip_lib):
+    """The reference's 15-function ABI, one write, pull every picture."""
+    fx, es, offs = load_case(path)
+    frames, idx, info = cabi.decode_stream(hip_lib, es)
+    assert frames == fx["frame_md5"]
+    assert idx == fx["bit_index_after_decode"]
+    assert info["coded_size"] == fx["info"]["coded_size"]
+    assert info["width"] == fx["info"]["width"] and info["height"] == fx["info"]["height"]
+    assert abs(info["frame_rate"] - fx["info"]["frame_rate"]) < 1e-6
+
+
+def test_decoder_abi_streaming_evict(hip_lib):
+    """EVICT store, a picture written / a picture pulled (how ts.js + Player drive it)."""
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_cfg0_240p_intra.json"))
+    got = []
+    with cabi.Mpeg1Decoder(hip_lib, 24 * 1024, cabi.MODE_EVICT) as dec:
+        n = len(offs) - 1
+        for k in range(n):
+            end = len(es) if k == n - 1 else int(offs[k + 1])
+            dec.write(es[int(offs[k]):end])
+            while dec.decode():
+                got.append(md5_planes(dec.planes()))
+    assert got == fx["frame_md5"]
+
+
+def test_decoder_abi_per_picture_writes_expand(hip_lib):
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_long_gop_p_chain.json"))
+    frames, _, _ = cabi.decode_stream(hip_lib, es, offs, buffer_size=4096)  # forces the store to grow
+    assert frames == fx["frame_md5"]
+
+
+def test_batch_many_streams_vs_oracle(hip_lib, libs):
+    """8 streams with distinct seeds in one batch; every frame against the oracle."""
+    streams, want = [], []
+    for s in range(8):
+        es, _ = synth.generate_config("cfg1_720p", n_frames=13, stream=s, width=352, height=288)
+        streams.append(es)
+        frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+        want.append([hashing.frame_hash(*f) for f in frames])
+    with jb.Batch(352, 288, 8, 8 * 13 + 4, sum(len(s) for s in streams) + 4096) as b:
+        b.upload(streams)
+        n = b.decode()
+        assert n == 8 * 13
+        dev = b.frame_hashes()
+        counters = b.counters()
+        assert counters["levels"] == 12 and counters["decoded"] == n
+        per_stream = {}
+        for p, info in enumerate(b.pictures()):
+            per_stream.setdefault(info.stream, []).append(int(dev[p]))
+        for s in range(8):
+            assert per_stream[s] == want[s], "stream %d" % s
+        # decode again into the same batch object: epochs, not memsets, invalidate old records
+        b.decode()
+        assert np.array_equal(b.frame_hashes(), dev)
