@@ -61,6 +61,30 @@ def build_hip(force=False):
     return LIB_HIP
 
 
+def check_kernel_resources():
+    """The hot kernels must not touch scratch memory (private-segment spills
+    measured wrong results AND cost bandwidth on this path): recompile
+    kernels.hip device-only with resource remarks and fail on any scratch."""
+    import re
+    src = os.path.join(CSRC, "kernels.hip")
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                          "-I", CSRC, "--cuda-device-only", "-c", src, "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True).stderr
+    usage, name = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    bad = {k: v for k, v in usage.items() if v.get("ScratchSize", 0) != 0}
+    if bad or not usage:
+        raise RuntimeError("kernels using scratch memory (or no kernels found): %r" % (bad or out[-400:],))
+    return usage
+
+
 def build_addon(force=False):
     """N-API addon: thin glue from the Node host side to the C ABI."""
     src = [os.path.join(CSRC, "napi_addon.c")]

@@ -579,13 +579,19 @@ static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
  * the device scan of the new tail (the reference finds start codes with a
  * serial byte loop each time it needs one, buffer.c:73-110). */
 static int dec_scan_new_bytes(mpeg1_decoder_t *d, unsigned old_length) {
-	if (d->mirrored > old_length) d->mirrored = old_length;
-	unsigned from_copy = d->mirrored;
-	unsigned scan_from = d->mirrored == old_length ? (old_length >= 3 ? old_length - 3 : 0) : 0;
-	if (d->mirrored != old_length) { d->codes.clear(); from_copy = 0; } /* full re-send after an evict */
-	scan_from &= ~15u;
+	/* may re-allocate the device mirror (store grew) and then forgets what was mirrored */
+	if (dec_ensure_scan(d, d->length) != 0) return -1;
+	unsigned from_copy, scan_from;
+	if (d->mirrored == old_length) {
+		/* incremental: send the new tail, rescan from 3 bytes before it (16-byte aligned for the scan loads) */
+		from_copy = old_length;
+		scan_from = (old_length >= 3 ? old_length - 3 : 0) & ~15u;
+	} else {
+		/* after an evict / reset / re-allocation: re-send and re-scan everything */
+		from_copy = 0; scan_from = 0;
+		d->codes.clear();
+	}
 	unsigned n = d->length - scan_from;
-	if (dec_ensure_scan(d, n) != 0) return -1;
 	HIP_TRY(hipMemcpyAsync(d->d_es + from_copy, d->bytes + from_copy, d->length - from_copy, hipMemcpyHostToDevice, d->stream));
 	HIP_TRY(hipMemsetAsync(d->d_es + d->length, 0xff, JM_ES_PAD, d->stream));
 	d->mirrored = d->length;
