@@ -1,0 +1,58 @@
+"""Turns the rocprofv3 (rocpd sqlite) outputs that a gpurun call left under
+gpurun_out/ into the small tracked summaries under profiles/:
+  profiles/<tag>_kernel_stats.txt   -- `--kernel-trace --stats` per-kernel table
+  profiles/<tag>_pmc.txt            -- FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
+  profiles/pmc_traffic.json         -- HBM bytes per launch, per kernel (read by bench.py)
+FETCH_SIZE is doubled (gfx950 reports half of streamed reads, MI355X_MICROARCH.md
+section HBM; checked here on k_hash, which reads a known byte count).
+    python tools/rocprof_summary.py r01 gpurun_out/prof_trace gpurun_out/prof_fetch gpurun_out/prof_write
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, d_trace, d_fetch, d_write = sys.argv[1:5]
+
+
+def db(d):
+    return sqlite3.connect(glob.glob(os.path.join(d, "*.db"))[0])
+
+
+def short(n):
+    return n.split("(")[0]
+
+
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline\n")
+    f.write("# (durations in microseconds; 6 decode passes = 1 warm-up + 5 timed)\n")
+    f.write("%-28s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    for name, calls, total, avg, pct in db(d_trace).execute("select * from top_kernels"):
+        f.write("%-28s %8d %14.1f %12.2f %7.2f%%\n" % (short(name)[:28], calls, total / 1e3, avg / 1e3, pct))
+    f.write("\n# per-dispatch register / LDS / scratch usage\n")
+    for row in db(d_trace).execute("select name, max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+                                   "max(workgroup_x), min(grid_x), max(grid_x) from kernels group by name"):
+        f.write("%-28s vgpr %3d sgpr %3d lds %6d scratch %d wg %d grid %d..%d\n" % ((short(row[0])[:28],) + row[1:]))
+
+q = ("select kernel_name, count(*), avg(value), min(value), max(value) from counters_collection "
+     "where counter_name = ? group by kernel_name")
+fetch = {short(r[0]): r[1:] for r in db(d_fetch).execute(q, ("FETCH_SIZE",))}
+write = {short(r[0]): r[1:] for r in db(d_write).execute(q, ("WRITE_SIZE",))}
+traffic = {}
+with open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), KiB per dispatch\n")
+    f.write("# hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950 FETCH_SIZE counts half)\n")
+    f.write("%-16s %6s %14s %14s %14s %16s\n" % ("kernel", "n", "fetch_avg_KiB", "fetch_max_KiB", "write_avg_KiB", "hbm_MB_per_launch"))
+    for k in sorted(set(fetch) | set(write)):
+        fa = fetch.get(k, (0, 0, 0, 0))
+        wa = write.get(k, (0, 0, 0, 0))
+        hbm = (2 * fa[1] + wa[1]) * 1024
+        traffic[k] = int(hbm)
+        f.write("%-16s %6d %14.1f %14.1f %14.1f %16.1f\n" % (k[:16], fa[0], fa[1], fa[3], wa[1], hbm / 1e6))
+json.dump({k: v for k, v in traffic.items() if k.startswith("k_")},
+          open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag)).read())
+print(open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag)).read())
