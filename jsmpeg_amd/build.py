@@ -92,7 +92,7 @@ def build_addon(force=False):
         return None
     build_hip(force)
     if force or _newer(ADDON_NODE, src + _csrc_headers() + [LIB_HIP]):
-        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-I", NODE_INCLUDE,
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-DNODE_GYP_MODULE_NAME=jsmpeg_hip", "-I", NODE_INCLUDE,
               "-I", os.path.join(ROOT, "include"), "-o", ADDON_NODE] + src +
              ["-L", PKG, "-ljsmpeg_hip", "-Wl,-rpath,$ORIGIN/.."])
     return ADDON_NODE

@@ -31,7 +31,7 @@ with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag), "w") as f
     f.write("# (durations in microseconds; 6 decode passes = 1 warm-up + 5 timed)\n")
     f.write("%-28s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in db(d_trace).execute("select * from top_kernels"):
-        f.write("%-28s %8d %14.1f %12.2f %7.2f%%\n" % (short(name)[:28], calls, total / 1e3, avg / 1e3, pct))
+        f.write("%-28s %8d %14.1f %12.2f %7.2f%%\n" % (short(name)[:28], calls, total, avg, pct))
     f.write("\n# per-dispatch register / LDS / scratch usage\n")
     for row in db(d_trace).execute("select name, max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
                                    "max(workgroup_x), min(grid_x), max(grid_x) from kernels group by name"):
