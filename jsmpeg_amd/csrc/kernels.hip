@@ -170,41 +170,82 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
 }
 
 /* ------------------------------------------------------------------------
- * Slice parse: one lane per start-code entry that a picture owns.
+ * Slice parse: one lane per start-code entry that a picture owns.  A
+ * workgroup is four independent wavefronts sharing the VLC tables; each
+ * wavefront owns a [32][64]-dword compressed-data ring tile and a
+ * [32][64]-dword token ring tile in LDS (slice_parse.h) and schedules itself:
+ * at every turn it runs the step kind most of its lanes are waiting for.
  * ---------------------------------------------------------------------- */
+#define JM_PARSE_WAVES (JM_WG / 64)
+
 __global__ __launch_bounds__(JM_WG) void k_parse(JmParseBufs b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
+	__shared__ uint32_t es_ring[JM_PARSE_WAVES][JM_ES_RING_DW][JM_RING_STRIDE];
+	__shared__ uint32_t tk_ring[JM_PARSE_WAVES][JM_TK_RING / 2][JM_RING_STRIDE];
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(b.luts);
 		uint4 *dst = reinterpret_cast<uint4 *>(&lut);
 		for (uint32_t i = threadIdx.x; i < sizeof(JmVlcLuts) / 16; i += blockDim.x) dst[i] = src[i];
 	}
-	__syncthreads();
+	__syncthreads();   /* the only workgroup barrier: from here on the wavefronts run on their own */
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.n_sc) return;
-	const uint32_t p = b.sc_owner[i];
-	if (p == JM_NONE) return;
-	const JmPic pic = b.pics[p];
-	const JmStream *sp = b.streams + pic.stream;
-	const uint32_t pos = b.sc_pos[i];
-	uint32_t end = sp->es_end;
-	if (i + 1 < b.n_sc) { uint32_t nx = b.sc_pos[i + 1]; if (nx < end) end = nx; }
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	JmLane L;
+	L.es_ring = &es_ring[wave][0][lane];
+	L.tk_ring = &tk_ring[wave][0][lane];
+	L.state = JM_ST_DONE;
 	JmSliceCtx c;
-	c.lut = (b.debug_flags & 1) ? b.luts : &lut;
-	c.pic_type = pic.type; c.full_pel = pic.full_pel; c.f_code = pic.f_code;
-	c.mb_width = sp->mb_width; c.mb_size = sp->mb_size;
-	c.limit_bytes = end > pos + 4 ? end - (pos + 4) : 0;
-	c.epoch = b.epoch;
-	c.dbg = b.dbg ? b.dbg + 4 * (size_t)i : nullptr;
-	if (c.limit_bytes == 0 || c.mb_size != b.mb_size) return;
-	jm_parse_slice(b.es + pos + 4, b.sc_code[i], c, b.mb + (size_t)p * b.mb_size, b.tokens + pic.tok_off,
-	               (pos - pic.pos) * JM_TOKENS_PER_BYTE);
+	c.lut = &lut;
+	c.pic_type = 0; c.full_pel = 0; c.f_code = 0; c.mb_width = 0; c.mb_size = 0; c.epoch = b.epoch;
+	bool mine = false;
+	if (i < b.n_sc) {
+		const uint32_t p = b.sc_owner[i];
+		if (p != JM_NONE) {
+			const JmPic pic = b.pics[p];
+			const JmStream *sp = b.streams + pic.stream;
+			const uint32_t pos = b.sc_pos[i];
+			uint32_t end = sp->es_end;
+			if (i + 1 < b.n_sc) { uint32_t nx = b.sc_pos[i + 1]; if (nx < end) end = nx; }
+			c.pic_type = pic.type; c.full_pel = pic.full_pel; c.f_code = pic.f_code;
+			c.mb_width = sp->mb_width; c.mb_size = sp->mb_size;
+			const uint32_t limit_bytes = end > pos + 4 ? end - (pos + 4) : 0;
+			if (limit_bytes != 0 && c.mb_size == b.mb_size) {
+				/* token slots: 4 per ES byte from the slice's start code, rounded up to a 32-byte group
+				 * of the batch token buffer; slot numbers are relative to that group of the picture's base */
+				const uint32_t rel = (uint32_t)(pic.tok_off & (JM_TK_GROUP - 1));
+				const uint32_t slot = (rel + (pos - pic.pos) * JM_TOKENS_PER_BYTE + JM_TK_GROUP - 1) & ~(uint32_t)(JM_TK_GROUP - 1);
+				jm_lane_init(L, b.es + pos + 4, limit_bytes, b.sc_code[i], c, b.mb + (size_t)p * b.mb_size,
+				             b.tokens + (pic.tok_off - rel), slot, rel);
+				mine = true;
+			}
+		}
+	}
+	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
+	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
+	for (uint32_t turn = 0; turn < (1u << 26); turn++) {
+		const int want = jm_lane_wants(L);
+		const int n_coef = __popcll(__ballot(want == JM_ST_COEF)), n_block = __popcll(__ballot(want == JM_ST_BLOCK));
+		const int n_cold = __popcll(__ballot(want == JM_ST_COLD)), n_wait = __popcll(__ballot(want == JM_ST_WAIT));
+		if (n_coef + n_block + n_cold + n_wait == 0) break;
+		const int pick = jm_pick_step(n_coef, n_block, n_cold, n_wait);
+		if (pick == JM_ST_COEF) {
+#pragma unroll 1
+			for (int k = 0; k < JM_COEF_BURST; k++)
+				if (L.state == JM_ST_COEF && !jm_lane_blocked(L)) jm_step_coef(L, c);
+		} else if (pick == JM_ST_BLOCK) {
+			if (want == JM_ST_BLOCK) jm_step_block(L, c);
+		} else if (pick == JM_ST_COLD) {
+			if (want == JM_ST_COLD) jm_step_cold(L, c);
+		} else {
+			if (want != JM_ST_DONE) jm_lane_service(L);
+		}
+	}
+	if (mine) jm_lane_finish(L);
 }
 
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
 	if (b.n_sc == 0) return hipSuccess;
-	uint32_t wg = (b.debug_flags & 2) ? 64 : JM_WG;
-	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + wg - 1) / wg), dim3(wg), 0, st, b);
+	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + JM_WG - 1) / JM_WG), dim3(JM_WG), 0, st, b);
 	return hipGetLastError();
 }
 
@@ -213,27 +254,34 @@ hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
  * dispatched to the same XCD (workgroup b runs on XCD b % 8) so the forward
  * frame's prediction reads hit one L2.
  * ---------------------------------------------------------------------- */
-struct LdsColumn {
+#define JM_SLOT_HALVES 72   /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
+
+struct LdsSlot {
 	int16_t *base;
-	__device__ __forceinline__ int16_t &operator()(int k) { return base[k * JM_WG]; }
+	__device__ __forceinline__ void zero() {
+		const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(base)[i] = z;
+	}
+	__device__ __forceinline__ void put(int pos, int level) { base[pos] = (int16_t)level; }
+	__device__ __forceinline__ void get8(int i, int16_t (&t)[8]) {
+		const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+		t[0] = (int16_t)(v.x & 0xffffu); t[1] = (int16_t)(v.x >> 16); t[2] = (int16_t)(v.y & 0xffffu); t[3] = (int16_t)(v.y >> 16);
+		t[4] = (int16_t)(v.z & 0xffffu); t[5] = (int16_t)(v.z >> 16); t[6] = (int16_t)(v.w & 0xffffu); t[7] = (int16_t)(v.w >> 16);
+	}
 };
 
 __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
-	__shared__ __attribute__((aligned(16))) int16_t coef[64 * JM_WG];
+	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_WG];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[128];
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
 	const uint32_t p = b.order[k];
 	const JmPic pic = b.pics[p];
-	{
-		uint4 z = make_uint4(0, 0, 0, 0);
-		uint4 *c4 = reinterpret_cast<uint4 *>(coef);
-		for (uint32_t i = threadIdx.x; i < 64 * JM_WG * 2 / 16; i += JM_WG) c4[i] = z;
-		if (threadIdx.x < 128) {
-			const JmStream *sp = b.streams + pic.stream;
-			qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
-		}
+	if (threadIdx.x < 128) {
+		const JmStream *sp = b.streams + pic.stream;
+		qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
 	}
 	__syncthreads();
 	const int g = (int)(blk * JM_WG + threadIdx.x);
@@ -242,18 +290,23 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	c.g = b.g;
 	c.mb = b.mb + (size_t)p * b.g.mb_size;
 	c.tok = b.tokens + pic.tok_off;
+	uint64_t dst_off, fwd_off;
 	if (b.dst_off) {
-		c.dst = b.pool + b.dst_off[k];
-		c.fwd = b.fwd_off[k] < 0 ? nullptr : b.pool + b.fwd_off[k];
+		dst_off = b.dst_off[k];
+		c.has_fwd = b.fwd_off[k] >= 0;
+		fwd_off = c.has_fwd ? (uint64_t)b.fwd_off[k] : dst_off;
 	} else {
-		c.dst = b.pool + (uint64_t)p * b.g.frame_bytes;
-		c.fwd = pic.fwd < 0 ? nullptr : b.pool + (uint64_t)pic.fwd * b.g.frame_bytes;
+		dst_off = (uint64_t)p * b.g.frame_bytes;
+		c.has_fwd = pic.fwd >= 0;
+		fwd_off = c.has_fwd ? (uint64_t)pic.fwd * b.g.frame_bytes : dst_off;
 	}
-	c.intra_q = qm; c.nonintra_q = qm + 64;
+	c.dst = b.pool + dst_off;
+	c.fwd = b.pool + fwd_off;
+	c.qm = qm;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;
-	LdsColumn col = { coef + threadIdx.x };
-	jm_recon_block(c, g, col);
+	LdsSlot slot = { coef + threadIdx.x * JM_SLOT_HALVES };
+	jm_recon_block(c, g, slot);
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

@@ -43,14 +43,16 @@ enum { JM_PIC_INTRA = 1, JM_PIC_PREDICTIVE = 2 };
 
 #define JM_NONE 0xffffffffu
 
-/* Slack the host keeps after the last ES byte so that window refills and the
- * 16-byte scan loads never leave the allocation. */
-#define JM_ES_PAD 64
+/* Slack the host keeps after the last ES byte so that the parser's 16-byte
+ * ring refills (up to 8 chunks ahead of the bit cursor) and the 16-byte scan
+ * loads never leave the allocation. */
+#define JM_ES_PAD 256
 /* Bytes written between two streams of a batch so no start code can straddle. */
 #define JM_STREAM_GAP 8
-/* Worst case is one token per 3 bits (an intra block of (0,+-1) pairs, "11s");
- * 4 token slots per ES byte gives every slice a private, statically addressed
- * token region: slot(slice) = 4 * slice_start_byte. */
+/* Worst case is one token slot per 2 bits (a non-intra block "1s 10": one
+ * token + one slot of padding to keep runs dword aligned, in 4 bits); 4 token
+ * slots per ES byte gives every slice a private, statically addressed token
+ * region: slot(slice) = 4 * slice_start_byte rounded up to a 32-byte group. */
 #define JM_TOKENS_PER_BYTE 4
 
 /* One stream of a batch. */

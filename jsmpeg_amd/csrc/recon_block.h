@@ -9,9 +9,21 @@
  *   half-pel forward prediction                  mpeg1.c:1208-1437 (copy_macroblock)
  *   overwrite (intra) or add (non-intra), clamp  mpeg1.c:1614-1671
  *   plane placement, block 4 -> Cb, 5 -> Cr      mpeg1.c:1559-1574
- * The dequantised 12-bit levels are staged in a per-lane column of a
- * [64][lanes] int16 LDS tile (bank = lane / 2: conflict-free for any
- * coefficient position), then pulled into registers with static indices.
+ *
+ * gfx950 shape of the work:
+ *   - tokens of a block are one dword-aligned run (the parser pads runs to an
+ *     even count), fetched 8 at a time with one dwordx4 load;
+ *   - the dequantised 12-bit levels go to the lane's private 144-byte LDS slot
+ *     (ds_write_b16 at a data-dependent position), and come back as eight
+ *     ds_read_b128 -- the slot stride of 36 dwords makes those conflict-free;
+ *   - every multiplication of the IDCT network is a 24-bit one (v_mad_i32_i24,
+ *     full rate; v_mul_lo_u32 is quarter rate): operands are bounded by
+ *     5.3e6 < 2^23 for ANY token stream (levels are clipped to +-2048 before
+ *     the premultiplier; tools/idct_bounds.py), and the low 32 bits of the
+ *     result equal the reference's wrapping int32 arithmetic;
+ *   - the four half-pel cases are one branch-free formula on packed bytes
+ *     built on v_lerp_u8 (lanes of a wave have different vectors: a branch per
+ *     case would execute all four).
  */
 #ifndef JSMPEG_AMD_RECON_BLOCK_H
 #define JSMPEG_AMD_RECON_BLOCK_H
@@ -24,55 +36,80 @@ struct JmReconCtx {
 	const JmMbRec *mb;       /* this picture's macroblock records        */
 	const uint16_t *tok;     /* this picture's token base                */
 	uint8_t *dst;            /* this picture's frame: Y | Cr | Cb        */
-	const uint8_t *fwd;      /* forward reference frame, null = no frame */
-	const uint8_t *intra_q;  /* 64-entry raster quantiser matrices       */
-	const uint8_t *nonintra_q;
+	const uint8_t *fwd;      /* forward reference frame (any valid address when has_fwd == 0) */
+	int has_fwd;
+	const uint8_t *qm;       /* raster quantiser matrices: intra at [0, 64), non-intra at [64, 128) */
 	uint8_t epoch;
 	int zero_uncovered;      /* batch mode: unwritten macroblocks become 0 */
 };
 
 static constexpr int JM_PREMULT[64] = MPEG1_PREMULTIPLIER_INIT;
 
-/* ---- packed-byte helpers ---- */
-JM_HD uint32_t jm_avg2(uint32_t a, uint32_t b) {              /* per byte (a + b + 1) >> 1 */
-	return (a | b) - (((a ^ b) & 0xfefefefeu) >> 1);
+/* ---- instructions the path leans on, with their plain-C meaning (the C forms
+ * are what the test-only simulator compiles) ---- */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* a * b and a * k + acc on the low 24 bits of the operands, low 32 bits of the result.  Spelled as
+ * instructions: the compiler only selects the 24-bit forms when it can prove the operand ranges, and
+ * falls back to the quarter-rate v_mul_lo_u32 for the data-dependent IDCT values. */
+JM_D int jm_mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+JM_D int jm_mad24(int a, int k, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc)); return d; }
+/* per byte (a + b + (c & 1)) >> 1 */
+JM_D uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
+/* 4 bytes starting `shift` (0..3) bytes into lo:hi */
+JM_D uint32_t jm_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
+#else
+JM_HD int jm_mul24(int a, int b) {
+	int64_t x = (int32_t)((uint32_t)a << 8) >> 8, y = (int32_t)((uint32_t)b << 8) >> 8;
+	return (int)(uint32_t)(uint64_t)(x * y);
 }
-JM_HD uint32_t jm_avg4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { /* (a+b+c+d+2) >> 2 */
-	const uint32_t M = 0x00ff00ffu;
-	uint32_t lo = (a & M) + (b & M) + (c & M) + (d & M) + 0x00020002u;
-	uint32_t hi = ((a >> 8) & M) + ((b >> 8) & M) + ((c >> 8) & M) + ((d >> 8) & M) + 0x00020002u;
-	return ((lo >> 2) & M) | (((hi >> 2) & M) << 8);
+JM_HD int jm_mad24(int a, int k, int acc) { return (int)((uint32_t)jm_mul24(a, k) + (uint32_t)acc); }
+JM_HD uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) {
+	uint32_t r = 0;
+	for (int i = 0; i < 32; i += 8) r |= ((((a >> i) & 255u) + ((b >> i) & 255u) + ((c >> i) & 1u)) >> 1) << i;
+	return r;
 }
-JM_HD uint32_t jm_bytes_at(uint32_t lo, uint32_t hi, int byte_shift) { /* 4 bytes starting byte_shift (0..4) into lo:hi */
-	return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * byte_shift));
+JM_HD uint32_t jm_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) {
+	return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3)));
 }
+#endif
 JM_HD int jm_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-/* the reference's 1-D butterfly (mpeg1.c:1683-1708 columns, 1713-1738 rows) */
-#define JM_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7, FIN)                          \
+/* (x * c + 128) >> 8 and (x * c + y * d + 128) >> 8 of the reference network */
+#define JM_RS1(x, c) (jm_mad24((x), (c), c128) >> 8)
+#define JM_RS2(x, c, y, d) (jm_mad24((x), (c), jm_mad24((y), (d), c128)) >> 8)
+
+/* the reference's 1-D butterfly (mpeg1.c:1683-1708 columns, 1713-1738 rows);
+ * `bias` is added to every output (rows: the + 128 of the final rounding,
+ * folded into the even part). */
+#define JM_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7, bias, FIN)                    \
 	{                                                                            \
 		int b1 = s4, b3 = s2 + s6, b4 = s5 - s3, tmp1 = s1 + s7, tmp2 = s3 + s5; \
-		int b6 = s1 - s7, b7 = tmp1 + tmp2, m0 = s0;                             \
-		int x4 = ((b6 * 473 - b4 * 196 + 128) >> 8) - b7;                        \
-		int x0 = x4 - (((tmp1 - tmp2) * 362 + 128) >> 8);                        \
+		int b6 = s1 - s7, b7 = tmp1 + tmp2, m0 = s0 + (bias);                    \
+		int x4 = JM_RS2(b6, 473, b4, -196) - b7;                                 \
+		int x0 = x4 - JM_RS1(tmp1 - tmp2, 362);                                  \
 		int x1 = m0 - b1;                                                        \
-		int x2 = (((s2 - s6) * 362 + 128) >> 8) - b3;                            \
+		int x2 = JM_RS1(s2 - s6, 362) - b3;                                      \
 		int x3 = m0 + b1;                                                        \
 		int y3 = x1 + x2, y4 = x3 + b3, y5 = x1 - x2, y6 = x3 - b3;              \
-		int y7 = -x0 - ((b4 * 473 + b6 * 196 + 128) >> 8);                       \
-		s0 = FIN(b7 + y4); s1 = FIN(x4 + y3); s2 = FIN(y5 - x0); s3 = FIN(y6 - y7); \
-		s4 = FIN(y6 + y7); s5 = FIN(x0 + y5); s6 = FIN(y3 - x4); s7 = FIN(y4 - b7); \
+		int u7 = x0 + JM_RS2(b4, 473, b6, 196);            /* -y7 */             \
+		s0 = FIN(b7 + y4); s1 = FIN(x4 + y3); s2 = FIN(y5 - x0); s3 = FIN(y6 + u7); \
+		s4 = FIN(y6 - u7); s5 = FIN(x0 + y5); s6 = FIN(y3 - x4); s7 = FIN(y4 - b7); \
 	}
 #define JM_FIN_NONE(v) (v)
-#define JM_FIN_ROUND(v) (((v) + 128) >> 8)
+#define JM_FIN_SHIFT(v) ((v) >> 8)
 
-/* `Scratch` gives the lane its private 64-entry int16 column: s(k) is an
- * lvalue.  It must be all-zero on entry and is left all-zero on exit. */
-template <class Scratch>
-JM_HD void jm_recon_block(const JmReconCtx &c, int g, Scratch &s) {
+/* token k (0..7) of a run of eight packed in four dwords */
+#define JM_TOK16(w, k) (uint16_t)(((k) & 1) ? ((w)[(k) >> 1] >> 16) : ((w)[(k) >> 1] & 0xffffu))
+
+/* `Slot` is the lane's private 64-entry int16 coefficient store (LDS on the
+ * device): zero(), put(pos, level), get8(i, out[8]) = entries 8i .. 8i+7. */
+template <class Slot>
+JM_HD void jm_recon_block(const JmReconCtx &c, int g, Slot &s) {
 	const JmGeom &G = c.g;
+	s.zero();
+
 	/* ---- which block am I ---- */
-	int mbaddr, bnum, x0, y0, stride;
+	int mbaddr, bnum, x0, y0, stride, ph;
 	uint32_t plane_off;
 	if (g < 4 * G.mb_size) {
 		int bw = 2 * G.mb_width;
@@ -80,7 +117,7 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Scratch &s) {
 		mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
 		bnum = ((by & 1) << 1) | (bx & 1);
 		x0 = bx << 3; y0 = by << 3;
-		stride = G.coded_width;
+		stride = G.coded_width; ph = G.coded_height;
 		plane_off = 0;
 	} else {
 		int h = g - 4 * G.mb_size;
@@ -89,7 +126,7 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Scratch &s) {
 		int my = mbaddr / G.mb_width, mx = mbaddr - my * G.mb_width;
 		bnum = 4 + pl;
 		x0 = mx << 3; y0 = my << 3;
-		stride = G.coded_width >> 1;
+		stride = G.coded_width >> 1; ph = G.coded_height >> 1;
 		/* frame layout Y | Cr | Cb; block 4 goes to the Cb plane, block 5 to Cr (mpeg1.c:1571) */
 		plane_off = G.luma_bytes + (pl ? 0u : G.chroma_bytes);
 	}
@@ -107,88 +144,122 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Scratch &s) {
 		return;
 	}
 	const bool intra = rec_qf & JM_MB_INTRA;
+	const bool pred = (rec_qf & JM_MB_PRED) && c.has_fwd;
 	const int qscale = (int)(rec_qf & 31);
 	const int cnt = (int)((rec_cnt >> (8 * bnum)) & 0xff);
 
-	/* ---- forward prediction: 8 rows of 8 packed bytes ---- */
-	uint32_t P[16];
+	/* ---- token run of this block: runs are padded to an even count, so dword aligned ---- */
+	uint32_t t0 = rec_tok;
 #pragma unroll
-	for (int i = 0; i < 16; i++) P[i] = 0;
-	if ((rec_qf & JM_MB_PRED) && c.fwd) {
+	for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)(((rec_cnt >> (8 * j)) & 0xff) + 1) & ~1u;
+	const uint32_t *tkw = reinterpret_cast<const uint32_t *>(c.tok + t0);
+	uint32_t tw[4] = { 0, 0, 0, 0 };
+	if (cnt > 0) { tw[0] = tkw[0]; tw[1] = tkw[1]; tw[2] = tkw[2]; tw[3] = tkw[3]; }
+
+	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
+	uint32_t R[27];
+	uint32_t m = 0, oh = 0, ov = 0;
+	if (pred) {
 		int mh = rec_mvh, mv = rec_mvv;
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
-		int H = mh >> 1, V = mv >> 1, oh = mh & 1, ov = mv & 1;
+		int H = mh >> 1, V = mv >> 1;
+		oh = (uint32_t)(mh & 1); ov = (uint32_t)(mv & 1);
 		int sx = x0 + H, sy = y0 + V;
-		int ph = (bnum < 4) ? G.coded_height : (G.coded_height >> 1);
 		/* the reference reads out of bounds for vectors leaving the picture
 		 * (outside the contract); keep the reads inside the plane */
 		if (sx < 0) sx = 0;
 		if (sy < 0) sy = 0;
-		if (sx + 8 + oh > stride) sx = stride - 8 - oh;
-		if (sy + 8 + ov > ph) sy = ph - 8 - ov;
-		const uint8_t *src = c.fwd + plane_off + (uint32_t)(sy * stride + sx);
-		const uint32_t *w = (const uint32_t *)((uintptr_t)src & ~(uintptr_t)3);
-		const int m = (int)((uintptr_t)src & 3);
+		if (sx + 8 + (int)oh > stride) sx = stride - 8 - (int)oh;
+		if (sy + 8 + (int)ov > ph) sy = ph - 8 - (int)ov;
+		const uint32_t off = (uint32_t)(sy * stride + sx);
+		const uint32_t *w = reinterpret_cast<const uint32_t *>(c.fwd + plane_off + (off & ~3u));
+		m = off & 3u;
 		const int wstride = stride >> 2;
-		uint32_t a0, a1, b0 = 0, b1 = 0;                   /* current row: bytes 0..7 and 1..8 */
-		{
-			uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-			a0 = jm_bytes_at(w0, w1, m); a1 = jm_bytes_at(w1, w2, m);
-			if (oh) { b0 = jm_bytes_at(w0, w1, m + 1); b1 = jm_bytes_at(w1, w2, m + 1); }
-		}
+		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
-		for (int r = 0; r < 8; r++) {
-			uint32_t n0 = 0, n1 = 0, nb0 = 0, nb1 = 0;     /* next row */
-			if (ov || r < 7) {
-				const uint32_t *wr = w + (r + 1) * wstride;
-				uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2];
-				n0 = jm_bytes_at(w0, w1, m); n1 = jm_bytes_at(w1, w2, m);
-				if (oh) { nb0 = jm_bytes_at(w0, w1, m + 1); nb1 = jm_bytes_at(w1, w2, m + 1); }
+		for (int r = 0; r < 9; r++) {
+			const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
+			R[3 * r] = wr[0]; R[3 * r + 1] = wr[1]; R[3 * r + 2] = wr[2];
+		}
+	}
+
+	/* ---- dequantise the tokens into the slot (mpeg1.c:1535-1548) ---- */
+	int dc = 0;
+	if (cnt > 0) {
+		const uint8_t *q = c.qm + (intra ? 0 : 64);
+		const int nz_bias = intra ? 0 : 1;
+		for (int base = 0;;) {
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				if (base + k < cnt) {
+					const uint16_t tv = JM_TOK16(tw, k);
+					if (intra && base + k == 0) dc = (int)(int16_t)tv;      /* first token of an intra block: dc, mpeg1.c:1489 */
+					else {
+						int pos = jm_token_pos(tv), level = jm_token_level(tv);
+						level = (level << 1) + (nz_bias ? ((level >> 31) | 1) : 0);
+						level = jm_mul24(level, qscale * (int)q[pos]) >> 4;
+						level = (level - (level > 0 ? 1 : 0)) | 1;           /* even -> toward zero, 0 -> +1 */
+						if (level > 2047) level = 2047; else if (level < -2048) level = -2048;
+						s.put(pos, level);
+					}
+				}
 			}
-			if (oh && ov) { P[2 * r] = jm_avg4(a0, b0, n0, nb0); P[2 * r + 1] = jm_avg4(a1, b1, n1, nb1); }
-			else if (oh) { P[2 * r] = jm_avg2(a0, b0); P[2 * r + 1] = jm_avg2(a1, b1); }
-			else if (ov) { P[2 * r] = jm_avg2(a0, n0); P[2 * r + 1] = jm_avg2(a1, n1); }
-			else { P[2 * r] = a0; P[2 * r + 1] = a1; }
-			a0 = n0; a1 = n1; b0 = nb0; b1 = nb1;
+			base += 8;
+			if (base >= cnt) break;
+			tw[0] = tkw[base / 2]; tw[1] = tkw[base / 2 + 1]; tw[2] = tkw[base / 2 + 2]; tw[3] = tkw[base / 2 + 3];
+		}
+	}
+
+	/* ---- prediction: P = (A + B + C + D + 2) >> 2 with B = A shifted by oh bytes, C/D = the row
+	 * below when ov; exact for all four half-pel cases (mpeg1.c:1232-1436):
+	 *   u = (A + B + 1) >> 1 per row, P = (u_r + u_r' + [A+B even in both rows]) >> 1 ---- */
+	uint32_t P[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) P[i] = 0;
+	if (pred) {
+		uint32_t u0p = 0, u1p = 0, e0p = 0, e1p = 0;
+#pragma unroll
+		for (int r = 0; r < 9; r++) {
+			const uint32_t a0 = jm_alignbyte(R[3 * r + 1], R[3 * r], m), a1 = jm_alignbyte(R[3 * r + 2], R[3 * r + 1], m);
+			/* bytes m+1 .. : shift by one more byte when oh (m + oh may be 4: take the next dword) */
+			const uint32_t mo = m + oh, ms = mo & 3u;
+			const uint32_t lo = mo > 3 ? R[3 * r + 1] : R[3 * r], mid = mo > 3 ? R[3 * r + 2] : R[3 * r + 1];
+			const uint32_t hi = mo > 3 ? 0u : R[3 * r + 2];
+			const uint32_t b0 = jm_alignbyte(mid, lo, ms), b1 = jm_alignbyte(hi, mid, ms);
+			const uint32_t u0 = jm_lerp(a0, b0, 0x01010101u), u1 = jm_lerp(a1, b1, 0x01010101u);
+			const uint32_t e0 = ~(a0 ^ b0), e1 = ~(a1 ^ b1);       /* bit 0 of each byte: A + B even */
+			if (r > 0) {
+				/* output row r - 1 pairs row r - 1 with row r - 1 + ov */
+				const uint32_t v0 = ov ? u0 : u0p, v1 = ov ? u1 : u1p, f0 = ov ? e0 : e0p, f1 = ov ? e1 : e1p;
+				P[2 * (r - 1)] = jm_lerp(u0p, v0, e0p & f0);
+				P[2 * (r - 1) + 1] = jm_lerp(u1p, v1, e1p & f1);
+			}
+			u0p = u0; u1p = u1; e0p = e0; e1p = e1;
 		}
 	}
 
 	/* ---- residual ---- */
 	if (cnt > 0) {
-		uint32_t t0 = rec_tok;
-#pragma unroll
-		for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)((rec_cnt >> (8 * j)) & 0xff);
-		const uint16_t *tk = c.tok + t0;
-		const uint8_t *q = intra ? c.intra_q : c.nonintra_q;
-		int first = 0;
-		if (intra) { s(0) = (int16_t)((int)(int16_t)tk[0] * 8); first = 1; } /* dc << 8 == (dc * 8) * PREMULT[0] (mpeg1.c:1489) */
-		for (int t = first; t < cnt; t++) {
-			uint16_t tv = tk[t];
-			int pos = jm_token_pos(tv), level = jm_token_level(tv);
-			level <<= 1;                                            /* mpeg1.c:1535-1548 */
-			if (!intra) level += (level < 0 ? -1 : 1);
-			level = (level * qscale * (int)q[pos]) >> 4;
-			if ((level & 1) == 0) level -= level > 0 ? 1 : -1;
-			if (level > 2047) level = 2047; else if (level < -2048) level = -2048;
-			s(pos) = (int16_t)level;
-		}
-		/* into registers, premultiplied (mpeg1.c:1551), static indices only */
 		int v[64];
 #pragma unroll
-		for (int k = 0; k < 64; k++) v[k] = (int)s(k) * JM_PREMULT[k];
-		/* leave the scratch column clean for the next block */
-		if (intra) s(0) = 0;
-		for (int t = first; t < cnt; t++) s(jm_token_pos(tk[t])) = 0;
+		for (int i = 0; i < 8; i++) {
+			int16_t t[8];
+			s.get8(i, t);
+#pragma unroll
+			for (int k = 0; k < 8; k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
+		}
+		if (intra) v[0] = (int)((uint32_t)dc << 8);
+		const int c128 = 128;
 
 		/* columns, then rows with the final rounding (mpeg1.c:1682-1739).  A
 		 * DC-only block gives (dc + 128) >> 8 everywhere: same as the
 		 * reference's n == 1 shortcut (mpeg1.c:1578-1581). */
 #pragma unroll
 		for (int i = 0; i < 8; i++)
-			JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], JM_FIN_NONE)
+			JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
 #pragma unroll
 		for (int i = 0; i < 64; i += 8)
-			JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], JM_FIN_ROUND)
+			JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_SHIFT)
 
 		/* add to the prediction (zero for intra: overwrite) and clamp (mpeg1.c:1620-1644) */
 #pragma unroll

@@ -14,10 +14,17 @@
 #include "recon_block.h"
 #include "slice_parse.h"
 
-struct HostColumn {
+struct HostSlot {
 	int16_t v[64];
-	int16_t &operator()(int k) { return v[k]; }
+	void zero() { memset(v, 0, sizeof(v)); }
+	void put(int pos, int level) { v[pos] = (int16_t)level; }
+	void get8(int i, int16_t (&t)[8]) { memcpy(t, v + 8 * i, 16); }
 };
+
+// Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
+// kind, and lanes that were served in those turns.
+static uint64_t g_turns[5], g_served[5];
+static int g_policy[5];   // experiments only: weights of coef, block, cold, wait; coef burst length
 
 extern "C" {
 
@@ -33,6 +40,10 @@ void sim_set_dumps(uint32_t *sc_pos, uint8_t *sc_code, uint32_t *owner, uint8_t 
 	g_dump_sc_pos = sc_pos; g_dump_sc_code = sc_code; g_dump_owner = owner; g_dump_mb = mb; g_dump_tok = tok;
 }
 const uint32_t *sim_dump_counts(void) { return g_dump_counts; }
+const uint64_t *sim_turns(void);
+const uint64_t *sim_served(void);
+void sim_reset_counters(void);
+void sim_set_policy(int a, int b, int c, int d, int e);
 
 int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, uint8_t *frames_out, int max_frames) {
 	const uint32_t begin = 16;
@@ -75,19 +86,63 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 	std::vector<uint16_t> tokens((size_t)es.size() * JM_TOKENS_PER_BYTE);
 	const uint8_t epoch = 1;
 
-	for (uint32_t i = 0; i < n_sc; i++) {
-		uint32_t p = owner[i];
-		if (p == JM_NONE) continue;
-		const JmPic &pic = pics[p];
-		uint32_t pos = sc_pos[i], end = st.es_end;
-		if (i + 1 < n_sc && sc_pos[i + 1] < end) end = sc_pos[i + 1];
-		JmSliceCtx c;
-		c.lut = &luts; c.pic_type = pic.type; c.full_pel = pic.full_pel; c.f_code = pic.f_code;
-		c.mb_width = st.mb_width; c.mb_size = st.mb_size;
-		c.limit_bytes = end > pos + 4 ? end - (pos + 4) : 0; c.epoch = epoch; c.dbg = nullptr;
-		if (!c.limit_bytes) continue;
-		jm_parse_slice(es.data() + pos + 4, sc_code[i], c, mb.data() + (size_t)p * g.mb_size,
-		               tokens.data() + pic.tok_off, (pos - pic.pos) * JM_TOKENS_PER_BYTE);
+	// k_parse, one emulated 64-lane wavefront at a time: same lane functions, same scheduling rule
+	// (results do not depend on the rule; the counters do)
+	static uint32_t es_ring[JM_ES_RING_DW][JM_RING_STRIDE], tk_ring[JM_TK_RING / 2][JM_RING_STRIDE];
+	for (uint32_t w0 = 0; w0 < n_sc; w0 += 64) {
+		JmLane L[64];
+		JmSliceCtx C[64];
+		bool mine[64];
+		for (int l = 0; l < 64; l++) {
+			const uint32_t i = w0 + (uint32_t)l;
+			L[l].es_ring = &es_ring[0][l]; L[l].tk_ring = &tk_ring[0][l];
+			L[l].state = JM_ST_DONE; L[l].fillc = L[l].rd = 0; L[l].tw = L[l].tflushed = 0;
+			mine[l] = false;
+			C[l].lut = &luts; C[l].epoch = epoch;
+			if (i >= n_sc || owner[i] == JM_NONE) continue;
+			const uint32_t p = owner[i];
+			const JmPic &pic = pics[p];
+			uint32_t pos = sc_pos[i], end = st.es_end;
+			if (i + 1 < n_sc && sc_pos[i + 1] < end) end = sc_pos[i + 1];
+			C[l].pic_type = pic.type; C[l].full_pel = pic.full_pel; C[l].f_code = pic.f_code;
+			C[l].mb_width = st.mb_width; C[l].mb_size = st.mb_size;
+			const uint32_t limit_bytes = end > pos + 4 ? end - (pos + 4) : 0;
+			if (!limit_bytes) continue;
+			const uint32_t rel = (uint32_t)(pic.tok_off & (JM_TK_GROUP - 1));
+			const uint32_t slot = (rel + (pos - pic.pos) * JM_TOKENS_PER_BYTE + JM_TK_GROUP - 1) & ~(uint32_t)(JM_TK_GROUP - 1);
+			jm_lane_init(L[l], es.data() + pos + 4, limit_bytes, sc_code[i], C[l], mb.data() + (size_t)p * g.mb_size,
+			             tokens.data() + (pic.tok_off - rel), slot, rel);
+			mine[l] = true;
+		}
+		for (;;) {
+			int want[64], n[5] = { 0, 0, 0, 0, 0 };
+			for (int l = 0; l < 64; l++) { want[l] = jm_lane_wants(L[l]); n[want[l]]++; }
+			if (n[JM_ST_COEF] + n[JM_ST_BLOCK] + n[JM_ST_COLD] + n[JM_ST_WAIT] == 0) break;
+			int pick = jm_pick_step(n[JM_ST_COEF], n[JM_ST_BLOCK], n[JM_ST_COLD], n[JM_ST_WAIT]);
+			if (g_policy[0]) {   // experiments: weighted choice
+				long best = -1;
+				const int kinds[4] = { JM_ST_COEF, JM_ST_BLOCK, JM_ST_COLD, JM_ST_WAIT };
+				for (int q = 0; q < 4; q++) { long sc = (long)n[kinds[q]] * g_policy[q]; if (n[kinds[q]] && sc > best) { best = sc; pick = kinds[q]; } }
+			}
+			if (pick == JM_ST_COEF) {
+				for (int k = 0; k < (g_policy[4] ? g_policy[4] : JM_COEF_BURST); k++) {
+					int served = 0;
+					for (int l = 0; l < 64; l++)
+						if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) { jm_step_coef(L[l], C[l]); served++; }
+					if (served) { g_turns[JM_ST_COEF]++; g_served[JM_ST_COEF] += served; }
+				}
+			} else if (pick == JM_ST_BLOCK) {
+				g_turns[JM_ST_BLOCK]++; g_served[JM_ST_BLOCK] += n[JM_ST_BLOCK];
+				for (int l = 0; l < 64; l++) if (want[l] == JM_ST_BLOCK) jm_step_block(L[l], C[l]);
+			} else if (pick == JM_ST_COLD) {
+				g_turns[JM_ST_COLD]++; g_served[JM_ST_COLD] += n[JM_ST_COLD];
+				for (int l = 0; l < 64; l++) if (want[l] == JM_ST_COLD) jm_step_cold(L[l], C[l]);
+			} else {
+				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n[JM_ST_WAIT];
+				for (int l = 0; l < 64; l++) if (want[l] != JM_ST_DONE) jm_lane_service(L[l]);
+			}
+		}
+		for (int l = 0; l < 64; l++) if (mine[l]) jm_lane_finish(L[l]);
 	}
 
 	g_dump_counts[0] = n_sc; g_dump_counts[1] = n_pics; g_dump_counts[2] = (uint32_t)g.mb_size; g_dump_counts[3] = (uint32_t)tokens.size();
@@ -106,14 +161,13 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			JmReconCtx c;
 			c.g = g; c.mb = mb.data() + (size_t)p * g.mb_size; c.tok = tokens.data() + pic.tok_off;
 			c.dst = base + (uint64_t)p * g.frame_bytes;
-			c.fwd = pic.fwd < 0 ? nullptr : base + (uint64_t)pic.fwd * g.frame_bytes;
-			c.intra_q = st.intra_q; c.nonintra_q = st.nonintra_q; c.epoch = epoch; c.zero_uncovered = 1;
-			HostColumn col;
-			memset(&col, 0, sizeof(col));
-			for (int b = 0; b < 6 * g.mb_size; b++) {
-				jm_recon_block(c, b, col);
-				for (int k = 0; k < 64; k++) if (col.v[k] != 0) return -3;   // scratch must be left clean
-			}
+			c.has_fwd = pic.fwd >= 0;
+			c.fwd = base + (uint64_t)(pic.fwd < 0 ? p : (uint32_t)pic.fwd) * g.frame_bytes;
+			uint8_t qm[128];
+			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
+			c.qm = qm; c.epoch = epoch; c.zero_uncovered = 1;
+			HostSlot slot;
+			for (int b = 0; b < 6 * g.mb_size; b++) jm_recon_block(c, b, slot);
 		}
 	int out = 0;
 	const size_t fb = (size_t)g.luma_bytes + 2 * g.chroma_bytes;
@@ -121,5 +175,10 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 		if (pics[p].decoded) memcpy(frames_out + (size_t)(out++) * fb, base + (uint64_t)p * g.frame_bytes, fb);
 	return out;
 }
+
+const uint64_t *sim_turns(void) { return g_turns; }
+const uint64_t *sim_served(void) { return g_served; }
+void sim_set_policy(int a, int b, int c, int d, int e) { g_policy[0] = a; g_policy[1] = b; g_policy[2] = c; g_policy[3] = d; g_policy[4] = e; }
+void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); }
 
 }  // extern "C"
