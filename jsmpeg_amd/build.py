@@ -54,10 +54,11 @@ def build_hip(force=False):
     """The product: HIP kernels + C-ABI runtime for gfx950 (cross-compiles
     without a GPU)."""
     src = hip_sources()
-    if force or _newer(LIB_HIP, src + _csrc_headers()):
+    defs = os.environ.get("JSMPEG_HIP_DEFS", "").split()   # tuning experiments only (-DJM_...=...)
+    if force or defs or _newer(LIB_HIP, src + _csrc_headers()):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-              "-o", LIB_HIP] + src)
+              "-o", LIB_HIP] + defs + src)
     return LIB_HIP
 
 

@@ -304,7 +304,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 4. reconstruct, one launch per dependency level ---- */
 	JmReconBufs rb;
-	rb.g = b->g; rb.pics = b->d_pics; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens;
+	rb.g = b->g; rb.pics = b->d_pics; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens; rb.luts = b->d_luts;
 	rb.pool = b->d_pool; rb.dst_off = nullptr; rb.fwd_off = nullptr; rb.epoch = b->epoch; rb.zero_uncovered = 1;
 	for (uint32_t l = 0; l < b->n_levels; l++) {
 		rb.order = b->d_order + b->level_off[l];
@@ -742,7 +742,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.pics = d->d_pic; rb.streams = d->d_stream; rb.order = d->d_order; rb.n_level_pics = 1;
-	rb.mb = d->d_mb; rb.tokens = d->d_tokens; rb.pool = d->d_pool;
+	rb.mb = d->d_mb; rb.tokens = d->d_tokens; rb.luts = d->d_luts; rb.pool = d->d_pool;
 	rb.dst_off = d->d_offs; rb.fwd_off = reinterpret_cast<const int64_t *>(d->d_offs + 1);
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
 	HIP_TRY(jm_launch_recon(rb, st));

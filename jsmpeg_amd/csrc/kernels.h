@@ -64,6 +64,7 @@ struct JmReconBufs {
 	uint32_t n_level_pics;
 	const JmMbRec *mb;
 	const uint16_t *tokens;
+	const JmVlcLuts *luts;       /* device global copy (zig-zag order) */
 	uint8_t *pool;               /* frame p at pool + p * g.frame_bytes ... */
 	const uint64_t *dst_off;     /* ... unless non-null: explicit byte offsets per order entry */
 	const int64_t *fwd_off;      /*     and forward offsets (-1 = none)                          */

@@ -176,11 +176,14 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
  * [32][64]-dword token ring tile in LDS (slice_parse.h) and schedules itself:
  * at every turn it runs the step kind most of its lanes are waiting for.
  * ---------------------------------------------------------------------- */
-#define JM_PARSE_WAVES (JM_WG / 64)
+#ifndef JM_PARSE_WG
+#define JM_PARSE_WG 512   /* 8 wavefronts share one copy of the tables: 2 workgroups = 16 wavefronts per CU */
+#endif
+#define JM_PARSE_WAVES (JM_PARSE_WG / 64)
 
-__global__ __launch_bounds__(JM_WG) void k_parse(JmParseBufs b) {
+__global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
-	__shared__ uint32_t es_ring[JM_PARSE_WAVES][JM_ES_RING_DW][JM_RING_STRIDE];
+	__shared__ uint32_t es_ring[JM_PARSE_WAVES][JM_ES_RING_ROWS][JM_RING_STRIDE];
 	__shared__ uint32_t tk_ring[JM_PARSE_WAVES][JM_TK_RING / 2][JM_RING_STRIDE];
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(b.luts);
@@ -214,28 +217,37 @@ __global__ __launch_bounds__(JM_WG) void k_parse(JmParseBufs b) {
 				 * of the batch token buffer; slot numbers are relative to that group of the picture's base */
 				const uint32_t rel = (uint32_t)(pic.tok_off & (JM_TK_GROUP - 1));
 				const uint32_t slot = (rel + (pos - pic.pos) * JM_TOKENS_PER_BYTE + JM_TK_GROUP - 1) & ~(uint32_t)(JM_TK_GROUP - 1);
-				jm_lane_init(L, b.es + pos + 4, limit_bytes, b.sc_code[i], c, b.mb + (size_t)p * b.mb_size,
-				             b.tokens + (pic.tok_off - rel), slot, rel);
+				jm_lane_init(L, reinterpret_cast<const uint4_like_t *>(b.es), pos + 4, limit_bytes, b.sc_code[i], c,
+				             b.mb + (size_t)p * b.mb_size,
+				             reinterpret_cast<uint4_like_t *>(b.tokens) + ((pic.tok_off - rel) >> 3), slot, rel);
 				mine = true;
 			}
 		}
 	}
 	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
-	for (uint32_t turn = 0; turn < (1u << 26); turn++) {
+	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
 		const int want = jm_lane_wants(L);
-		const int n_coef = __popcll(__ballot(want == JM_ST_COEF)), n_block = __popcll(__ballot(want == JM_ST_BLOCK));
-		const int n_cold = __popcll(__ballot(want == JM_ST_COLD)), n_wait = __popcll(__ballot(want == JM_ST_WAIT));
-		if (n_coef + n_block + n_cold + n_wait == 0) break;
-		const int pick = jm_pick_step(n_coef, n_block, n_cold, n_wait);
+		int n[JM_ST_KINDS];
+		n[JM_ST_COLD] = __popcll(__ballot(want == JM_ST_COLD)); n[JM_ST_BLOCK] = __popcll(__ballot(want == JM_ST_BLOCK));
+		n[JM_ST_COEF] = __popcll(__ballot(want == JM_ST_COEF)); n[JM_ST_SLOW] = __popcll(__ballot(want == JM_ST_SLOW));
+		n[JM_ST_WAIT] = __popcll(__ballot(want == JM_ST_WAIT)); n[JM_ST_DONE] = 0;
+		if (n[JM_ST_COLD] + n[JM_ST_BLOCK] + n[JM_ST_COEF] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
+		const int pick = jm_pick_step(n);
 		if (pick == JM_ST_COEF) {
+			/* the common kind: keep going while enough lanes still have a coefficient to read */
 #pragma unroll 1
-			for (int k = 0; k < JM_COEF_BURST; k++)
-				if (L.state == JM_ST_COEF && !jm_lane_blocked(L)) jm_step_coef(L, c);
+			for (int k = 0; k < 64; k++) {
+				const bool go = L.state == JM_ST_COEF && !jm_lane_blocked(L);
+				if (__popcll(__ballot(go)) < (k ? JM_STICKY : 1)) break;
+				if (go) jm_step_coef(L, c);
+			}
 		} else if (pick == JM_ST_BLOCK) {
 			if (want == JM_ST_BLOCK) jm_step_block(L, c);
 		} else if (pick == JM_ST_COLD) {
 			if (want == JM_ST_COLD) jm_step_cold(L, c);
+		} else if (pick == JM_ST_SLOW) {
+			if (want == JM_ST_SLOW) jm_step_slow(L, c);
 		} else {
 			if (want != JM_ST_DONE) jm_lane_service(L);
 		}
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(JM_WG) void k_parse(JmParseBufs b) {
 
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
 	if (b.n_sc == 0) return hipSuccess;
-	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + JM_WG - 1) / JM_WG), dim3(JM_WG), 0, st, b);
+	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + JM_PARSE_WG - 1) / JM_PARSE_WG), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }
 
@@ -273,7 +285,7 @@ struct LdsSlot {
 
 __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_WG];
-	__shared__ __attribute__((aligned(16))) uint8_t qm[128];
+	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	if (threadIdx.x < 128) {
 		const JmStream *sp = b.streams + pic.stream;
 		qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
-	}
+	} else if (threadIdx.x < 192) qm[threadIdx.x] = b.luts->zigzag[threadIdx.x - 128];
 	__syncthreads();
 	const int g = (int)(blk * JM_WG + threadIdx.x);
 	if (g >= 6 * b.g.mb_size) return;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	}
 	c.dst = b.pool + dst_off;
 	c.fwd = b.pool + fwd_off;
-	c.qm = qm;
+	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;
 	LdsSlot slot = { coef + threadIdx.x * JM_SLOT_HALVES };

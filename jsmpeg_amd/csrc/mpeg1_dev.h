@@ -99,7 +99,7 @@ struct alignas(16) JmMbRec {
 #define JM_MB_INTRA 0x20
 #define JM_MB_PRED 0x40
 
-/* 16-bit coefficient token: raster position << 10 | level (10-bit two's
+/* 16-bit coefficient token: zig-zag scan index << 10 | level (10-bit two's
  * complement, -256..255: the full range of the escape forms, mpeg1.js:767-780).
  * The first token of an intra block is the raw DC value (int16). */
 JM_HD uint16_t jm_token(int pos, int level) { return (uint16_t)((pos << 10) | (level & 1023)); }

@@ -39,6 +39,7 @@ struct JmReconCtx {
 	const uint8_t *fwd;      /* forward reference frame (any valid address when has_fwd == 0) */
 	int has_fwd;
 	const uint8_t *qm;       /* raster quantiser matrices: intra at [0, 64), non-intra at [64, 128) */
+	const uint8_t *zz;       /* zig-zag scan index -> raster position (mpeg1.c ZIG_ZAG) */
 	uint8_t epoch;
 	int zero_uncovered;      /* batch mode: unwritten macroblocks become 0 */
 };
@@ -195,7 +196,7 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Slot &s) {
 					const uint16_t tv = JM_TOK16(tw, k);
 					if (intra && base + k == 0) dc = (int)(int16_t)tv;      /* first token of an intra block: dc, mpeg1.c:1489 */
 					else {
-						int pos = jm_token_pos(tv), level = jm_token_level(tv);
+						int pos = (int)c.zz[jm_token_pos(tv)], level = jm_token_level(tv);
 						level = (level << 1) + (nz_bias ? ((level >> 31) | 1) : 0);
 						level = jm_mul24(level, qscale * (int)q[pos]) >> 4;
 						level = (level - (level > 0 ? 1 : 0)) | 1;           /* even -> toward zero, 0 -> +1 */

@@ -10,23 +10,31 @@
  * (mpeg1.c:1000-1205, 1442-1552; src/mpeg1.js:255-457, 698-811) but, instead of
  * reconstructing pixels, emits
  *   - one 16-byte JmMbRec per macroblock (coded or skipped), and
- *   - one 16-bit token per coefficient (quantised level + raster position),
- * which the reconstruct kernel consumes.  VLCs are decoded with multi-bit LUTs
- * (vlc_lut.h) out of a 64-bit left-aligned bit window.
+ *   - one 16-bit token per coefficient (quantised level + zig-zag scan index),
+ * which the reconstruct kernel consumes.
  *
- * gfx950 shape of the work:
+ * gfx950 shape of the work.  The kernel is bound by
+ * instruction issue (serial bit parsing, lanes of a wave in different places),
+ * so the design minimises instructions per symbol and keeps lanes busy:
  *   - A lane never touches HBM from inside the symbol loop.  Its compressed
- *     bytes come from a private 128-byte ring in LDS that is topped up with
- *     16-byte loads, and its tokens go to a private 64-token ring in LDS that
- *     is drained with 32-byte stores to 32-byte aligned addresses (whole HBM
- *     sectors, no partial-line read-modify-write).  Both happen in a "service"
- *     step that the whole wave takes together.
- *   - The walk is cut into three kinds of steps -- COLD (macroblock header),
- *     BLOCK (pick the next coded block, intra DC), COEF (one run/level symbol)
- *     -- and the wave runs, at every turn, the kind most of its lanes are
- *     waiting for (kernels.hip: k_parse).  Lanes of a wave are in different
- *     macroblocks and blocks; nested loops would make every lane wait for the
- *     longest block of the 64 at each block boundary.
+ *     bytes live in a private 64-byte ring in LDS, topped up with 16-byte
+ *     loads; its tokens go to a private 32-token ring in LDS, drained with
+ *     32-byte stores to 32-byte aligned addresses (whole HBM sectors).  Both
+ *     happen in a "service" step that the whole wave takes together.  (Ring
+ *     sizes are what lets 16 wavefronts share a CU's 160 KB of LDS.)
+ *   - No bit window is carried: the next 32 bits at any bit position are one
+ *     LDS read of two ring rows (ds_read2st64_b32) and one 64-bit shift.  The
+ *     ring holds the stream as big-endian dwords so that is all it takes.
+ *   - The walk is cut into steps -- COLD (macroblock header), BLOCK (end of a
+ *     block, pick the next coded one, intra DC), COEF (one run/level symbol of
+ *     at most 8 bits + sign, or end_of_block: ONE table lookup), SLOW (escapes
+ *     and the long codes) -- and the wave runs, at every turn, the kind most
+ *     of its lanes are waiting for (jm_pick_step).  Everything rare per lane
+ *     but certain per 64 lanes (escapes, ring service, block boundaries) is
+ *     thereby out of the coefficient step.  Measured alternatives (profiles/
+ *     r01_parse_notes.md): one generic symbol step for all lanes (85 % of the
+ *     lanes busy but every handler issued every turn: more instructions), and
+ *     nested per-block loops (every lane waits for the longest block of 64).
  *
  * Robustness: a lane never reads past `limit_bits` + ring slack, never writes
  * outside its picture's MbRec array or its slice's token region (a token costs
@@ -42,13 +50,18 @@
 #include "mpeg1_dev.h"
 #include "vlc_lut.h"
 
-#define JM_ES_RING_DW 32   /* dwords of compressed data per lane in LDS (8 chunks of 16 bytes) */
-#define JM_TK_RING 64      /* token slots per lane in LDS                                   */
-#define JM_TK_GROUP 16     /* tokens per drain: 32 bytes = one HBM sector                   */
-#define JM_STEP_DW 4       /* a step may pull at most this many dwords out of the ring      */
-#define JM_RING_STRIDE 64  /* rings are [dword][lane] tiles of one wavefront: conflict-free for any per-lane dword index */
+#ifndef JM_ES_RING_DW
+#define JM_ES_RING_DW 16   /* dwords of compressed data per lane in LDS (chunks of 16 bytes) ...          */
+#endif
+#define JM_ES_RING_ROWS (JM_ES_RING_DW + 1) /* ... plus a copy of row 0 after the last, so "dword d and d + 1" never wraps */
+#ifndef JM_TK_RING
+#define JM_TK_RING 32      /* token slots per lane in LDS                                                 */
+#endif
+#define JM_TK_GROUP 16     /* tokens per drain: 32 bytes = one HBM sector                                 */
+#define JM_STEP_BITS 96    /* a step consumes at most this many bits (COLD: 11 + 6 + 5 + 2 * 17 + 9)       */
+#define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
 
-enum { JM_ST_COLD = 0, JM_ST_BLOCK = 1, JM_ST_COEF = 2, JM_ST_DONE = 3, JM_ST_WAIT = 4 };
+enum { JM_ST_COLD = 0, JM_ST_BLOCK = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
 
 struct JmSliceCtx {
 	const JmVlcLuts *lut;
@@ -61,19 +74,18 @@ struct JmSliceCtx {
 
 /* Everything a lane carries between steps. */
 struct JmLane {
-	/* compressed data: es16[] is the slice's bytes as 16-byte chunks from a 16-byte aligned address */
+	/* compressed data: es16[] is the slice's bytes as 16-byte chunks from a 16-byte aligned address;
+	 * bit positions count from the first bit of es16[0] */
 	const uint4_like_t *es16;
 	uint32_t *es_ring;      /* this lane's column of the LDS ring: dword d at es_ring[(d & 31) * JM_RING_STRIDE] */
 	uint32_t *tk_ring;      /* token ring, two tokens per dword, same indexing */
 	uint32_t fillc;         /* chunks [0, fillc) have been loaded; the ring holds the last 8 */
-	uint32_t rd;            /* next dword to pull into the window */
-	uint64_t win;           /* upcoming bits, left aligned */
-	int avail;              /* valid bits in win (> 32 between reads) */
-	uint32_t consumed;      /* bits consumed since the first payload bit */
-	uint32_t limit_bits, limit_bytes;
+	uint32_t bp;            /* bit position of the next unread bit */
+	uint32_t bp0, bp_end;   /* first payload bit; first bit past the payload */
+	uint32_t limit_bytes;
 	/* output */
-	uint16_t *tokens;       /* batch token buffer */
-	uint32_t tw;            /* next token slot (absolute) */
+	uint4_like_t *tokens;   /* batch token buffer, from the picture's 32-byte aligned base, as 8-token units */
+	uint32_t tw;            /* next token slot */
 	uint32_t tflushed;      /* slots below this are in HBM; multiple of JM_TK_GROUP */
 	uint32_t tok_rel;       /* the picture's first slot: JmMbRec.tok = slot - tok_rel */
 	JmMbRec *mb;            /* the picture's records */
@@ -85,45 +97,50 @@ struct JmLane {
 	int addr, inc;          /* macroblock_address; pending escape increments */
 	int slice_begin;
 	/* current macroblock */
-	int intra, cbp, blk, cur;
+	int intra, cbp, blk, cur;   /* cur: block being parsed, -1 before the first */
 	uint32_t qf, tok_first;
 	int rec_mvh, rec_mvv;
 	uint64_t cnts;
 	/* current block */
 	int n, cnt;
+	uint32_t tsel;          /* 512 while the next coefficient is the first of its block, else 0 (coeff9 variant) */
 };
 
-/* ---- bit window over the LDS ring: MSB-first reads like bit_buffer_peek/read (buffer.c:113-135) ---- */
-JM_HD uint32_t jm_ring_dword(const JmLane &L, uint32_t d) {
-	return __builtin_bswap32(L.es_ring[(d & (JM_ES_RING_DW - 1)) * JM_RING_STRIDE]);
+/* ---- bits: MSB-first like bit_buffer_peek/read (buffer.c:113-135) ---- */
+JM_HD uint32_t jm_bits32(const JmLane &L, uint32_t bp) {
+	const uint32_t d = (bp >> 5) & (JM_ES_RING_DW - 1);
+	const uint32_t hi = L.es_ring[d * JM_RING_STRIDE], lo = L.es_ring[(d + 1) * JM_RING_STRIDE];
+	return (uint32_t)(((((uint64_t)hi << 32) | lo) << (bp & 31)) >> 32);
 }
-JM_HD uint32_t jm_peek(const JmLane &L, int n) { return (uint32_t)(L.win >> (64 - n)); } /* 1..32 */
-JM_HD void jm_skip(JmLane &L, int n) {                                                   /* 0..32 */
-	L.win <<= n;
-	L.avail -= n;
-	L.consumed += (uint32_t)n;
-	if (L.avail <= 32) {
-		L.win |= (uint64_t)jm_ring_dword(L, L.rd++) << (32 - L.avail);
-		L.avail += 32;
-	}
-}
-JM_HD uint32_t jm_read(JmLane &L, int n) {
-	if (n == 0) return 0;
-	uint32_t v = jm_peek(L, n);
-	jm_skip(L, n);
+JM_HD uint32_t jm_get(JmLane &L, int n) {           /* 1..32 */
+	const uint32_t v = jm_bits32(L, L.bp) >> (32 - n);
+	L.bp += (uint32_t)n;
 	return v;
 }
+JM_HD uint32_t jm_consumed(const JmLane &L) { return L.bp - L.bp0; }
+/* next_bytes_are_start_code as the reference uses it at macroblock boundaries (mpeg1.c:1018-1020) */
+JM_HD bool jm_slice_ended(const JmLane &L) { return ((jm_consumed(L) + 7) >> 3) >= L.limit_bytes; }
 
 /* ---- service: top up the compressed-data ring, drain whole token groups ---- */
 JM_HD void jm_lane_refill(JmLane &L) {
-	const uint32_t target = (L.rd >> 2) + JM_ES_RING_DW / 4;   /* keep the chunk being read, load up to 7 ahead + itself */
+	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;   /* the chunk being read + the rest of the ring ahead */
+	/* all loads first, then the LDS writes: one memory latency per refill, not one per chunk */
+	uint4_like_t v[JM_ES_RING_DW / 4];
+#pragma unroll
+	for (int i = 0; i < JM_ES_RING_DW / 4; i++) {
+		const uint32_t ch = L.fillc + (uint32_t)i;
+		v[i] = L.es16[ch < target ? ch : target - 1];   /* unconditional (a chunk not needed re-reads the last one): no branch between the loads */
+	}
 #pragma unroll
 	for (int i = 0; i < JM_ES_RING_DW / 4; i++) {
 		const uint32_t ch = L.fillc + (uint32_t)i;
 		if (ch < target) {
-			const uint4_like_t v = L.es16[ch];
-			uint32_t *r = L.es_ring + ((ch & (JM_ES_RING_DW / 4 - 1)) * 4) * JM_RING_STRIDE;
-			r[0] = v.x; r[JM_RING_STRIDE] = v.y; r[2 * JM_RING_STRIDE] = v.z; r[3 * JM_RING_STRIDE] = v.w;
+			const uint32_t row = (ch & (JM_ES_RING_DW / 4 - 1)) * 4;
+			uint32_t *r = L.es_ring + row * JM_RING_STRIDE;
+			const uint32_t x = __builtin_bswap32(v[i].x);
+			r[0] = x; r[JM_RING_STRIDE] = __builtin_bswap32(v[i].y);
+			r[2 * JM_RING_STRIDE] = __builtin_bswap32(v[i].z); r[3 * JM_RING_STRIDE] = __builtin_bswap32(v[i].w);
+			if (row == 0) L.es_ring[JM_ES_RING_DW * JM_RING_STRIDE] = x;
 		}
 	}
 	if (L.fillc < target) L.fillc = target;
@@ -135,7 +152,7 @@ JM_HD void jm_lane_drain(JmLane &L) {
 		const uint32_t *r = L.tk_ring + d0 * JM_RING_STRIDE;
 		a.x = r[0]; a.y = r[JM_RING_STRIDE]; a.z = r[2 * JM_RING_STRIDE]; a.w = r[3 * JM_RING_STRIDE];
 		b.x = r[4 * JM_RING_STRIDE]; b.y = r[5 * JM_RING_STRIDE]; b.z = r[6 * JM_RING_STRIDE]; b.w = r[7 * JM_RING_STRIDE];
-		uint4_like_t *dst = reinterpret_cast<uint4_like_t *>(L.tokens + L.tflushed);
+		uint4_like_t *dst = L.tokens + (L.tflushed >> 3);                 /* 32-byte aligned: two dwordx4 stores */
 		dst[0] = a; dst[1] = b;
 		L.tflushed += JM_TK_GROUP;
 	}
@@ -144,9 +161,9 @@ JM_HD void jm_lane_service(JmLane &L) {
 	jm_lane_refill(L);
 	jm_lane_drain(L);
 }
-/* a step needs JM_STEP_DW dwords in the ring and room for 3 tokens (coefficient or DC + padding) */
+/* a step needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for 3 tokens (coefficient or DC, padding) */
 JM_HD bool jm_lane_blocked(const JmLane &L) {
-	return L.fillc * 4 - L.rd < JM_STEP_DW || L.tw - L.tflushed > JM_TK_RING - 3;
+	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 3;
 }
 JM_HD void jm_emit(JmLane &L, uint16_t t) {
 	const uint32_t slot = L.tw & (JM_TK_RING - 1);
@@ -157,7 +174,7 @@ JM_HD void jm_emit(JmLane &L, uint16_t t) {
 JM_HD void jm_lane_finish(JmLane &L) {
 	jm_lane_drain(L);
 	const uint32_t d0 = (L.tflushed & (JM_TK_RING - 1)) >> 1;
-	uint32_t *dst = reinterpret_cast<uint32_t *>(L.tokens + L.tflushed);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(L.tokens + (L.tflushed >> 3));
 #pragma unroll
 	for (uint32_t j = 0; j < JM_TK_GROUP / 2; j++)
 		if (L.tflushed + 2 * j < L.tw) dst[j] = L.tk_ring[(d0 + j) * JM_RING_STRIDE];
@@ -178,155 +195,172 @@ JM_HD void jm_store_mbrec(JmMbRec *dst, uint32_t tok, int mvh, int mvv, uint64_t
 
 /* Start of a slice.  `payload` = first byte after the slice start code,
  * `slice_code` = the start code value (vertical position + 1), `tok_slot` =
- * the slice's first token slot (multiple of JM_TK_GROUP).  The rings must be
- * assigned before the call. */
-JM_HD void jm_lane_init(JmLane &L, const uint8_t *payload, uint32_t limit_bytes, int slice_code, const JmSliceCtx &c,
-                        JmMbRec *mb, uint16_t *tokens, uint32_t tok_slot, uint32_t tok_rel) {
-	const uintptr_t a = (uintptr_t)payload;
-	L.es16 = reinterpret_cast<const uint4_like_t *>(a & ~(uintptr_t)15);
-	const uint32_t mis = (uint32_t)(a & 15);
-	L.fillc = 0; L.rd = 0;
+ * the slice's first token slot (multiple of JM_TK_GROUP) counted from `tokens`.
+ * The rings must be assigned before the call. */
+JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t payload_off, uint32_t limit_bytes, int slice_code,
+                        const JmSliceCtx &c, JmMbRec *mb, uint4_like_t *tokens, uint32_t tok_slot, uint32_t tok_rel) {
+	/* es_base16: the 16-byte aligned ES buffer; payload_off: byte offset of the first payload byte in it
+	 * (offsets, not pointer arithmetic on integers: the loads stay global_load, not flat_load) */
+	L.es16 = es_base16 + (payload_off >> 4);
+	L.bp0 = (payload_off & 15u) * 8u;
+	L.bp = L.bp0;
+	L.limit_bytes = limit_bytes; L.bp_end = L.bp0 + limit_bytes * 8u;
+	L.fillc = 0;
 	L.tokens = tokens; L.tw = L.tflushed = tok_slot; L.tok_rel = tok_rel; L.mb = mb;
 	jm_lane_refill(L);
-	L.rd = mis >> 2;
-	const int sub = (int)(mis & 3) * 8;
-	L.win = (((uint64_t)jm_ring_dword(L, L.rd) << 32) | jm_ring_dword(L, L.rd + 1)) << sub;
-	L.avail = 64 - sub;
-	L.rd += 2;
-	L.consumed = 0;
-	L.limit_bytes = limit_bytes; L.limit_bits = limit_bytes * 8u;
 	L.dc = JM_DC_RESET;
 	L.mvh = L.mvv = L.pmh = L.pmv = 0;
 	L.inc = 0; L.slice_begin = 1;
-	L.intra = 0; L.cbp = 0; L.blk = 0; L.cur = 0; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
-	L.n = 0; L.cnt = 0;
+	L.intra = 0; L.cbp = 0; L.blk = 0; L.cur = -1; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
+	L.n = 0; L.cnt = 0; L.tsel = 0;
 	/* decode_slice header (mpeg1.c:1011-1016) */
-	L.qscale = (int)jm_read(L, 5);
-	L.state = JM_ST_COLD;
-	while (jm_read(L, 1)) {
-		jm_skip(L, 8);
-		if (L.consumed >= L.limit_bits || L.fillc * 4 - L.rd < JM_STEP_DW) { L.state = JM_ST_DONE; break; }
+	L.qscale = (int)jm_get(L, 5);
+	int st = JM_ST_COLD;
+	while (jm_get(L, 1)) {
+		L.bp += 8;
+		if (L.bp >= L.bp_end || L.fillc * 128u - L.bp < JM_STEP_BITS + 32) { st = JM_ST_DONE; break; }
 	}
+	L.state = st;
 	L.addr = (slice_code - 1) * c.mb_width - 1;
 }
 
 /* decode_motion_vectors, one component (mpeg1.c:1149-1172): the new predictor value, by value
  * (a reference into the lane state would make the state addressable: scratch memory) */
 JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &bad) {
-	uint32_t e = c.lut->motion[jm_peek(L, 11)];
-	int len = (int)(e >> 8);
-	if (!len) { bad = true; return prev; }
-	jm_skip(L, len);
-	int code = (int)(e & 0xff) - 16, r_size = c.f_code - 1, f = 1 << r_size, d = code;
+	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t e = c.lut->motion[w >> 21];
+	const int len = (int)(e >> 8);
+	if (!len) bad = true;
+	const int code = (int)(e & 0xff) - 16, r_size = c.f_code - 1, f = 1 << r_size;
+	int d = code, used = len;
 	if (code != 0 && f != 1) {
-		int r = (int)jm_read(L, r_size);
+		const int r = (int)((w << len) >> (32 - r_size));           /* len + r_size <= 17 bits */
 		d = (((code < 0 ? -code : code) - 1) << r_size) + r + 1;
 		if (code < 0) d = -d;
+		used += r_size;
 	}
+	L.bp += (uint32_t)used;
 	prev += d;
 	if (prev > (f << 4) - 1) prev -= f << 5;
 	else if (prev < -(f << 4)) prev += f << 5;
 	return prev;
 }
 
-/* BLOCK step: the next coded block of the macroblock (mpeg1.c:1130-1139) and,
- * for intra blocks, its DC (mpeg1.c:1449-1489); or the end of the macroblock. */
+/* BLOCK step: close the block that just ended, then the next coded block of the
+ * macroblock (mpeg1.c:1130-1139) and, for intra blocks, its DC (mpeg1.c:1449-1489);
+ * or the end of the macroblock. */
 JM_HD void jm_step_block(JmLane &L, const JmSliceCtx &c) {
-	const int rem = L.cbp & ((0x40 >> L.blk) - 1);     /* pattern bits of blocks blk .. 5 (block b = bit 0x20 >> b) */
-	if (rem == 0) {
-		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
-		/* next_bytes_are_start_code, mpeg1.c:1018-1020 */
-		L.state = (((L.consumed + 7) >> 3) < L.limit_bytes) ? JM_ST_COLD : JM_ST_DONE;
-		return;
-	}
-	const int b = __builtin_clz((unsigned)rem) - 26;
-	L.cur = b; L.blk = b + 1;
-	L.n = 0; L.cnt = 0;
-	L.state = JM_ST_COEF;
-	if (L.intra) {
-		int size, len;
-		if (b < 4) { uint32_t e = c.lut->dcl[jm_peek(L, 7)]; len = (int)(e >> 4); size = (int)(e & 15); }
-		else { uint32_t e = c.lut->dcc[jm_peek(L, 8)]; len = (int)(e >> 4); size = (int)(e & 15); }
-		if (!len) { L.state = JM_ST_DONE; return; }
-		jm_skip(L, len);
-		const int dsh = b < 4 ? 0 : (b - 3) * 16;
-		int dcv = (int)(int16_t)(L.dc >> dsh);
-		if (size > 0) {
-			int diff = (int)jm_read(L, size);
-			dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
-		}
-		L.dc = (L.dc & ~(0xffffull << dsh)) | ((uint64_t)(uint16_t)dcv << dsh);
-		jm_emit(L, (uint16_t)(int16_t)dcv);
-		L.cnt = 1;
-		L.n = 1;
-	}
-}
-
-/* COEF step: one run/level symbol or the end of the block (mpeg1.c:1491-1552),
- * a token instead of block_data. */
-JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
-	const uint32_t w = jm_peek(L, 32);
-	int run = 0, level = 1, nbits = 2;
-	bool neg, eob = false, esc = false, bad = L.consumed >= L.limit_bits;
-	if (w >> 31) {
-		/* "1": end_of_block ("10") unless first coefficient of a non-intra
-		 * block, else (0, +-1) as "1s" / "11s"  (mpeg1.js:763-766, 784-790) */
-		const bool first = L.n == 0;
-		eob = !first && !((w >> 30) & 1);
-		neg = ((w >> (first ? 30 : 29)) & 1) != 0;
-		nbits = (first || eob) ? 2 : 3;
-	} else {
-		const uint32_t top8 = w >> 24;
-		const int lz = __builtin_clz(w | 1u);
-		const bool far = top8 < 4;                       /* codes of 10 .. 16 bits: 6 .. 11 leading zeros */
-		if (far && lz > 11) bad = true;
-		const uint32_t i2 = (uint32_t)((lz - 6) & 7) * 16u + ((w >> ((27 - lz) & 31)) & 15u);
-		const uint32_t e = far ? c.lut->coeff2[i2 < 96 ? i2 : 0] : c.lut->coeff1[top8];
-		const int len = (int)(e >> 11);
-		if (!len) bad = true;
-		esc = (e & 0x7ff) == 0;
-		run = (int)((e >> 6) & 31);
-		level = (int)(e & 63);
-		neg = ((w >> ((31 - len) & 31)) & 1) != 0;
-		nbits = len + 1;
-	}
-	if (bad) { L.state = JM_ST_DONE; return; }
-	if (esc) {
-		/* escape: 6-bit run, 8- or 16-bit level (mpeg1.js:767-780) */
-		jm_skip(L, 6);
-		run = (int)jm_read(L, 6);
-		level = (int)jm_read(L, 8);
-		if (level == 0) level = (int)jm_read(L, 8);
-		else if (level == 128) level = (int)jm_read(L, 8) - 256;
-		else if (level > 128) level -= 256;
-	} else {
-		jm_skip(L, nbits);
-		if (neg) level = -level;
-	}
-	if (eob) {
+	if (L.cur >= 0) {
 		if (L.cnt & 1) jm_emit(L, 0);                    /* runs are dword aligned for the reconstruct loads */
 		L.cnts |= (uint64_t)L.cnt << (8 * L.cur);
-		L.state = JM_ST_BLOCK;
-		return;
 	}
-	L.n += run;
-	if (L.n > 63) { L.state = JM_ST_DONE; return; }      /* reference indexes ZIG_ZAG out of range here */
-	const int pos = c.lut->zigzag[L.n++];
-	jm_emit(L, jm_token(pos, level));
-	L.cnt++;
+	const int rem = L.cbp & ((0x40 >> L.blk) - 1);     /* pattern bits of blocks blk .. 5 (block b = bit 0x20 >> b) */
+	int st = JM_ST_COEF;
+	if (rem == 0) {
+		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
+		st = jm_slice_ended(L) ? JM_ST_DONE : JM_ST_COLD;
+	} else {
+		const int b = __builtin_clz((unsigned)rem) - 26;
+		L.cur = b; L.blk = b + 1;
+		int n = 0;
+		if (L.intra) {
+			const uint32_t w = jm_bits32(L, L.bp);
+			const uint32_t e = b < 4 ? c.lut->dcl[w >> 25] : c.lut->dcc[w >> 24];
+			const int len = (int)(e >> 8), size = (int)(e & 15);
+			if (!len) st = JM_ST_DONE;
+			const int dsh = b < 4 ? 0 : (b - 3) * 16;
+			int dcv = (int)(int16_t)(L.dc >> dsh);
+			if (size > 0) {
+				const int diff = (int)((w << len) >> (32 - size));   /* len + size <= 16 bits */
+				dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
+			}
+			L.bp += (uint32_t)(len + size);
+			L.dc = (L.dc & ~(0xffffull << dsh)) | ((uint64_t)(uint16_t)dcv << dsh);
+			jm_emit(L, (uint16_t)(int16_t)dcv);
+			n = 1;
+		}
+		L.n = n; L.cnt = n;
+		L.tsel = n ? 0u : 512u;
+	}
+	L.state = st;
+}
+
+/* COEF step: one run/level symbol of at most 8 bits + sign, or end_of_block
+ * (mpeg1.c:1491-1552), a token instead of block_data.  Anything else hands the
+ * lane to the SLOW step without consuming a bit. */
+JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
+	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t e = (&c.lut->coeff9[0][0])[L.tsel + (w >> 23)];
+	const int len = (int)(e >> 12);
+	const int level = (int)((int32_t)(e << 25) >> 25);
+	const int n = L.n + (int)((e >> 7) & 31);
+	int st = JM_ST_COEF;
+	if (len == 0) st = JM_ST_SLOW;
+	else if (level == 0) st = JM_ST_BLOCK;             /* end_of_block */
+	else if (n > 63 || L.bp >= L.bp_end) st = JM_ST_DONE;   /* reference indexes ZIG_ZAG out of range here */
+	if (st == JM_ST_COEF) {
+		jm_emit(L, jm_token(n, level));
+		L.n = n + 1;
+		L.cnt++;
+		L.tsel = 0;
+	}
+	if (st != JM_ST_SLOW && st != JM_ST_DONE) L.bp += (uint32_t)len;
+	L.state = st;
+}
+
+/* SLOW step: one symbol the 9-bit table does not resolve -- the escape
+ * (mpeg1.js:767-780) and the codes of 10 to 16 bits. */
+JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
+	const uint32_t w = jm_bits32(L, L.bp);
+	bool bad = L.bp >= L.bp_end;
+	int run, level, used;
+	if ((w >> 26) == 1) {
+		/* escape: 6 + 6-bit run, 8- or 16-bit level */
+		run = (int)((w >> 20) & 63);
+		level = (int)((w >> 12) & 255);
+		used = 20;
+		if ((level & 127) == 0) {
+			const int low = (int)((w >> 4) & 255);
+			level = level ? low - 256 : low;
+			used = 28;
+		} else if (level > 128) level -= 256;
+	} else {
+		/* 6 .. 11 leading zeros, a 1, and 4 bits into the far table */
+		const int lz = __builtin_clz(w | 1u);
+		const uint32_t i2 = (uint32_t)((lz - 6) & 7) * 16u + ((w >> ((27 - lz) & 31)) & 15u);
+		const uint32_t f = c.lut->far_[i2 < 96 ? i2 : 0];
+		const int flen = (int)(f >> 11);
+		if (!flen || lz < 6 || lz > 11) bad = true;
+		run = (int)((f >> 6) & 31);
+		level = (int)(f & 63);
+		if ((w >> ((31 - flen) & 31)) & 1) level = -level;
+		used = flen + 1;
+	}
+	const int n = L.n + run;
+	if (n > 63) bad = true;
+	int st = JM_ST_DONE;
+	if (!bad) {
+		L.bp += (uint32_t)used;
+		jm_emit(L, jm_token(n, level));
+		L.n = n + 1;
+		L.cnt++;
+		L.tsel = 0;
+		st = JM_ST_COEF;
+	}
+	L.state = st;
 }
 
 /* COLD step: one macroblock_address_increment code; when the increment is
- * complete, the skipped macroblocks, the macroblock header, and the first
- * block (mpeg1.c:1026-1139). */
+ * complete, the skipped macroblocks and the macroblock header
+ * (mpeg1.c:1026-1136).  The blocks follow in BLOCK / COEF steps. */
 JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	const JmVlcLuts *T = c.lut;
 	const bool is_p = c.pic_type == JM_PIC_PREDICTIVE;
 	/* ---- macroblock_address_increment (mpeg1.c:1028-1043) ---- */
 	{
-		const uint32_t e = T->mba[jm_peek(L, 11)];
-		if (!(e >> 8) || L.consumed >= L.limit_bits) { L.state = JM_ST_DONE; return; }
-		jm_skip(L, (int)(e >> 8));
+		const uint32_t e = T->mba[jm_bits32(L, L.bp) >> 21];
+		if (!(e >> 8) || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
+		L.bp += e >> 8;
 		const int t = (int)(e & 0xff);
 		/* 34 = macroblock_stuffing (adds nothing), 35 = macroblock_escape (adds 33): both want another code */
 		L.inc += t == 35 ? 33 : (t == 34 ? 0 : t);
@@ -341,7 +375,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 		L.addr += inc;
 	} else {
 		if (L.addr + inc >= c.mb_size) {                 /* illegal increment: mpeg1.c:1053-1057 */
-			if (((L.consumed + 7) >> 3) >= L.limit_bytes) L.state = JM_ST_DONE;
+			if (jm_slice_ended(L)) L.state = JM_ST_DONE;
 			return;
 		}
 		if (inc > 1) {
@@ -359,16 +393,19 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	}
 	if (L.addr < 0 || L.addr >= c.mb_size) { L.state = JM_ST_DONE; return; }   /* reference would write out of bounds */
 
-	/* ---- macroblock_type, quantizer_scale (mpeg1.c:1092-1108) ---- */
+	/* ---- macroblock_type, quantizer_scale (mpeg1.c:1092-1108): at most 6 + 5 bits, one look ---- */
 	int type;
 	{
-		const uint32_t e = is_p ? T->mbtype_p[jm_peek(L, 6)] : T->mbtype_i[jm_peek(L, 2)];
-		if (!(e >> 5)) { L.state = JM_ST_DONE; return; }
-		jm_skip(L, (int)(e >> 5));
+		const uint32_t w = jm_bits32(L, L.bp);
+		const uint32_t e = is_p ? T->type_p[w >> 26] : T->type_i[w >> 30];
+		const int len = (int)(e >> 8);
+		if (!len) { L.state = JM_ST_DONE; return; }
 		type = (int)(e & 31);
+		int used = len;
+		if (type & 0x10) { L.qscale = (int)((w << len) >> 27); used += 5; }
+		L.bp += (uint32_t)used;
 	}
 	L.intra = type & 0x01;
-	if (type & 0x10) L.qscale = (int)jm_read(L, 5);
 	if (L.intra) {
 		L.mvh = L.mvv = L.pmh = L.pmv = 0;              /* mpeg1.c:1110-1114 */
 		L.qf = (uint32_t)(L.qscale | JM_MB_INTRA);
@@ -391,31 +428,37 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	/* ---- coded_block_pattern (mpeg1.c:1130-1136) ---- */
 	int cbp = L.intra ? 0x3f : 0;
 	if (type & 0x02) {
-		const uint32_t e = T->cbp[jm_peek(L, 9)];
-		jm_skip(L, (int)(e >> 8));
+		const uint32_t e = T->cbp[jm_bits32(L, L.bp) >> 23];
+		L.bp += e >> 8;
 		cbp = (e >> 8) ? (int)(e & 0xff) : -1;
 	}
 	if (cbp < 0) { L.state = JM_ST_DONE; return; }
 	L.cbp = cbp;
 	L.cnts = 0;
-	L.blk = 0;
-	jm_step_block(L, c);
-}
-
-/* The wavefront's scheduling rule: given how many of its lanes wait for each kind of step, the
- * kind to run this turn -- the one most lanes wait for (ties: the cheaper step first). */
-#define JM_COEF_BURST 4    /* coefficient symbols per COEF turn before the wave looks again */
-JM_HD int jm_pick_step(int n_coef, int n_block, int n_cold, int n_wait) {
-	if (n_coef >= n_block && n_coef >= n_cold && n_coef >= n_wait) return JM_ST_COEF;
-	if (n_block >= n_cold && n_block >= n_wait) return JM_ST_BLOCK;
-	if (n_cold >= n_wait) return JM_ST_COLD;
-	return JM_ST_WAIT;
+	L.blk = 0; L.cur = -1;
+	L.state = JM_ST_BLOCK;
 }
 
 /* What the lane is waiting for. */
 JM_HD int jm_lane_wants(const JmLane &L) {
 	if (L.state == JM_ST_DONE) return JM_ST_DONE;
 	return jm_lane_blocked(L) ? JM_ST_WAIT : L.state;
+}
+
+/* The wavefront's scheduling rule: given how many of its lanes wait for each kind of step, the
+ * kind to run next -- the one most lanes wait for (ties: the lower kind number).  The wave then
+ * keeps running that kind while at least JM_STICKY lanes still want it (one ballot per turn
+ * instead of five). */
+#ifndef JM_STICKY
+#define JM_STICKY 4
+#endif
+JM_HD int jm_pick_step(const int n[JM_ST_KINDS]) {
+	int best = JM_ST_COEF;
+	if (n[JM_ST_BLOCK] > n[best]) best = JM_ST_BLOCK;
+	if (n[JM_ST_COLD] > n[best]) best = JM_ST_COLD;
+	if (n[JM_ST_SLOW] > n[best]) best = JM_ST_SLOW;
+	if (n[JM_ST_WAIT] > n[best]) best = JM_ST_WAIT;
+	return best;
 }
 
 #endif

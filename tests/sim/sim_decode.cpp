@@ -23,8 +23,9 @@ struct HostSlot {
 
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
 // kind, and lanes that were served in those turns.
-static uint64_t g_turns[5], g_served[5];
-static int g_policy[5];   // experiments only: weights of coef, block, cold, wait; coef burst length
+static int g_sticky = JM_STICKY;   // experiments: keep running COEF turns while this many lanes want one
+static uint64_t g_picks;           // full scheduling decisions (five counts)
+static uint64_t g_turns[8], g_served[8], g_states[8];   // [0] symbol turns, [1] service turns; symbols per state
 
 extern "C" {
 
@@ -43,7 +44,9 @@ const uint32_t *sim_dump_counts(void) { return g_dump_counts; }
 const uint64_t *sim_turns(void);
 const uint64_t *sim_served(void);
 void sim_reset_counters(void);
-void sim_set_policy(int a, int b, int c, int d, int e);
+const uint64_t *sim_states(void);
+void sim_sticky(int v);
+uint64_t sim_picks(void);
 
 int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, uint8_t *frames_out, int max_frames) {
 	const uint32_t begin = 16;
@@ -88,7 +91,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 
 	// k_parse, one emulated 64-lane wavefront at a time: same lane functions, same scheduling rule
 	// (results do not depend on the rule; the counters do)
-	static uint32_t es_ring[JM_ES_RING_DW][JM_RING_STRIDE], tk_ring[JM_TK_RING / 2][JM_RING_STRIDE];
+	static uint32_t es_ring[JM_ES_RING_ROWS][JM_RING_STRIDE], tk_ring[JM_TK_RING / 2][JM_RING_STRIDE];
 	for (uint32_t w0 = 0; w0 < n_sc; w0 += 64) {
 		JmLane L[64];
 		JmSliceCtx C[64];
@@ -96,7 +99,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 		for (int l = 0; l < 64; l++) {
 			const uint32_t i = w0 + (uint32_t)l;
 			L[l].es_ring = &es_ring[0][l]; L[l].tk_ring = &tk_ring[0][l];
-			L[l].state = JM_ST_DONE; L[l].fillc = L[l].rd = 0; L[l].tw = L[l].tflushed = 0;
+			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].tw = L[l].tflushed = 0;
 			mine[l] = false;
 			C[l].lut = &luts; C[l].epoch = epoch;
 			if (i >= n_sc || owner[i] == JM_NONE) continue;
@@ -110,36 +113,37 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			if (!limit_bytes) continue;
 			const uint32_t rel = (uint32_t)(pic.tok_off & (JM_TK_GROUP - 1));
 			const uint32_t slot = (rel + (pos - pic.pos) * JM_TOKENS_PER_BYTE + JM_TK_GROUP - 1) & ~(uint32_t)(JM_TK_GROUP - 1);
-			jm_lane_init(L[l], es.data() + pos + 4, limit_bytes, sc_code[i], C[l], mb.data() + (size_t)p * g.mb_size,
-			             tokens.data() + (pic.tok_off - rel), slot, rel);
+			jm_lane_init(L[l], reinterpret_cast<const uint4_like_t *>(es.data()), pos + 4, limit_bytes, sc_code[i], C[l],
+			             mb.data() + (size_t)p * g.mb_size,
+			             reinterpret_cast<uint4_like_t *>(tokens.data()) + ((pic.tok_off - rel) >> 3), slot, rel);
 			mine[l] = true;
 		}
 		for (;;) {
-			int want[64], n[5] = { 0, 0, 0, 0, 0 };
+			int want[64], n[JM_ST_KINDS] = { 0, 0, 0, 0, 0, 0 };
 			for (int l = 0; l < 64; l++) { want[l] = jm_lane_wants(L[l]); n[want[l]]++; }
-			if (n[JM_ST_COEF] + n[JM_ST_BLOCK] + n[JM_ST_COLD] + n[JM_ST_WAIT] == 0) break;
-			int pick = jm_pick_step(n[JM_ST_COEF], n[JM_ST_BLOCK], n[JM_ST_COLD], n[JM_ST_WAIT]);
-			if (g_policy[0]) {   // experiments: weighted choice
-				long best = -1;
-				const int kinds[4] = { JM_ST_COEF, JM_ST_BLOCK, JM_ST_COLD, JM_ST_WAIT };
-				for (int q = 0; q < 4; q++) { long sc = (long)n[kinds[q]] * g_policy[q]; if (n[kinds[q]] && sc > best) { best = sc; pick = kinds[q]; } }
-			}
+			n[JM_ST_DONE] = 0;
+			if (n[JM_ST_COEF] + n[JM_ST_BLOCK] + n[JM_ST_COLD] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
+			const int pick = jm_pick_step(n);
+			g_picks++;
 			if (pick == JM_ST_COEF) {
-				for (int k = 0; k < (g_policy[4] ? g_policy[4] : JM_COEF_BURST); k++) {
+				for (int k = 0; k < 64; k++) {
 					int served = 0;
+					for (int l = 0; l < 64; l++) if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) served++;
+					if (served < (k ? g_sticky : 1)) break;
 					for (int l = 0; l < 64; l++)
-						if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) { jm_step_coef(L[l], C[l]); served++; }
-					if (served) { g_turns[JM_ST_COEF]++; g_served[JM_ST_COEF] += served; }
+						if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) jm_step_coef(L[l], C[l]);
+					g_turns[JM_ST_COEF]++; g_served[JM_ST_COEF] += served;
 				}
-			} else if (pick == JM_ST_BLOCK) {
-				g_turns[JM_ST_BLOCK]++; g_served[JM_ST_BLOCK] += n[JM_ST_BLOCK];
-				for (int l = 0; l < 64; l++) if (want[l] == JM_ST_BLOCK) jm_step_block(L[l], C[l]);
-			} else if (pick == JM_ST_COLD) {
-				g_turns[JM_ST_COLD]++; g_served[JM_ST_COLD] += n[JM_ST_COLD];
-				for (int l = 0; l < 64; l++) if (want[l] == JM_ST_COLD) jm_step_cold(L[l], C[l]);
-			} else {
+			} else if (pick == JM_ST_WAIT) {
 				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n[JM_ST_WAIT];
 				for (int l = 0; l < 64; l++) if (want[l] != JM_ST_DONE) jm_lane_service(L[l]);
+			} else {
+				g_turns[pick]++; g_served[pick] += n[pick];
+				for (int l = 0; l < 64; l++) if (want[l] == pick) {
+					if (pick == JM_ST_COLD) jm_step_cold(L[l], C[l]);
+					else if (pick == JM_ST_BLOCK) jm_step_block(L[l], C[l]);
+					else jm_step_slow(L[l], C[l]);
+				}
 			}
 		}
 		for (int l = 0; l < 64; l++) if (mine[l]) jm_lane_finish(L[l]);
@@ -165,7 +169,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			c.fwd = base + (uint64_t)(pic.fwd < 0 ? p : (uint32_t)pic.fwd) * g.frame_bytes;
 			uint8_t qm[128];
 			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
-			c.qm = qm; c.epoch = epoch; c.zero_uncovered = 1;
+			c.qm = qm; c.zz = luts.zigzag; c.epoch = epoch; c.zero_uncovered = 1;
 			HostSlot slot;
 			for (int b = 0; b < 6 * g.mb_size; b++) jm_recon_block(c, b, slot);
 		}
@@ -177,8 +181,10 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 }
 
 const uint64_t *sim_turns(void) { return g_turns; }
+const uint64_t *sim_states(void) { return g_states; }
+void sim_sticky(int v) { g_sticky = v; }
+uint64_t sim_picks(void) { return g_picks; }
 const uint64_t *sim_served(void) { return g_served; }
-void sim_set_policy(int a, int b, int c, int d, int e) { g_policy[0] = a; g_policy[1] = b; g_policy[2] = c; g_policy[3] = d; g_policy[4] = e; }
-void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); }
+void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; }
 
 }  // extern "C"
