@@ -58,16 +58,7 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 	return 0;
 }
 
-static void geom_init(JmGeom &g, int width, int height) {
-	g.mb_width = (width + 15) >> 4;
-	g.mb_height = (height + 15) >> 4;
-	g.mb_size = g.mb_width * g.mb_height;
-	g.coded_width = g.mb_width << 4;
-	g.coded_height = g.mb_height << 4;
-	g.luma_bytes = (uint32_t)(g.coded_width * g.coded_height);
-	g.chroma_bytes = g.luma_bytes >> 2;
-	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 255) & ~255ull;
-}
+static void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g, width, height); }
 
 #define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
 

@@ -273,7 +273,7 @@ struct LdsSlot {
 	__device__ __forceinline__ void zero() {
 		const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-		for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(base)[i] = z;
+		for (int i = 0; i < JM_SLOT_HALVES / 8; i++) reinterpret_cast<uint4 *>(base)[i] = z;
 	}
 	__device__ __forceinline__ void put(int pos, int level) { base[pos] = (int16_t)level; }
 	__device__ __forceinline__ void get8(int i, int16_t (&t)[8]) {
@@ -281,23 +281,35 @@ struct LdsSlot {
 		t[0] = (int16_t)(v.x & 0xffffu); t[1] = (int16_t)(v.x >> 16); t[2] = (int16_t)(v.y & 0xffffu); t[3] = (int16_t)(v.y >> 16);
 		t[4] = (int16_t)(v.z & 0xffffu); t[5] = (int16_t)(v.z >> 16); t[6] = (int16_t)(v.w & 0xffffu); t[7] = (int16_t)(v.w >> 16);
 	}
+	__device__ __forceinline__ void put8p(int i, const uint32_t (&pk)[4]) {
+		reinterpret_cast<uint4 *>(base)[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+	}
+	__device__ __forceinline__ void get8p(int i, uint32_t (&pk)[4]) {
+		const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+		pk[0] = v.x; pk[1] = v.y; pk[2] = v.z; pk[3] = v.w;
+	}
 };
 
 __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_WG];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
+	__shared__ uint32_t wave_total[JM_WG / 64];
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
 	const uint32_t p = b.order[k];
+	/* the record of this lane's macroblock depends on nothing but g: request it first */
+	const int g = (int)(blk * JM_WG + threadIdx.x);
+	const bool valid = g < 6 * b.g.mb_size;
+	JmLoc Q;
+	jm_recon_locate(b.g, b.mb + (size_t)p * b.g.mb_size, valid ? g : 0, Q);
 	const JmPic pic = b.pics[p];
 	if (threadIdx.x < 128) {
 		const JmStream *sp = b.streams + pic.stream;
 		qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
 	} else if (threadIdx.x < 192) qm[threadIdx.x] = b.luts->zigzag[threadIdx.x - 128];
-	__syncthreads();
-	const int g = (int)(blk * JM_WG + threadIdx.x);
-	if (g >= 6 * b.g.mb_size) return;
+	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
+	own.zero();
 	JmReconCtx c;
 	c.g = b.g;
 	c.mb = b.mb + (size_t)p * b.g.mb_size;
@@ -317,8 +329,36 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;
-	LdsSlot slot = { coef + threadIdx.x * JM_SLOT_HALVES };
-	jm_recon_block(c, g, slot);
+
+	/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the loads) */
+	JmBlk B;
+	B.idct = false; B.k00 = false; B.live = false;
+	if (valid) jm_recon_front(c, Q, B);
+#ifdef JM_EXP_NO_PRED
+	B.pred = false;
+#endif
+#ifdef JM_EXP_NO_IDCT
+	B.idct = false;
+#endif
+	/* the blocks that need the transform, packed to the front of the workgroup's slots */
+	const uint64_t need = __ballot(B.idct);
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0));
+	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(need);
+	__syncthreads();
+	uint32_t rank = before, total = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < JM_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) rank += t; total += t; }
+	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
+	jm_recon_konst(c, B);
+	if (B.idct) jm_recon_scatter(c, B, mine);
+	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
+	__syncthreads();
+	/* phase 2: wavefronts past the last packed block skip the transform altogether */
+	if (threadIdx.x < total) jm_recon_idct(own);
+	__syncthreads();
+	/* phase 3 */
+	if (valid) jm_recon_back(c, B, mine);
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

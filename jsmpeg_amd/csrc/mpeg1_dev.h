@@ -112,6 +112,19 @@ struct JmGeom {
 	int32_t coded_width, coded_height;
 	uint32_t luma_bytes, chroma_bytes; /* per plane */
 	uint64_t frame_bytes;              /* luma + 2 chroma, rounded up to 256 */
+	uint32_t rcp_bw, rcp_mbw;          /* ceil(2^32 / (2 * mb_width)), ceil(2^32 / mb_width): n / d == mulhi(n, rcp) for n < 2^32 / d */
 };
+JM_HD void jm_geom_init(JmGeom &g, int width, int height) {
+	g.mb_width = (width + 15) >> 4;
+	g.mb_height = (height + 15) >> 4;
+	g.mb_size = g.mb_width * g.mb_height;
+	g.coded_width = g.mb_width << 4;
+	g.coded_height = g.mb_height << 4;
+	g.luma_bytes = (uint32_t)(g.coded_width * g.coded_height);
+	g.chroma_bytes = g.luma_bytes >> 2;
+	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 255) & ~255ull;
+	g.rcp_bw = g.mb_width > 0 ? (uint32_t)(((1ull << 32) + 2 * g.mb_width - 1) / (uint64_t)(2 * g.mb_width)) : 0;
+	g.rcp_mbw = g.mb_width > 1 ? (uint32_t)(((1ull << 32) + g.mb_width - 1) / (uint64_t)g.mb_width) : 0xffffffffu;
+}
 
 #endif

@@ -102,122 +102,222 @@ JM_HD int jm_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 /* token k (0..7) of a run of eight packed in four dwords */
 #define JM_TOK16(w, k) (uint16_t)(((k) & 1) ? ((w)[(k) >> 1] >> 16) : ((w)[(k) >> 1] & 0xffffu))
 
-/* `Slot` is the lane's private 64-entry int16 coefficient store (LDS on the
- * device): zero(), put(pos, level), get8(i, out[8]) = entries 8i .. 8i+7. */
-template <class Slot>
-JM_HD void jm_recon_block(const JmReconCtx &c, int g, Slot &s) {
-	const JmGeom &G = c.g;
-	s.zero();
+/* What a lane carries from the front phase to the back phase of its block. */
+struct JmBlk {
+	uint8_t *out;            /* top-left pixel of the block in the destination plane */
+	int stride;
+	int cnt;                 /* tokens of the block */
+	bool live;               /* the macroblock was written this batch */
+	bool intra, pred;
+	bool idct;               /* the block goes through the transform (phase 2); else `konst` is its whole residual */
+	bool k00;                /* non-intra block with only the (0,0) coefficient: konst holds its level until jm_recon_konst */
+	int konst;               /* no tokens: 0; intra DC only: dc; only the (0,0) coefficient: (level * 32 + 128) >> 8
+	                            -- what the full transform gives for those (mpeg1.c:1578-1581) */
+	int qscale;
+	const uint32_t *tkw;     /* the block's token run, dword aligned */
+	uint32_t tw[4];          /* its first eight tokens */
+	uint32_t R[27];          /* raw prediction rows (front -> predict) */
+	uint32_t m, oh, ov;
+	uint32_t P[16];          /* the predicted block, 8 rows of 8 packed bytes (predict -> back) */
+};
 
-	/* ---- which block am I ---- */
+/* saturating int32 -> int16 pair (the final clamp to 0..255 of pred + residual is unchanged by it) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short jm_short2 __attribute__((ext_vector_type(2)));
+JM_D uint32_t jm_pack_sat16(int a, int b) { jm_short2 r = __builtin_amdgcn_cvt_pk_i16(a, b); return *reinterpret_cast<uint32_t *>(&r); }
+JM_D uint32_t jm_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+#else
+JM_HD uint32_t jm_pack_sat16(int a, int b) {
+	a = a < -32768 ? -32768 : (a > 32767 ? 32767 : a); b = b < -32768 ? -32768 : (b > 32767 ? 32767 : b);
+	return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+}
+JM_HD uint32_t jm_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+#endif
+
+/* one token: dequantise + oddify + clip (mpeg1.c:1535-1548) */
+JM_HD int jm_dequant(int level, bool intra, int qq) {
+	level = (level << 1) + (intra ? 0 : ((level >> 31) | 1));
+	level = jm_mul24(level, qq) >> 4;
+	level = (level - (level > 0 ? 1 : 0)) | 1;           /* even -> toward zero, 0 -> +1 */
+	return level > 2047 ? 2047 : (level < -2048 ? -2048 : level);
+}
+
+/* Where block g of the picture is, and its macroblock's record: no dependence on anything but g,
+ * so the record load is the first thing a lane issues (before the workgroup's set-up barrier). */
+struct JmLoc {
 	int mbaddr, bnum, x0, y0, stride, ph;
 	uint32_t plane_off;
+	uint4_like_t rw;         /* the 16-byte JmMbRec */
+};
+JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) {
+	/* divisions by multiplication: g < 2^32 / divisor */
 	if (g < 4 * G.mb_size) {
-		int bw = 2 * G.mb_width;
-		int by = g / bw, bx = g - by * bw;
-		mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
-		bnum = ((by & 1) << 1) | (bx & 1);
-		x0 = bx << 3; y0 = by << 3;
-		stride = G.coded_width; ph = G.coded_height;
-		plane_off = 0;
+		const int bw = 2 * G.mb_width;
+		const int by = (int)jm_mulhi((uint32_t)g, G.rcp_bw), bx = g - by * bw;
+		Q.mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
+		Q.bnum = ((by & 1) << 1) | (bx & 1);
+		Q.x0 = bx << 3; Q.y0 = by << 3;
+		Q.stride = G.coded_width; Q.ph = G.coded_height;
+		Q.plane_off = 0;
 	} else {
-		int h = g - 4 * G.mb_size;
-		int pl = h >= G.mb_size;
-		mbaddr = h - pl * G.mb_size;
-		int my = mbaddr / G.mb_width, mx = mbaddr - my * G.mb_width;
-		bnum = 4 + pl;
-		x0 = mx << 3; y0 = my << 3;
-		stride = G.coded_width >> 1; ph = G.coded_height >> 1;
+		const int h = g - 4 * G.mb_size;
+		const int pl = h >= G.mb_size;
+		Q.mbaddr = h - pl * G.mb_size;
+		const int my = G.mb_width == 1 ? Q.mbaddr : (int)jm_mulhi((uint32_t)Q.mbaddr, G.rcp_mbw), mx = Q.mbaddr - my * G.mb_width;
+		Q.bnum = 4 + pl;
+		Q.x0 = mx << 3; Q.y0 = my << 3;
+		Q.stride = G.coded_width >> 1; Q.ph = G.coded_height >> 1;
 		/* frame layout Y | Cr | Cb; block 4 goes to the Cb plane, block 5 to Cr (mpeg1.c:1571) */
-		plane_off = G.luma_bytes + (pl ? 0u : G.chroma_bytes);
+		Q.plane_off = G.luma_bytes + (pl ? 0u : G.chroma_bytes);
 	}
-	uint8_t *out = c.dst + plane_off + (uint32_t)(y0 * stride + x0);
+	Q.rw = *reinterpret_cast<const uint4_like_t *>(mb + Q.mbaddr);
+}
+
+/* PHASE 1 (every lane, its own block): what the block holds, the token and prediction loads. */
+JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
+	const int bnum = Q.bnum, x0 = Q.x0, y0 = Q.y0, stride = Q.stride, ph = Q.ph;
+	const uint32_t plane_off = Q.plane_off;
+	B.out = c.dst + plane_off + (uint32_t)(y0 * stride + x0);
+	B.stride = stride;
 
 	/* the 16-byte record as four dwords; fields by shifts (no indexed local) */
-	const uint4_like_t rw = *reinterpret_cast<const uint4_like_t *>(c.mb + mbaddr);
+	const uint4_like_t rw = Q.rw;
 	const uint32_t rec_tok = rw.x;
 	const int rec_mvh = (int)(int16_t)(rw.y & 0xffffu), rec_mvv = (int)(int16_t)(rw.y >> 16);
 	const uint64_t rec_cnt = (uint64_t)rw.z | ((uint64_t)(rw.w & 0xffffu) << 32);
 	const uint32_t rec_qf = (rw.w >> 16) & 0xffu, rec_epoch = rw.w >> 24;
-	if (rec_epoch != c.epoch) {
-		if (c.zero_uncovered)
-			for (int r = 0; r < 8; r++) { uint32_t *o = (uint32_t *)(out + r * stride); o[0] = 0; o[1] = 0; }
-		return;
-	}
-	const bool intra = rec_qf & JM_MB_INTRA;
-	const bool pred = (rec_qf & JM_MB_PRED) && c.has_fwd;
-	const int qscale = (int)(rec_qf & 31);
-	const int cnt = (int)((rec_cnt >> (8 * bnum)) & 0xff);
+	B.live = rec_epoch == c.epoch;
+	B.intra = rec_qf & JM_MB_INTRA;
+	B.pred = B.live && (rec_qf & JM_MB_PRED) && c.has_fwd;
+	B.qscale = (int)(rec_qf & 31);
+	B.cnt = B.live ? (int)((rec_cnt >> (8 * bnum)) & 0xff) : 0;
+	B.idct = false; B.k00 = false; B.konst = 0;
 
 	/* ---- token run of this block: runs are padded to an even count, so dword aligned ---- */
 	uint32_t t0 = rec_tok;
 #pragma unroll
 	for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)(((rec_cnt >> (8 * j)) & 0xff) + 1) & ~1u;
-	const uint32_t *tkw = reinterpret_cast<const uint32_t *>(c.tok + t0);
-	uint32_t tw[4] = { 0, 0, 0, 0 };
-	if (cnt > 0) { tw[0] = tkw[0]; tw[1] = tkw[1]; tw[2] = tkw[2]; tw[3] = tkw[3]; }
+	B.tkw = reinterpret_cast<const uint32_t *>(c.tok + t0);
+	B.tw[0] = B.tw[1] = B.tw[2] = B.tw[3] = 0;
+	if (B.cnt > 0) { B.tw[0] = B.tkw[0]; B.tw[1] = B.tkw[1]; B.tw[2] = B.tkw[2]; B.tw[3] = B.tkw[3]; }
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
-	uint32_t R[27];
-	uint32_t m = 0, oh = 0, ov = 0;
-	if (pred) {
+	B.m = B.oh = B.ov = 0;
+	if (B.pred) {
 		int mh = rec_mvh, mv = rec_mvv;
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
-		int H = mh >> 1, V = mv >> 1;
-		oh = (uint32_t)(mh & 1); ov = (uint32_t)(mv & 1);
+		const int H = mh >> 1, V = mv >> 1;
+		B.oh = (uint32_t)(mh & 1); B.ov = (uint32_t)(mv & 1);
 		int sx = x0 + H, sy = y0 + V;
 		/* the reference reads out of bounds for vectors leaving the picture
 		 * (outside the contract); keep the reads inside the plane */
 		if (sx < 0) sx = 0;
 		if (sy < 0) sy = 0;
-		if (sx + 8 + (int)oh > stride) sx = stride - 8 - (int)oh;
-		if (sy + 8 + (int)ov > ph) sy = ph - 8 - (int)ov;
+		if (sx + 8 + (int)B.oh > stride) sx = stride - 8 - (int)B.oh;
+		if (sy + 8 + (int)B.ov > ph) sy = ph - 8 - (int)B.ov;
 		const uint32_t off = (uint32_t)(sy * stride + sx);
 		const uint32_t *w = reinterpret_cast<const uint32_t *>(c.fwd + plane_off + (off & ~3u));
-		m = off & 3u;
+		B.m = off & 3u;
 		const int wstride = stride >> 2;
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
 			const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
-			R[3 * r] = wr[0]; R[3 * r + 1] = wr[1]; R[3 * r + 2] = wr[2];
+			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
 		}
 	}
 
-	/* ---- dequantise the tokens into the slot (mpeg1.c:1535-1548) ---- */
-	int dc = 0;
-	if (cnt > 0) {
-		const uint8_t *q = c.qm + (intra ? 0 : 64);
-		const int nz_bias = intra ? 0 : 1;
-		for (int base = 0;;) {
+	/* ---- does the block need the transform?  Blocks that hold nothing but the (0,0) term do not:
+	 * every output is (term + 128) >> 8 (the reference's own shortcut, mpeg1.c:1578-1581) ---- */
+	if (B.cnt > 0) {
+		const uint16_t t = (uint16_t)(B.tw[0] & 0xffffu);
+		if (B.intra) {
+			if (B.cnt == 1) B.konst = (int)(int16_t)t;                       /* (dc << 8 + 128) >> 8 */
+			else B.idct = true;
+		} else if (B.cnt == 1 && jm_token_pos(t) == 0) { B.k00 = true; B.konst = jm_token_level(t); }
+		else B.idct = true;
+	}
+}
+
+/* PHASE 1a (after the workgroup's set-up barrier: the quantiser matrices are in LDS): the residual of
+ * a non-intra block that holds only the (0,0) coefficient. */
+JM_HD void jm_recon_konst(const JmReconCtx &c, JmBlk &B) {
+	if (B.k00) {
+		const int lv = jm_dequant(B.konst, false, B.qscale * (int)c.qm[64]);
+		B.konst = (lv * JM_PREMULT[0] + 128) >> 8;
+	}
+}
+
+/* PHASE 1b (lanes whose block needs the transform): dequantise the tokens into a slot
+ * (mpeg1.c:1535-1548).  `Slot`: 72 int16 in LDS, all zero on entry; [0, 64) raster coefficients,
+ * [64] the intra dc.  zero(), put(pos, v), get8(i, out[8]) / put8(i, in[8]) = entries 8i .. 8i+7. */
+template <class Slot>
+JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
+	const uint8_t *q = c.qm + (B.intra ? 0 : 64);
+	uint32_t tw[4] = { B.tw[0], B.tw[1], B.tw[2], B.tw[3] };
+	for (int base = 0;;) {
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				if (base + k < cnt) {
-					const uint16_t tv = JM_TOK16(tw, k);
-					if (intra && base + k == 0) dc = (int)(int16_t)tv;      /* first token of an intra block: dc, mpeg1.c:1489 */
-					else {
-						int pos = (int)c.zz[jm_token_pos(tv)], level = jm_token_level(tv);
-						level = (level << 1) + (nz_bias ? ((level >> 31) | 1) : 0);
-						level = jm_mul24(level, qscale * (int)q[pos]) >> 4;
-						level = (level - (level > 0 ? 1 : 0)) | 1;           /* even -> toward zero, 0 -> +1 */
-						if (level > 2047) level = 2047; else if (level < -2048) level = -2048;
-						s.put(pos, level);
-					}
+		for (int k = 0; k < 8; k++) {
+			if (base + k < B.cnt) {
+				const uint16_t tv = JM_TOK16(tw, k);
+				if (B.intra && base + k == 0) s.put(64, (int)(int16_t)tv);       /* first token of an intra block: dc, mpeg1.c:1489 */
+				else {
+					const int pos = (int)c.zz[jm_token_pos(tv)];
+					s.put(pos, jm_dequant(jm_token_level(tv), B.intra, B.qscale * (int)q[pos]));
 				}
 			}
-			base += 8;
-			if (base >= cnt) break;
-			tw[0] = tkw[base / 2]; tw[1] = tkw[base / 2 + 1]; tw[2] = tkw[base / 2 + 2]; tw[3] = tkw[base / 2 + 3];
 		}
+		base += 8;
+		if (base >= B.cnt) break;
+		tw[0] = B.tkw[base / 2]; tw[1] = B.tkw[base / 2 + 1]; tw[2] = B.tkw[base / 2 + 2]; tw[3] = B.tkw[base / 2 + 3];
 	}
+}
 
-	/* ---- prediction: P = (A + B + C + D + 2) >> 2 with B = A shifted by oh bytes, C/D = the row
-	 * below when ov; exact for all four half-pel cases (mpeg1.c:1232-1436):
-	 *   u = (A + B + 1) >> 1 per row, P = (u_r + u_r' + [A+B even in both rows]) >> 1 ---- */
-	uint32_t P[16];
+/* PHASE 2 (one lane per block that needs it, blocks packed to the front of the workgroup's slots):
+ * premultiply + 8x8 integer IDCT (mpeg1.c:1551, 1673-1740), in place: levels in, residual out
+ * (saturated to int16). */
+template <class Slot>
+JM_HD void jm_recon_idct(Slot &s) {
+	int v[64];
 #pragma unroll
-	for (int i = 0; i < 16; i++) P[i] = 0;
-	if (pred) {
+	for (int i = 0; i < 8; i++) {
+		int16_t t[8];
+		s.get8(i, t);
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
+	}
+	{
+		int16_t t[8];
+		s.get8(8, t);
+		v[0] += (int)((uint32_t)(int)t[0] << 8);             /* intra: dc << 8 (zero otherwise) */
+	}
+	const int c128 = 128;
+	/* columns, then rows with the final rounding (mpeg1.c:1682-1739) */
+#pragma unroll
+	for (int i = 0; i < 8; i++)
+		JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
+#pragma unroll
+	for (int i = 0; i < 64; i += 8)
+		JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_SHIFT)
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		uint32_t pk[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) pk[k] = jm_pack_sat16(v[8 * i + 2 * k], v[8 * i + 2 * k + 1]);
+		s.put8p(i, pk);
+	}
+}
+
+/* PHASE 1c (every lane, its own block, once the raw rows have arrived): half-pel prediction
+ * (mpeg1.c:1208-1437).  P = (A + B + C + D + 2) >> 2 with B = A shifted by oh bytes, C/D = the
+ * row below when ov; exact for all four half-pel cases (mpeg1.c:1232-1436):
+ *   u = (A + B + 1) >> 1 per row, P = (u_r + u_r' + [A+B even in both rows]) >> 1 */
+JM_HD void jm_recon_predict(JmBlk &B) {
+#pragma unroll
+	for (int i = 0; i < 16; i++) B.P[i] = 0;
+	if (B.pred) {
+		const uint32_t m = B.m, oh = B.oh, ov = B.ov;
+		const uint32_t *R = B.R;
 		uint32_t u0p = 0, u1p = 0, e0p = 0, e1p = 0;
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
@@ -232,44 +332,43 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Slot &s) {
 			if (r > 0) {
 				/* output row r - 1 pairs row r - 1 with row r - 1 + ov */
 				const uint32_t v0 = ov ? u0 : u0p, v1 = ov ? u1 : u1p, f0 = ov ? e0 : e0p, f1 = ov ? e1 : e1p;
-				P[2 * (r - 1)] = jm_lerp(u0p, v0, e0p & f0);
-				P[2 * (r - 1) + 1] = jm_lerp(u1p, v1, e1p & f1);
+				B.P[2 * (r - 1)] = jm_lerp(u0p, v0, e0p & f0);
+				B.P[2 * (r - 1) + 1] = jm_lerp(u1p, v1, e1p & f1);
 			}
 			u0p = u0; u1p = u1; e0p = e0; e1p = e1;
 		}
 	}
+}
 
-	/* ---- residual ---- */
-	if (cnt > 0) {
-		int v[64];
+/* PHASE 3 (every lane, its own block): add the residual to the prediction or overwrite, clamp
+ * (mpeg1.c:1614-1671), coalesced row stores.  `s` = the slot that holds the block's residual when
+ * B.idct. */
+template <class Slot>
+JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
+	if (!B.live) {
+		if (c.zero_uncovered)
+			for (int r = 0; r < 8; r++) { uint32_t *o = (uint32_t *)(B.out + r * B.stride); o[0] = 0; o[1] = 0; }
+		return;
+	}
+	uint32_t P[16];
 #pragma unroll
-		for (int i = 0; i < 8; i++) {
-			int16_t t[8];
-			s.get8(i, t);
-#pragma unroll
-			for (int k = 0; k < 8; k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
-		}
-		if (intra) v[0] = (int)((uint32_t)dc << 8);
-		const int c128 = 128;
+	for (int i = 0; i < 16; i++) P[i] = B.P[i];
 
-		/* columns, then rows with the final rounding (mpeg1.c:1682-1739).  A
-		 * DC-only block gives (dc + 128) >> 8 everywhere: same as the
-		 * reference's n == 1 shortcut (mpeg1.c:1578-1581). */
-#pragma unroll
-		for (int i = 0; i < 8; i++)
-			JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
-#pragma unroll
-		for (int i = 0; i < 64; i += 8)
-			JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_SHIFT)
-
-		/* add to the prediction (zero for intra: overwrite) and clamp (mpeg1.c:1620-1644) */
+	/* ---- residual: from the slot, or the same value everywhere; add and clamp (mpeg1.c:1620-1644) ---- */
+	if (B.idct || B.konst != 0) {
+		const uint32_t kk = ((uint32_t)B.konst & 0xffffu) * 0x00010001u;
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
-			uint32_t p0 = P[2 * r], p1 = P[2 * r + 1], o0 = 0, o1 = 0;
+			uint32_t pk[4] = { kk, kk, kk, kk };
+			if (B.idct) s.get8p(r, pk);
+			const uint32_t p0 = P[2 * r], p1 = P[2 * r + 1];
+			uint32_t o0 = 0, o1 = 0;
 #pragma unroll
 			for (int k = 0; k < 4; k++) {
-				o0 |= (uint32_t)jm_clamp255((int)((p0 >> (8 * k)) & 255) + v[8 * r + k]) << (8 * k);
-				o1 |= (uint32_t)jm_clamp255((int)((p1 >> (8 * k)) & 255) + v[8 * r + 4 + k]) << (8 * k);
+				const int r0 = (int)(int16_t)((k & 1) ? (pk[k >> 1] >> 16) : (pk[k >> 1] & 0xffffu));
+				const int r1 = (int)(int16_t)((k & 1) ? (pk[2 + (k >> 1)] >> 16) : (pk[2 + (k >> 1)] & 0xffffu));
+				o0 |= (uint32_t)jm_clamp255((int)((p0 >> (8 * k)) & 255) + r0) << (8 * k);
+				o1 |= (uint32_t)jm_clamp255((int)((p1 >> (8 * k)) & 255) + r1) << (8 * k);
 			}
 			P[2 * r] = o0; P[2 * r + 1] = o1;
 		}
@@ -278,7 +377,7 @@ JM_HD void jm_recon_block(const JmReconCtx &c, int g, Slot &s) {
 	/* ---- coalesced row stores: 8 bytes per lane per row ---- */
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
-		uint32_t *o = (uint32_t *)(out + r * stride);
+		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
 		o[0] = P[2 * r]; o[1] = P[2 * r + 1];
 	}
 }

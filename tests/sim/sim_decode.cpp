@@ -15,10 +15,12 @@
 #include "slice_parse.h"
 
 struct HostSlot {
-	int16_t v[64];
+	int16_t v[72];
 	void zero() { memset(v, 0, sizeof(v)); }
 	void put(int pos, int level) { v[pos] = (int16_t)level; }
 	void get8(int i, int16_t (&t)[8]) { memcpy(t, v + 8 * i, 16); }
+	void put8p(int i, const uint32_t (&pk)[4]) { memcpy(v + 8 * i, pk, 16); }
+	void get8p(int i, uint32_t (&pk)[4]) { memcpy(pk, v + 8 * i, 16); }
 };
 
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
@@ -77,10 +79,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 	int deepest = jm_index_chain(st, pics.data());
 
 	JmGeom g;
-	g.mb_width = st.mb_width; g.mb_height = st.mb_height; g.mb_size = st.mb_size;
-	g.coded_width = g.mb_width << 4; g.coded_height = g.mb_height << 4;
-	g.luma_bytes = (uint32_t)(g.coded_width * g.coded_height); g.chroma_bytes = g.luma_bytes >> 2;
-	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 255) & ~255ull;
+	jm_geom_init(g, st.width, st.height);
 
 	JmVlcLuts luts;
 	jm_build_luts(&luts);
@@ -170,8 +169,29 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			uint8_t qm[128];
 			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
 			c.qm = qm; c.zz = luts.zigzag; c.epoch = epoch; c.zero_uncovered = 1;
-			HostSlot slot;
-			for (int b = 0; b < 6 * g.mb_size; b++) jm_recon_block(c, b, slot);
+			// k_recon, one emulated 256-lane workgroup at a time: front, rank the blocks that need the
+			// transform, scatter into the packed slots, transform slots [0, total), back
+			static HostSlot slots[256];
+			static JmBlk B[256];
+			for (int g0 = 0; g0 < 6 * g.mb_size; g0 += 256) {
+				int rank[256], total = 0;
+				for (int l = 0; l < 256; l++) {
+					slots[l].zero();
+					B[l].idct = false; B[l].k00 = false; B[l].live = false;
+					if (g0 + l < 6 * g.mb_size) {
+						JmLoc Q;
+						jm_recon_locate(c.g, c.mb, g0 + l, Q);
+						jm_recon_front(c, Q, B[l]);
+						jm_recon_konst(c, B[l]);
+					}
+					rank[l] = total;
+					if (B[l].idct) total++;
+				}
+				for (int l = 0; l < 256; l++) if (B[l].idct) jm_recon_scatter(c, B[l], slots[rank[l]]);
+				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_predict(B[l]);
+				for (int l = 0; l < total; l++) jm_recon_idct(slots[l]);
+				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_back(c, B[l], slots[rank[l]]);
+			}
 		}
 	int out = 0;
 	const size_t fb = (size_t)g.luma_bytes + 2 * g.chroma_bytes;

@@ -1,0 +1,29 @@
+"""Kernel-timing experiments (no parity gate, no torch): decode the cfg2 batch a few times and print the engine's
+phase timings.  For -D experiment builds whose output is deliberately wrong.
+    python tools/kbench.py [streams] [frames] [reps]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = sys.argv[:1] + sys.argv[1:]
+import bench  # noqa: E402  (generate_streams only)
+from jsmpeg_amd import batch as jb, synth  # noqa: E402
+
+n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+cfg = synth.CONFIGS[bench.CONFIG]
+gen = bench.generate_streams(0, n_streams, frames)
+streams = [g[0] for g in gen]
+total = sum(len(s) for s in streams)
+with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, total + 64 * n_streams + 4096) as b:
+    b.upload(streams)
+    acc = None
+    for r in range(reps):
+        b.decode()
+        t = b.timings()
+        if r:
+            acc = t if acc is None else {k: acc[k] + t[k] for k in t}
+    lv = b.counters()["levels"]
+    print({k: round(v / (reps - 1), 3) for k, v in acc.items()}, "recon per level %.3f" % (acc["recon_ms"] / (reps - 1) / lv))
