@@ -174,7 +174,7 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
  * workgroup is four independent wavefronts sharing the VLC tables; each
  * wavefront owns a [32][64]-dword compressed-data ring tile and a
  * [32][64]-dword token ring tile in LDS (slice_parse.h) and schedules itself:
- * at every turn it runs the step kind most of its lanes are waiting for.
+ * at every turn it runs the step kinds enough of its lanes are waiting for.
  * ---------------------------------------------------------------------- */
 #ifndef JM_PARSE_WG
 #define JM_PARSE_WG 512   /* 8 wavefronts share one copy of the tables: 2 workgroups = 16 wavefronts per CU */
@@ -226,30 +226,23 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
+	const int thr[JM_ST_KINDS] = { JM_T_COLD, JM_T_DC, JM_T_COEF, JM_T_SLOW, JM_T_WAIT, 0 };
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
-		const int want = jm_lane_wants(L);
+		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, 3 token slots) */
+		const int want = L.state == JM_ST_DONE ? JM_ST_DONE : (ready ? L.state : JM_ST_WAIT);
 		int n[JM_ST_KINDS];
-		n[JM_ST_COLD] = __popcll(__ballot(want == JM_ST_COLD)); n[JM_ST_BLOCK] = __popcll(__ballot(want == JM_ST_BLOCK));
-		n[JM_ST_COEF] = __popcll(__ballot(want == JM_ST_COEF)); n[JM_ST_SLOW] = __popcll(__ballot(want == JM_ST_SLOW));
-		n[JM_ST_WAIT] = __popcll(__ballot(want == JM_ST_WAIT)); n[JM_ST_DONE] = 0;
-		if (n[JM_ST_COLD] + n[JM_ST_BLOCK] + n[JM_ST_COEF] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
-		const int pick = jm_pick_step(n);
-		if (pick == JM_ST_COEF) {
-			/* the common kind: keep going while enough lanes still have a coefficient to read */
-#pragma unroll 1
-			for (int k = 0; k < 64; k++) {
-				const bool go = L.state == JM_ST_COEF && !jm_lane_blocked(L);
-				if (__popcll(__ballot(go)) < (k ? JM_STICKY : 1)) break;
-				if (go) jm_step_coef(L, c);
-			}
-		} else if (pick == JM_ST_BLOCK) {
-			if (want == JM_ST_BLOCK) jm_step_block(L, c);
-		} else if (pick == JM_ST_COLD) {
-			if (want == JM_ST_COLD) jm_step_cold(L, c);
-		} else if (pick == JM_ST_SLOW) {
-			if (want == JM_ST_SLOW) jm_step_slow(L, c);
-		} else {
-			if (want != JM_ST_DONE) jm_lane_service(L);
+		n[JM_ST_COLD] = __builtin_popcountll(__ballot(want == JM_ST_COLD)); n[JM_ST_DC] = __builtin_popcountll(__ballot(want == JM_ST_DC));
+		n[JM_ST_COEF] = __builtin_popcountll(__ballot(want == JM_ST_COEF)); n[JM_ST_SLOW] = __builtin_popcountll(__ballot(want == JM_ST_SLOW));
+		n[JM_ST_WAIT] = __builtin_popcountll(__ballot(want == JM_ST_WAIT)); n[JM_ST_DONE] = 0;
+		if (n[JM_ST_COLD] + n[JM_ST_DC] + n[JM_ST_COEF] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
+		const uint32_t run = jm_turn_mask(n, thr);
+		if (run & (1u << JM_ST_WAIT)) { if (want != JM_ST_DONE) jm_lane_service(L); }
+		if (run & (1u << JM_ST_SLOW)) { if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c); }
+		if (run & (1u << JM_ST_COLD)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		if (run & (1u << JM_ST_DC)) { if (ready && L.state == JM_ST_DC) jm_step_dc(L, c); }
+		if (run & (1u << JM_ST_COEF)) {
+#pragma unroll
+			for (int k = 0; k < JM_COEF_REPEAT; k++) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
 		}
 	}
 	if (mine) jm_lane_finish(L);

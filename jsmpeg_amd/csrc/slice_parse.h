@@ -25,13 +25,14 @@
  *   - No bit window is carried: the next 32 bits at any bit position are one
  *     LDS read of two ring rows (ds_read2st64_b32) and one 64-bit shift.  The
  *     ring holds the stream as big-endian dwords so that is all it takes.
- *   - The walk is cut into steps -- COLD (macroblock header), BLOCK (end of a
- *     block, pick the next coded one, intra DC), COEF (one run/level symbol of
- *     at most 8 bits + sign, or end_of_block: ONE table lookup), SLOW (escapes
- *     and the long codes) -- and the wave runs, at every turn, the kind most
- *     of its lanes are waiting for (jm_pick_step).  Everything rare per lane
- *     but certain per 64 lanes (escapes, ring service, block boundaries) is
- *     thereby out of the coefficient step.  Measured alternatives (profiles/
+ *   - The walk is cut into steps -- COLD (macroblock header, and the record of
+ *     the macroblock before it), DC (intra DC), COEF (one run/level symbol of
+ *     at most 8 bits + sign: ONE table lookup; or end_of_block and the choice
+ *     of the next coded block), SLOW (escapes and the long codes) -- and at
+ *     every turn the wave runs each kind that enough of its lanes are waiting
+ *     for (jm_turn_mask).  Everything rare per lane but certain per 64 lanes
+ *     (escapes, ring service, headers) is thereby out of the coefficient step
+ *     and shared by the lanes queued for it.  Measured alternatives (profiles/
  *     r01_parse_notes.md): one generic symbol step for all lanes (85 % of the
  *     lanes busy but every handler issued every turn: more instructions), and
  *     nested per-block loops (every lane waits for the longest block of 64).
@@ -58,10 +59,13 @@
 #define JM_TK_RING 32      /* token slots per lane in LDS                                                 */
 #endif
 #define JM_TK_GROUP 16     /* tokens per drain: 32 bytes = one HBM sector                                 */
-#define JM_STEP_BITS 96    /* a step consumes at most this many bits (COLD: 11 + 6 + 5 + 2 * 17 + 9)       */
+#ifndef JM_COEF_REPEAT
+#define JM_COEF_REPEAT 2   /* COEF steps per turn                                                         */
+#endif
+#define JM_STEP_BITS (88 + 9 * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, COEF 9 each; or SLOW 28 + COEF */
 #define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
 
-enum { JM_ST_COLD = 0, JM_ST_BLOCK = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
+enum { JM_ST_COLD = 0, JM_ST_DC = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
 
 struct JmSliceCtx {
 	const JmVlcLuts *lut;
@@ -97,7 +101,7 @@ struct JmLane {
 	int addr, inc;          /* macroblock_address; pending escape increments */
 	int slice_begin;
 	/* current macroblock */
-	int intra, cbp, blk, cur;   /* cur: block being parsed, -1 before the first */
+	int intra, cbp, cur;        /* cur: block being parsed; 6: macroblock without (more) blocks; -1: no macroblock open */
 	uint32_t qf, tok_first;
 	int rec_mvh, rec_mvv;
 	uint64_t cnts;
@@ -161,9 +165,9 @@ JM_HD void jm_lane_service(JmLane &L) {
 	jm_lane_refill(L);
 	jm_lane_drain(L);
 }
-/* a step needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for 3 tokens (coefficient or DC, padding) */
+/* a turn needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for its tokens (DC; per COEF step a coefficient, or the alignment slot) */
 JM_HD bool jm_lane_blocked(const JmLane &L) {
-	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 3;
+	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 2 - 2 * JM_COEF_REPEAT;
 }
 JM_HD void jm_emit(JmLane &L, uint16_t t) {
 	const uint32_t slot = L.tw & (JM_TK_RING - 1);
@@ -211,7 +215,7 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	L.dc = JM_DC_RESET;
 	L.mvh = L.mvv = L.pmh = L.pmv = 0;
 	L.inc = 0; L.slice_begin = 1;
-	L.intra = 0; L.cbp = 0; L.blk = 0; L.cur = -1; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
+	L.intra = 0; L.cbp = 0; L.cur = -1; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
 	L.n = 0; L.cnt = 0; L.tsel = 0;
 	/* decode_slice header (mpeg1.c:1011-1016) */
 	L.qscale = (int)jm_get(L, 5);
@@ -246,66 +250,64 @@ JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &ba
 	return prev;
 }
 
-/* BLOCK step: close the block that just ended, then the next coded block of the
- * macroblock (mpeg1.c:1130-1139) and, for intra blocks, its DC (mpeg1.c:1449-1489);
- * or the end of the macroblock. */
-JM_HD void jm_step_block(JmLane &L, const JmSliceCtx &c) {
-	if (L.cur >= 0) {
-		if (L.cnt & 1) jm_emit(L, 0);                    /* runs are dword aligned for the reconstruct loads */
-		L.cnts |= (uint64_t)L.cnt << (8 * L.cur);
-	}
-	const int rem = L.cbp & ((0x40 >> L.blk) - 1);     /* pattern bits of blocks blk .. 5 (block b = bit 0x20 >> b) */
-	int st = JM_ST_COEF;
-	if (rem == 0) {
-		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
-		st = jm_slice_ended(L) ? JM_ST_DONE : JM_ST_COLD;
-	} else {
-		const int b = __builtin_clz((unsigned)rem) - 26;
-		L.cur = b; L.blk = b + 1;
-		int n = 0;
-		if (L.intra) {
-			const uint32_t w = jm_bits32(L, L.bp);
-			const uint32_t e = b < 4 ? c.lut->dcl[w >> 25] : c.lut->dcc[w >> 24];
-			const int len = (int)(e >> 8), size = (int)(e & 15);
-			if (!len) st = JM_ST_DONE;
-			const int dsh = b < 4 ? 0 : (b - 3) * 16;
-			int dcv = (int)(int16_t)(L.dc >> dsh);
-			if (size > 0) {
-				const int diff = (int)((w << len) >> (32 - size));   /* len + size <= 16 bits */
-				dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
-			}
-			L.bp += (uint32_t)(len + size);
-			L.dc = (L.dc & ~(0xffffull << dsh)) | ((uint64_t)(uint16_t)dcv << dsh);
-			jm_emit(L, (uint16_t)(int16_t)dcv);
-			n = 1;
-		}
-		L.n = n; L.cnt = n;
-		L.tsel = n ? 0u : 512u;
-	}
-	L.state = st;
+/* The first coded block of blocks `rem` (pattern bits, block b = bit 0x20 >> b; rem != 0) becomes the
+ * current one (mpeg1.c:1130-1139); intra blocks start with their DC (a DC step), the others with
+ * the "first coefficient" table. */
+JM_HD int jm_open_block(JmLane &L, int rem) {
+	L.cur = __builtin_clz((unsigned)rem) - 26;
+	L.n = 0; L.cnt = 0;
+	L.tsel = 512u;
+	return L.intra ? JM_ST_DC : JM_ST_COEF;
 }
 
-/* COEF step: one run/level symbol of at most 8 bits + sign, or end_of_block
- * (mpeg1.c:1491-1552), a token instead of block_data.  Anything else hands the
- * lane to the SLOW step without consuming a bit. */
+/* DC step: dct_dc_size + differential of an intra block (mpeg1.c:1449-1489); the DC goes out as the
+ * block's first token. */
+JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
+	const int b = L.cur;
+	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t e = b < 4 ? c.lut->dcl[w >> 25] : c.lut->dcc[w >> 24];
+	const int len = (int)(e >> 8), size = (int)(e & 15);
+	const int dsh = b < 4 ? 0 : (b - 3) * 16;
+	int dcv = (int)(int16_t)(L.dc >> dsh);
+	if (size > 0) {
+		const int diff = (int)((w << len) >> (32 - size));   /* len + size <= 16 bits */
+		dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
+	}
+	L.bp += (uint32_t)(len + size);
+	L.dc = (L.dc & ~(0xffffull << dsh)) | ((uint64_t)(uint16_t)dcv << dsh);
+	jm_emit(L, (uint16_t)(int16_t)dcv);
+	L.n = 1; L.cnt = 1;
+	L.tsel = 0;
+	L.state = len ? JM_ST_COEF : JM_ST_DONE;
+}
+
+/* COEF step: one run/level symbol of at most 8 bits + sign (mpeg1.c:1491-1552; a token instead of
+ * block_data), or end_of_block -- which closes the block and opens the next coded one of the
+ * macroblock, or leaves the macroblock to the COLD step (that stores its record).  Anything else
+ * hands the lane to the SLOW step without consuming a bit. */
 JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 	const uint32_t w = jm_bits32(L, L.bp);
 	const uint32_t e = (&c.lut->coeff9[0][0])[L.tsel + (w >> 23)];
 	const int len = (int)(e >> 12);
 	const int level = (int)((int32_t)(e << 25) >> 25);
 	const int n = L.n + (int)((e >> 7) & 31);
-	int st = JM_ST_COEF;
-	if (len == 0) st = JM_ST_SLOW;
-	else if (level == 0) st = JM_ST_BLOCK;             /* end_of_block */
-	else if (n > 63 || L.bp >= L.bp_end) st = JM_ST_DONE;   /* reference indexes ZIG_ZAG out of range here */
-	if (st == JM_ST_COEF) {
-		jm_emit(L, jm_token(n, level));
-		L.n = n + 1;
-		L.cnt++;
-		L.tsel = 0;
+	if (len == 0) { L.state = JM_ST_SLOW; return; }
+	if (level == 0) {
+		/* end_of_block.  Runs are dword aligned for the reconstruct loads: an odd run leaves one slot
+		 * unused (never read: the record carries the count). */
+		L.bp += (uint32_t)len;
+		L.tw += (uint32_t)(L.cnt & 1);
+		L.cnts |= (uint64_t)(uint32_t)L.cnt << (8 * L.cur);
+		const int rem = L.cbp & (0x1f >> L.cur);         /* pattern bits of the blocks after this one */
+		L.state = rem ? jm_open_block(L, rem) : JM_ST_COLD;
+		return;
 	}
-	if (st != JM_ST_SLOW && st != JM_ST_DONE) L.bp += (uint32_t)len;
-	L.state = st;
+	if (n > 63 || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }   /* reference indexes ZIG_ZAG out of range here */
+	jm_emit(L, jm_token(n, level));
+	L.n = n + 1;
+	L.cnt++;
+	L.tsel = 0;
+	L.bp += (uint32_t)len;
 }
 
 /* SLOW step: one symbol the 9-bit table does not resolve -- the escape
@@ -356,6 +358,13 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	const JmVlcLuts *T = c.lut;
 	const bool is_p = c.pic_type == JM_PIC_PREDICTIVE;
+	/* ---- the macroblock whose last block just ended: its record, and the end of the slice
+	 * (mpeg1.c:1018-1020) ---- */
+	if (L.cur >= 0) {
+		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
+		L.cur = -1;
+		if (jm_slice_ended(L)) { L.state = JM_ST_DONE; return; }
+	}
 	/* ---- macroblock_address_increment (mpeg1.c:1028-1043) ---- */
 	{
 		const uint32_t e = T->mba[jm_bits32(L, L.bp) >> 21];
@@ -435,8 +444,8 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	if (cbp < 0) { L.state = JM_ST_DONE; return; }
 	L.cbp = cbp;
 	L.cnts = 0;
-	L.blk = 0; L.cur = -1;
-	L.state = JM_ST_BLOCK;
+	if (cbp) L.state = jm_open_block(L, cbp);
+	else L.cur = 6;                                    /* no coded block: the next COLD step stores the record */
 }
 
 /* What the lane is waiting for. */
@@ -445,20 +454,41 @@ JM_HD int jm_lane_wants(const JmLane &L) {
 	return jm_lane_blocked(L) ? JM_ST_WAIT : L.state;
 }
 
-/* The wavefront's scheduling rule: given how many of its lanes wait for each kind of step, the
- * kind to run next -- the one most lanes wait for (ties: the lower kind number).  The wave then
- * keeps running that kind while at least JM_STICKY lanes still want it (one ballot per turn
- * instead of five). */
-#ifndef JM_STICKY
-#define JM_STICKY 4
+/* The wavefront's scheduling rule.  At every turn each kind of step whose queue (lanes waiting for
+ * it) has reached its threshold runs, in the order WAIT (ring service), SLOW, COLD, DC, COEF -- a lane
+ * can take several steps in one turn (header, DC and first coefficient of a macroblock: at most
+ * 65 + 16 + 9 bits, within JM_STEP_BITS).  Cheap common steps have a threshold of 1; the long rare
+ * ones wait until enough lanes share their cost.  When no queue has reached its threshold the
+ * longest one runs. */
+#ifndef JM_T_COLD
+#define JM_T_COLD 16
 #endif
-JM_HD int jm_pick_step(const int n[JM_ST_KINDS]) {
-	int best = JM_ST_COEF;
-	if (n[JM_ST_BLOCK] > n[best]) best = JM_ST_BLOCK;
-	if (n[JM_ST_COLD] > n[best]) best = JM_ST_COLD;
-	if (n[JM_ST_SLOW] > n[best]) best = JM_ST_SLOW;
-	if (n[JM_ST_WAIT] > n[best]) best = JM_ST_WAIT;
-	return best;
+#ifndef JM_T_DC
+#define JM_T_DC 1
+#endif
+#ifndef JM_T_COEF
+#define JM_T_COEF 1
+#endif
+#ifndef JM_T_SLOW
+#define JM_T_SLOW 6
+#endif
+#ifndef JM_T_WAIT
+#define JM_T_WAIT 6
+#endif
+JM_HD uint32_t jm_turn_mask(const int n[JM_ST_KINDS], const int thr[JM_ST_KINDS]) {
+	uint32_t m = (n[JM_ST_COLD] >= thr[JM_ST_COLD] ? 1u << JM_ST_COLD : 0u) | (n[JM_ST_DC] >= thr[JM_ST_DC] ? 1u << JM_ST_DC : 0u) |
+	             (n[JM_ST_COEF] >= thr[JM_ST_COEF] ? 1u << JM_ST_COEF : 0u) | (n[JM_ST_SLOW] >= thr[JM_ST_SLOW] ? 1u << JM_ST_SLOW : 0u) |
+	             (n[JM_ST_WAIT] >= thr[JM_ST_WAIT] ? 1u << JM_ST_WAIT : 0u);
+	if (m == 0) {
+		/* (count << 3 | kind) orders by count */
+		uint32_t best = ((uint32_t)n[JM_ST_COLD] << 3) | JM_ST_COLD, v;
+		v = ((uint32_t)n[JM_ST_DC] << 3) | JM_ST_DC; if (v > best) best = v;
+		v = ((uint32_t)n[JM_ST_COEF] << 3) | JM_ST_COEF; if (v > best) best = v;
+		v = ((uint32_t)n[JM_ST_SLOW] << 3) | JM_ST_SLOW; if (v > best) best = v;
+		v = ((uint32_t)n[JM_ST_WAIT] << 3) | JM_ST_WAIT; if (v > best) best = v;
+		m = 1u << (best & 7u);
+	}
+	return m;
 }
 
 #endif

@@ -25,8 +25,10 @@ struct HostSlot {
 
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
 // kind, and lanes that were served in those turns.
-static int g_sticky = JM_STICKY;   // experiments: keep running COEF turns while this many lanes want one
-static uint64_t g_picks;           // full scheduling decisions (five counts)
+static int g_thr[JM_ST_KINDS] = { JM_T_COLD, JM_T_DC, JM_T_COEF, JM_T_SLOW, JM_T_WAIT, 0 };   // experiments: the scheduler's thresholds
+static uint64_t g_picks;           // turns (scheduling decisions)
+static uint64_t g_cost;            // cost model: instructions issued by the wavefronts
+static int g_kcost[JM_ST_KINDS + 1] = { 430, 60, 95, 110, 270, 0, 50 };   // per handler; [KINDS] = per turn
 static uint64_t g_turns[8], g_served[8], g_states[8];   // [0] symbol turns, [1] service turns; symbols per state
 
 extern "C" {
@@ -47,8 +49,10 @@ const uint64_t *sim_turns(void);
 const uint64_t *sim_served(void);
 void sim_reset_counters(void);
 const uint64_t *sim_states(void);
-void sim_sticky(int v);
+void sim_thresholds(const int *t);
 uint64_t sim_picks(void);
+uint64_t sim_cost(void);
+void sim_kcost(const int *t);
 
 int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, uint8_t *frames_out, int max_frames) {
 	const uint32_t begin = 16;
@@ -119,30 +123,33 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 		}
 		for (;;) {
 			int want[64], n[JM_ST_KINDS] = { 0, 0, 0, 0, 0, 0 };
-			for (int l = 0; l < 64; l++) { want[l] = jm_lane_wants(L[l]); n[want[l]]++; }
+			bool ready[64];
+			for (int l = 0; l < 64; l++) {
+				ready[l] = !jm_lane_blocked(L[l]);
+				want[l] = L[l].state == JM_ST_DONE ? JM_ST_DONE : (ready[l] ? L[l].state : JM_ST_WAIT);
+				n[want[l]]++;
+			}
 			n[JM_ST_DONE] = 0;
-			if (n[JM_ST_COEF] + n[JM_ST_BLOCK] + n[JM_ST_COLD] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
-			const int pick = jm_pick_step(n);
-			g_picks++;
-			if (pick == JM_ST_COEF) {
-				for (int k = 0; k < 64; k++) {
-					int served = 0;
-					for (int l = 0; l < 64; l++) if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) served++;
-					if (served < (k ? g_sticky : 1)) break;
-					for (int l = 0; l < 64; l++)
-						if (L[l].state == JM_ST_COEF && !jm_lane_blocked(L[l])) jm_step_coef(L[l], C[l]);
-					g_turns[JM_ST_COEF]++; g_served[JM_ST_COEF] += served;
-				}
-			} else if (pick == JM_ST_WAIT) {
-				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n[JM_ST_WAIT];
+			if (n[JM_ST_COEF] + n[JM_ST_DC] + n[JM_ST_COLD] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
+			const uint32_t run = jm_turn_mask(n, g_thr);
+			g_picks++; g_cost += (uint64_t)g_kcost[JM_ST_KINDS];
+			if (run & (1u << JM_ST_WAIT)) {
+				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n[JM_ST_WAIT]; g_cost += (uint64_t)g_kcost[JM_ST_WAIT];
 				for (int l = 0; l < 64; l++) if (want[l] != JM_ST_DONE) jm_lane_service(L[l]);
-			} else {
-				g_turns[pick]++; g_served[pick] += n[pick];
-				for (int l = 0; l < 64; l++) if (want[l] == pick) {
-					if (pick == JM_ST_COLD) jm_step_cold(L[l], C[l]);
-					else if (pick == JM_ST_BLOCK) jm_step_block(L[l], C[l]);
+			}
+			static const int order[3 + 4] = { JM_ST_SLOW, JM_ST_COLD, JM_ST_DC, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF };
+			for (int oi = 0; oi < 3 + JM_COEF_REPEAT; oi++) {
+				const int k = order[oi];
+				if (!(run & (1u << k))) continue;
+				int served = 0;
+				for (int l = 0; l < 64; l++) if (ready[l] && L[l].state == k) {
+					served++;
+					if (k == JM_ST_COLD) jm_step_cold(L[l], C[l]);
+					else if (k == JM_ST_DC) jm_step_dc(L[l], C[l]);
+					else if (k == JM_ST_COEF) jm_step_coef(L[l], C[l]);
 					else jm_step_slow(L[l], C[l]);
 				}
+				g_turns[k]++; g_served[k] += served; if (served) g_cost += (uint64_t)g_kcost[k];
 			}
 		}
 		for (int l = 0; l < 64; l++) if (mine[l]) jm_lane_finish(L[l]);
@@ -202,9 +209,11 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 
 const uint64_t *sim_turns(void) { return g_turns; }
 const uint64_t *sim_states(void) { return g_states; }
-void sim_sticky(int v) { g_sticky = v; }
+void sim_thresholds(const int *t) { for (int k = 0; k < JM_ST_DONE; k++) g_thr[k] = t[k]; }
 uint64_t sim_picks(void) { return g_picks; }
+uint64_t sim_cost(void) { return g_cost; }
+void sim_kcost(const int *t) { for (int k = 0; k <= JM_ST_KINDS; k++) g_kcost[k] = t[k]; }
 const uint64_t *sim_served(void) { return g_served; }
-void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; }
+void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; g_cost = 0; }
 
 }  // extern "C"
