@@ -82,7 +82,7 @@ struct jsmpeg_hip_batch_t {
 	uint64_t *d_block_counts;
 	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
-	uint32_t *d_order; std::vector<uint32_t> h_order, level_off;
+	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
 	uint32_t *d_dbg;
@@ -98,7 +98,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
-	hipFree(b->d_pics); hipFree(b->d_order); hipFree(b->d_mb); hipFree(b->d_tokens);
+	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
@@ -122,7 +122,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(hipMalloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipMalloc(&b->d_counters, 4 * sizeof(uint32_t)));
 	HIP_TRY(hipMalloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
-	HIP_TRY(hipMalloc(&b->d_order, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(hipMalloc(&b->d_desc, sizeof(JmReconDesc) * std::max(1u, c.max_pictures)));
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
 	HIP_TRY(hipMalloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
@@ -151,7 +151,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
-	b->d_pics = nullptr; b->d_order = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
+	b->d_pics = nullptr; b->d_desc = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr;
 	for (auto &e : b->ev) e = nullptr;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
@@ -265,12 +265,21 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	b->level_off.assign(b->n_levels + 1, 0);
 	for (const JmPic &p : b->h_pics) if (p.decoded) { b->level_off[p.level + 1]++; b->n_decoded++; b->n_slices += p.n_slices; }
 	for (uint32_t l = 0; l < b->n_levels; l++) b->level_off[l + 1] += b->level_off[l];
-	b->h_order.resize(std::max<size_t>(1, b->n_decoded));
+	b->h_desc.resize(std::max<size_t>(1, b->n_decoded));
 	{
 		std::vector<uint32_t> cur(b->level_off.begin(), b->level_off.end());
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) b->h_order[cur[b->h_pics[p].level]++] = p;
+		for (uint32_t p = 0; p < b->n_pics; p++) {
+			const JmPic &pic = b->h_pics[p];
+			if (!pic.decoded) continue;
+			JmReconDesc &D = b->h_desc[cur[pic.level]++];
+			D.dst_off = (uint64_t)p * b->g.frame_bytes;
+			D.fwd_off = pic.fwd >= 0 ? (uint64_t)pic.fwd * b->g.frame_bytes : JM_NO_FWD;
+			D.tok_off = pic.tok_off;
+			D.mb_first = p * (uint32_t)b->g.mb_size;
+			D.stream = pic.stream;
+		}
 	}
-	if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_order, b->h_order.data(), sizeof(uint32_t) * b->n_decoded,
+	if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * b->n_decoded,
 	                                         hipMemcpyHostToDevice, st));
 	if (++b->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
@@ -295,10 +304,10 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 4. reconstruct, one launch per dependency level ---- */
 	JmReconBufs rb;
-	rb.g = b->g; rb.pics = b->d_pics; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens; rb.luts = b->d_luts;
-	rb.pool = b->d_pool; rb.dst_off = nullptr; rb.fwd_off = nullptr; rb.epoch = b->epoch; rb.zero_uncovered = 1;
+	rb.g = b->g; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens; rb.luts = b->d_luts;
+	rb.pool = b->d_pool; rb.epoch = b->epoch; rb.zero_uncovered = 1;
 	for (uint32_t l = 0; l < b->n_levels; l++) {
-		rb.order = b->d_order + b->level_off[l];
+		rb.desc = b->d_desc + b->level_off[l];
 		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
 		HIP_TRY(jm_launch_recon(rb, st));
 	}
@@ -435,10 +444,9 @@ struct mpeg1_decoder_t {
 	JmStream h_stream;           /* quant matrices etc. */
 
 	/* per-picture device state */
-	JmStream *d_stream; JmPic *d_pic; uint32_t *d_order;
+	JmStream *d_stream; JmPic *d_pic; JmReconDesc *d_desc;   /* one picture at a time */
 	JmMbRec *d_mb; uint16_t *d_tokens; size_t tokens_cap;
 	uint8_t *d_pool_alloc, *d_pool;  /* two frames */
-	uint64_t *d_offs;                /* [0] dst offset, [1] fwd offset (as int64) */
 	int cur;                         /* frame index being written next (planes_current) */
 	uint8_t *h_frame;                /* pinned: last decoded Y | Cr | Cb */
 	uint8_t epoch;
@@ -457,8 +465,8 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	mpeg1_decoder_t *d = new mpeg1_decoder_t();
 	d->bytes = nullptr; d->d_es = nullptr; d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr;
 	d->d_sc_owner = nullptr; d->d_pic_sc = nullptr; d->d_counters = nullptr; d->h_scan_pos = nullptr;
-	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_order = nullptr;
-	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr; d->d_offs = nullptr;
+	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_desc = nullptr;
+	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr;
 	d->h_frame = nullptr; d->stream = nullptr;
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->d_es_cap = 0; d->mirrored = 0; d->scan_cap = 0; d->tokens_cap = 0;
@@ -470,8 +478,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	          hipHostMalloc(&d->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
 	          hipMalloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && hipMalloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
-	          hipMalloc(&d->d_order, sizeof(uint32_t)) == hipSuccess && hipMalloc(&d->d_offs, 2 * sizeof(uint64_t)) == hipSuccess;
-	if (ok) { uint32_t zero = 0; ok = hipMemcpy(d->d_order, &zero, 4, hipMemcpyHostToDevice) == hipSuccess; }
+	          hipMalloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess;
 	if (!ok) {
 		if (!g_err[0]) fail("decoder allocation failed: %s", hipGetErrorString(hipGetLastError()));
 		dec_fail_cleanup(d);
@@ -485,8 +492,8 @@ static int dec_fail_cleanup(mpeg1_decoder_t *d) {
 	if (d->stream) hipStreamSynchronize(d->stream);
 	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
 	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
-	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_order);
-	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_offs); hipHostFree(d->h_frame);
+	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_desc);
+	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipHostFree(d->h_frame);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
 	return -1;
@@ -712,7 +719,9 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	p.sc = JM_NONE; p.stream = 0; p.first_slice_sc = 0; p.n_slices = (uint32_t)n_slices;
 	p.type = (uint8_t)type; p.full_pel = (uint8_t)full_pel; p.f_code = (uint8_t)f_code; p.decoded = 1;
 	p.level = 0; p.fwd = -1; p.end_sc = (uint32_t)n_slices; p.pos = pic_pos; p.tok_off = 0;
-	int64_t offs[2] = { (int64_t)((uint64_t)d->cur * d->g.frame_bytes), (int64_t)((uint64_t)(d->cur ^ 1) * d->g.frame_bytes) };
+	JmReconDesc desc;
+	desc.dst_off = (uint64_t)d->cur * d->g.frame_bytes; desc.fwd_off = (uint64_t)(d->cur ^ 1) * d->g.frame_bytes;
+	desc.tok_off = 0; desc.mb_first = 0; desc.stream = 0;
 
 	hipStream_t st = d->stream;
 	HIP_TRY(hipMemcpyAsync(d->d_sc_pos, d->stage_pos.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
@@ -720,7 +729,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	HIP_TRY(hipMemcpyAsync(d->d_sc_owner, owner.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d->d_stream, &s, sizeof(s), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d->d_pic, &p, sizeof(p), hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(d->d_offs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d->d_desc, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st)); /* the staged host vectors are pageable */
 	if (++d->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(d->d_mb, 0, sizeof(JmMbRec) * (size_t)d->g.mb_size, st));
@@ -732,9 +741,8 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	pb.n_sc = (uint32_t)n_entries; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
-	rb.g = d->g; rb.pics = d->d_pic; rb.streams = d->d_stream; rb.order = d->d_order; rb.n_level_pics = 1;
+	rb.g = d->g; rb.streams = d->d_stream; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.mb = d->d_mb; rb.tokens = d->d_tokens; rb.luts = d->d_luts; rb.pool = d->d_pool;
-	rb.dst_off = d->d_offs; rb.fwd_off = reinterpret_cast<const int64_t *>(d->d_offs + 1);
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,

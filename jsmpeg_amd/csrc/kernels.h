@@ -56,18 +56,26 @@ struct JmParseBufs {
 };
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);
 
+/* One picture of a reconstruct launch: everything a workgroup needs to start, in one 32-byte scalar
+ * load (the picture / order / offset tables cost a chain of dependent loads per workgroup). */
+struct alignas(32) JmReconDesc {
+	uint64_t dst_off;            /* byte offset of the picture's frame in the pool */
+	uint64_t fwd_off;            /* ... of its forward reference, JM_NO_FWD if none */
+	uint64_t tok_off;            /* first token slot of the picture */
+	uint32_t mb_first;           /* index of its first macroblock record */
+	uint32_t stream;             /* whose quantiser matrices apply */
+};
+#define JM_NO_FWD (~0ull)
+
 struct JmReconBufs {
 	JmGeom g;
-	const JmPic *pics;
-	const JmStream *streams;
-	const uint32_t *order;       /* picture indices of this level */
+	const JmReconDesc *desc;     /* the pictures of this level */
 	uint32_t n_level_pics;
+	const JmStream *streams;
 	const JmMbRec *mb;
 	const uint16_t *tokens;
 	const JmVlcLuts *luts;       /* device global copy (zig-zag order) */
-	uint8_t *pool;               /* frame p at pool + p * g.frame_bytes ... */
-	const uint64_t *dst_off;     /* ... unless non-null: explicit byte offsets per order entry */
-	const int64_t *fwd_off;      /*     and forward offsets (-1 = none)                          */
+	uint8_t *pool;
 	uint8_t epoch;
 	int zero_uncovered;
 };

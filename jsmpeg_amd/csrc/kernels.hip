@@ -290,35 +290,25 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
-	const uint32_t p = b.order[k];
-	/* the record of this lane's macroblock depends on nothing but g: request it first */
+	const JmReconDesc D = b.desc[k];                 /* uniform: one scalar load */
+	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	const int g = (int)(blk * JM_WG + threadIdx.x);
 	const bool valid = g < 6 * b.g.mb_size;
 	JmLoc Q;
-	jm_recon_locate(b.g, b.mb + (size_t)p * b.g.mb_size, valid ? g : 0, Q);
-	const JmPic pic = b.pics[p];
-	if (threadIdx.x < 128) {
-		const JmStream *sp = b.streams + pic.stream;
-		qm[threadIdx.x] = threadIdx.x < 64 ? sp->intra_q[threadIdx.x] : sp->nonintra_q[threadIdx.x - 64];
-	} else if (threadIdx.x < 192) qm[threadIdx.x] = b.luts->zigzag[threadIdx.x - 128];
+	jm_recon_locate(b.g, b.mb + D.mb_first, valid ? g : 0, Q);
+	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
+	uint4 tq = make_uint4(0, 0, 0, 0);
+	if (threadIdx.x < 8) tq = reinterpret_cast<const uint4 *>(b.streams[D.stream].intra_q)[threadIdx.x];
+	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
 	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
 	own.zero();
 	JmReconCtx c;
 	c.g = b.g;
-	c.mb = b.mb + (size_t)p * b.g.mb_size;
-	c.tok = b.tokens + pic.tok_off;
-	uint64_t dst_off, fwd_off;
-	if (b.dst_off) {
-		dst_off = b.dst_off[k];
-		c.has_fwd = b.fwd_off[k] >= 0;
-		fwd_off = c.has_fwd ? (uint64_t)b.fwd_off[k] : dst_off;
-	} else {
-		dst_off = (uint64_t)p * b.g.frame_bytes;
-		c.has_fwd = pic.fwd >= 0;
-		fwd_off = c.has_fwd ? (uint64_t)pic.fwd * b.g.frame_bytes : dst_off;
-	}
-	c.dst = b.pool + dst_off;
-	c.fwd = b.pool + fwd_off;
+	c.mb = b.mb + D.mb_first;
+	c.tok = b.tokens + D.tok_off;
+	c.has_fwd = D.fwd_off != JM_NO_FWD;
+	c.dst = b.pool + D.dst_off;
+	c.fwd = b.pool + (c.has_fwd ? D.fwd_off : D.dst_off);
 	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;
@@ -338,19 +328,25 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0));
 	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(need);
+	if (threadIdx.x < 12) reinterpret_cast<uint4 *>(qm)[threadIdx.x] = tq;
 	__syncthreads();
 	uint32_t rank = before, total = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < JM_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) rank += t; total += t; }
 	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
+#ifndef JM_EXP_NO_SCATTER
 	if (B.idct) jm_recon_scatter(c, B, mine);
+#endif
 	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
 	__syncthreads();
 	/* phase 2: wavefronts past the last packed block skip the transform altogether */
 	if (threadIdx.x < total) jm_recon_idct(own);
 	__syncthreads();
 	/* phase 3 */
+#ifdef JM_EXP_NO_BACK
+	B.idct = false; B.konst = 0;
+#endif
 	if (valid) jm_recon_back(c, B, mine);
 }
 

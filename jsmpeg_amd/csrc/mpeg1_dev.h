@@ -19,6 +19,7 @@
 #ifndef JSMPEG_AMD_MPEG1_DEV_H
 #define JSMPEG_AMD_MPEG1_DEV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -65,9 +66,11 @@ struct JmStream {
 	int32_t width, height;
 	int32_t mb_width, mb_height, mb_size;
 	int32_t rate_code;
+	int32_t pad_[2];               /* intra_q | nonintra_q: 128 contiguous bytes at a 16-byte aligned offset (k_recon stages them with eight 16-byte loads) */
 	uint8_t intra_q[64];           /* raster order (de-zig-zagged, mpeg1.c:887-904) */
 	uint8_t nonintra_q[64];
 };
+static_assert(offsetof(JmStream, intra_q) % 16 == 0 && offsetof(JmStream, nonintra_q) == offsetof(JmStream, intra_q) + 64 && sizeof(JmStream) % 16 == 0, "JmStream layout");
 
 /* One picture start code of a batch. */
 struct JmPic {

@@ -18,7 +18,7 @@
  *     ds_read_b128 -- the slot stride of 36 dwords makes those conflict-free;
  *   - every multiplication of the IDCT network is a 24-bit one (v_mad_i32_i24,
  *     full rate; v_mul_lo_u32 is quarter rate): operands are bounded by
- *     5.3e6 < 2^23 for ANY token stream (levels are clipped to +-2048 before
+ *     4.4e6 < 2^23 for ANY token stream (levels are clipped to +-2048 before
  *     the premultiplier; tools/idct_bounds.py), and the low 32 bits of the
  *     result equal the reference's wrapping int32 arithmetic;
  *   - the four half-pel cases are one branch-free formula on packed bytes
@@ -56,6 +56,11 @@ JM_D int jm_mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d
 JM_D int jm_mad24(int a, int k, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc)); return d; }
 /* per byte (a + b + (c & 1)) >> 1 */
 JM_D uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
+/* bytes of b:a picked by the selector (byte k of the result = byte sel_k of the 8 bytes b3..b0 a3..a0 -- a is the low dword; 0x0c = 0) */
+JM_D uint32_t jm_perm(uint32_t b, uint32_t a, uint32_t sel) { return __builtin_amdgcn_perm(b, a, sel); }
+/* two int16 lanes: saturating add; saturate each to 0..255 and pack into the low 16 bits */
+JM_D uint32_t jm_pk_add_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+JM_D uint32_t jm_sat_pk_u8(uint32_t a) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(a)); return d & 0xffffu; }
 /* 4 bytes starting `shift` (0..3) bytes into lo:hi */
 JM_D uint32_t jm_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
 #else
@@ -71,6 +76,28 @@ JM_HD uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) {
 }
 JM_HD uint32_t jm_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) {
 	return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (shift & 3)));
+}
+JM_HD uint32_t jm_perm(uint32_t b, uint32_t a, uint32_t sel) {
+	const uint64_t v = ((uint64_t)b << 32) | a;
+	uint32_t r = 0;
+	for (int k = 0; k < 4; k++) {
+		const uint32_t q = (sel >> (8 * k)) & 255u;
+		r |= (q < 8 ? (uint32_t)((v >> (8 * q)) & 255u) : 0u) << (8 * k);   /* only selectors 0..7 and 0x0c are used here */
+	}
+	return r;
+}
+JM_HD uint32_t jm_pk_add_sat(uint32_t a, uint32_t b) {
+	uint32_t r = 0;
+	for (int k = 0; k < 32; k += 16) {
+		int v = (int)(int16_t)(a >> k) + (int)(int16_t)(b >> k);
+		v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+		r |= ((uint32_t)v & 0xffffu) << k;
+	}
+	return r;
+}
+JM_HD uint32_t jm_sat_pk_u8(uint32_t a) {
+	const int lo = (int)(int16_t)a, hi = (int)(int16_t)(a >> 16);
+	return (uint32_t)(lo < 0 ? 0 : (lo > 255 ? 255 : lo)) | ((uint32_t)(hi < 0 ? 0 : (hi > 255 ? 255 : hi)) << 8);
 }
 #endif
 JM_HD int jm_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -298,12 +325,14 @@ JM_HD void jm_recon_idct(Slot &s) {
 		JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
 #pragma unroll
 	for (int i = 0; i < 64; i += 8)
-		JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_SHIFT)
+		JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_NONE)
+	/* the final >> 8 and the int16 pair in one v_perm: bytes 1..2 of each value.  No saturation is
+	 * needed: |output| <= 18473 for any levels in [-2048, 2047] (tools/idct_bounds.py). */
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
 		uint32_t pk[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) pk[k] = jm_pack_sat16(v[8 * i + 2 * k], v[8 * i + 2 * k + 1]);
+		for (int k = 0; k < 4; k++) pk[k] = jm_perm((uint32_t)v[8 * i + 2 * k + 1], (uint32_t)v[8 * i + 2 * k], 0x06050201u);
 		s.put8p(i, pk);
 	}
 }
@@ -321,19 +350,16 @@ JM_HD void jm_recon_predict(JmBlk &B) {
 		uint32_t u0p = 0, u1p = 0, e0p = 0, e1p = 0;
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
+			/* bytes m .. m + 11 of the row, then one byte further when oh */
 			const uint32_t a0 = jm_alignbyte(R[3 * r + 1], R[3 * r], m), a1 = jm_alignbyte(R[3 * r + 2], R[3 * r + 1], m);
-			/* bytes m+1 .. : shift by one more byte when oh (m + oh may be 4: take the next dword) */
-			const uint32_t mo = m + oh, ms = mo & 3u;
-			const uint32_t lo = mo > 3 ? R[3 * r + 1] : R[3 * r], mid = mo > 3 ? R[3 * r + 2] : R[3 * r + 1];
-			const uint32_t hi = mo > 3 ? 0u : R[3 * r + 2];
-			const uint32_t b0 = jm_alignbyte(mid, lo, ms), b1 = jm_alignbyte(hi, mid, ms);
+			const uint32_t a2 = R[3 * r + 2] >> (8 * m);
+			const uint32_t b0 = jm_alignbyte(a1, a0, oh), b1 = jm_alignbyte(a2, a1, oh);
 			const uint32_t u0 = jm_lerp(a0, b0, 0x01010101u), u1 = jm_lerp(a1, b1, 0x01010101u);
 			const uint32_t e0 = ~(a0 ^ b0), e1 = ~(a1 ^ b1);       /* bit 0 of each byte: A + B even */
 			if (r > 0) {
-				/* output row r - 1 pairs row r - 1 with row r - 1 + ov */
-				const uint32_t v0 = ov ? u0 : u0p, v1 = ov ? u1 : u1p, f0 = ov ? e0 : e0p, f1 = ov ? e1 : e1p;
-				B.P[2 * (r - 1)] = jm_lerp(u0p, v0, e0p & f0);
-				B.P[2 * (r - 1) + 1] = jm_lerp(u1p, v1, e1p & f1);
+				/* output row r - 1 pairs row r - 1 with row r - 1 + ov (with itself the carry operand does not matter) */
+				B.P[2 * (r - 1)] = jm_lerp(u0p, ov ? u0 : u0p, e0p & e0);
+				B.P[2 * (r - 1) + 1] = jm_lerp(u1p, ov ? u1 : u1p, e1p & e1);
 			}
 			u0p = u0; u1p = u1; e0p = e0; e1p = e1;
 		}
@@ -354,23 +380,22 @@ JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 #pragma unroll
 	for (int i = 0; i < 16; i++) P[i] = B.P[i];
 
-	/* ---- residual: from the slot, or the same value everywhere; add and clamp (mpeg1.c:1620-1644) ---- */
+	/* ---- residual: from the slot, or the same value everywhere; add and clamp (mpeg1.c:1620-1644),
+	 * two pixels per instruction: bytes -> int16 pairs (v_perm), saturating packed add, saturate to
+	 * 0..255 and pack (v_sat_pk_u8_i16) ---- */
 	if (B.idct || B.konst != 0) {
 		const uint32_t kk = ((uint32_t)B.konst & 0xffffu) * 0x00010001u;
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
 			uint32_t pk[4] = { kk, kk, kk, kk };
 			if (B.idct) s.get8p(r, pk);
-			const uint32_t p0 = P[2 * r], p1 = P[2 * r + 1];
-			uint32_t o0 = 0, o1 = 0;
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int r0 = (int)(int16_t)((k & 1) ? (pk[k >> 1] >> 16) : (pk[k >> 1] & 0xffffu));
-				const int r1 = (int)(int16_t)((k & 1) ? (pk[2 + (k >> 1)] >> 16) : (pk[2 + (k >> 1)] & 0xffffu));
-				o0 |= (uint32_t)jm_clamp255((int)((p0 >> (8 * k)) & 255) + r0) << (8 * k);
-				o1 |= (uint32_t)jm_clamp255((int)((p1 >> (8 * k)) & 255) + r1) << (8 * k);
+			for (int h = 0; h < 2; h++) {
+				const uint32_t p = P[2 * r + h];
+				const uint32_t lo = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c010c00u), pk[2 * h]));
+				const uint32_t hi = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c030c02u), pk[2 * h + 1]));
+				P[2 * r + h] = lo | (hi << 16);
 			}
-			P[2 * r] = o0; P[2 * r + 1] = o1;
 		}
 	}
 
