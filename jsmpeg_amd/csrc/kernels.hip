@@ -226,24 +226,20 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
-	const int thr[JM_ST_KINDS] = { JM_T_COLD, JM_T_DC, JM_T_COEF, JM_T_SLOW, JM_T_WAIT, 0 };
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
-		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, 3 token slots) */
-		const int want = L.state == JM_ST_DONE ? JM_ST_DONE : (ready ? L.state : JM_ST_WAIT);
-		int n[JM_ST_KINDS];
-		n[JM_ST_COLD] = __builtin_popcountll(__ballot(want == JM_ST_COLD)); n[JM_ST_DC] = __builtin_popcountll(__ballot(want == JM_ST_DC));
-		n[JM_ST_COEF] = __builtin_popcountll(__ballot(want == JM_ST_COEF)); n[JM_ST_SLOW] = __builtin_popcountll(__ballot(want == JM_ST_SLOW));
-		n[JM_ST_WAIT] = __builtin_popcountll(__ballot(want == JM_ST_WAIT)); n[JM_ST_DONE] = 0;
-		if (n[JM_ST_COLD] + n[JM_ST_DC] + n[JM_ST_COEF] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
-		const uint32_t run = jm_turn_mask(n, thr);
-		if (run & (1u << JM_ST_WAIT)) { if (want != JM_ST_DONE) jm_lane_service(L); }
-		if (run & (1u << JM_ST_SLOW)) { if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c); }
-		if (run & (1u << JM_ST_COLD)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
-		if (run & (1u << JM_ST_DC)) { if (ready && L.state == JM_ST_DC) jm_step_dc(L, c); }
-		if (run & (1u << JM_ST_COEF)) {
+		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, its token slots) */
+		const bool live = L.state != JM_ST_DONE;
+		const int n_cold = __builtin_popcountll(__ballot(live && ready && L.state == JM_ST_COLD));
+		const uint64_t blocked = __ballot(live && !ready);
+		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
+		if (n_cold == 0 && !others) break;
+		if (blocked) { if (live) jm_lane_service(L); }
+		if (jm_run_cold(n_cold, others ? 1 : 0, JM_T_COLD)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
+		if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
 #pragma unroll
-			for (int k = 0; k < JM_COEF_REPEAT; k++) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
-		}
+		for (int k = 1; k < JM_COEF_REPEAT; k++) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
 	}
 	if (mine) jm_lane_finish(L);
 }

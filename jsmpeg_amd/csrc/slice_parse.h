@@ -62,7 +62,7 @@
 #ifndef JM_COEF_REPEAT
 #define JM_COEF_REPEAT 2   /* COEF steps per turn                                                         */
 #endif
-#define JM_STEP_BITS (88 + 9 * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, COEF 9 each; or SLOW 28 + COEF */
+#define JM_STEP_BITS (116 + 9 * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 9 each */
 #define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
 
 enum { JM_ST_COLD = 0, JM_ST_DC = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
@@ -454,41 +454,14 @@ JM_HD int jm_lane_wants(const JmLane &L) {
 	return jm_lane_blocked(L) ? JM_ST_WAIT : L.state;
 }
 
-/* The wavefront's scheduling rule.  At every turn each kind of step whose queue (lanes waiting for
- * it) has reached its threshold runs, in the order WAIT (ring service), SLOW, COLD, DC, COEF -- a lane
- * can take several steps in one turn (header, DC and first coefficient of a macroblock: at most
- * 65 + 16 + 9 bits, within JM_STEP_BITS).  Cheap common steps have a threshold of 1; the long rare
- * ones wait until enough lanes share their cost.  When no queue has reached its threshold the
- * longest one runs. */
+/* The wavefront's scheduling rule.  Every turn runs, in this order: ring service (if a lane is
+ * blocked), COLD (if enough lanes queue for it), DC, COEF, SLOW, COEF -- a lane can take several
+ * steps in one turn (header, DC and the first coefficients of a macroblock: at most JM_STEP_BITS
+ * bits).  Only the long header step is worth queueing for (measured, profiles/r01_parse_notes.md):
+ * it runs when JM_T_COLD lanes wait for it, or when nothing else in the wave can move. */
 #ifndef JM_T_COLD
-#define JM_T_COLD 16
+#define JM_T_COLD 20
 #endif
-#ifndef JM_T_DC
-#define JM_T_DC 1
-#endif
-#ifndef JM_T_COEF
-#define JM_T_COEF 1
-#endif
-#ifndef JM_T_SLOW
-#define JM_T_SLOW 6
-#endif
-#ifndef JM_T_WAIT
-#define JM_T_WAIT 6
-#endif
-JM_HD uint32_t jm_turn_mask(const int n[JM_ST_KINDS], const int thr[JM_ST_KINDS]) {
-	uint32_t m = (n[JM_ST_COLD] >= thr[JM_ST_COLD] ? 1u << JM_ST_COLD : 0u) | (n[JM_ST_DC] >= thr[JM_ST_DC] ? 1u << JM_ST_DC : 0u) |
-	             (n[JM_ST_COEF] >= thr[JM_ST_COEF] ? 1u << JM_ST_COEF : 0u) | (n[JM_ST_SLOW] >= thr[JM_ST_SLOW] ? 1u << JM_ST_SLOW : 0u) |
-	             (n[JM_ST_WAIT] >= thr[JM_ST_WAIT] ? 1u << JM_ST_WAIT : 0u);
-	if (m == 0) {
-		/* (count << 3 | kind) orders by count */
-		uint32_t best = ((uint32_t)n[JM_ST_COLD] << 3) | JM_ST_COLD, v;
-		v = ((uint32_t)n[JM_ST_DC] << 3) | JM_ST_DC; if (v > best) best = v;
-		v = ((uint32_t)n[JM_ST_COEF] << 3) | JM_ST_COEF; if (v > best) best = v;
-		v = ((uint32_t)n[JM_ST_SLOW] << 3) | JM_ST_SLOW; if (v > best) best = v;
-		v = ((uint32_t)n[JM_ST_WAIT] << 3) | JM_ST_WAIT; if (v > best) best = v;
-		m = 1u << (best & 7u);
-	}
-	return m;
-}
+JM_HD bool jm_run_cold(int n_cold, int n_other, int threshold) { return n_cold >= threshold || (n_cold > 0 && n_other == 0); }
 
 #endif

@@ -25,7 +25,7 @@ struct HostSlot {
 
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
 // kind, and lanes that were served in those turns.
-static int g_thr[JM_ST_KINDS] = { JM_T_COLD, JM_T_DC, JM_T_COEF, JM_T_SLOW, JM_T_WAIT, 0 };   // experiments: the scheduler's thresholds
+static int g_thr[JM_ST_KINDS] = { JM_T_COLD, 1, 1, 1, 1, 0 };   // experiments: the scheduler's COLD threshold
 static uint64_t g_picks;           // turns (scheduling decisions)
 static uint64_t g_cost;            // cost model: instructions issued by the wavefronts
 static int g_kcost[JM_ST_KINDS + 1] = { 430, 60, 95, 110, 270, 0, 50 };   // per handler; [KINDS] = per turn
@@ -122,25 +122,26 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			mine[l] = true;
 		}
 		for (;;) {
-			int want[64], n[JM_ST_KINDS] = { 0, 0, 0, 0, 0, 0 };
 			bool ready[64];
+			int n_cold = 0, n_other = 0, n_blocked = 0;
 			for (int l = 0; l < 64; l++) {
 				ready[l] = !jm_lane_blocked(L[l]);
-				want[l] = L[l].state == JM_ST_DONE ? JM_ST_DONE : (ready[l] ? L[l].state : JM_ST_WAIT);
-				n[want[l]]++;
+				if (L[l].state == JM_ST_DONE) continue;
+				if (!ready[l]) { n_blocked++; n_other++; }
+				else if (L[l].state == JM_ST_COLD) n_cold++;
+				if (L[l].state != JM_ST_COLD) n_other++;
 			}
-			n[JM_ST_DONE] = 0;
-			if (n[JM_ST_COEF] + n[JM_ST_DC] + n[JM_ST_COLD] + n[JM_ST_SLOW] + n[JM_ST_WAIT] == 0) break;
-			const uint32_t run = jm_turn_mask(n, g_thr);
+			if (n_cold == 0 && n_other == 0) break;
 			g_picks++; g_cost += (uint64_t)g_kcost[JM_ST_KINDS];
-			if (run & (1u << JM_ST_WAIT)) {
-				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n[JM_ST_WAIT]; g_cost += (uint64_t)g_kcost[JM_ST_WAIT];
-				for (int l = 0; l < 64; l++) if (want[l] != JM_ST_DONE) jm_lane_service(L[l]);
+			if (n_blocked) {
+				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n_blocked; g_cost += (uint64_t)g_kcost[JM_ST_WAIT];
+				for (int l = 0; l < 64; l++) if (L[l].state != JM_ST_DONE) jm_lane_service(L[l]);
 			}
-			static const int order[3 + 4] = { JM_ST_SLOW, JM_ST_COLD, JM_ST_DC, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF };
+			const bool cold = jm_run_cold(n_cold, n_other, g_thr[JM_ST_COLD]);
+			static const int order[4 + 4] = { JM_ST_COLD, JM_ST_DC, JM_ST_COEF, JM_ST_SLOW, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF };
 			for (int oi = 0; oi < 3 + JM_COEF_REPEAT; oi++) {
 				const int k = order[oi];
-				if (!(run & (1u << k))) continue;
+				if (k == JM_ST_COLD && !cold) continue;
 				int served = 0;
 				for (int l = 0; l < 64; l++) if (ready[l] && L[l].state == k) {
 					served++;
