@@ -303,7 +303,7 @@ def main():
         "metric": "1080p MPEG-1 decode throughput", "value": round(fps, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8 planes / int32 arithmetic", "data": "synthetic",
+        "dtype": "int32", "data": "synthetic",
         "config": {"workload": "%s: %d streams x %d pictures 1920x1080 I+P (GOP 12) per GPU, batched; cfg3 sharding at N>1"
                                % (CONFIG, n_streams, frames),
                    "streams": g_streams, "pictures_per_step": g_pictures, "es_bytes_per_gpu": es_bytes,

@@ -255,6 +255,9 @@ hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
  * dispatched to the same XCD (workgroup b runs on XCD b % 8) so the forward
  * frame's prediction reads hit one L2.
  * ---------------------------------------------------------------------- */
+#ifndef JM_RECON_WG
+#define JM_RECON_WG 256   /* lanes = 8x8 blocks per workgroup; LDS: 144 bytes per lane */
+#endif
 #define JM_SLOT_HALVES 72   /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
 
 struct LdsSlot {
@@ -279,16 +282,16 @@ struct LdsSlot {
 	}
 };
 
-__global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
-	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_WG];
+__global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
+	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_WG];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
-	__shared__ uint32_t wave_total[JM_WG / 64];
+	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
 	const JmReconDesc D = b.desc[k];                 /* uniform: one scalar load */
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
-	const int g = (int)(blk * JM_WG + threadIdx.x);
+	const int g = (int)(blk * JM_RECON_WG + threadIdx.x);
 	const bool valid = g < 6 * b.g.mb_size;
 	JmLoc Q;
 	jm_recon_locate(b.g, b.mb + D.mb_first, valid ? g : 0, Q);
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 	__syncthreads();
 	uint32_t rank = before, total = 0;
 #pragma unroll
-	for (uint32_t i = 0; i < JM_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) rank += t; total += t; }
+	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) rank += t; total += t; }
 	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
 #ifndef JM_EXP_NO_SCATTER
@@ -348,9 +351,9 @@ __global__ __launch_bounds__(JM_WG) void k_recon(JmReconBufs b, uint32_t blocks_
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	if (b.n_level_pics == 0) return hipSuccess;
-	uint32_t bpp = (uint32_t)(6 * b.g.mb_size + JM_WG - 1) / JM_WG;
+	uint32_t bpp = (uint32_t)(6 * b.g.mb_size + JM_RECON_WG - 1) / JM_RECON_WG;
 	uint32_t groups = (b.n_level_pics + 7) / 8;
-	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * bpp), dim3(JM_WG), 0, st, b, bpp);
+	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * bpp), dim3(JM_RECON_WG), 0, st, b, bpp);
 	return hipGetLastError();
 }
 

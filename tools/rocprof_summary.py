@@ -18,7 +18,7 @@ tag, d_trace, d_fetch, d_write = sys.argv[1:5]
 
 
 def db(d):
-    return sqlite3.connect(glob.glob(os.path.join(d, "*.db"))[0])
+    return sqlite3.connect(sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))[-1])
 
 
 def short(n):
