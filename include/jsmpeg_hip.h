@@ -72,6 +72,16 @@ bool mpeg1_decoder_decode(mpeg1_decoder_t *self);
  * contiguous, 1.5 * coded_size bytes), for consumers that stay on the GPU. */
 void *jsmpeg_hip_decoder_get_device_frame(mpeg1_decoder_t *self);
 
+/* Additive, renderer stage: the most recently decoded picture
+ * as RGBA -- exactly the bytes the reference's Canvas2D renderer leaves in
+ * imageData.data (src/canvas2d.js:48-122: integer BT.601 per 2x2 pixels,
+ * display size width * height * 4, alpha 255; with an odd width the
+ * reference's running indices shear the picture by a pixel per row pair and
+ * leave unwritten pixels opaque white -- reproduced) -- converted on the
+ * device, copied to `host_rgba`.
+ * Returns 0 or < 0. */
+int jsmpeg_hip_decoder_render_rgba(mpeg1_decoder_t *self, void *host_rgba);
+
 /* ------------------------------------------------------------------ part 2
  * Batch decode: N elementary streams, every picture, planes stay in HBM.   */
 
@@ -130,6 +140,13 @@ int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t picture, void *y
 /* 64-bit content hash of every picture's planes, computed on the device
  * (jsmpeg_amd/hashing.py gives the same value for host planes). out[picture_count]. */
 int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *out);
+/* Renderer stage (src/canvas2d.js:53-122) for pictures [first_picture,
+ * first_picture + count): RGBA frames of width * height * 4 bytes, packed one
+ * after the other into the DEVICE buffer `dev_rgba`, enqueued on `hip_stream`. */
+int jsmpeg_hip_batch_render_rgba(jsmpeg_hip_batch_t *b, uint32_t first_picture, uint32_t count,
+                                 void *dev_rgba, void *hip_stream);
+/* Same conversion for ONE picture, copied to host memory (width * height * 4 bytes). */
+int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba);
 /* hipEvent timings of the last decode, milliseconds: [0] start-code index +
  * tables, [1] host table turn-around, [2] slice parse, [3] reconstruct,
  * [4] total.  Valid after jsmpeg_hip_batch_sync. */

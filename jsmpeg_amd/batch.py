@@ -24,7 +24,9 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
-                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_last_error",
+                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
+                 "jsmpeg_hip_batch_read_rgba",
+                 "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
                  "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
 
 _lib = None
@@ -64,6 +66,10 @@ def lib():
         L.jsmpeg_hip_batch_read_frame.argtypes = [vp, u32, vp, vp, vp]
         L.jsmpeg_hip_batch_frame_hashes.restype = ctypes.c_int
         L.jsmpeg_hip_batch_frame_hashes.argtypes = [vp, vp]
+        L.jsmpeg_hip_batch_render_rgba.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_render_rgba.argtypes = [vp, u32, u32, vp, vp]
+        L.jsmpeg_hip_batch_read_rgba.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_read_rgba.argtypes = [vp, u32, vp]
         L.jsmpeg_hip_batch_timings.restype = ctypes.c_int
         L.jsmpeg_hip_batch_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.jsmpeg_hip_batch_counters.restype = ctypes.c_int
@@ -84,6 +90,7 @@ class Batch:
     def __init__(self, width, height, max_streams, max_pictures, max_es_bytes, device=-1):
         self.L = lib()
         cfg = BatchConfig(width, height, max_streams, max_pictures, max_es_bytes, device)
+        self.width, self.height = width, height
         self.h = self.L.jsmpeg_hip_batch_create(ctypes.byref(cfg))
         if not self.h:
             raise RuntimeError("jsmpeg_hip_batch_create: " + last_error())
@@ -154,6 +161,17 @@ class Batch:
         out = np.zeros(max(1, self.picture_count), dtype=np.uint64)
         self._ok(self.L.jsmpeg_hip_batch_frame_hashes(self.h, out.ctypes.data))
         return out[:self.picture_count]
+
+    def render_rgba_device(self, first, count, dev_ptr, stream=None):
+        """Renderer stage on the device: pictures [first, first + count) -> RGBA (width * height * 4 bytes each,
+        display size) into the device buffer `dev_ptr`, enqueued on `stream`."""
+        self._ok(self.L.jsmpeg_hip_batch_render_rgba(self.h, first, count, dev_ptr, stream))
+
+    def read_rgba(self, p):
+        """Picture p as RGBA uint8[height, width, 4]: device conversion, then a copy to the host."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_batch_read_rgba(self.h, p, out.ctypes.data))
+        return out
 
     def timings(self):
         ms = (ctypes.c_float * 5)()

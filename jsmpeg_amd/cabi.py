@@ -104,6 +104,17 @@ class Mpeg1Decoder:
     def height(self):
         return self.lib.mpeg1_decoder_get_height(self.h)
 
+    def render_rgba(self):
+        """Product only (libjsmpeg_hip.so): the most recently decoded picture as RGBA, converted on the
+        device (jsmpeg_hip_decoder_render_rgba); uint8[height, width, 4]."""
+        fn = self.lib.jsmpeg_hip_decoder_render_rgba
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        if fn(self.h, out.ctypes.data) < 0:
+            raise RuntimeError("jsmpeg_hip_decoder_render_rgba failed")
+        return out
+
     def planes(self):
         """Copies of the most recently decoded (Y, Cr, Cb) coded-size planes."""
         n = self.coded_size
@@ -148,3 +159,16 @@ def decode_stream(path, es, pic_offsets=None, buffer_size=None, mode=MODE_EXPAND
             pull()
         info = dict(width=dec.width, height=dec.height, coded_size=dec.coded_size, frame_rate=dec.frame_rate)
     return frames, indices, info
+
+
+def oracle_rgba(oracle_path, y, cr, cb, width, height):
+    """CHECKER ONLY: the reference's Canvas2D colour conversion restated on the CPU (oracle/ycbcr_oracle.c);
+    uint8[height, width, 4]."""
+    lib = ctypes.CDLL(oracle_path)
+    fn = lib.ycbcr_oracle_to_rgba
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    y, cr, cb = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cr, cb))
+    out = np.empty((height, width, 4), dtype=np.uint8)
+    fn(y.ctypes.data, cr.ctypes.data, cb.ctypes.data, width, height, out.ctypes.data)
+    return out

@@ -52,6 +52,7 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 		JmVlcLuts *d = nullptr;
 		HIP_TRY(hipMalloc(&d, sizeof(JmVlcLuts)));
 		HIP_TRY(hipMemcpy(d, &host, sizeof(host), hipMemcpyHostToDevice));
+		HIP_TRY(hipDeviceSynchronize());   /* the tables are read from streams that are not ordered against the null stream */
 		g_luts_dev[dev] = d;
 	}
 	*out = g_luts_dev[dev];
@@ -85,6 +86,7 @@ struct jsmpeg_hip_batch_t {
 	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
+	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
 	uint32_t *d_dbg;
 	uint8_t epoch;
 
@@ -99,7 +101,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_mb); hipFree(b->d_tokens);
-	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg);
+	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	delete b;
@@ -126,6 +128,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
 	HIP_TRY(hipMalloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
+	HIP_TRY(hipDeviceSynchronize());   /* the memsets ran on the null stream; decode may use a stream that is not ordered against it */
 	HIP_TRY(hipMalloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
 	size_t pool_bytes = (size_t)b->g.frame_bytes * std::max(1u, c.max_pictures) + 2 * POOL_GUARD;
 	HIP_TRY(hipMalloc(&b->d_pool_alloc, pool_bytes));
@@ -152,7 +155,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
-	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr;
+	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	for (auto &e : b->ev) e = nullptr;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
 	b->timed = false; b->stream = nullptr;
@@ -200,6 +203,7 @@ extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams
 	if (batch_layout(b, n_streams, es_bytes) != 0) return -1;
 	/* gaps (and everything else) 0xff: can never complete a 00 00 01 */
 	HIP_TRY(hipMemset(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD));
+	HIP_TRY(hipDeviceSynchronize());
 	for (uint32_t i = 0; i < n_streams; i++)
 		HIP_TRY(hipMemcpy(b->d_es + b->h_streams[i].es_begin, es[i], es_bytes[i], hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice));
@@ -372,6 +376,37 @@ extern "C" int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *ou
 	return 0;
 }
 
+/* Renderer stage on the device (reference src/canvas2d.js:53-122): pictures [first, first + count) of the pool
+ * -> RGBA, display size, into a device buffer. */
+extern "C" int jsmpeg_hip_batch_render_rgba(jsmpeg_hip_batch_t *b, uint32_t first_picture, uint32_t count,
+                                            void *dev_rgba, void *hip_stream) {
+	g_err[0] = 0;
+	if (!b || !dev_rgba) return fail("null argument");
+	if ((uint64_t)first_picture + count > b->n_pics) return fail("picture range [%u, %u) outside the %u decoded pictures", first_picture, first_picture + count, b->n_pics);
+	HIP_TRY(hipSetDevice(b->device));
+	JmRgbaBufs r;
+	r.frames = b->d_pool; r.first_frame = first_picture; r.n_frames = count;
+	r.frame_stride = b->g.frame_bytes; r.luma_bytes = b->g.luma_bytes; r.chroma_bytes = b->g.chroma_bytes;
+	r.coded_width = b->g.coded_width; r.coded_height = b->g.coded_height; r.width = b->cfg.width; r.height = b->cfg.height;
+	r.rgba = (uint8_t *)dev_rgba; r.rgba_stride = (uint64_t)b->cfg.width * b->cfg.height * 4;
+	HIP_TRY(jm_launch_rgba(r, (hipStream_t)hip_stream));
+	return 0;
+}
+
+/* One picture as RGBA in host memory (device conversion into a scratch frame, then a copy). */
+extern "C" int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba) {
+	g_err[0] = 0;
+	if (!b || !host_rgba) return fail("null argument");
+	if (picture >= b->n_pics) return fail("bad picture index");
+	HIP_TRY(hipSetDevice(b->device));
+	const size_t bytes = (size_t)b->cfg.width * b->cfg.height * 4;
+	if (!b->d_rgba) HIP_TRY(hipMalloc(&b->d_rgba, bytes));
+	if (jsmpeg_hip_batch_render_rgba(b, picture, 1, b->d_rgba, b->stream) < 0) return -1;
+	HIP_TRY(hipMemcpyAsync(host_rgba, b->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
 extern "C" int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]) {
 	g_err[0] = 0;
 	if (!b || !b->timed) return fail("no timed decode");
@@ -449,6 +484,7 @@ struct mpeg1_decoder_t {
 	uint8_t *d_pool_alloc, *d_pool;  /* two frames */
 	int cur;                         /* frame index being written next (planes_current) */
 	uint8_t *h_frame;                /* pinned: last decoded Y | Cr | Cb */
+	uint8_t *d_rgba; size_t rgba_cap; /* renderer stage scratch (jsmpeg_hip_decoder_render_rgba) */
 	uint8_t epoch;
 	std::vector<uint32_t> stage_pos; std::vector<uint8_t> stage_code;
 };
@@ -467,7 +503,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	d->d_sc_owner = nullptr; d->d_pic_sc = nullptr; d->d_counters = nullptr; d->h_scan_pos = nullptr;
 	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_desc = nullptr;
 	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr;
-	d->h_frame = nullptr; d->stream = nullptr;
+	d->h_frame = nullptr; d->stream = nullptr; d->d_rgba = nullptr; d->rgba_cap = 0;
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->d_es_cap = 0; d->mirrored = 0; d->scan_cap = 0; d->tokens_cap = 0;
 	d->has_sequence_header = 0; d->frame_rate = 0; d->width = d->height = 0; d->cur = 0; d->epoch = 0;
@@ -493,7 +529,7 @@ static int dec_fail_cleanup(mpeg1_decoder_t *d) {
 	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
 	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
 	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_desc);
-	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipHostFree(d->h_frame);
+	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_rgba); hipHostFree(d->h_frame);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
 	return -1;
@@ -551,7 +587,8 @@ static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
 	if (d->d_es_cap < need_es) {
 		hipFree(d->d_es); d->d_es = nullptr;
 		HIP_TRY(hipMalloc(&d->d_es, need_es));
-		HIP_TRY(hipMemset(d->d_es, 0xff, need_es));
+		/* on the decoder's stream: it is a non-blocking stream, work on the null stream is NOT ordered against it */
+		HIP_TRY(hipMemsetAsync(d->d_es, 0xff, need_es, d->stream));
 		d->d_es_cap = need_es; d->mirrored = 0;
 	}
 	unsigned need = bytes / 4 + 64; /* at most one start code per 4 bytes */
@@ -648,10 +685,10 @@ static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
 	if (d->g.mb_size <= 0) return fail("sequence header with empty picture");
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)d->g.mb_size;
 	HIP_TRY(hipMalloc(&d->d_mb, mb_bytes));
-	HIP_TRY(hipMemset(d->d_mb, 0, mb_bytes));
+	HIP_TRY(hipMemsetAsync(d->d_mb, 0, mb_bytes, d->stream));
 	size_t pool = 2 * (size_t)d->g.frame_bytes + 2 * POOL_GUARD;
 	HIP_TRY(hipMalloc(&d->d_pool_alloc, pool));
-	HIP_TRY(hipMemset(d->d_pool_alloc, 0, pool));   /* zero planes like the JS typed arrays (mpeg1.js:131-152) */
+	HIP_TRY(hipMemsetAsync(d->d_pool_alloc, 0, pool, d->stream));   /* zero planes like the JS typed arrays (mpeg1.js:131-152) */
 	d->d_pool = d->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(hipHostMalloc(&d->h_frame, d->g.frame_bytes, hipHostMallocDefault));
 	memset(d->h_frame, 0, d->g.frame_bytes);
@@ -688,6 +725,31 @@ extern "C" void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *d) {
 }
 extern "C" void *jsmpeg_hip_decoder_get_device_frame(mpeg1_decoder_t *d) {
 	return d && d->d_pool ? d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes : nullptr;
+}
+
+/* Renderer stage for the one-picture interface: the most recently decoded picture as RGBA (display size,
+ * width * height * 4 bytes) in host memory -- what CanvasRenderer.render leaves in imageData.data
+ * (reference src/canvas2d.js:48-122). */
+extern "C" int jsmpeg_hip_decoder_render_rgba(mpeg1_decoder_t *d, void *host_rgba) {
+	g_err[0] = 0;
+	if (!d || !host_rgba) return fail("null argument");
+	if (!d->has_sequence_header || !d->d_pool) return fail("no picture decoded yet");
+	HIP_TRY(hipSetDevice(d->device));
+	const size_t bytes = (size_t)d->width * d->height * 4;
+	if (d->rgba_cap < bytes) {
+		hipFree(d->d_rgba); d->d_rgba = nullptr; d->rgba_cap = 0;
+		HIP_TRY(hipMalloc(&d->d_rgba, bytes));
+		d->rgba_cap = bytes;
+	}
+	JmRgbaBufs r;
+	r.frames = d->d_pool; r.first_frame = (uint32_t)(d->cur ^ 1); r.n_frames = 1;
+	r.frame_stride = d->g.frame_bytes; r.luma_bytes = d->g.luma_bytes; r.chroma_bytes = d->g.chroma_bytes;
+	r.coded_width = d->g.coded_width; r.coded_height = d->g.coded_height; r.width = d->width; r.height = d->height;
+	r.rgba = d->d_rgba; r.rgba_stride = bytes;
+	HIP_TRY(jm_launch_rgba(r, d->stream));
+	HIP_TRY(hipMemcpyAsync(host_rgba, d->d_rgba, bytes, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return 0;
 }
 
 /* One picture on the GPU: slices [first, end) of d->codes. */

@@ -85,4 +85,16 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,
                           uint64_t *out, hipStream_t st);
 
+/* Y | Cr | Cb frames -> RGBA (reference src/canvas2d.js:53-122), display size, rows packed */
+struct JmRgbaBufs {
+	const uint8_t *frames;       /* frame f at frames + (first_frame + f) * frame_stride, Y | Cr | Cb */
+	uint32_t first_frame, n_frames;
+	uint64_t frame_stride;
+	uint32_t luma_bytes, chroma_bytes;
+	int32_t coded_width, coded_height, width, height;
+	uint8_t *rgba;               /* out: frame f at rgba + f * rgba_stride */
+	uint64_t rgba_stride;
+};
+hipError_t jm_launch_rgba(const JmRgbaBufs &b, hipStream_t st);
+
 #endif

@@ -397,3 +397,99 @@ hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t ha
 	hipLaunchKernelGGL(k_hash, dim3(n_frames * bpf), dim3(JM_WG), 0, st, pool, frame_bytes, n_words, bpf, out);
 	return hipGetLastError();
 }
+
+/* ------------------------------------------------------------------------
+ * Renderer stage: Y/Cr/Cb planes -> RGBA, the reference's Canvas2D integer
+ * BT.601 (src/canvas2d.js:53-122): per 2x2 pixels one chroma pair,
+ *   r = (cr + ((cr * 103) >> 8)) - 179
+ *   g = ((cb * 88) >> 8) - 44 + ((cr * 183) >> 8) - 91
+ *   b = (cb + ((cb * 198) >> 8)) - 227
+ *   R = clamp(y + r), G = clamp(y - g), B = clamp(y + b), A = 255
+ * (the reference's parameter names are swapped against what it is called with,
+ * canvas2d.js:48 / mpeg1.js:235: the formula above is in TRUE Cr / Cb).  The
+ * output is display-sized (width x height, rows packed).
+ * Common sizes (k_rgba): one lane per 4 x 2 pixels -- two dword luma loads, two
+ * 16-bit chroma loads, two 16-byte stores; a wavefront writes 1 KiB contiguous
+ * per row.  HBM-bound: 1.5 B read + 4 B written per pixel.
+ * ---------------------------------------------------------------------- */
+static __device__ __forceinline__ uint32_t rgba_px(int y, int r, int g, int b) {
+	const int R = min(max(y + r, 0), 255), G = min(max(y - g, 0), 255), B = min(max(y + b, 0), 255);
+	return (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xff000000u;
+}
+
+/* width % 4 == 0 and even height: one lane per 4 x 2 pixels, rows 16-byte aligned */
+__global__ __launch_bounds__(JM_WG) void k_rgba(JmRgbaBufs b, uint32_t lanes_per_row, uint32_t blocks_per_frame) {
+	const uint32_t f = blockIdx.x / blocks_per_frame;
+	const uint32_t t = (blockIdx.x % blocks_per_frame) * JM_WG + threadIdx.x;
+	const uint32_t rp = t / lanes_per_row, j = t - rp * lanes_per_row;          /* row pair, 4-pixel column */
+	if (rp >= (uint32_t)(b.height >> 1)) return;
+	const uint8_t *frame = b.frames + (uint64_t)(b.first_frame + f) * b.frame_stride;
+	const uint8_t *Y = frame, *Cr = frame + b.luma_bytes, *Cb = Cr + b.chroma_bytes;
+	const uint32_t cw = (uint32_t)b.coded_width, x0 = 4 * j;
+	const uint32_t y0 = *reinterpret_cast<const uint32_t *>(Y + (size_t)(2 * rp) * cw + x0);
+	const uint32_t y1 = *reinterpret_cast<const uint32_t *>(Y + (size_t)(2 * rp + 1) * cw + x0);
+	const uint32_t cr2 = *reinterpret_cast<const uint16_t *>(Cr + (size_t)rp * (cw >> 1) + 2 * j);
+	const uint32_t cb2 = *reinterpret_cast<const uint16_t *>(Cb + (size_t)rp * (cw >> 1) + 2 * j);
+	uint32_t px[2][4];
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		const int cr = (int)((cr2 >> (8 * h)) & 255u), cb = (int)((cb2 >> (8 * h)) & 255u);
+		const int r = (cr + ((cr * 103) >> 8)) - 179;
+		const int g = ((cb * 88) >> 8) - 44 + ((cr * 183) >> 8) - 91;
+		const int bl = (cb + ((cb * 198) >> 8)) - 227;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			px[0][2 * h + k] = rgba_px((int)((y0 >> (8 * (2 * h + k))) & 255u), r, g, bl);
+			px[1][2 * h + k] = rgba_px((int)((y1 >> (8 * (2 * h + k))) & 255u), r, g, bl);
+		}
+	}
+	uint8_t *out = b.rgba + (uint64_t)f * b.rgba_stride;
+	uint4 *o0 = reinterpret_cast<uint4 *>(out + ((size_t)(2 * rp) * b.width + x0) * 4);
+	uint4 *o1 = reinterpret_cast<uint4 *>(out + ((size_t)(2 * rp + 1) * b.width + x0) * 4);
+	*o0 = make_uint4(px[0][0], px[0][1], px[0][2], px[0][3]);
+	*o1 = make_uint4(px[1][0], px[1][1], px[1][2], px[1][3]);
+}
+
+/* Any size, one lane per OUTPUT pixel, following the reference's running indices exactly
+ * (canvas2d.js:64-119).  Per row pair the loop advances the output by 2 * cols + width pixels and the
+ * luma index by 2 * cols + 2 * coded_width - width: with an odd width both drift by one pixel per row
+ * pair (the reference's picture is sheared), and the pixels the loop never writes keep the 255 of
+ * resize() (canvas2d.js:33).  Reproduced, not "fixed". */
+__global__ __launch_bounds__(JM_WG) void k_rgba_any(JmRgbaBufs b, uint32_t blocks_per_frame) {
+	const uint32_t f = blockIdx.x / blocks_per_frame;
+	const uint32_t p = (blockIdx.x % blocks_per_frame) * JM_WG + threadIdx.x;    /* output pixel index */
+	const uint32_t n_px = (uint32_t)b.width * (uint32_t)b.height;
+	if (p >= n_px) return;
+	const uint32_t w = (uint32_t)b.width, cw = (uint32_t)b.coded_width, cols = w >> 1, rows = (uint32_t)b.height >> 1;
+	const uint32_t S = 2 * cols + w, rp = p / S, q = p - rp * S;
+	uint32_t v = 0xffffffffu;
+	int line = -1;
+	uint32_t k = 0;
+	if (rp < rows) {
+		if (q < 2 * cols) { line = 0; k = q; }
+		else if (q >= w && q < w + 2 * cols) { line = 1; k = q - w; }
+	}
+	if (line >= 0) {
+		const uint8_t *frame = b.frames + (uint64_t)(b.first_frame + f) * b.frame_stride;
+		const uint32_t yi = rp * (2 * cols + 2 * cw - w) + (uint32_t)line * cw + k, ci = rp * (cw >> 1) + (k >> 1);
+		const int y = frame[yi], cr = frame[b.luma_bytes + ci], cb = frame[b.luma_bytes + b.chroma_bytes + ci];
+		const int r = (cr + ((cr * 103) >> 8)) - 179;
+		const int g = ((cb * 88) >> 8) - 44 + ((cr * 183) >> 8) - 91;
+		const int bl = (cb + ((cb * 198) >> 8)) - 227;
+		v = rgba_px(y, r, g, bl);
+	}
+	reinterpret_cast<uint32_t *>(b.rgba + (uint64_t)f * b.rgba_stride)[p] = v;
+}
+
+hipError_t jm_launch_rgba(const JmRgbaBufs &b, hipStream_t st) {
+	if (b.n_frames == 0 || b.width <= 0 || b.height <= 0) return hipSuccess;
+	if ((b.width & 3) == 0 && (b.height & 1) == 0) {
+		const uint32_t lanes_per_row = (uint32_t)b.width / 4, rows = (uint32_t)b.height / 2;
+		const uint32_t bpf = (lanes_per_row * rows + JM_WG - 1) / JM_WG;
+		hipLaunchKernelGGL(k_rgba, dim3(b.n_frames * bpf), dim3(JM_WG), 0, st, b, lanes_per_row, bpf);
+	} else {
+		const uint32_t bpf = ((uint32_t)b.width * (uint32_t)b.height + JM_WG - 1) / JM_WG;
+		hipLaunchKernelGGL(k_rgba_any, dim3(b.n_frames * bpf), dim3(JM_WG), 0, st, b, bpf);
+	}
+	return hipGetLastError();
+}

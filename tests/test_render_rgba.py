@@ -1,0 +1,92 @@
+"""Renderer stage: Y/Cr/Cb -> RGBA, the reference's Canvas2D integer conversion
+(src/canvas2d.js:53-122).  The fixtures tests/golden/rgba_*.json were agreed between the unmodified reference
+(mpeg1.js + canvas2d.js under Node) and the CPU restatement (tests/golden/make_golden_rgba.py).
+CPU tests pin the restatement to the fixtures; GPU tests compare k_rgba (through the C ABI) with both."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from jsmpeg_amd import cabi, synth
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "rgba_*.json")))
+IDS = [os.path.basename(p)[5:-5] for p in FIXTURES]
+
+
+def load_case(path):
+    fx = json.load(open(path))
+    es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"]
+    return fx, es, offs
+
+
+def md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_oracle_matches_reference_fixture(path, libs):
+    fx, es, _ = load_case(path)
+    frames, _, info = cabi.decode_stream(libs["oracle"], es, keep="planes")
+    got = [md5(cabi.oracle_rgba(libs["oracle"], y, cr, cb, info["width"], info["height"])) for y, cr, cb in frames]
+    assert got == fx["rgba_md5"]
+
+
+def test_oracle_odd_width_is_sheared_like_the_reference(libs):
+    """With an odd width the reference's running indices drift by one pixel per row pair (canvas2d.js:74-76, 115-119:
+    the inner loop advances 2 * cols pixels, the row step adds `width`), and what the loop never writes keeps
+    resize()'s 255 fill (canvas2d.js:33).  The fixtures pin that against the reference; this spells it out."""
+    w, h, cw, ch = 17, 33, 32, 48
+    rng = np.random.default_rng(1)
+    y = rng.integers(0, 256, cw * ch, dtype=np.uint8)
+    cr = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
+    cb = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
+    out = cabi.oracle_rgba(libs["oracle"], y, cr, cb, w, h).reshape(-1, 4)
+    cols, rows = w >> 1, h >> 1
+    S = 2 * cols + w
+    assert (out[:, 3] == 255).all()
+    assert (out[rows * S:] == 255).all()                       # never reached
+    assert all((out[rp * S + 2 * cols] == 255).all() for rp in range(rows))   # the one-pixel gap between the two lines
+    # first pixel of row pair 3, line 2: luma index 3 * (2 * cols + 2 * cw - w) + cw, chroma index 3 * (cw / 2)
+    yy, c_r, c_b = int(y[3 * (2 * cols + 2 * cw - w) + cw]), int(cr[3 * (cw >> 1)]), int(cb[3 * (cw >> 1)])
+    r = (c_r + ((c_r * 103) >> 8)) - 179
+    g = ((c_b * 88) >> 8) - 44 + ((c_r * 183) >> 8) - 91
+    b = (c_b + ((c_b * 198) >> 8)) - 227
+    want = [min(max(yy + r, 0), 255), min(max(yy - g, 0), 255), min(max(yy + b, 0), 255), 255]
+    assert out[3 * S + w].tolist() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_decoder_abi_render_rgba(path, hip_lib, libs):
+    """One-picture interface: decode, then jsmpeg_hip_decoder_render_rgba (device conversion, RGBA to the host)."""
+    fx, es, _ = load_case(path)
+    got = []
+    with cabi.Mpeg1Decoder(hip_lib, len(es) + 1024, cabi.MODE_EXPAND) as dec:
+        dec.write(es)
+        while dec.decode():
+            rgba = dec.render_rgba()
+            if len(got) < 2:   # also against the restatement on the very planes this decoder returned
+                y, cr, cb = dec.planes()
+                assert np.array_equal(rgba, cabi.oracle_rgba(libs["oracle"], y, cr, cb, dec.width, dec.height))
+            got.append(md5(rgba))
+    assert got == fx["rgba_md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_batch_render_rgba(path, hip_lib):
+    """Batch interface: pictures of the pool -> RGBA (jsmpeg_hip_batch_render_rgba behind read_rgba)."""
+    from jsmpeg_amd import batch as jb
+    fx, es, _ = load_case(path)
+    n, w, h = fx["n_frames"], fx["width"], fx["height"]
+    with jb.Batch(w, h, 1, n + 2, len(es) + 1024) as b:
+        b.upload([es])
+        assert b.decode() == n
+        assert [md5(b.read_rgba(p)) for p in range(n)] == fx["rgba_md5"]
+        with pytest.raises(RuntimeError):
+            b.read_rgba(n)
