@@ -119,6 +119,26 @@ int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, ui
                                    uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
                                    void *hip_stream);
 
+/* Ingest side on the device (reference src/ts.js:25-210): n_streams
+ * MPEG-TS buffers (host) -> the elementary streams of `stream_id` (0xE0 = the
+ * first video stream, ts.js:212-222), demultiplexed by GPU kernels straight into
+ * the batch's HBM buffer.  Per stream the result equals feeding the buffer to one
+ * JSMpeg.Demuxer.TS with that stream id connected, in one write(): the same
+ * bytes, the same destination.write(pts, buffers) boundaries (completion by
+ * PES_packet_length and by the stuffing guess, ts.js:127-147).  Input must be
+ * packet aligned (every 188th byte a sync byte): the call fails on anything
+ * else instead of resyncing.  Returns 0 or < 0. */
+int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                               const uint64_t *ts_bytes, uint32_t stream_id);
+/* The destination.write calls of stream `stream` of the last upload_ts: pts in
+ * seconds, byte range inside that stream's elementary stream.  Returns their
+ * number (fills at most `cap` entries; any array may be NULL) or < 0. */
+int jsmpeg_hip_batch_ts_writes(jsmpeg_hip_batch_t *b, uint32_t stream, double *pts, uint32_t *offset,
+                               uint32_t *length, uint32_t cap);
+/* Device-to-host copy of one stream's resident elementary stream; returns its
+ * size in bytes (copies at most `cap`) or < 0. */
+int64_t jsmpeg_hip_batch_read_es(jsmpeg_hip_batch_t *b, uint32_t stream, void *out, uint64_t cap);
+
 /* The hot path over the resident batch: start-code index -> tables -> slice
  * parse -> reconstruct, level by level.  Work is enqueued on `hip_stream`; the
  * call returns once everything is enqueued (it synchronises once internally,

@@ -25,7 +25,8 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
-                 "jsmpeg_hip_batch_read_rgba",
+                 "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_ts_writes",
+                 "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
                  "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
 
@@ -68,6 +69,12 @@ def lib():
         L.jsmpeg_hip_batch_frame_hashes.argtypes = [vp, vp]
         L.jsmpeg_hip_batch_render_rgba.restype = ctypes.c_int
         L.jsmpeg_hip_batch_render_rgba.argtypes = [vp, u32, u32, vp, vp]
+        L.jsmpeg_hip_batch_upload_ts.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_upload_ts.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), u32]
+        L.jsmpeg_hip_batch_ts_writes.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_ts_writes.argtypes = [vp, u32, vp, vp, vp, u32]
+        L.jsmpeg_hip_batch_read_es.restype = ctypes.c_int64
+        L.jsmpeg_hip_batch_read_es.argtypes = [vp, u32, vp, u64]
         L.jsmpeg_hip_batch_read_rgba.restype = ctypes.c_int
         L.jsmpeg_hip_batch_read_rgba.argtypes = [vp, u32, vp]
         L.jsmpeg_hip_batch_timings.restype = ctypes.c_int
@@ -122,6 +129,29 @@ class Batch:
         ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
         self._ok(self.L.jsmpeg_hip_batch_upload(self.h, n, ptrs, lens))
+
+    def upload_ts(self, ts_buffers, stream_id=0xE0):
+        """MPEG-TS in, demultiplexed on the device (reference src/ts.js semantics, one write() per buffer)."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in ts_buffers]
+        n = len(arrs)
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
+        self._ok(self.L.jsmpeg_hip_batch_upload_ts(self.h, n, ptrs, lens, stream_id))
+
+    def ts_writes(self, stream):
+        """[(pts seconds, offset, length)]: the destination.write calls ts.js would have made for `stream`."""
+        n = self._ok(self.L.jsmpeg_hip_batch_ts_writes(self.h, stream, None, None, None, 0))
+        pts = np.zeros(max(1, n), dtype=np.float64)
+        off = np.zeros(max(1, n), dtype=np.uint32)
+        ln = np.zeros(max(1, n), dtype=np.uint32)
+        self._ok(self.L.jsmpeg_hip_batch_ts_writes(self.h, stream, pts.ctypes.data, off.ctypes.data, ln.ctypes.data, n))
+        return [(float(pts[i]), int(off[i]), int(ln[i])) for i in range(n)]
+
+    def read_es(self, stream):
+        n = self._ok(self.L.jsmpeg_hip_batch_read_es(self.h, stream, None, 0))
+        out = np.empty(max(1, n), dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_batch_read_es(self.h, stream, out.ctypes.data, n))
+        return out[:n]
 
     def upload_device(self, dev_ptr, total_bytes, begin, end, stream=None):
         begin = np.ascontiguousarray(begin, dtype=np.uint32)

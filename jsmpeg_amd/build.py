@@ -101,7 +101,7 @@ def build_addon(force=False):
 
 def build_oracle(force=False):
     """CPU restatement (test infrastructure only)."""
-    src = [os.path.join(ORACLE, "mpeg1_oracle.c"), os.path.join(ORACLE, "ycbcr_oracle.c")]
+    src = [os.path.join(ORACLE, f) for f in ("mpeg1_oracle.c", "ycbcr_oracle.c", "ts_oracle.c")]
     if force or _newer(LIB_ORACLE, src + [os.path.join(ORACLE, "mpeg1_oracle.h")]):
         _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", LIB_ORACLE] + src)
     return LIB_ORACLE

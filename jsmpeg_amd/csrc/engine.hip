@@ -87,6 +87,11 @@ struct jsmpeg_hip_batch_t {
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
 	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
+	/* ingest side (jsmpeg_hip_batch_upload_ts): scratch sized to the largest upload so far */
+	uint8_t *d_ts; uint64_t ts_cap;
+	JmTsRec *d_ts_rec; uint32_t *d_ts_es_off; JmTsWrite *d_ts_writes; uint32_t ts_pkt_cap;
+	uint64_t *d_ts_begin, *d_ts_len; uint32_t *d_ts_small;   /* [max_streams] each; d_ts_small: pkt_first[n+1] | n_writes | es_total | es_given | status | es_begin */
+	std::vector<uint32_t> ts_pkt_first, ts_n_writes;
 	uint32_t *d_dbg;
 	uint8_t epoch;
 
@@ -102,6 +107,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
+	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	delete b;
@@ -156,6 +162,8 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
+	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
+	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (auto &e : b->ev) e = nullptr;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
 	b->timed = false; b->stream = nullptr;
@@ -208,6 +216,120 @@ extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams
 		HIP_TRY(hipMemcpy(b->d_es + b->h_streams[i].es_begin, es[i], es_bytes[i], hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice));
 	return 0;
+}
+
+/* Ingest side on the device (reference src/ts.js): n_streams MPEG-TS buffers -> the video elementary streams,
+ * demultiplexed by k_ts_* straight into the batch's ES buffer.  Equivalent to feeding each buffer to one
+ * JSMpeg.Demuxer.TS with `stream_id` connected in ONE write() and concatenating what the destination receives. */
+extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                                          const uint64_t *ts_bytes, uint32_t stream_id) {
+	g_err[0] = 0;
+	if (!b || (n_streams && (!ts || !ts_bytes))) return fail("null argument");
+	if (n_streams > b->cfg.max_streams) return fail("%u streams > max_streams %u", n_streams, b->cfg.max_streams);
+	if (stream_id == 0 || stream_id > 255) return fail("stream id %u out of range", stream_id);
+	HIP_TRY(hipSetDevice(b->device));
+	/* layout of the TS scratch: 16-byte aligned stream regions, 16 readable bytes behind each */
+	std::vector<uint64_t> begin(n_streams), len(n_streams);
+	b->ts_pkt_first.assign(n_streams + 1, 0);
+	uint64_t off = 0;
+	uint32_t max_packets = 0;
+	for (uint32_t i = 0; i < n_streams; i++) {
+		begin[i] = off; len[i] = ts_bytes[i];
+		off += (ts_bytes[i] + 16 + 15) & ~15ull;
+		const uint64_t pk = ts_bytes[i] / 188;
+		if (b->ts_pkt_first[i] + pk > 0x3fffffffull) return fail("too many TS packets in one batch");
+		b->ts_pkt_first[i + 1] = b->ts_pkt_first[i] + (uint32_t)pk;
+		max_packets = std::max(max_packets, (uint32_t)pk);
+	}
+	const uint32_t n_packets = b->ts_pkt_first[n_streams];
+	if (off > b->ts_cap) {
+		hipFree(b->d_ts); b->d_ts = nullptr; b->ts_cap = 0;
+		HIP_TRY(hipMalloc(&b->d_ts, off));
+		b->ts_cap = off;
+	}
+	if (n_packets > b->ts_pkt_cap) {
+		hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_writes);
+		b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
+		HIP_TRY(hipMalloc(&b->d_ts_rec, sizeof(JmTsRec) * (size_t)n_packets));
+		HIP_TRY(hipMalloc(&b->d_ts_es_off, sizeof(uint32_t) * (size_t)n_packets));
+		HIP_TRY(hipMalloc(&b->d_ts_writes, sizeof(JmTsWrite) * 2 * (size_t)n_packets));
+		b->ts_pkt_cap = n_packets;
+	}
+	const uint32_t ms = std::max(1u, b->cfg.max_streams);
+	if (!b->d_ts_begin) {
+		HIP_TRY(hipMalloc(&b->d_ts_begin, sizeof(uint64_t) * ms));
+		HIP_TRY(hipMalloc(&b->d_ts_len, sizeof(uint64_t) * ms));
+		HIP_TRY(hipMalloc(&b->d_ts_small, sizeof(uint32_t) * (6 * (size_t)ms + 1)));
+	}
+	uint32_t *d_pkt_first = b->d_ts_small, *d_n_writes = d_pkt_first + ms + 1, *d_es_total = d_n_writes + ms,
+	         *d_es_given = d_es_total + ms, *d_status = d_es_given + ms, *d_es_begin = d_status + ms;
+	if (n_streams == 0) { b->ts_n_writes.clear(); return batch_layout(b, 0, nullptr); }
+	hipStream_t st = nullptr;
+	for (uint32_t i = 0; i < n_streams; i++)
+		if (ts_bytes[i]) HIP_TRY(hipMemcpy(b->d_ts + begin[i], ts[i], ts_bytes[i], hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(b->d_ts_begin, begin.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(b->d_ts_len, len.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_pkt_first, b->ts_pkt_first.data(), sizeof(uint32_t) * (n_streams + 1), hipMemcpyHostToDevice));
+	HIP_TRY(hipDeviceSynchronize());
+	JmTsBufs tb;
+	tb.ts = b->d_ts; tb.ts_begin = b->d_ts_begin; tb.ts_len = b->d_ts_len; tb.pkt_first = d_pkt_first;
+	tb.n_streams = n_streams; tb.stream_id = stream_id;
+	tb.rec = b->d_ts_rec; tb.es_off = b->d_ts_es_off; tb.writes = b->d_ts_writes;
+	tb.n_writes = d_n_writes; tb.es_total = d_es_total; tb.es_given = d_es_given; tb.status = d_status;
+	tb.es = b->d_es; tb.es_begin = d_es_begin;
+	HIP_TRY(jm_launch_ts_parse_walk(tb, max_packets, st));
+	std::vector<uint32_t> small(4 * (size_t)ms);
+	HIP_TRY(hipMemcpy(small.data(), d_n_writes, sizeof(uint32_t) * 4 * (size_t)ms, hipMemcpyDeviceToHost));
+	const uint32_t *h_n_writes = small.data(), *h_es_given = small.data() + 2 * ms, *h_status = small.data() + 3 * ms;
+	std::vector<uint64_t> es_len(n_streams);
+	for (uint32_t i = 0; i < n_streams; i++) {
+		if (h_status[i] == 1) return fail("stream %u: a TS packet does not start with the sync byte: the device demux needs "
+		                                  "packet-aligned input (feed unaligned input through the reference's ts.js, which resyncs)", i);
+		if (h_status[i]) return fail("stream %u: more than 16 PIDs carry PES headers", i);
+		es_len[i] = h_es_given[i];     /* what the destination received; a PES still open at the end of the input stays pending, like in ts.js */
+	}
+	if (batch_layout(b, n_streams, es_len.data()) != 0) return -1;
+	b->ts_n_writes.assign(h_n_writes, h_n_writes + n_streams);
+	std::vector<uint32_t> es_begin(n_streams);
+	for (uint32_t i = 0; i < n_streams; i++) es_begin[i] = b->h_streams[i].es_begin;
+	HIP_TRY(hipMemset(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD));
+	HIP_TRY(hipMemcpy(d_es_begin, es_begin.data(), sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice));
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(jm_launch_ts_gather(tb, max_packets, st));
+	HIP_TRY(hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice));
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+/* The destination.write(pts, buffers) calls the reference's demuxer would have made for stream `stream` of the last
+ * jsmpeg_hip_batch_upload_ts: pts in seconds (ts.js:109), byte range in that stream's elementary stream.
+ * Returns the number of calls (fills at most `cap`) or < 0. */
+extern "C" int jsmpeg_hip_batch_ts_writes(jsmpeg_hip_batch_t *b, uint32_t stream, double *pts, uint32_t *offset,
+                                          uint32_t *length, uint32_t cap) {
+	g_err[0] = 0;
+	if (!b || stream >= b->ts_n_writes.size()) return fail("no TS upload for stream %u", stream);
+	HIP_TRY(hipSetDevice(b->device));
+	const uint32_t n = b->ts_n_writes[stream], k = std::min(n, cap);
+	std::vector<JmTsWrite> w(k);
+	if (k) HIP_TRY(hipMemcpy(w.data(), b->d_ts_writes + 2 * (size_t)b->ts_pkt_first[stream], sizeof(JmTsWrite) * k, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < k; i++) {
+		if (pts) pts[i] = (double)(((uint64_t)w[i].pts_hi << 32) | w[i].pts_lo) / 90000.0;
+		if (offset) offset[i] = w[i].begin;
+		if (length) length[i] = w[i].length;
+	}
+	return (int)n;
+}
+
+/* Copies stream `stream`'s elementary stream (as resident in the batch) to the host; returns its size in bytes
+ * (copies at most `cap`) or < 0. */
+extern "C" int64_t jsmpeg_hip_batch_read_es(jsmpeg_hip_batch_t *b, uint32_t stream, void *out, uint64_t cap) {
+	g_err[0] = 0;
+	if (!b || stream >= b->n_streams) return fail("bad stream index");
+	HIP_TRY(hipSetDevice(b->device));
+	const JmStream &s = b->h_streams[stream];
+	const uint64_t n = s.es_end - s.es_begin, k = std::min(n, cap);
+	if (k && out) HIP_TRY(hipMemcpy(out, b->d_es + s.es_begin, k, hipMemcpyDeviceToHost));
+	return (int64_t)n;
 }
 
 extern "C" int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,

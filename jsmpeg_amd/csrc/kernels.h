@@ -97,4 +97,28 @@ struct JmRgbaBufs {
 };
 hipError_t jm_launch_rgba(const JmRgbaBufs &b, hipStream_t st);
 
+/* ---- ingest side: MPEG-TS -> elementary streams (ts_kernels.hip; reference src/ts.js) ---- */
+struct JmTsRec {                 /* what one 188-byte packet says by itself, 16 bytes */
+	uint32_t w0;                 /* pid | payload_unit_start << 13 | adaptation_field_control << 14 | pes header << 16 |
+	                                sync byte ok << 17 | has pts << 18 | stream id << 24 */
+	uint32_t w1;                 /* offset of the first payload byte in the packet (16 bits) | pts bit 32 << 16 */
+	int32_t total;               /* PES_packet_length - header_length - 3, or 0 (ts.js:118-120) */
+	uint32_t pts_lo;
+};
+struct JmTsWrite { uint32_t pts_lo, pts_hi, begin, length; };   /* one destination.write: 33-bit pts ticks, byte range in the stream's ES */
+struct JmTsBufs {
+	const uint8_t *ts;           /* every stream's TS bytes; stream s at ts + ts_begin[s] (16-byte aligned), ts_len[s] bytes */
+	const uint64_t *ts_begin, *ts_len;
+	const uint32_t *pkt_first;   /* [n_streams + 1] prefix sums of whole packets per stream */
+	uint32_t n_streams, stream_id;
+	JmTsRec *rec;                /* [packets] */
+	uint32_t *es_off;            /* [packets] where the packet's payload starts in its stream's ES, JM_NONE = not part of it */
+	JmTsWrite *writes;           /* [2 * packets]; stream s from 2 * pkt_first[s] */
+	uint32_t *n_writes, *es_total, *es_given, *status;   /* [n_streams]; status: 0 ok, 1 packet without sync byte, 2 too many PIDs */
+	uint8_t *es;                 /* gather target ... */
+	const uint32_t *es_begin;    /* ... stream s at es + es_begin[s] */
+};
+hipError_t jm_launch_ts_parse_walk(const JmTsBufs &b, uint32_t max_packets, hipStream_t st);
+hipError_t jm_launch_ts_gather(const JmTsBufs &b, uint32_t max_packets, hipStream_t st);
+
 #endif

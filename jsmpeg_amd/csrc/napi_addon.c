@@ -16,6 +16,10 @@
  *   getPlanes(handle) -> {y, cr, cb}                   Uint8Array views over the decoder's
  *                                                      host planes (get_{y,cr,cb}_ptr), like the
  *                                                      heapU8.subarray views (mpeg1-wasm.js:109-116)
+ *   renderRGBA(handle, Uint8ClampedArray) -> bool     jsmpeg_hip_decoder_render_rgba: the last decoded
+ *                                                      picture converted on the device into the caller's
+ *                                                      width * height * 4 array (what CanvasRenderer.render
+ *                                                      leaves in imageData.data, src/canvas2d.js:48-122)
  *   deviceCount() / lastError()
  */
 #include <node_api.h>
@@ -176,6 +180,25 @@ static napi_value fn_get_planes(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+static napi_value fn_render_rgba(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	mpeg1_decoder_t *d = handle_arg(env, argv[0]);
+	if (!d) return NULL;
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (argc < 2 || napi_get_typedarray_info(env, argv[1], &t, &len, &data, &ab, &off) != napi_ok ||
+	    (t != napi_uint8_clamped_array && t != napi_uint8_array)) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: renderRGBA needs a Uint8ClampedArray / Uint8Array");
+		return NULL;
+	}
+	const size_t need = (size_t)mpeg1_decoder_get_width(d) * (size_t)mpeg1_decoder_get_height(d) * 4;
+	if (!need || len < need) { napi_throw_range_error(env, NULL, "jsmpeg_hip: RGBA array smaller than width * height * 4"); return NULL; }
+	if (jsmpeg_hip_decoder_render_rgba(d, data) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_get_boolean(env, true, &out));
+	return out;
+}
+
 static napi_value fn_device_count(napi_env env, napi_callback_info info) {
 	napi_value out;
 	(void)info;
@@ -196,7 +219,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "getIndex", fn_get_index }, { "setIndex", fn_set_index },
 		{ "hasSequenceHeader", fn_has_sequence_header }, { "getFrameRate", fn_get_frame_rate },
 		{ "getCodedSize", fn_get_coded_size }, { "getWidth", fn_get_width }, { "getHeight", fn_get_height },
-		{ "decode", fn_decode }, { "getPlanes", fn_get_planes },
+		{ "decode", fn_decode }, { "getPlanes", fn_get_planes }, { "renderRGBA", fn_render_rgba },
 		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error },
 	};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {

@@ -1,0 +1,54 @@
+"""Regenerates tests/golden/ts_*.json (container only: needs /root/reference).
+
+Ingest side.  Each crafted TS (tests/ts_craft.py, deterministic) is demuxed by
+  1. the reference's src/ts.js under Node (oracle/ref_node_ts.js), ONE write() of the whole buffer, stream 0xE0
+     connected;
+  2. the CPU restatement oracle/ts_oracle.c.
+The fixture (md5 of the TS, and per destination.write call its pts, byte count and md5) is written only if both agree.
+
+    python tests/golden/make_golden_ts.py
+"""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ts_craft  # noqa: E402
+from jsmpeg_amd import build, cabi  # noqa: E402
+
+
+def main():
+    build.build_synth(); build.build_oracle()
+    for name, fn in ts_craft.CASES.items():
+        ts = fn()
+        with tempfile.NamedTemporaryFile(suffix=".ts", delete=False) as f:
+            f.write(ts.tobytes())
+        try:
+            ref = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "oracle", "ref_node_ts.js"), f.name]))
+        finally:
+            os.unlink(f.name)
+        es, writes = cabi.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
+        mine = [dict(pts=p, length=int(n), md5=hashlib.md5(es[o:o + n].tobytes()).hexdigest()) for p, o, n in writes]
+        assert len(mine) == len(ref["writes"]), (name, len(mine), len(ref["writes"]))
+        for a, b in zip(mine, ref["writes"]):
+            assert a["length"] == b["length"] and a["md5"] == b["md5"] and a["pts"] == b["pts"], (name, a, b)
+        out = dict(case=name, ts_md5=hashlib.md5(ts.tobytes()).hexdigest(), ts_bytes=int(len(ts)), stream_id=0xE0,
+                   writes=ref["writes"], total_md5=ref["total_md5"],
+                   agreed_by=["reference src/ts.js under Node", "oracle/ts_oracle.c"])
+        with open(os.path.join(HERE, "ts_%s.json" % name), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(name, "ok:", len(mine), "writes,", sum(w["length"] for w in mine), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -32,7 +32,8 @@ def test_addon_loads_and_exports_the_abi():
     out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
     names = set(json.loads(out))
     assert {"create", "destroy", "bufferWrite", "getIndex", "setIndex", "hasSequenceHeader", "getFrameRate",
-            "getCodedSize", "getWidth", "getHeight", "decode", "getPlanes", "deviceCount", "lastError"} <= names
+            "getCodedSize", "getWidth", "getHeight", "decode", "getPlanes", "renderRGBA", "deviceCount",
+            "lastError"} <= names
 
 
 def test_class_fails_loudly_without_gpu():
@@ -82,3 +83,33 @@ def test_node_class_on_gpu_matches_golden(case, mode, hip_lib):
     assert out["hashes"] == fx["frame_md5"]
     assert out["sizes"] == [[fx["info"]["width"], fx["info"]["height"]]]
     assert abs(out["frameRate"] - 30.0) < 1e-6
+
+
+def test_renderer_refuses_to_convert_without_the_device_path():
+    """JSMpeg.Renderer.HIPRGBA is the device path: without a live MPEG1VideoHIP handle render() throws, it never
+    converts in JS."""
+    script = ("const {install}=require(%r);const {HIPRGBA}=install();const r=new HIPRGBA({});r.resize(16,16);"
+              "try{r.render(new Uint8Array(256),new Uint8Array(64),new Uint8Array(64));console.log('NO THROW')}"
+              "catch(e){console.log('THROWS:'+e.message)}" % os.path.join(ROOT, "jsmpeg_amd", "js", "renderer-hip.js"))
+    out = subprocess.check_output([NODE, "-e", script]).decode()
+    assert out.startswith("THROWS:")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cfg0_240p_intra", "cif_352x288", "odd_size_17x33"])
+def test_node_renderer_on_gpu_matches_reference_canvas2d(case, hip_lib):
+    """TS file -> MPEG1VideoHIP -> Renderer.HIPRGBA: imageData.data per picture equals what the reference's
+    Canvas2D renderer produced for the same stream (tests/golden/rgba_*.json)."""
+    build.build_addon()
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rgba_%s.json" % case)))
+    es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"]
+    f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+    f.write(synth.mux_ts(es, offs).tobytes())
+    f.close()
+    try:
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_render_rgba.js"), f.name]))
+    finally:
+        os.unlink(f.name)
+    assert out["hashes"] == fx["rgba_md5"]
+    assert (out["width"], out["height"]) == (fx["width"], fx["height"])
