@@ -89,7 +89,7 @@ struct jsmpeg_hip_batch_t {
 	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
 	/* ingest side (jsmpeg_hip_batch_upload_ts): scratch sized to the largest upload so far */
 	uint8_t *d_ts; uint64_t ts_cap;
-	JmTsRec *d_ts_rec; uint32_t *d_ts_es_off; JmTsWrite *d_ts_writes; uint32_t ts_pkt_cap;
+	JmTsRec *d_ts_rec; uint32_t *d_ts_es_off; JmTsCand *d_ts_cand; JmTsWrite *d_ts_writes; uint32_t ts_pkt_cap;
 	uint64_t *d_ts_begin, *d_ts_len; uint32_t *d_ts_small;   /* [max_streams] each; d_ts_small: pkt_first[n+1] | n_writes | es_total | es_given | status | es_begin */
 	std::vector<uint32_t> ts_pkt_first, ts_n_writes;
 	uint32_t *d_dbg;
@@ -107,7 +107,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
-	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
+	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	delete b;
@@ -162,7 +162,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
-	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
+	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (auto &e : b->ev) e = nullptr;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
@@ -248,10 +248,11 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 		b->ts_cap = off;
 	}
 	if (n_packets > b->ts_pkt_cap) {
-		hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_writes);
-		b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
+		hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
+		b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 		HIP_TRY(hipMalloc(&b->d_ts_rec, sizeof(JmTsRec) * (size_t)n_packets));
 		HIP_TRY(hipMalloc(&b->d_ts_es_off, sizeof(uint32_t) * (size_t)n_packets));
+		HIP_TRY(hipMalloc(&b->d_ts_cand, sizeof(JmTsCand) * (size_t)n_packets));
 		HIP_TRY(hipMalloc(&b->d_ts_writes, sizeof(JmTsWrite) * 2 * (size_t)n_packets));
 		b->ts_pkt_cap = n_packets;
 	}
@@ -274,7 +275,7 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 	JmTsBufs tb;
 	tb.ts = b->d_ts; tb.ts_begin = b->d_ts_begin; tb.ts_len = b->d_ts_len; tb.pkt_first = d_pkt_first;
 	tb.n_streams = n_streams; tb.stream_id = stream_id;
-	tb.rec = b->d_ts_rec; tb.es_off = b->d_ts_es_off; tb.writes = b->d_ts_writes;
+	tb.rec = b->d_ts_rec; tb.es_off = b->d_ts_es_off; tb.cand = b->d_ts_cand; tb.writes = b->d_ts_writes;
 	tb.n_writes = d_n_writes; tb.es_total = d_es_total; tb.es_given = d_es_given; tb.status = d_status;
 	tb.es = b->d_es; tb.es_begin = d_es_begin;
 	HIP_TRY(jm_launch_ts_parse_walk(tb, max_packets, st));
@@ -285,6 +286,7 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 	for (uint32_t i = 0; i < n_streams; i++) {
 		if (h_status[i] == 1) return fail("stream %u: a TS packet does not start with the sync byte: the device demux needs "
 		                                  "packet-aligned input (feed unaligned input through the reference's ts.js, which resyncs)", i);
+		if (h_status[i] == 3) return fail("stream %u: a PES / adaptation-field header runs past the end of its TS packet", i);
 		if (h_status[i]) return fail("stream %u: more than 16 PIDs carry PES headers", i);
 		es_len[i] = h_es_given[i];     /* what the destination received; a PES still open at the end of the input stays pending, like in ts.js */
 	}

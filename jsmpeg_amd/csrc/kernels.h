@@ -105,6 +105,7 @@ struct JmTsRec {                 /* what one 188-byte packet says by itself, 16 
 	int32_t total;               /* PES_packet_length - header_length - 3, or 0 (ts.js:118-120) */
 	uint32_t pts_lo;
 };
+struct JmTsCand { uint32_t packet, flags, pos, bytes; };          /* a packet that can end a write / change the PES state */
 struct JmTsWrite { uint32_t pts_lo, pts_hi, begin, length; };   /* one destination.write: 33-bit pts ticks, byte range in the stream's ES */
 struct JmTsBufs {
 	const uint8_t *ts;           /* every stream's TS bytes; stream s at ts + ts_begin[s] (16-byte aligned), ts_len[s] bytes */
@@ -113,8 +114,9 @@ struct JmTsBufs {
 	uint32_t n_streams, stream_id;
 	JmTsRec *rec;                /* [packets] */
 	uint32_t *es_off;            /* [packets] where the packet's payload starts in its stream's ES, JM_NONE = not part of it */
+	JmTsCand *cand;              /* [packets] scratch of k_ts_walk */
 	JmTsWrite *writes;           /* [2 * packets]; stream s from 2 * pkt_first[s] */
-	uint32_t *n_writes, *es_total, *es_given, *status;   /* [n_streams]; status: 0 ok, 1 packet without sync byte, 2 too many PIDs */
+	uint32_t *n_writes, *es_total, *es_given, *status;   /* [n_streams]; status: 0 ok, 1 packet without sync byte, 2 too many PIDs, 3 header longer than its packet */
 	uint8_t *es;                 /* gather target ... */
 	const uint32_t *es_begin;    /* ... stream s at es + es_begin[s] */
 };
