@@ -67,11 +67,13 @@ def check_kernel_resources():
     measured wrong results AND cost bandwidth on this path): recompile
     kernels.hip device-only with resource remarks and fail on any scratch."""
     import re
-    src = os.path.join(CSRC, "kernels.hip")
-    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
-                          "-I", CSRC, "--cuda-device-only", "-c", src, "-o", os.devnull,
-                          "-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True).stderr
     usage, name = {}, None
+    out = ""
+    for f in ("kernels.hip", "ts_kernels.hip"):
+        src = os.path.join(CSRC, f)
+        out += subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                               "-I", CSRC, "--cuda-device-only", "-c", src, "-o", os.devnull,
+                               "-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True).stderr
     for line in out.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
