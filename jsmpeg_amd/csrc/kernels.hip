@@ -300,7 +300,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	if (threadIdx.x < 8) tq = reinterpret_cast<const uint4 *>(b.streams[D.stream].intra_q)[threadIdx.x];
 	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
 	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
+#ifndef JM_EXP_NO_ZERO
 	own.zero();
+#endif
 	JmReconCtx c;
 	c.g = b.g;
 	c.mb = b.mb + D.mb_first;
@@ -322,16 +324,21 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 #ifdef JM_EXP_NO_IDCT
 	B.idct = false;
 #endif
-	/* the blocks that need the transform, packed to the front of the workgroup's slots */
-	const uint64_t need = __ballot(B.idct);
+	/* the blocks that need the transform, packed to the front of the workgroup's slots: first the ones
+	 * whose coefficients all lie in the top-left 4x4 (wavefronts that hold only those run the cheap
+	 * transform), then the rest */
+	const uint64_t needA = __ballot(B.idct && B.lowf), needB = __ballot(B.idct && !B.lowf);
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0));
-	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(need);
+	const uint32_t beforeA = __builtin_amdgcn_mbcnt_hi((uint32_t)(needA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needA, 0));
+	const uint32_t beforeB = __builtin_amdgcn_mbcnt_hi((uint32_t)(needB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needB, 0));
+	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(needA) | ((uint32_t)__popcll(needB) << 16);
 	if (threadIdx.x < 12) reinterpret_cast<uint4 *>(qm)[threadIdx.x] = tq;
 	__syncthreads();
-	uint32_t rank = before, total = 0;
+	uint32_t prior = 0, sum = 0;
 #pragma unroll
-	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) rank += t; total += t; }
+	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
+	const uint32_t totalA = sum & 0xffffu, total = totalA + (sum >> 16);
+	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : totalA + (prior >> 16) + beforeB;
 	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
 #ifndef JM_EXP_NO_SCATTER
@@ -340,7 +347,10 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
 	__syncthreads();
 	/* phase 2: wavefronts past the last packed block skip the transform altogether */
-	if (threadIdx.x < total) jm_recon_idct(own);
+	if (threadIdx.x < total) {
+		if ((threadIdx.x | 63u) < totalA) jm_recon_idct<true>(own);      /* wave-uniform */
+		else jm_recon_idct<false>(own);
+	}
 	__syncthreads();
 	/* phase 3 */
 #ifdef JM_EXP_NO_BACK

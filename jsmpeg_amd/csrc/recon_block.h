@@ -53,7 +53,10 @@ static constexpr int JM_PREMULT[64] = MPEG1_PREMULTIPLIER_INIT;
  * instructions: the compiler only selects the 24-bit forms when it can prove the operand ranges, and
  * falls back to the quarter-rate v_mul_lo_u32 for the data-dependent IDCT values. */
 JM_D int jm_mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-JM_D int jm_mad24(int a, int k, int acc) { int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc)); return d; }
+JM_D int jm_mad24(int a, int k, int acc) {
+	if (__builtin_constant_p(a) && a == 0) return acc;   /* the low-frequency transform passes literal zeros: nothing to multiply */
+	int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc)); return d;
+}
 /* per byte (a + b + (c & 1)) >> 1 */
 JM_D uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
 /* bytes of b:a picked by the selector (byte k of the result = byte sel_k of the 8 bytes b3..b0 a3..a0 -- a is the low dword; 0x0c = 0) */
@@ -137,6 +140,7 @@ struct JmBlk {
 	bool live;               /* the macroblock was written this batch */
 	bool intra, pred;
 	bool idct;               /* the block goes through the transform (phase 2); else `konst` is its whole residual */
+	bool lowf;               /* ... and all its coefficients lie in the top-left 4x4 (scan positions 0..9): the cheap transform will do */
 	bool k00;                /* non-intra block with only the (0,0) coefficient: konst holds its level until jm_recon_konst */
 	int konst;               /* no tokens: 0; intra DC only: dc; only the (0,0) coefficient: (level * 32 + 128) >> 8
 	                            -- what the full transform gives for those (mpeg1.c:1578-1581) */
@@ -218,7 +222,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	B.pred = B.live && (rec_qf & JM_MB_PRED) && c.has_fwd;
 	B.qscale = (int)(rec_qf & 31);
 	B.cnt = B.live ? (int)((rec_cnt >> (8 * bnum)) & 0xff) : 0;
-	B.idct = false; B.k00 = false; B.konst = 0;
+	B.idct = false; B.lowf = false; B.k00 = false; B.konst = 0;
 
 	/* ---- token run of this block: runs are padded to an even count, so dword aligned ---- */
 	uint32_t t0 = rec_tok;
@@ -263,6 +267,13 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 			else B.idct = true;
 		} else if (B.cnt == 1 && jm_token_pos(t) == 0) { B.k00 = true; B.konst = jm_token_level(t); }
 		else B.idct = true;
+		/* tokens come in scan order: the last one bounds them all.  Scan positions 0..9 are rows 0..3 x columns 0..3. */
+		if (B.idct && B.cnt <= 8) {
+			const int k = B.cnt - 1;
+			const uint32_t w = (k >> 1) == 0 ? B.tw[0] : ((k >> 1) == 1 ? B.tw[1] : ((k >> 1) == 2 ? B.tw[2] : B.tw[3]));
+			const uint16_t last = (uint16_t)((k & 1) ? (w >> 16) : (w & 0xffffu));
+			B.lowf = jm_token_pos(last) <= 9;
+		}
 	}
 }
 
@@ -303,15 +314,20 @@ JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 /* PHASE 2 (one lane per block that needs it, blocks packed to the front of the workgroup's slots):
  * premultiply + 8x8 integer IDCT (mpeg1.c:1551, 1673-1740), in place: levels in, residual out
  * (saturated to int16). */
-template <class Slot>
+template <bool LOW, class Slot>
 JM_HD void jm_recon_idct(Slot &s) {
+	/* LOW: only rows 0..3 x columns 0..3 can be non-zero.  The very same network with literal zeros for the
+	 * rest -- the compiler drops what they feed (4 of the 8 column transforms, a third of every row
+	 * transform); results are identical by construction. */
 	int v[64];
 #pragma unroll
-	for (int i = 0; i < 8; i++) {
+	for (int i = 0; i < 64; i++) v[i] = 0;
+#pragma unroll
+	for (int i = 0; i < (LOW ? 4 : 8); i++) {
 		int16_t t[8];
 		s.get8(i, t);
 #pragma unroll
-		for (int k = 0; k < 8; k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
+		for (int k = 0; k < (LOW ? 4 : 8); k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
 	}
 	{
 		int16_t t[8];
@@ -321,7 +337,7 @@ JM_HD void jm_recon_idct(Slot &s) {
 	const int c128 = 128;
 	/* columns, then rows with the final rounding (mpeg1.c:1682-1739) */
 #pragma unroll
-	for (int i = 0; i < 8; i++)
+	for (int i = 0; i < (LOW ? 4 : 8); i++)
 		JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
 #pragma unroll
 	for (int i = 0; i < 64; i += 8)
@@ -400,6 +416,9 @@ JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	}
 
 	/* ---- coalesced row stores: 8 bytes per lane per row ---- */
+#ifdef JM_EXP_NO_STORE
+	if (P[0] != 0x12345678u) return;
+#endif
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		uint32_t *o = (uint32_t *)(B.out + r * B.stride);

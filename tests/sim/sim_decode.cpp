@@ -26,6 +26,7 @@ struct HostSlot {
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
 // kind, and lanes that were served in those turns.
 static int g_thr[JM_ST_KINDS] = { JM_T_COLD, 1, 1, 1, 1, 0 };   // experiments: the scheduler's COLD threshold
+static uint64_t g_idct[4];         // reconstruct: low-frequency / other blocks through the transform, wavefronts that run the cheap / any transform
 static uint64_t g_picks;           // turns (scheduling decisions)
 static uint64_t g_cost;            // cost model: instructions issued by the wavefronts
 static int g_kcost[JM_ST_KINDS + 1] = { 430, 60, 95, 110, 270, 0, 50 };   // per handler; [KINDS] = per turn
@@ -51,6 +52,7 @@ void sim_reset_counters(void);
 const uint64_t *sim_states(void);
 void sim_thresholds(const int *t);
 uint64_t sim_picks(void);
+const uint64_t *sim_idct_counts(void);
 uint64_t sim_cost(void);
 void sim_kcost(const int *t);
 
@@ -182,22 +184,27 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			static HostSlot slots[256];
 			static JmBlk B[256];
 			for (int g0 = 0; g0 < 6 * g.mb_size; g0 += 256) {
-				int rank[256], total = 0;
+				int rank[256], totalA = 0, totalB = 0;
 				for (int l = 0; l < 256; l++) {
 					slots[l].zero();
-					B[l].idct = false; B[l].k00 = false; B[l].live = false;
+					B[l].idct = false; B[l].lowf = false; B[l].k00 = false; B[l].live = false;
 					if (g0 + l < 6 * g.mb_size) {
 						JmLoc Q;
 						jm_recon_locate(c.g, c.mb, g0 + l, Q);
 						jm_recon_front(c, Q, B[l]);
 						jm_recon_konst(c, B[l]);
 					}
-					rank[l] = total;
-					if (B[l].idct) total++;
+					if (B[l].idct && B[l].lowf) totalA++; else if (B[l].idct) totalB++;
 				}
+				for (int l = 0, a = 0, bb = 0; l < 256; l++) rank[l] = B[l].idct ? (B[l].lowf ? a++ : totalA + bb++) : 0;
+				const int total = totalA + totalB;
+				g_idct[0] += (uint64_t)totalA; g_idct[1] += (uint64_t)totalB; g_idct[2] += (uint64_t)(totalA / 64); g_idct[3] += (uint64_t)((total + 63) / 64);
 				for (int l = 0; l < 256; l++) if (B[l].idct) jm_recon_scatter(c, B[l], slots[rank[l]]);
 				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_predict(B[l]);
-				for (int l = 0; l < total; l++) jm_recon_idct(slots[l]);
+				for (int l = 0; l < total; l++) {
+					if ((l | 63) < totalA) jm_recon_idct<true>(slots[l]);   // wavefronts that hold only low-frequency blocks
+					else jm_recon_idct<false>(slots[l]);
+				}
 				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_back(c, B[l], slots[rank[l]]);
 			}
 		}
@@ -212,6 +219,7 @@ const uint64_t *sim_turns(void) { return g_turns; }
 const uint64_t *sim_states(void) { return g_states; }
 void sim_thresholds(const int *t) { for (int k = 0; k < JM_ST_DONE; k++) g_thr[k] = t[k]; }
 uint64_t sim_picks(void) { return g_picks; }
+const uint64_t *sim_idct_counts(void) { return g_idct; }
 uint64_t sim_cost(void) { return g_cost; }
 void sim_kcost(const int *t) { for (int k = 0; k <= JM_ST_KINDS; k++) g_kcost[k] = t[k]; }
 const uint64_t *sim_served(void) { return g_served; }
