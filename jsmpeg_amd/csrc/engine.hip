@@ -434,6 +434,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmReconBufs rb;
 	rb.g = b->g; rb.streams = b->d_streams; rb.mb = b->d_mb; rb.tokens = b->d_tokens; rb.luts = b->d_luts;
 	rb.pool = b->d_pool; rb.epoch = b->epoch; rb.zero_uncovered = 1;
+	rb.dbg = nullptr;
+	if (getenv("JSMPEG_HIP_TIMING")) {   /* diagnostics: phase timestamps of k_recon (needs a -DJM_EXP_TIMING build) */
+		if (!b->d_dbg) { HIP_TRY(hipMalloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
+		HIP_TRY(hipMemsetAsync(b->d_dbg, 0, (size_t)b->sc_cap * 16, st));
+		rb.dbg = reinterpret_cast<uint64_t *>(b->d_dbg);
+	}
 	for (uint32_t l = 0; l < b->n_levels; l++) {
 		rb.desc = b->d_desc + b->level_off[l];
 		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
@@ -930,6 +936,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.streams = d->d_stream; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.mb = d->d_mb; rb.tokens = d->d_tokens; rb.luts = d->d_luts; rb.pool = d->d_pool;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
+	rb.dbg = nullptr;
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));

@@ -78,6 +78,7 @@ struct JmReconBufs {
 	uint8_t *pool;
 	uint8_t epoch;
 	int zero_uncovered;
+	uint64_t *dbg;               /* diagnostics only (builds with -DJM_EXP_TIMING): phase timestamps, or null */
 };
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 

@@ -282,13 +282,24 @@ struct LdsSlot {
 	}
 };
 
+#ifdef JM_EXP_TIMING
+#define JM_STAMP(i) { __builtin_amdgcn_s_waitcnt(0); if (b.dbg && (blockIdx.x & 63) == 7 && (threadIdx.x & 63) == 0 && blockIdx.x / 64 < 4096) b.dbg[((blockIdx.x / 64) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); }
+#else
+#define JM_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t blocks_per_pic) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_WG];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
+#ifdef JM_EXP_LDS_PAD
+	__shared__ uint32_t lds_pad[JM_EXP_LDS_PAD / 4];   /* experiment: fewer workgroups per CU */
+	if (blocks_per_pic == 0xffffffffu) lds_pad[threadIdx.x] = 1;
+#endif
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
+	JM_STAMP(0)
 	const JmReconDesc D = b.desc[k];                 /* uniform: one scalar load */
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	const int g = (int)(blk * JM_RECON_WG + threadIdx.x);
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	JmBlk B;
 	B.idct = false; B.k00 = false; B.live = false;
 	if (valid) jm_recon_front(c, Q, B);
+	JM_STAMP(1)
 #ifdef JM_EXP_NO_PRED
 	B.pred = false;
 #endif
@@ -340,23 +352,29 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	const uint32_t totalA = sum & 0xffffu, total = totalA + (sum >> 16);
 	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : totalA + (prior >> 16) + beforeB;
 	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
+	JM_STAMP(2)
 	jm_recon_konst(c, B);
 #ifndef JM_EXP_NO_SCATTER
 	if (B.idct) jm_recon_scatter(c, B, mine);
 #endif
 	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
+	JM_STAMP(3)
 	__syncthreads();
+	JM_STAMP(4)
 	/* phase 2: wavefronts past the last packed block skip the transform altogether */
 	if (threadIdx.x < total) {
 		if ((threadIdx.x | 63u) < totalA) jm_recon_idct<true>(own);      /* wave-uniform */
 		else jm_recon_idct<false>(own);
 	}
+	JM_STAMP(5)
 	__syncthreads();
+	JM_STAMP(6)
 	/* phase 3 */
 #ifdef JM_EXP_NO_BACK
 	B.idct = false; B.konst = 0;
 #endif
 	if (valid) jm_recon_back(c, B, mine);
+	JM_STAMP(7)
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

@@ -236,6 +236,9 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	B.m = B.oh = B.ov = 0;
 	if (B.pred) {
 		int mh = rec_mvh, mv = rec_mvv;
+#ifdef JM_EXP_ZERO_MV
+		mh = mh & 1; mv = mv & 1;   /* experiment: coherent vectors (keeps the half-pel work) */
+#endif
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
 		const int H = mh >> 1, V = mv >> 1;
 		B.oh = (uint32_t)(mh & 1); B.ov = (uint32_t)(mv & 1);
@@ -254,7 +257,13 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
 			const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
+#if defined(JM_EXP_PRED_X2)
+			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = 0;   /* experiment: two dwords per row (wrong pixels) */
+#elif defined(JM_EXP_PRED_X1)
+			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = 0; B.R[3 * r + 2] = 0;
+#else
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
+#endif
 		}
 	}
 
