@@ -373,7 +373,13 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 #ifdef JM_EXP_NO_BACK
 	B.idct = false; B.konst = 0;
 #endif
-	if (valid) jm_recon_back(c, B, mine);
+	JmPix X;
+	X.store = false;
+	if (valid) X = jm_recon_pixels(c, B, mine);
+#ifdef JM_EXP_NO_STORE
+	if (X.p[0] != 0x12345678u) return;
+#endif
+	if (X.store) jm_recon_store(B, X);
 	JM_STAMP(7)
 }
 

@@ -394,21 +394,21 @@ JM_HD void jm_recon_predict(JmBlk &B) {
 /* PHASE 3 (every lane, its own block): add the residual to the prediction or overwrite, clamp
  * (mpeg1.c:1614-1671), coalesced row stores.  `s` = the slot that holds the block's residual when
  * B.idct. */
+/* The final pixels of the block (8 rows of 8 packed bytes); store == false: the block stores nothing (a
+ * macroblock this picture never wrote, outside batch mode: the plane keeps its old content). */
+struct JmPix { uint32_t p[16]; bool store; };
+
 template <class Slot>
-JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
-	if (!B.live) {
-		if (c.zero_uncovered)
-			for (int r = 0; r < 8; r++) { uint32_t *o = (uint32_t *)(B.out + r * B.stride); o[0] = 0; o[1] = 0; }
-		return;
-	}
-	uint32_t P[16];
+JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
+	JmPix X;
 #pragma unroll
-	for (int i = 0; i < 16; i++) P[i] = B.P[i];
+	for (int i = 0; i < 16; i++) X.p[i] = B.live ? B.P[i] : 0u;
+	X.store = B.live || c.zero_uncovered != 0;
 
 	/* ---- residual: from the slot, or the same value everywhere; add and clamp (mpeg1.c:1620-1644),
 	 * two pixels per instruction: bytes -> int16 pairs (v_perm), saturating packed add, saturate to
 	 * 0..255 and pack (v_sat_pk_u8_i16) ---- */
-	if (B.idct || B.konst != 0) {
+	if (B.live && (B.idct || B.konst != 0)) {
 		const uint32_t kk = ((uint32_t)B.konst & 0xffffu) * 0x00010001u;
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
@@ -416,23 +416,30 @@ JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 			if (B.idct) s.get8p(r, pk);
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const uint32_t p = P[2 * r + h];
+				const uint32_t p = X.p[2 * r + h];
 				const uint32_t lo = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c010c00u), pk[2 * h]));
 				const uint32_t hi = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c030c02u), pk[2 * h + 1]));
-				P[2 * r + h] = lo | (hi << 16);
+				X.p[2 * r + h] = lo | (hi << 16);
 			}
 		}
 	}
+	return X;
+}
 
-	/* ---- coalesced row stores: 8 bytes per lane per row ---- */
-#ifdef JM_EXP_NO_STORE
-	if (P[0] != 0x12345678u) return;
-#endif
+/* coalesced row stores: 8 bytes per lane per row */
+JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
-		o[0] = P[2 * r]; o[1] = P[2 * r + 1];
+		o[0] = X.p[2 * r]; o[1] = X.p[2 * r + 1];
 	}
+}
+
+/* PHASE 3 as one call (the simulator; the kernel pairs lanes for wider stores where it can) */
+template <class Slot>
+JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
+	const JmPix X = jm_recon_pixels(c, B, s);
+	if (X.store) jm_recon_store(B, X);
 }
 
 #endif
