@@ -55,7 +55,7 @@ def build_hip(force=False):
     without a GPU)."""
     src = hip_sources()
     defs = os.environ.get("JSMPEG_HIP_DEFS", "").split()   # tuning experiments only (-DJM_...=...)
-    if force or defs or _newer(LIB_HIP, src + _csrc_headers()):
+    if force or defs or os.environ.get("JSMPEG_HIP_FORCE") or _newer(LIB_HIP, src + _csrc_headers()):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
               "-o", LIB_HIP] + defs + src)

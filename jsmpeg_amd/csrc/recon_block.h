@@ -180,7 +180,7 @@ struct JmLoc {
 	uint32_t plane_off;
 	uint4_like_t rw;         /* the 16-byte JmMbRec */
 };
-JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) {
+JM_HD void jm_recon_where(const JmGeom &G, int g, JmLoc &Q) {
 	/* divisions by multiplication: g < 2^32 / divisor */
 	if (g < 4 * G.mb_size) {
 		const int bw = 2 * G.mb_width;
@@ -201,6 +201,9 @@ JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) 
 		/* frame layout Y | Cr | Cb; block 4 goes to the Cb plane, block 5 to Cr (mpeg1.c:1571) */
 		Q.plane_off = G.luma_bytes + (pl ? 0u : G.chroma_bytes);
 	}
+}
+JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) {
+	jm_recon_where(G, g, Q);
 	Q.rw = *reinterpret_cast<const uint4_like_t *>(mb + Q.mbaddr);
 }
 

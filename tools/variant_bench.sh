@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for v in "$@"; do
   name="${v%%:*}"; defs="${v#*:}"
-  JSMPEG_HIP_DEFS="$defs" python -m jsmpeg_amd.build hip > gpurun_out/build_$name.log 2>&1 || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/build_$name.log; continue; }
+  JSMPEG_HIP_DEFS="$defs" JSMPEG_HIP_FORCE=1 python -m jsmpeg_amd.build hip > gpurun_out/build_$name.log 2>&1 || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/build_$name.log; continue; }
   timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err || { echo "$name: BENCH FAILED"; tail -3 gpurun_out/v_$name.err; continue; }
   python - "$name" <<'PY'
 import json, sys

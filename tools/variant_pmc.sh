@@ -6,7 +6,7 @@ counters="$1"; shift
 ROOT=$(pwd)
 for v in "$@"; do
   name="${v%%:*}"; defs="${v#*:}"
-  JSMPEG_HIP_DEFS="$defs" python -m jsmpeg_amd.build hip > gpurun_out/build_$name.log 2>&1 || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/build_$name.log; continue; }
+  JSMPEG_HIP_DEFS="$defs" JSMPEG_HIP_FORCE=1 python -m jsmpeg_amd.build hip > gpurun_out/build_$name.log 2>&1 || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/build_$name.log; continue; }
   rm -rf gpurun_out/pmcv_$name
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --pmc $counters -d $ROOT/gpurun_out/pmcv_$name -- python $ROOT/tools/kbench.py 64 120 2 > /dev/null 2> $ROOT/gpurun_out/pmcv_$name.err)
   echo "== $name"; python tools/pmc_dump.py gpurun_out/pmcv_$name | grep "^k_recon\|^k_parse"
