@@ -258,7 +258,9 @@ hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
 #ifndef JM_RECON_WG
 #define JM_RECON_WG 256   /* lanes = 8x8 blocks per workgroup; LDS: 144 bytes per lane */
 #endif
-#define JM_SLOT_HALVES 72   /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
+#ifndef JM_SLOT_HALVES
+#define JM_SLOT_HALVES 72
+#endif   /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
 
 struct LdsSlot {
 	int16_t *base;
@@ -362,10 +364,12 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	__syncthreads();
 	JM_STAMP(4)
 	/* phase 2: wavefronts past the last packed block skip the transform altogether */
+#ifndef JM_EXP_NO_IDCT_CODE
 	if (threadIdx.x < total) {
 		if ((threadIdx.x | 63u) < totalA) jm_recon_idct<true>(own);      /* wave-uniform */
 		else jm_recon_idct<false>(own);
 	}
+#endif
 	JM_STAMP(5)
 	__syncthreads();
 	JM_STAMP(6)
