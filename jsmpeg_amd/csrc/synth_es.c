@@ -39,6 +39,9 @@ typedef struct synth_params_t {
 	int32_t dc_size_max;     /* dct_dc_size ~ U[0, dc_size_max]                 */
 	int32_t coded_permille;  /* P pictures: probability a cbp bit is set         */
 	int32_t f_code_max;      /* P pictures: forward_f_code ~ U[1, f_code_max]   */
+	int32_t syntax_quirks;   /* 1: valid but unusual syntax -- slices that start / end mid-row or span rows,
+	                            extra_information_slice / _picture, macroblock_stuffing, extension and
+	                            user_data start codes after the picture header (0: one plain slice per row) */
 } synth_params_t;
 
 /* ------------------------------------------------------------------ rng */
@@ -311,6 +314,15 @@ static void put_picture_header(gen_t *G, int temporal_ref, int type, int full_pe
 	bw_put(w, (uint32_t)type, 3);
 	bw_put(w, 0xffff, 16);     /* vbv_delay */
 	if (type == 2) { bw_put(w, (uint32_t)full_pel, 1); bw_put(w, (uint32_t)f_code, 3); }
+	if (G->p->syntax_quirks) {
+		/* extra_information_picture, then extension_data and user_data: the reference skips all of it by
+		 * scanning for the next start code (mpeg1.c:961-966) */
+		for (int k = rng_range(&G->r, 0, 2); k > 0; k--) { bw_put(w, 1, 1); bw_put(w, (uint32_t)rng_range(&G->r, 0x11, 0xee), 8); }
+		bw_put(w, 0, 1);
+		if (rng_next(&G->r) & 1) { bw_start_code(w, 0xB5); for (int k = rng_range(&G->r, 1, 9); k > 0; k--) bw_put(w, (uint32_t)rng_range(&G->r, 0x11, 0xee), 8); }
+		if (rng_next(&G->r) & 1) { bw_start_code(w, 0xB2); for (int k = rng_range(&G->r, 1, 40); k > 0; k--) bw_put(w, (uint32_t)rng_range(&G->r, 0x11, 0xee), 8); }
+		return;
+	}
 	bw_put(w, 0, 1);           /* extra_bit_picture */
 }
 
@@ -320,24 +332,29 @@ static int has_aligned_start_code(const uint8_t *b, size_t from, size_t to) {
 	return 0;
 }
 
-static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
+/* One slice over macroblock addresses [a0, a1) (plain streams: one row; with syntax_quirks any range, also across
+ * row ends: the slice start code carries the row of a0, the first increment its column, mpeg1.c:1005, 1046-1051). */
+static void put_slice(gen_t *G, int a0, int a1, int type, int full_pel, int f_code) {
 	const synth_params_t *p = G->p;
 	bitw_t *w = &G->w;
 	for (int attempt = 0; attempt < 64; attempt++) {
 		bitw_t save_w = *w;
 		synth_stats_t save_st = G->st;
-		bw_start_code(w, row + 1);
+		bw_start_code(w, a0 / G->g.mbw + 1);
 		size_t payload = w->pos;
 		int qscale = rng_range(&G->r, p->qscale_lo, p->qscale_hi);
 		bw_put(w, (uint32_t)qscale, 5);
+		if (p->syntax_quirks)      /* extra_information_slice (mpeg1.c:1013-1016) */
+			for (int k = rng_range(&G->r, 0, 2); k > 0; k--) { bw_put(w, 1, 1); bw_put(w, (uint32_t)rng_range(&G->r, 1, 255), 8); }
 		bw_put(w, 0, 1); /* extra_bit_slice */
 
 		dcpred_t dc = { 128, 128, 128 };
 		int pmh = 0, pmv = 0;             /* motion predictors, coded units */
 		int r_size = f_code - 1, f = 1 << r_size;
-		int pending_skip = 0;
-		for (int col = 0; col < G->g.mbw; col++) {
-			int last = (col == G->g.mbw - 1), firstmb = (col == 0);
+		int pending_skip = a0 % G->g.mbw;   /* the first increment of a slice counts from the row start and skips nothing */
+		for (int a = a0; a < a1; a++) {
+			const int col = a % G->g.mbw, row = a / G->g.mbw;
+			int last = (a == a1 - 1), firstmb = (a == a0);
 			int kind; /* 0 intra, 1 mc+coded, 2 coded no mc, 3 mc not coded, 4 skipped */
 			if (type == 1) kind = 0;
 			else {
@@ -348,7 +365,9 @@ static void put_slice(gen_t *G, int row, int type, int full_pel, int f_code) {
 			G->st.macroblocks++;
 			if (kind != 0) G->st.predicted++;
 			if (kind == 4) { pending_skip++; continue; }
+			if (p->syntax_quirks) for (int k = (rng_next(&G->r) % 8u) == 0 ? rng_range(&G->r, 1, 3) : 0; k > 0; k--) bw_put_code(w, N_MBA[34]);   /* macroblock_stuffing */
 			put_mba_increment(w, pending_skip + 1);
+			if (firstmb) pending_skip = 0;
 			if (pending_skip) {
 				/* skipped macroblocks reset DC predictors and, in P pictures,
 				 * the motion predictors (mpeg1.c:1058-1069) */
@@ -453,7 +472,15 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 			f_code = rng_range(&G.r, 1, p->f_code_max < 1 ? 1 : p->f_code_max);
 		}
 		put_picture_header(&G, in_gop, type, full_pel, f_code);
-		for (int row = 0; row < G.g.mbh; row++) put_slice(&G, row, type, full_pel, f_code);
+		if (!p->syntax_quirks)
+			for (int row = 0; row < G.g.mbh; row++) put_slice(&G, row * G.g.mbw, (row + 1) * G.g.mbw, type, full_pel, f_code);
+		else
+			for (int a = 0, n = G.g.mbw * G.g.mbh; a < n; ) {
+				int len = rng_range(&G.r, 1, 2 * G.g.mbw + G.g.mbw / 2);
+				if (a + len > n) len = n - a;
+				put_slice(&G, a, a + len, type, full_pel, f_code);
+				a += len;
+			}
 	}
 	bw_start_code(&G.w, 0xB7); /* sequence_end */
 	if (pic_offsets) pic_offsets[p->n_frames] = (uint32_t)(G.w.pos - 4);

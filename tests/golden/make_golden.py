@@ -40,6 +40,11 @@ CASES = {
     "dense_high_rate": ("cfg1_720p", 7, dict(width=640, height=368, ac_max=40, coded_permille=950, qscale_lo=1,
                                              qscale_hi=31, dc_size_max=8)),
     "long_gop_p_chain": ("cfg1_720p", 40, dict(width=320, height=192, gop=40)),
+    # valid but unusual syntax: slices starting / ending mid-row and spanning rows (first increments > 1, > 33 with
+    # macroblock_escape on the wide one), extra_information_slice / _picture, macroblock_stuffing, extension and
+    # user_data after the picture header
+    "syntax_quirks_352x288": ("cfg1_720p", 14, dict(width=352, height=288, syntax_quirks=1)),
+    "syntax_quirks_1280x96": ("cfg1_720p", 14, dict(width=1280, height=96, syntax_quirks=1, f_code_max=2)),
 }
 
 
@@ -50,7 +55,10 @@ def node_hashes(ts_path, impl):
 
 def main():
     build.build_synth(); build.build_oracle(); build.build_ref()
+    only = sys.argv[1:]
     for name, (cfg, n, ov) in CASES.items():
+        if only and name not in only:
+            continue
         es, offs = synth.generate_config(cfg, n_frames=n, **ov)
         ts = synth.mux_ts(es, offs)
         with tempfile.NamedTemporaryFile(suffix=".ts", delete=False) as f:
