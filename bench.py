@@ -294,6 +294,25 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- what this GPU's HBM gives a plain kernel with k_recon's traffic mix (half reads, half writes): a device copy ----
+    copy_gbs = None
+    try:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        src.fill_(1)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(4 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception as e:  # a reported reference point, never fatal
+        log("copy probe failed: %r" % (e,))
+
     # ---- accounting: ES read once + planes written once + predicted MBs read once ----
     g_streams, g_pictures = n_streams * world, n_pictures * world
     mb_per_pic = ((width + 15) // 16) * ((height + 15) // 16)
@@ -323,7 +342,10 @@ def main():
                                "frac": round(alg_bytes_rank * world / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                                "note": "all kernels + host turn-around of a step, per-GPU peak x n_gpus"},
                 "phases_ms": {kk: round(v / k, 4) for kk, v in phase.items()},
-                "peak_measured_achievable": 6290.0}
+                "peak_measured_achievable": 6290.0,
+                "device_copy_measured": {"value": copy_gbs, "unit": "GB/s",
+                                         "note": "read + write traffic of a 1 GiB torch device-to-device copy on this GPU, same run: "
+                                                 "what HBM gives a plain kernel with the dominant kernel's half-read half-write mix"}}
     line = {
         "metric": "1080p MPEG-1 decode throughput", "value": round(fps, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
