@@ -21,9 +21,24 @@
  *                                                      width * height * 4 array (what CanvasRenderer.render
  *                                                      leaves in imageData.data, src/canvas2d.js:48-122)
  *   deviceCount() / lastError()
+ *
+ * Batch interface (include/jsmpeg_hip.h part 2; no reference counterpart -- the reference decodes one picture per
+ * call on one thread): many streams in, every picture's planes in HBM, read back on demand.
+ *   batchCreate(width, height, maxStreams, maxPictures, maxEsBytes) -> handle | throws
+ *   batchDestroy(handle)
+ *   batchUpload(handle, [Uint8Array ES, ...])                       jsmpeg_hip_batch_upload
+ *   batchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xE0)    jsmpeg_hip_batch_upload_ts (device demux, ts.js semantics)
+ *   batchDecode(handle) -> pictures                                  jsmpeg_hip_batch_decode + _sync
+ *   batchPictureInfo(handle, p) -> {stream, esOffset, type, decoded, level, forward}
+ *   batchTsWrites(handle, stream) -> [{pts, offset, length}, ...]   jsmpeg_hip_batch_ts_writes
+ *   batchReadPlanes(handle, p, y, cr, cb)   (Uint8Arrays of coded size) jsmpeg_hip_batch_read_frame
+ *   batchReadRGBA(handle, p, Uint8ClampedArray)                      jsmpeg_hip_batch_read_rgba
+ *   batchGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
+ *   batchTimings(handle) -> {indexMs, hostMs, parseMs, reconMs, totalMs}
  */
 #include <node_api.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "jsmpeg_hip.h"
@@ -199,6 +214,215 @@ static napi_value fn_render_rgba(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* ---------------------------------------------------------------- batch interface */
+
+static jsmpeg_hip_batch_t *batch_arg(napi_env env, napi_value v) {
+	void *p = NULL;
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: bad batch handle");
+		return NULL;
+	}
+	return (jsmpeg_hip_batch_t *)p;
+}
+
+static napi_value set_u32(napi_env env, napi_value obj, const char *name, double v) {
+	napi_value x;
+	if (napi_create_double(env, v, &x) != napi_ok || napi_set_named_property(env, obj, name, x) != napi_ok) return NULL;
+	return obj;
+}
+
+static napi_value fn_batch_create(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	if (argc < 5) { napi_throw_type_error(env, NULL, "jsmpeg_hip: batchCreate(width, height, maxStreams, maxPictures, maxEsBytes)"); return NULL; }
+	jsmpeg_hip_batch_config_t c;
+	double es = 0;
+	uint32_t w = 0, h = 0;
+	NAPI_OK(napi_get_value_uint32(env, argv[0], &w));
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &h));
+	NAPI_OK(napi_get_value_uint32(env, argv[2], &c.max_streams));
+	NAPI_OK(napi_get_value_uint32(env, argv[3], &c.max_pictures));
+	NAPI_OK(napi_get_value_double(env, argv[4], &es));
+	c.width = (int32_t)w; c.height = (int32_t)h; c.max_es_bytes = (uint64_t)es; c.device = -1;
+	jsmpeg_hip_batch_t *b = jsmpeg_hip_batch_create(&c);
+	if (!b) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }   /* no GPU: loud, never a CPU decode */
+	NAPI_OK(napi_create_external(env, b, NULL, NULL, &out));
+	return out;
+}
+
+static napi_value fn_batch_destroy(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (b) jsmpeg_hip_batch_destroy(b);
+	return NULL;
+}
+
+/* shared by batchUpload / batchUploadTS: pointers and sizes of an array of typed arrays */
+#define JM_MAX_JS_STREAMS 4096
+static int collect_buffers(napi_env env, napi_value arr, const uint8_t **ptrs, uint64_t *lens, uint32_t *n_out) {
+	uint32_t n = 0;
+	if (napi_get_array_length(env, arr, &n) != napi_ok || n > JM_MAX_JS_STREAMS) return -1;
+	for (uint32_t i = 0; i < n; i++) {
+		napi_value el;
+		void *data; size_t len; napi_typedarray_type t; napi_value ab; size_t off;
+		if (napi_get_element(env, arr, i, &el) != napi_ok ||
+		    napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off) != napi_ok) return -1;
+		ptrs[i] = (const uint8_t *)data; lens[i] = len;
+	}
+	*n_out = n;
+	return 0;
+}
+
+static napi_value batch_upload_common(napi_env env, napi_callback_info info, int ts) {
+	size_t argc = 3;
+	napi_value argv[3], out;
+	static const uint8_t *ptrs[JM_MAX_JS_STREAMS];
+	static uint64_t lens[JM_MAX_JS_STREAMS];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	uint32_t n = 0, sid = 0xE0;
+	if (argc < 2 || collect_buffers(env, argv[1], ptrs, lens, &n) != 0) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: expected an array of Uint8Arrays");
+		return NULL;
+	}
+	if (ts && argc > 2) napi_get_value_uint32(env, argv[2], &sid);
+	const int rc = ts ? jsmpeg_hip_batch_upload_ts(b, n, ptrs, lens, sid) : jsmpeg_hip_batch_upload(b, n, ptrs, lens);
+	if (rc < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_uint32(env, n, &out));
+	return out;
+}
+static napi_value fn_batch_upload(napi_env env, napi_callback_info info) { return batch_upload_common(env, info, 0); }
+static napi_value fn_batch_upload_ts(napi_env env, napi_callback_info info) { return batch_upload_common(env, info, 1); }
+
+static napi_value fn_batch_decode(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	const int n = jsmpeg_hip_batch_decode(b, NULL);
+	if (n < 0 || jsmpeg_hip_batch_sync(b) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_int32(env, n, &out));
+	return out;
+}
+
+static napi_value fn_batch_picture_info(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t p = 0;
+	if (!b) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &p));
+	jsmpeg_hip_picture_info_t pi;
+	if (jsmpeg_hip_batch_picture_info(b, p, &pi) < 0) { napi_throw_range_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_object(env, &out));
+	if (!set_u32(env, out, "stream", pi.stream) || !set_u32(env, out, "esOffset", pi.es_offset) || !set_u32(env, out, "type", pi.type) ||
+	    !set_u32(env, out, "decoded", pi.decoded) || !set_u32(env, out, "level", pi.level) || !set_u32(env, out, "forward", pi.forward)) {
+		napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the picture info"); return NULL;
+	}
+	return out;
+}
+
+static napi_value fn_batch_ts_writes(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t s = 0;
+	if (!b) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &s));
+	const int n = jsmpeg_hip_batch_ts_writes(b, s, NULL, NULL, NULL, 0);
+	if (n < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	double *pts = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+	uint32_t *off = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1)), *len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+	napi_value res = NULL;
+	if (pts && off && len && jsmpeg_hip_batch_ts_writes(b, s, pts, off, len, (uint32_t)n) >= 0 &&
+	    napi_create_array_with_length(env, (size_t)n, &out) == napi_ok) {
+		res = out;
+		for (int i = 0; i < n && res; i++) {
+			napi_value o;
+			if (napi_create_object(env, &o) != napi_ok || !set_u32(env, o, "pts", pts[i]) || !set_u32(env, o, "offset", off[i]) ||
+			    !set_u32(env, o, "length", len[i]) || napi_set_element(env, out, (uint32_t)i, o) != napi_ok) res = NULL;
+		}
+	}
+	free(pts); free(off); free(len);
+	if (!res) napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the write list");
+	return res;
+}
+
+static void *typed_arg(napi_env env, napi_value v, size_t need) {
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (napi_get_typedarray_info(env, v, &t, &len, &data, &ab, &off) != napi_ok || len < need ||
+	    (t != napi_uint8_array && t != napi_uint8_clamped_array)) return NULL;
+	return data;
+}
+
+static napi_value fn_batch_read_planes(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t p = 0, luma = 0, chroma = 0;
+	int32_t cw, ch; uint64_t stride;
+	if (!b || argc < 5) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &p));
+	jsmpeg_hip_batch_geometry(b, &cw, &ch, &luma, &chroma, &stride);
+	void *y = typed_arg(env, argv[2], luma), *cr = typed_arg(env, argv[3], chroma), *cb = typed_arg(env, argv[4], chroma);
+	if (!y || !cr || !cb) { napi_throw_range_error(env, NULL, "jsmpeg_hip: plane arrays must be Uint8Arrays of the coded plane sizes"); return NULL; }
+	if (jsmpeg_hip_batch_read_frame(b, p, y, cr, cb) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_get_boolean(env, true, &out));
+	return out;
+}
+
+static napi_value fn_batch_read_rgba(napi_env env, napi_callback_info info) {
+	size_t argc = 3;
+	napi_value argv[3], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t p = 0;
+	if (!b || argc < 3) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &p));
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (napi_get_typedarray_info(env, argv[2], &t, &len, &data, &ab, &off) != napi_ok) { napi_throw_type_error(env, NULL, "jsmpeg_hip: RGBA target must be a typed array"); return NULL; }
+	/* the ABI writes width * height * 4 bytes: the caller sized the array from the batch's dimensions (checked in batch-hip.js) */
+	if (jsmpeg_hip_batch_read_rgba(b, p, data) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_get_boolean(env, true, &out));
+	return out;
+}
+
+static napi_value fn_batch_geometry(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	int32_t cw, ch; uint32_t luma, chroma; uint64_t stride;
+	if (jsmpeg_hip_batch_geometry(b, &cw, &ch, &luma, &chroma, &stride) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_object(env, &out));
+	if (!set_u32(env, out, "codedWidth", cw) || !set_u32(env, out, "codedHeight", ch) || !set_u32(env, out, "lumaBytes", luma) ||
+	    !set_u32(env, out, "chromaBytes", chroma)) { napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the geometry"); return NULL; }
+	return out;
+}
+
+static napi_value fn_batch_timings(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	float ms[5];
+	if (jsmpeg_hip_batch_timings(b, ms) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_object(env, &out));
+	if (!set_u32(env, out, "indexMs", ms[0]) || !set_u32(env, out, "hostMs", ms[1]) || !set_u32(env, out, "parseMs", ms[2]) ||
+	    !set_u32(env, out, "reconMs", ms[3]) || !set_u32(env, out, "totalMs", ms[4])) { napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the timings"); return NULL; }
+	return out;
+}
+
 static napi_value fn_device_count(napi_env env, napi_callback_info info) {
 	napi_value out;
 	(void)info;
@@ -221,6 +445,10 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "getCodedSize", fn_get_coded_size }, { "getWidth", fn_get_width }, { "getHeight", fn_get_height },
 		{ "decode", fn_decode }, { "getPlanes", fn_get_planes }, { "renderRGBA", fn_render_rgba },
 		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error },
+		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
+		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
+		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },
+		{ "batchGeometry", fn_batch_geometry }, { "batchTimings", fn_batch_timings },
 	};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
 		napi_value f;

@@ -1,0 +1,118 @@
+// JSMpeg.HIPBatch -- the server-side counterpart of the Player's per-frame loop (reference src/player.js:195-294:
+// one decode() per animation frame, one stream): many MPEG-TS (or elementary) streams in, every picture decoded on
+// the GPU in one go, pictures handed out per stream in presentation order with the timestamps the reference's
+// demuxer would have passed to video.write (src/ts.js:205-210).  Thin JS over the batch half of the addon
+// (jsmpeg_amd/csrc/napi_addon.c, include/jsmpeg_hip.h part 2); every byte of demux / decode / colour conversion
+// work happens in HIP kernels.  There is no JS or CPU fallback: creating a batch without a GPU throws.
+//
+//     const { HIPBatch } = require('./batch-hip.js').install(JSMpeg);          // or install() standalone
+//     const batch = new HIPBatch({ width: 1920, height: 1080, maxStreams: 64, maxPictures: 64 * 120,
+//                                  maxBytes: 600e6 });
+//     batch.decodeTS(tsBuffers, {                     // array of Uint8Array, one MPEG-TS per stream
+//       rgba: true,                                   // Canvas2D-identical RGBA (src/canvas2d.js:53-122) instead of planes
+//       onFrame(frame) { /* frame.stream, .index, .pts, .width, .height, .rgba | .y/.cr/.cb (valid during the call) */ },
+//     });
+//     batch.destroy();
+'use strict';
+const path = require('path');
+
+function install(JSMpeg, options) {
+  JSMpeg = JSMpeg || {};
+  const injected = options && options.binding;
+  let native = injected || null;
+  const binding = () => native || (native = require(path.join(__dirname, 'jsmpeg_hip.node')));
+
+  function HIPBatch(opts) {
+    opts = opts || {};
+    if (!(opts.width > 0 && opts.height > 0)) throw new Error('HIPBatch: width and height of the streams are required');
+    this.width = opts.width | 0;
+    this.height = opts.height | 0;
+    this.maxStreams = opts.maxStreams || 64;
+    this.maxPictures = opts.maxPictures || this.maxStreams * 64;
+    this.maxBytes = opts.maxBytes || 256 * 1024 * 1024;
+    this.native = binding();
+    this.handle = this.native.batchCreate(this.width, this.height, this.maxStreams, this.maxPictures, this.maxBytes);   // throws without a GPU
+    const g = this.native.batchGeometry(this.handle);
+    this.codedWidth = g.codedWidth; this.codedHeight = g.codedHeight;
+    this.lumaBytes = g.lumaBytes; this.chromaBytes = g.chromaBytes;
+    this.pictures = 0;
+    this.writes = null;
+  }
+
+  HIPBatch.prototype.destroy = function () {
+    if (this.handle) { this.native.batchDestroy(this.handle); this.handle = null; }
+  };
+
+  // MPEG-TS buffers (packet aligned) -> device demux with ts.js semantics -> decode.  Returns the picture count.
+  HIPBatch.prototype.uploadTS = function (buffers, streamId) {
+    this.native.batchUploadTS(this.handle, buffers, streamId || 0xE0);
+    this.writes = buffers.map((_, s) => this.native.batchTsWrites(this.handle, s));
+    return this;
+  };
+  // elementary streams, already demultiplexed
+  HIPBatch.prototype.upload = function (buffers) {
+    this.native.batchUpload(this.handle, buffers);
+    this.writes = null;
+    return this;
+  };
+  HIPBatch.prototype.decode = function () {
+    this.pictures = this.native.batchDecode(this.handle);
+    return this.pictures;
+  };
+  HIPBatch.prototype.pictureInfo = function (p) { return this.native.batchPictureInfo(this.handle, p); };
+  HIPBatch.prototype.timings = function () { return this.native.batchTimings(this.handle); };
+
+  HIPBatch.prototype.readPlanes = function (p, target) {
+    target = target || { y: new Uint8Array(this.lumaBytes), cr: new Uint8Array(this.chromaBytes), cb: new Uint8Array(this.chromaBytes) };
+    this.native.batchReadPlanes(this.handle, p, target.y, target.cr, target.cb);
+    return target;
+  };
+  HIPBatch.prototype.readRGBA = function (p, target) {
+    const need = this.width * this.height * 4;
+    target = target || new Uint8ClampedArray(need);
+    if (target.length < need) throw new RangeError('HIPBatch.readRGBA: target smaller than width * height * 4');
+    this.native.batchReadRGBA(this.handle, p, target);
+    return target;
+  };
+
+  // The scheduler: pictures of the last decode, stream by stream in decode (= presentation: no B pictures) order.
+  // Picture k of a stream carries the pts of the k-th PES the demuxer completed for it (one picture per PES is what
+  // jsmpeg's sources and the reference's own muxing advice produce, README.md "Encoding Video").
+  HIPBatch.prototype.forEachFrame = function (opts, cb) {
+    if (typeof opts === 'function') { cb = opts; opts = {}; }
+    const perStream = new Map();
+    for (let p = 0; p < this.pictures; p++) {
+      const info = this.pictureInfo(p);
+      if (!info.decoded) continue;
+      if (!perStream.has(info.stream)) perStream.set(info.stream, []);
+      perStream.get(info.stream).push(p);
+    }
+    const rgba = opts.rgba ? new Uint8ClampedArray(this.width * this.height * 4) : null;
+    const planes = opts.rgba ? null : this.readPlanes(0, null);
+    let n = 0;
+    for (const [stream, list] of Array.from(perStream.entries()).sort((a, b) => a[0] - b[0])) {
+      list.forEach((p, index) => {
+        const w = this.writes && this.writes[stream] && this.writes[stream][index];
+        const frame = { stream, index, picture: p, pts: w ? w.pts : index / 30, width: this.width, height: this.height,
+                        codedWidth: this.codedWidth, codedHeight: this.codedHeight };
+        if (rgba) frame.rgba = this.readRGBA(p, rgba);
+        else { this.readPlanes(p, planes); frame.y = planes.y; frame.cr = planes.cr; frame.cb = planes.cb; }
+        cb(frame);
+        n++;
+      });
+    }
+    return n;
+  };
+
+  HIPBatch.prototype.decodeTS = function (buffers, opts) {
+    opts = opts || {};
+    this.uploadTS(buffers, opts.streamId);
+    this.decode();
+    return opts.onFrame ? this.forEachFrame(opts, opts.onFrame) : this.pictures;
+  };
+
+  JSMpeg.HIPBatch = HIPBatch;
+  return { HIPBatch, JSMpeg };
+}
+
+module.exports = { install };

@@ -33,7 +33,8 @@ def test_addon_loads_and_exports_the_abi():
     names = set(json.loads(out))
     assert {"create", "destroy", "bufferWrite", "getIndex", "setIndex", "hasSequenceHeader", "getFrameRate",
             "getCodedSize", "getWidth", "getHeight", "decode", "getPlanes", "renderRGBA", "deviceCount",
-            "lastError"} <= names
+            "lastError", "batchCreate", "batchDestroy", "batchUpload", "batchUploadTS", "batchDecode", "batchPictureInfo",
+            "batchTsWrites", "batchReadPlanes", "batchReadRGBA", "batchGeometry", "batchTimings"} <= names
 
 
 def test_class_fails_loudly_without_gpu():
@@ -113,3 +114,48 @@ def test_node_renderer_on_gpu_matches_reference_canvas2d(case, hip_lib):
         os.unlink(f.name)
     assert out["hashes"] == fx["rgba_md5"]
     assert (out["width"], out["height"]) == (fx["width"], fx["height"])
+
+
+def test_batch_class_fails_loudly_without_gpu():
+    from conftest import have_gpu
+    if have_gpu():
+        pytest.skip("a GPU is present")
+    build.build_addon()
+    script = ("const {install}=require(%r);const {HIPBatch}=install();"
+              "try{new HIPBatch({width:320,height:240});console.log('NO THROW')}catch(e){console.log('THROWS:'+e.message)}"
+              % os.path.join(ROOT, "jsmpeg_amd", "js", "batch-hip.js"))
+    out = subprocess.check_output([NODE, "-e", script]).decode()
+    assert out.startswith("THROWS:") and "no CPU fallback" in out
+
+
+@pytest.mark.gpu
+def test_node_batch_ts_in_frames_out(hip_lib):
+    """Three TS files -> JSMpeg.HIPBatch (device demux, batch decode, device RGBA) under Node: planes against the
+    frame fixture, RGBA against the reference-Canvas2D fixture, pts as ts.js reports them."""
+    build.build_addon()
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "rgba_cif_352x288.json")))
+    paths, want = [], []
+    try:
+        for s in range(3):
+            es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], stream=s, **fx["overrides"])
+            f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+            f.write(synth.mux_ts(es, offs).tobytes())
+            f.close()
+            paths.append(f.name)
+            want.append(cabi_md5_frames(es))
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_batch_ts.js"), "352", "288"] + paths))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["pictures"] == 3 * fx["n_frames"]
+    for s in range(3):
+        assert out["streams"][s]["planes"] == want[s]
+        pts = out["streams"][s]["pts"]
+        assert len(pts) == fx["n_frames"] and abs(pts[0] - 0.1) < 1e-9 and abs(pts[1] - pts[0] - 1 / 30) < 1e-4
+    assert out["streams"][0]["rgba"] == fx["rgba_md5"]          # stream 0 is the fixture's stream
+
+
+def cabi_md5_frames(es):
+    """md5(Y|Cr|Cb) per frame from the oracle (checker)."""
+    from jsmpeg_amd import cabi
+    return cabi.decode_stream(build.build_oracle(), es)[0]
