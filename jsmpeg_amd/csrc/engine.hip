@@ -41,6 +41,17 @@ extern "C" int jsmpeg_hip_device_count(void) {
 	return n;
 }
 
+/* Every device allocation of the engine goes through here.  JSMPEG_HIP_POISON=<byte> fills fresh allocations with
+ * that byte (diagnostics: a kernel that reads memory nobody wrote then misbehaves the same way every time instead
+ * of depending on what the allocator hands back). */
+template <class T>
+static hipError_t jm_malloc(T **p, size_t bytes) {
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+	static const int poison = [] { const char *v = getenv("JSMPEG_HIP_POISON"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
+	if (e == hipSuccess && poison >= 0 && bytes) { e = hipMemset(*p, poison, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+	return e;
+}
+
 /* ------------------------------------------------------------ shared state */
 
 static JmVlcLuts *g_luts_dev[16] = { nullptr };
@@ -50,7 +61,7 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 		JmVlcLuts host;
 		jm_build_luts(&host);
 		JmVlcLuts *d = nullptr;
-		HIP_TRY(hipMalloc(&d, sizeof(JmVlcLuts)));
+		HIP_TRY(jm_malloc(&d, sizeof(JmVlcLuts)));
 		HIP_TRY(hipMemcpy(d, &host, sizeof(host), hipMemcpyHostToDevice));
 		HIP_TRY(hipDeviceSynchronize());   /* the tables are read from streams that are not ordered against the null stream */
 		g_luts_dev[dev] = d;
@@ -120,26 +131,26 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	b->es_cap = c.max_es_bytes + (uint64_t)JM_STREAM_GAP * (c.max_streams + 1) + JM_ES_PAD + 64;
 	b->sc_cap = (uint32_t)(b->es_cap / 16 + 4096);
 	b->scan_blocks_cap = (uint32_t)(b->es_cap / JM_SCAN_BLOCK_BYTES + 2);
-	HIP_TRY(hipMalloc(&b->d_es, b->es_cap));
+	HIP_TRY(jm_malloc(&b->d_es, b->es_cap));
 	HIP_TRY(hipMemset(b->d_es, 0xff, b->es_cap));
-	HIP_TRY(hipMalloc(&b->d_streams, sizeof(JmStream) * std::max(1u, c.max_streams)));
-	HIP_TRY(hipMalloc(&b->d_block_counts, sizeof(uint64_t) * (b->scan_blocks_cap + 1)));
-	HIP_TRY(hipMalloc(&b->d_sc_pos, sizeof(uint32_t) * b->sc_cap));
-	HIP_TRY(hipMalloc(&b->d_sc_code, b->sc_cap));
-	HIP_TRY(hipMalloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
-	HIP_TRY(hipMalloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
-	HIP_TRY(hipMalloc(&b->d_counters, 4 * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
-	HIP_TRY(hipMalloc(&b->d_desc, sizeof(JmReconDesc) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_streams, sizeof(JmStream) * std::max(1u, c.max_streams)));
+	HIP_TRY(jm_malloc(&b->d_block_counts, sizeof(uint64_t) * (b->scan_blocks_cap + 1)));
+	HIP_TRY(jm_malloc(&b->d_sc_pos, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(jm_malloc(&b->d_sc_code, b->sc_cap));
+	HIP_TRY(jm_malloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_counters, 4 * sizeof(uint32_t)));
+	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * std::max(1u, c.max_pictures)));
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
-	HIP_TRY(hipMalloc(&b->d_mb, mb_bytes));
+	HIP_TRY(jm_malloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
 	HIP_TRY(hipDeviceSynchronize());   /* the memsets ran on the null stream; decode may use a stream that is not ordered against it */
-	HIP_TRY(hipMalloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
+	HIP_TRY(jm_malloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
 	size_t pool_bytes = (size_t)b->g.frame_bytes * std::max(1u, c.max_pictures) + 2 * POOL_GUARD;
-	HIP_TRY(hipMalloc(&b->d_pool_alloc, pool_bytes));
+	HIP_TRY(jm_malloc(&b->d_pool_alloc, pool_bytes));
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
-	HIP_TRY(hipMalloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault));
 	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
 	return 0;
@@ -244,23 +255,23 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 	const uint32_t n_packets = b->ts_pkt_first[n_streams];
 	if (off > b->ts_cap) {
 		hipFree(b->d_ts); b->d_ts = nullptr; b->ts_cap = 0;
-		HIP_TRY(hipMalloc(&b->d_ts, off));
+		HIP_TRY(jm_malloc(&b->d_ts, off));
 		b->ts_cap = off;
 	}
 	if (n_packets > b->ts_pkt_cap) {
 		hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
 		b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
-		HIP_TRY(hipMalloc(&b->d_ts_rec, sizeof(JmTsRec) * (size_t)n_packets));
-		HIP_TRY(hipMalloc(&b->d_ts_es_off, sizeof(uint32_t) * (size_t)n_packets));
-		HIP_TRY(hipMalloc(&b->d_ts_cand, sizeof(JmTsCand) * (size_t)n_packets));
-		HIP_TRY(hipMalloc(&b->d_ts_writes, sizeof(JmTsWrite) * 2 * (size_t)n_packets));
+		HIP_TRY(jm_malloc(&b->d_ts_rec, sizeof(JmTsRec) * (size_t)n_packets));
+		HIP_TRY(jm_malloc(&b->d_ts_es_off, sizeof(uint32_t) * (size_t)n_packets));
+		HIP_TRY(jm_malloc(&b->d_ts_cand, sizeof(JmTsCand) * (size_t)n_packets));
+		HIP_TRY(jm_malloc(&b->d_ts_writes, sizeof(JmTsWrite) * 2 * (size_t)n_packets));
 		b->ts_pkt_cap = n_packets;
 	}
 	const uint32_t ms = std::max(1u, b->cfg.max_streams);
 	if (!b->d_ts_begin) {
-		HIP_TRY(hipMalloc(&b->d_ts_begin, sizeof(uint64_t) * ms));
-		HIP_TRY(hipMalloc(&b->d_ts_len, sizeof(uint64_t) * ms));
-		HIP_TRY(hipMalloc(&b->d_ts_small, sizeof(uint32_t) * (6 * (size_t)ms + 1)));
+		HIP_TRY(jm_malloc(&b->d_ts_begin, sizeof(uint64_t) * ms));
+		HIP_TRY(jm_malloc(&b->d_ts_len, sizeof(uint64_t) * ms));
+		HIP_TRY(jm_malloc(&b->d_ts_small, sizeof(uint32_t) * (6 * (size_t)ms + 1)));
 	}
 	uint32_t *d_pkt_first = b->d_ts_small, *d_n_writes = d_pkt_first + ms + 1, *d_es_total = d_n_writes + ms,
 	         *d_es_given = d_es_total + ms, *d_status = d_es_given + ms, *d_es_begin = d_status + ms;
@@ -423,7 +434,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
 	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */
-		if (!b->d_dbg) { HIP_TRY(hipMalloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
+		if (!b->d_dbg) { HIP_TRY(jm_malloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
 		HIP_TRY(hipMemsetAsync(b->d_dbg, 0xee, (size_t)b->sc_cap * 16, st));
 		pb.dbg = b->d_dbg;
 	}
@@ -436,7 +447,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	rb.pool = b->d_pool; rb.epoch = b->epoch; rb.zero_uncovered = 1;
 	rb.dbg = nullptr;
 	if (getenv("JSMPEG_HIP_TIMING")) {   /* diagnostics: phase timestamps of k_recon (needs a -DJM_EXP_TIMING build) */
-		if (!b->d_dbg) { HIP_TRY(hipMalloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
+		if (!b->d_dbg) { HIP_TRY(jm_malloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
 		HIP_TRY(hipMemsetAsync(b->d_dbg, 0, (size_t)b->sc_cap * 16, st));
 		rb.dbg = reinterpret_cast<uint64_t *>(b->d_dbg);
 	}
@@ -530,7 +541,7 @@ extern "C" int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t pictur
 	if (picture >= b->n_pics) return fail("bad picture index");
 	HIP_TRY(hipSetDevice(b->device));
 	const size_t bytes = (size_t)b->cfg.width * b->cfg.height * 4;
-	if (!b->d_rgba) HIP_TRY(hipMalloc(&b->d_rgba, bytes));
+	if (!b->d_rgba) HIP_TRY(jm_malloc(&b->d_rgba, bytes));
 	if (jsmpeg_hip_batch_render_rgba(b, picture, 1, b->d_rgba, b->stream) < 0) return -1;
 	HIP_TRY(hipMemcpyAsync(host_rgba, b->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
 	HIP_TRY(hipStreamSynchronize(b->stream));
@@ -642,9 +653,9 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipHostMalloc(&d->bytes, d->capacity + JM_ES_PAD, hipHostMallocDefault) == hipSuccess &&
 	          hipHostMalloc(&d->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
-	          hipMalloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && hipMalloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
-	          hipMalloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess;
+	          jm_malloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
+	          jm_malloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && jm_malloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
+	          jm_malloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess;
 	if (!ok) {
 		if (!g_err[0]) fail("decoder allocation failed: %s", hipGetErrorString(hipGetLastError()));
 		dec_fail_cleanup(d);
@@ -716,7 +727,7 @@ static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
 	unsigned need_es = d->capacity + JM_ES_PAD + 64;
 	if (d->d_es_cap < need_es) {
 		hipFree(d->d_es); d->d_es = nullptr;
-		HIP_TRY(hipMalloc(&d->d_es, need_es));
+		HIP_TRY(jm_malloc(&d->d_es, need_es));
 		/* on the decoder's stream: it is a non-blocking stream, work on the null stream is NOT ordered against it */
 		HIP_TRY(hipMemsetAsync(d->d_es, 0xff, need_es, d->stream));
 		d->d_es_cap = need_es; d->mirrored = 0;
@@ -728,11 +739,11 @@ static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
 		d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr; d->d_sc_owner = nullptr;
 		d->d_pic_sc = nullptr; d->h_scan_pos = nullptr; d->h_scan_code = nullptr; d->scan_cap = 0;
 		need = std::max(need * 2, 4096u);
-		HIP_TRY(hipMalloc(&d->d_block_counts, sizeof(uint64_t) * ((size_t)need * 4 / JM_SCAN_BLOCK_BYTES + 4)));
-		HIP_TRY(hipMalloc(&d->d_sc_pos, sizeof(uint32_t) * need));
-		HIP_TRY(hipMalloc(&d->d_sc_code, need));
-		HIP_TRY(hipMalloc(&d->d_sc_owner, sizeof(uint32_t) * need));
-		HIP_TRY(hipMalloc(&d->d_pic_sc, sizeof(uint32_t) * need));
+		HIP_TRY(jm_malloc(&d->d_block_counts, sizeof(uint64_t) * ((size_t)need * 4 / JM_SCAN_BLOCK_BYTES + 4)));
+		HIP_TRY(jm_malloc(&d->d_sc_pos, sizeof(uint32_t) * need));
+		HIP_TRY(jm_malloc(&d->d_sc_code, need));
+		HIP_TRY(jm_malloc(&d->d_sc_owner, sizeof(uint32_t) * need));
+		HIP_TRY(jm_malloc(&d->d_pic_sc, sizeof(uint32_t) * need));
 		HIP_TRY(hipHostMalloc(&d->h_scan_pos, sizeof(uint32_t) * need, hipHostMallocDefault));
 		HIP_TRY(hipHostMalloc(&d->h_scan_code, need, hipHostMallocDefault));
 		d->scan_cap = need;
@@ -814,10 +825,10 @@ static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
 	s.mb_size = d->g.mb_size; s.valid = 1; s.seq_sc = 0;
 	if (d->g.mb_size <= 0) return fail("sequence header with empty picture");
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)d->g.mb_size;
-	HIP_TRY(hipMalloc(&d->d_mb, mb_bytes));
+	HIP_TRY(jm_malloc(&d->d_mb, mb_bytes));
 	HIP_TRY(hipMemsetAsync(d->d_mb, 0, mb_bytes, d->stream));
 	size_t pool = 2 * (size_t)d->g.frame_bytes + 2 * POOL_GUARD;
-	HIP_TRY(hipMalloc(&d->d_pool_alloc, pool));
+	HIP_TRY(jm_malloc(&d->d_pool_alloc, pool));
 	HIP_TRY(hipMemsetAsync(d->d_pool_alloc, 0, pool, d->stream));   /* zero planes like the JS typed arrays (mpeg1.js:131-152) */
 	d->d_pool = d->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(hipHostMalloc(&d->h_frame, d->g.frame_bytes, hipHostMallocDefault));
@@ -868,7 +879,7 @@ extern "C" int jsmpeg_hip_decoder_render_rgba(mpeg1_decoder_t *d, void *host_rgb
 	const size_t bytes = (size_t)d->width * d->height * 4;
 	if (d->rgba_cap < bytes) {
 		hipFree(d->d_rgba); d->d_rgba = nullptr; d->rgba_cap = 0;
-		HIP_TRY(hipMalloc(&d->d_rgba, bytes));
+		HIP_TRY(jm_malloc(&d->d_rgba, bytes));
 		d->rgba_cap = bytes;
 	}
 	JmRgbaBufs r;
@@ -892,7 +903,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	if (d->tokens_cap < tok_need) {
 		hipFree(d->d_tokens); d->d_tokens = nullptr; d->tokens_cap = 0;
 		tok_need = std::max(tok_need * 2, (size_t)1 << 20);
-		HIP_TRY(hipMalloc(&d->d_tokens, tok_need * sizeof(uint16_t)));
+		HIP_TRY(jm_malloc(&d->d_tokens, tok_need * sizeof(uint16_t)));
 		d->tokens_cap = tok_need;
 	}
 	/* tables: entries [0, n) = the slices, entry n = what ends the last slice */

@@ -105,3 +105,13 @@ def test_batch_many_streams_vs_oracle(hip_lib, libs):
         # decode again into the same batch object: epochs, not memsets, invalidate old records
         b.decode()
         assert np.array_equal(b.frame_hashes(), dev)
+
+
+def test_randomised_sweep(hip_lib, libs):
+    """tools/fuzz_parity.py, a short run: random sizes and generator parameters (also the unusual-syntax option), batch +
+    one-picture ABI + device RGBA against the oracle."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "16", "3"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "16 cases, 0 mismatches" in out.stdout

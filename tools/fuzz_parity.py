@@ -1,0 +1,55 @@
+"""Randomised parity sweep on the GPU: random picture sizes and generator parameters (incl. the unusual-syntax option),
+every frame of every stream through the batch interface, the one-picture ABI and the device RGBA stage against the
+oracle (checker).  python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jsmpeg_amd import batch as jb, build, cabi, hashing, synth  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for c in range(cases):
+    w, h = int(rng.integers(1, 26)) * 16 - int(rng.integers(0, 16)), int(rng.integers(1, 20)) * 16 - int(rng.integers(0, 16))
+    ov = dict(width=max(w, 2), height=max(h, 2), gop=int(rng.integers(1, 16)), ac_max=int(rng.choice([0, 1, 3, 8, 24, 63])),
+              qscale_lo=int(rng.integers(1, 8)), qscale_hi=int(rng.integers(8, 32)), escape_permille=int(rng.choice([0, 20, 300, 1000])),
+              custom_quant=int(rng.integers(0, 2)), quirk_levels=int(rng.integers(0, 2)), dc_size_max=int(rng.integers(0, 9)),
+              coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 5)), syntax_quirks=int(rng.integers(0, 2)))
+    n = int(rng.integers(2, 20))
+    n_streams = int(rng.integers(1, 4))
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("case %d: frames=%d streams=%d %r" % (c, n, n_streams, ov), flush=True)
+    try:
+        streams = [synth.generate_config("cfg1_720p", n_frames=n, stream=1000 * c + s, **ov)[0] for s in range(n_streams)]
+    except RuntimeError as e:
+        print("case %d: generator: %s" % (c, e)); continue
+    want = []
+    for es in streams:
+        frames, _, info = cabi.decode_stream(build.LIB_ORACLE, es, keep="planes")
+        want.append(frames)
+    ok = True
+    with jb.Batch(ov["width"], ov["height"], n_streams, n_streams * n + 4, sum(len(s) for s in streams) + 4096) as b:
+        b.upload(streams)
+        got_n = b.decode()
+        dev = b.frame_hashes()
+        per = {}
+        for p, inf in enumerate(b.pictures()):
+            per.setdefault(inf.stream, []).append(p)
+        for s in range(n_streams):
+            if [int(dev[p]) for p in per.get(s, [])] != [hashing.frame_hash(*f) for f in want[s]]:
+                ok = False
+        p_last = per[0][-1]
+        if not np.array_equal(b.read_rgba(p_last), cabi.oracle_rgba(build.LIB_ORACLE, *want[0][-1], ov["width"], ov["height"])):
+            ok = False
+    got, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], keep="planes")
+    if len(got) != len(want[0]) or any(not all(np.array_equal(a, bb) for a, bb in zip(x, y)) for x, y in zip(got, want[0])):
+        ok = False
+    if not ok:
+        bad += 1
+        print("case %d MISMATCH: frames=%d streams=%d params=%r" % (c, n, n_streams, ov))
+print("%d cases, %d mismatches" % (cases, bad))
+sys.exit(1 if bad else 0)
