@@ -283,11 +283,37 @@ def main():
         dist.all_gather(gathered, h)
     infos = b.pictures()
     lib_oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
-    want, _, _ = cabi.decode_stream(lib_oracle, streams[0], keep="planes")
-    got0 = [int(dev_hashes[p]) for p, i in enumerate(infos) if i.stream == 0]
-    parity = got0 == [hashing.frame_hash(*f) for f in want]
-    if not parity:
-        raise SystemExit("rank %d: PARITY FAILURE against the oracle on stream 0 -- no number reported" % rank)
+    # every stream of the rank: the oracle decodes them on the host cores in parallel threads (the library releases the GIL)
+    per_stream = {}
+    for p, i in enumerate(infos):
+        per_stream.setdefault(i.stream, []).append(int(dev_hashes[p]))
+    check = list(range(n_streams)) if not os.environ.get("JSMPEG_BENCH_PARITY_STREAMS") else \
+        [int(x) for x in os.environ["JSMPEG_BENCH_PARITY_STREAMS"].split(",")]
+    failed = []
+
+    def verify(s):
+        want, _, _ = cabi.decode_stream(lib_oracle, streams[s], keep="planes")
+        if per_stream.get(s, []) != [hashing.frame_hash(*f) for f in want]:
+            failed.append(s)
+
+    t_par = time.perf_counter()
+    idx = iter(check)
+    lock = threading.Lock()
+
+    def runner():
+        while True:
+            with lock:
+                s = next(idx, None)
+            if s is None:
+                return
+            verify(s)
+
+    ts = [threading.Thread(target=runner) for _ in range(max(1, min(len(check), (os.cpu_count() or 8), 32)))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    log("rank %d: parity of %d streams against the oracle in %.1fs" % (rank, len(check), time.perf_counter() - t_par))
+    if failed:
+        raise SystemExit("rank %d: PARITY FAILURE against the oracle on streams %r -- no number reported" % (rank, sorted(failed)))
 
     if rank != 0:
         if multi:
@@ -363,7 +389,7 @@ def main():
                    "mbit_per_s_per_stream_at_30fps": round(es_bytes * 8 / n_streams / frames * 30 / 1e6, 2),
                    "parallelism": "gop/stream shards, %d rank(s)" % world},
         "mpixel_per_s": round(fps * width * height / 1e6, 1),
-        "parity_checked": "stream 0 of every rank, all %d pictures, device hash == oracle" % frames,
+        "parity_checked": "every stream of every rank (%d x %d pictures per rank), device hash == oracle" % (len(check), frames),
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and world == 1:

@@ -95,6 +95,9 @@ struct jsmpeg_hip_batch_t {
 	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
 	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
+	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
+	uint32_t desc_cap, n_uncovered;
+	hipEvent_t ev_cov;
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
 	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
@@ -116,10 +119,12 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
-	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_mb); hipFree(b->d_tokens);
+	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
+	if (b->h_covered) hipHostFree(b->h_covered);
+	if (b->ev_cov) hipEventDestroy(b->ev_cov);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	delete b;
 }
@@ -141,7 +146,11 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(jm_malloc(&b->d_counters, 4 * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
-	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * std::max(1u, c.max_pictures)));
+	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, and room for a second pass (step 4b) */
+	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
+	HIP_TRY(jm_malloc(&b->d_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(hipHostMalloc(&b->h_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures), hipHostMallocDefault));
+	HIP_TRY(hipEventCreate(&b->ev_cov));
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
 	HIP_TRY(jm_malloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
@@ -171,7 +180,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
-	b->d_pics = nullptr; b->d_desc = nullptr; b->d_mb = nullptr; b->d_tokens = nullptr;
+	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
@@ -367,6 +376,17 @@ extern "C" int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void 
 	return 0;
 }
 
+static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, int32_t stale) {
+	const JmPic &pic = b->h_pics[p];
+	D.tok_off = pic.tok_off;
+	D.mb_first = p * (uint32_t)b->g.mb_size;
+	D.stream = pic.stream;
+	D.dst = p;
+	D.fwd = pic.fwd >= 0 ? (uint32_t)pic.fwd : JM_NO_FRAME;
+	D.stale = stale >= 0 ? (uint32_t)stale : JM_NO_FRAME;
+	D.pad_ = 0;
+}
+
 extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) {
 	g_err[0] = 0;
 	if (!b) return fail("null batch");
@@ -404,22 +424,35 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	b->level_off.assign(b->n_levels + 1, 0);
 	for (const JmPic &p : b->h_pics) if (p.decoded) { b->level_off[p.level + 1]++; b->n_decoded++; b->n_slices += p.n_slices; }
 	for (uint32_t l = 0; l < b->n_levels; l++) b->level_off[l + 1] += b->level_off[l];
-	b->h_desc.resize(std::max<size_t>(1, b->n_decoded));
+	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
+	/* The reconstruct plan: dependency levels (a picture after its forward reference), and per picture the frame its
+	 * UNWRITTEN macroblocks keep showing.  The reference keeps two plane sets and rotates them after every picture
+	 * (mpeg1.c:986-994): a macroblock a picture never writes -- e.g. a last macroblock of 6 bits that hides in the
+	 * slack of the slice's last byte, so that next_bytes_are_start_code ends the slice before it (mpeg1.c:1018-1020)
+	 * -- keeps the decoded picture before last.  Here every picture has its own frame, so such a block is copied
+	 * from that picture's frame (`stale`).  Inside a chain that frame is two levels down; for the first two pictures
+	 * of a chain it belongs to the chain before: whether such a picture really has unwritten macroblocks is only
+	 * known after the parse (step 4b). */
+	std::vector<int32_t> level(b->n_pics, 0), stale(b->n_pics, -1);
 	{
-		std::vector<uint32_t> cur(b->level_off.begin(), b->level_off.end());
+		std::vector<int64_t> last1(b->n_streams, -1), last2(b->n_streams, -1);   /* the stream's last two decoded pictures */
+		uint32_t n_levels = 0;
 		for (uint32_t p = 0; p < b->n_pics; p++) {
 			const JmPic &pic = b->h_pics[p];
 			if (!pic.decoded) continue;
-			JmReconDesc &D = b->h_desc[cur[pic.level]++];
-			D.dst_off = (uint64_t)p * b->g.frame_bytes;
-			D.fwd_off = pic.fwd >= 0 ? (uint64_t)pic.fwd * b->g.frame_bytes : JM_NO_FWD;
-			D.tok_off = pic.tok_off;
-			D.mb_first = p * (uint32_t)b->g.mb_size;
-			D.stream = pic.stream;
+			level[p] = pic.fwd >= 0 ? level[pic.fwd] + 1 : 0;
+			n_levels = std::max(n_levels, (uint32_t)level[p] + 1);
+			if (pic.stream < b->n_streams) { stale[p] = (int32_t)last2[pic.stream]; last2[pic.stream] = last1[pic.stream]; last1[pic.stream] = p; }
 		}
+		b->n_levels = n_levels;
+		b->level_off.assign(n_levels + 1, 0);
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) b->level_off[level[p] + 1]++;
+		for (uint32_t l = 0; l < n_levels; l++) b->level_off[l + 1] += b->level_off[l];
+		b->h_desc.resize(std::max<size_t>(1, b->n_decoded));
+		std::vector<uint32_t> cur(b->level_off.begin(), b->level_off.end());
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) fill_desc(b, b->h_desc[cur[level[p]]++], p, stale[p]);
+		if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * b->n_decoded, hipMemcpyHostToDevice, st));
 	}
-	if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * b->n_decoded,
-	                                         hipMemcpyHostToDevice, st));
 	if (++b->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
 		b->epoch = 1;
@@ -430,7 +463,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmParseBufs pb;
 	pb.es = b->d_es; pb.sc_pos = b->d_sc_pos; pb.sc_code = b->d_sc_code; pb.sc_owner = b->d_sc_owner;
 	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
-	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch;
+	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
 	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */
@@ -440,6 +473,8 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	}
 	HIP_TRY(jm_launch_parse(pb, st));
 	HIP_TRY(hipEventRecord(b->ev[3], st));
+	if (b->n_pics) HIP_TRY(hipMemcpyAsync(b->h_covered, b->d_covered, sizeof(uint32_t) * b->n_pics, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(b->ev_cov, st));
 
 	/* ---- 4. reconstruct, one launch per dependency level ---- */
 	JmReconBufs rb;
@@ -455,6 +490,41 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		rb.desc = b->d_desc + b->level_off[l];
 		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
 		HIP_TRY(jm_launch_recon(rb, st));
+	}
+
+	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4 meanwhile).
+	 * A picture with unwritten macroblocks whose `stale` frame was not finished before its own level ran (only the
+	 * first two pictures of a chain can be that) has copied unfinished data: it, and what hangs on it, is
+	 * reconstructed again in stream order. ---- */
+	HIP_TRY(hipEventSynchronize(b->ev_cov));
+	{
+		std::vector<uint8_t> redo(b->n_pics, 0);
+		std::vector<uint32_t> again;
+		b->n_uncovered = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) {
+			const JmPic &pic = b->h_pics[p];
+			if (!pic.decoded) continue;
+			const bool uncovered = b->h_covered[p] < (uint32_t)b->g.mb_size;
+			b->n_uncovered += uncovered;
+			if ((uncovered && stale[p] >= 0 && (level[stale[p]] >= level[p] || redo[stale[p]])) || (pic.fwd >= 0 && redo[pic.fwd])) {
+				redo[p] = 1;
+				again.push_back(p);
+			}
+		}
+		if (getenv("JSMPEG_HIP_DEBUG_COVER"))
+			fprintf(stderr, "cover: %u of %u pictures with unwritten macroblocks, %zu reconstructed again\n", b->n_uncovered, b->n_pics, again.size());
+		if (!again.empty()) {
+			if (b->n_decoded + again.size() > b->desc_cap) return fail("internal: descriptor table too small for the second pass");
+			std::vector<JmReconDesc> d2(again.size());
+			for (size_t i = 0; i < again.size(); i++) fill_desc(b, d2[i], again[i], stale[again[i]]);
+			HIP_TRY(hipMemcpyAsync(b->d_desc + b->n_decoded, d2.data(), sizeof(JmReconDesc) * d2.size(), hipMemcpyHostToDevice, st));
+			HIP_TRY(hipStreamSynchronize(st));   /* d2 is pageable and goes out of scope */
+			for (size_t i = 0; i < again.size(); i++) {
+				rb.desc = b->d_desc + b->n_decoded + i;
+				rb.n_level_pics = 1;
+				HIP_TRY(jm_launch_recon(rb, st));
+			}
+		}
 	}
 	HIP_TRY(hipEventRecord(b->ev[4], st));
 	b->timed = true;
@@ -923,7 +993,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	p.type = (uint8_t)type; p.full_pel = (uint8_t)full_pel; p.f_code = (uint8_t)f_code; p.decoded = 1;
 	p.level = 0; p.fwd = -1; p.end_sc = (uint32_t)n_slices; p.pos = pic_pos; p.tok_off = 0;
 	JmReconDesc desc;
-	desc.dst_off = (uint64_t)d->cur * d->g.frame_bytes; desc.fwd_off = (uint64_t)(d->cur ^ 1) * d->g.frame_bytes;
+	desc.dst = (uint32_t)d->cur; desc.fwd = (uint32_t)(d->cur ^ 1); desc.stale = JM_NO_FRAME; desc.pad_ = 0;
 	desc.tok_off = 0; desc.mb_first = 0; desc.stream = 0;
 
 	hipStream_t st = d->stream;
@@ -941,7 +1011,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	JmParseBufs pb;
 	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
 	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
-	pb.n_sc = (uint32_t)n_entries; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr;
+	pb.n_sc = (uint32_t)n_entries; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.streams = d->d_stream; rb.desc = d->d_desc; rb.n_level_pics = 1;

@@ -50,6 +50,7 @@ struct JmParseBufs {
 	uint16_t *tokens;
 	uint32_t n_sc;
 	int mb_size;
+	uint32_t *covered;           /* [n_pics] += records written, per picture (zeroed by the caller), or null */
 	uint8_t epoch;
 	int debug_flags;             /* diagnostics only: 1 = LUTs from global memory, 2 = 64-lane workgroups */
 	uint32_t *dbg;               /* diagnostics only: 4 words per start-code entry, or null */
@@ -59,13 +60,18 @@ hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);
 /* One picture of a reconstruct launch: everything a workgroup needs to start, in one 32-byte scalar
  * load (the picture / order / offset tables cost a chain of dependent loads per workgroup). */
 struct alignas(32) JmReconDesc {
-	uint64_t dst_off;            /* byte offset of the picture's frame in the pool */
-	uint64_t fwd_off;            /* ... of its forward reference, JM_NO_FWD if none */
 	uint64_t tok_off;            /* first token slot of the picture */
 	uint32_t mb_first;           /* index of its first macroblock record */
 	uint32_t stream;             /* whose quantiser matrices apply */
+	uint32_t dst;                /* frame number (frame f at pool + f * frame_bytes) the picture is written to */
+	uint32_t fwd;                /* ... of its forward reference, JM_NO_FRAME if none */
+	uint32_t stale;              /* ... of what the reference's plane set held before this picture -- the decoded picture
+	                                before last of the stream (the reference rotates two plane sets, mpeg1.c:986-994):
+	                                macroblocks the picture never writes keep showing it.  JM_NO_FRAME: zeros (the JS
+	                                typed arrays start zeroed, mpeg1.js:131-152) */
+	uint32_t pad_;
 };
-#define JM_NO_FWD (~0ull)
+#define JM_NO_FRAME 0xffffffffu
 
 struct JmReconBufs {
 	JmGeom g;

@@ -241,7 +241,10 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 #pragma unroll
 		for (int k = 1; k < JM_COEF_REPEAT; k++) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
 	}
-	if (mine) jm_lane_finish(L);
+	if (mine) {
+		jm_lane_finish(L);
+		if (b.covered && L.stored) atomicAdd(&b.covered[b.sc_owner[i]], L.stored);
+	}
 }
 
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
@@ -320,9 +323,10 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	c.g = b.g;
 	c.mb = b.mb + D.mb_first;
 	c.tok = b.tokens + D.tok_off;
-	c.has_fwd = D.fwd_off != JM_NO_FWD;
-	c.dst = b.pool + D.dst_off;
-	c.fwd = b.pool + (c.has_fwd ? D.fwd_off : D.dst_off);
+	c.has_fwd = D.fwd != JM_NO_FRAME;
+	c.dst = b.pool + (uint64_t)D.dst * b.g.frame_bytes;
+	c.fwd = b.pool + (uint64_t)(c.has_fwd ? D.fwd : D.dst) * b.g.frame_bytes;
+	c.stale = D.stale != JM_NO_FRAME ? b.pool + (uint64_t)D.stale * b.g.frame_bytes : nullptr;
 	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;

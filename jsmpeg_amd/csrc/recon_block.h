@@ -38,6 +38,7 @@ struct JmReconCtx {
 	uint8_t *dst;            /* this picture's frame: Y | Cr | Cb        */
 	const uint8_t *fwd;      /* forward reference frame (any valid address when has_fwd == 0) */
 	int has_fwd;
+	const uint8_t *stale;    /* batch mode: the frame whose content unwritten macroblocks keep (null: zeros) */
 	const uint8_t *qm;       /* raster quantiser matrices: intra at [0, 64), non-intra at [64, 128) */
 	const uint8_t *zz;       /* zig-zag scan index -> raster position (mpeg1.c ZIG_ZAG) */
 	uint8_t epoch;
@@ -407,6 +408,15 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 #pragma unroll
 	for (int i = 0; i < 16; i++) X.p[i] = B.live ? B.P[i] : 0u;
 	X.store = B.live || c.zero_uncovered != 0;
+	if (!B.live && c.zero_uncovered && c.stale) {
+		/* a macroblock this picture never wrote: the reference's plane set still holds the picture before last there */
+		const uint8_t *src = c.stale + (B.out - c.dst);
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			const uint32_t *w = reinterpret_cast<const uint32_t *>(src + r * B.stride);
+			X.p[2 * r] = w[0]; X.p[2 * r + 1] = w[1];
+		}
+	}
 
 	/* ---- residual: from the slot, or the same value everywhere; add and clamp (mpeg1.c:1620-1644),
 	 * two pixels per instruction: bytes -> int16 pairs (v_perm), saturating packed add, saturate to

@@ -93,6 +93,7 @@ struct JmLane {
 	uint32_t tflushed;      /* slots below this are in HBM; multiple of JM_TK_GROUP */
 	uint32_t tok_rel;       /* the picture's first slot: JmMbRec.tok = slot - tok_rel */
 	JmMbRec *mb;            /* the picture's records */
+	uint32_t stored;        /* records written by this lane (the picture is fully covered when they add up to mb_size) */
 	/* parser state (mpeg1.c:694-751) */
 	int state;
 	int qscale;
@@ -210,7 +211,7 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	L.bp = L.bp0;
 	L.limit_bytes = limit_bytes; L.bp_end = L.bp0 + limit_bytes * 8u;
 	L.fillc = 0;
-	L.tokens = tokens; L.tw = L.tflushed = tok_slot; L.tok_rel = tok_rel; L.mb = mb;
+	L.tokens = tokens; L.tw = L.tflushed = tok_slot; L.tok_rel = tok_rel; L.mb = mb; L.stored = 0;
 	jm_lane_refill(L);
 	L.dc = JM_DC_RESET;
 	L.mvh = L.mvv = L.pmh = L.pmv = 0;
@@ -362,6 +363,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	 * (mpeg1.c:1018-1020) ---- */
 	if (L.cur >= 0) {
 		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
+		L.stored++;
 		L.cur = -1;
 		if (jm_slice_ended(L)) { L.state = JM_ST_DONE; return; }
 	}
@@ -395,7 +397,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 			/* skipped macroblock: prediction only (mpeg1.c:1072-1082) */
 			L.addr++;
 			if (L.addr >= 0)
-				jm_store_mbrec(L.mb + L.addr, L.tw - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch);
+				{ jm_store_mbrec(L.mb + L.addr, L.tw - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch); L.stored++; }
 			inc--;
 		}
 		L.addr++;

@@ -45,6 +45,17 @@ CASES = {
     # user_data after the picture header
     "syntax_quirks_352x288": ("cfg1_720p", 14, dict(width=352, height=288, syntax_quirks=1)),
     "syntax_quirks_1280x96": ("cfg1_720p", 14, dict(width=1280, height=96, syntax_quirks=1, f_code_max=2)),
+    # found by tools/fuzz_parity.py: the last macroblock of a slice is 6 bits long and sits in the slack of the slice's
+    # last byte -- next_bytes_are_start_code (buffer.c:140-150) is already true after the macroblock before it, the
+    # reference never decodes it and the picture shows what its plane set held two pictures earlier (mpeg1.c:1018-1020)
+    "uncovered_last_mb_118x197": ("cfg1_720p", 18, dict(width=118, height=197, gop=14, ac_max=1, qscale_lo=7, qscale_hi=8,
+                                                        escape_permille=0, custom_quant=1, quirk_levels=1, dc_size_max=2,
+                                                        coded_permille=50, f_code_max=2, stream=2000)),
+    # the same in the first P picture of a chain (picture 4 of I P P I P P ...): what it keeps showing belongs to the chain
+    # before -- the batch engine's second reconstruct pass
+    "uncovered_first_p_118x197": ("cfg1_720p", 12, dict(width=118, height=197, gop=3, ac_max=1, qscale_lo=7, qscale_hi=8,
+                                                        escape_permille=0, custom_quant=0, quirk_levels=0, dc_size_max=2,
+                                                        coded_permille=50, f_code_max=1, stream=3032)),
 }
 
 

@@ -167,14 +167,19 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 
 	std::vector<uint8_t> pool((size_t)g.frame_bytes * std::max(1u, n_pics) + 512, 0xAA);
 	uint8_t *base = pool.data() + 256;
-	for (int level = 0; level <= deepest; level++)
-		for (uint32_t p = 0; p < n_pics; p++) {
+	(void)deepest;
+	// k_recon, picture by picture in stream order (a picture after its forward reference and after the decoded picture
+	// before last, whose content its unwritten macroblocks keep -- the engine orders launches by those dependencies)
+	int64_t last1 = -1, last2 = -1;
+	for (uint32_t p = 0; p < n_pics; p++) {
 			const JmPic &pic = pics[p];
-			if (!pic.decoded || pic.level != level) continue;
+			if (!pic.decoded) continue;
 			JmReconCtx c;
 			c.g = g; c.mb = mb.data() + (size_t)p * g.mb_size; c.tok = tokens.data() + pic.tok_off;
 			c.dst = base + (uint64_t)p * g.frame_bytes;
 			c.has_fwd = pic.fwd >= 0;
+			c.stale = last2 >= 0 ? base + (uint64_t)last2 * g.frame_bytes : nullptr;
+			last2 = last1; last1 = p;
 			c.fwd = base + (uint64_t)(pic.fwd < 0 ? p : (uint32_t)pic.fwd) * g.frame_bytes;
 			uint8_t qm[128];
 			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
