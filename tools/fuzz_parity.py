@@ -24,7 +24,8 @@ for c in range(cases):
     if os.environ.get("FUZZ_VERBOSE"):
         print("case %d: frames=%d streams=%d %r" % (c, n, n_streams, ov), flush=True)
     try:
-        streams = [synth.generate_config("cfg1_720p", n_frames=n, stream=1000 * c + s, **ov)[0] for s in range(n_streams)]
+        gen = [synth.generate_config("cfg1_720p", n_frames=n, stream=1000 * c + s, **ov) for s in range(n_streams)]
+        streams = [g[0] for g in gen]
     except RuntimeError as e:
         print("case %d: generator: %s" % (c, e)); continue
     want = []
@@ -32,6 +33,7 @@ for c in range(cases):
         frames, _, info = cabi.decode_stream(build.LIB_ORACLE, es, keep="planes")
         want.append(frames)
     ok = True
+    why = []
     with jb.Batch(ov["width"], ov["height"], n_streams, n_streams * n + 4, sum(len(s) for s in streams) + 4096) as b:
         b.upload(streams)
         got_n = b.decode()
@@ -41,15 +43,39 @@ for c in range(cases):
             per.setdefault(inf.stream, []).append(p)
         for s in range(n_streams):
             if [int(dev[p]) for p in per.get(s, [])] != [hashing.frame_hash(*f) for f in want[s]]:
-                ok = False
+                ok = False; why.append("batch stream %d" % s)
         p_last = per[0][-1]
         if not np.array_equal(b.read_rgba(p_last), cabi.oracle_rgba(build.LIB_ORACLE, *want[0][-1], ov["width"], ov["height"])):
-            ok = False
+            ok = False; why.append("rgba")
     got, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], keep="planes")
     if len(got) != len(want[0]) or any(not all(np.array_equal(a, bb) for a, bb in zip(x, y)) for x, y in zip(got, want[0])):
-        ok = False
+        ok = False; why.append("decoder abi")
+    # streaming: one write per picture into an EVICT store a few pictures large (how ts.js + the Player drive it)
+    big = int(max(np.diff(gen[0][1]))) if n > 1 else len(streams[0])
+    got_s, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], gen[0][1], buffer_size=4 * big + 4096, mode=cabi.MODE_EVICT)
+    want_s, _, _ = cabi.decode_stream(build.LIB_ORACLE, streams[0], gen[0][1], buffer_size=4 * big + 4096, mode=cabi.MODE_EVICT)
+    if got_s != want_s:
+        ok = False; why.append("evict streaming: %d vs %d frames, first diff %s" % (len(got_s), len(want_s), [i for i, (a, bb) in enumerate(zip(got_s, want_s)) if a != bb][:3]))
+    # the same streams as MPEG-TS through the device demux, against the ts.js restatement feeding the oracle (a last
+    # PES that ends without stuffing stays pending in ts.js: that picture never reaches the decoder, in both)
+    tss = [synth.mux_ts(g[0], g[1]) for g in gen]
+    want_ts = []
+    for ts in tss:
+        demuxed, writes = cabi.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
+        given = demuxed[:sum(w[2] for w in writes)]
+        want_ts.append([hashing.frame_hash(*f) for f in cabi.decode_stream(build.LIB_ORACLE, given, keep="planes")[0]] if len(given) else [])
+    with jb.Batch(ov["width"], ov["height"], n_streams, n_streams * n + 4, sum(len(s) for s in streams) + 4096) as b:
+        b.upload_ts(tss)
+        b.decode()
+        dev_ts = b.frame_hashes()
+        per_ts = {}
+        for p, inf in enumerate(b.pictures()):
+            per_ts.setdefault(inf.stream, []).append(int(dev_ts[p]))
+        for s in range(n_streams):
+            if per_ts.get(s, []) != want_ts[s]:
+                ok = False; why.append("ts path stream %d: %d vs %d pictures" % (s, len(per_ts.get(s, [])), len(want_ts[s])))
     if not ok:
         bad += 1
-        print("case %d MISMATCH: frames=%d streams=%d params=%r" % (c, n, n_streams, ov))
+        print("case %d MISMATCH (%s): frames=%d streams=%d params=%r" % (c, "; ".join(why), n, n_streams, ov))
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
