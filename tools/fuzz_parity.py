@@ -14,11 +14,11 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for c in range(cases):
-    w, h = int(rng.integers(1, 26)) * 16 - int(rng.integers(0, 16)), int(rng.integers(1, 20)) * 16 - int(rng.integers(0, 16))
-    ov = dict(width=max(w, 2), height=max(h, 2), gop=int(rng.integers(1, 16)), ac_max=int(rng.choice([0, 1, 3, 8, 24, 63])),
+    w, h = int(rng.integers(1, 52)) * 16 - int(rng.integers(0, 16)), int(rng.integers(1, 30)) * 16 - int(rng.integers(0, 16))
+    ov = dict(width=max(w, 2), height=max(h, 2), gop=int(rng.choice([1, 2, 3, 5, 9, 12, 15, 40])), ac_max=int(rng.choice([0, 1, 3, 8, 24, 63])),
               qscale_lo=int(rng.integers(1, 8)), qscale_hi=int(rng.integers(8, 32)), escape_permille=int(rng.choice([0, 20, 300, 1000])),
               custom_quant=int(rng.integers(0, 2)), quirk_levels=int(rng.integers(0, 2)), dc_size_max=int(rng.integers(0, 9)),
-              coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 5)), syntax_quirks=int(rng.integers(0, 2)))
+              coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 8)), syntax_quirks=int(rng.integers(0, 2)))
     n = int(rng.integers(2, 20))
     n_streams = int(rng.integers(1, 4))
     if os.environ.get("FUZZ_VERBOSE"):
