@@ -72,14 +72,19 @@ __global__ __launch_bounds__(JM_WG) void k_scan_count(JmScanBufs b) {
 }
 
 __global__ __launch_bounds__(1024) void k_scan_prefix(uint64_t *counts, uint32_t n_blocks, uint32_t *counters) {
+	/* one workgroup, eight consecutive entries per lane and round (8192 per round): a serial add over a lane's eight,
+	 * a wave scan of the lane sums, wave totals through LDS */
 	__shared__ uint64_t wave_tot[16];
 	__shared__ uint64_t carry_s;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (threadIdx.x == 0) carry_s = 0;
 	__syncthreads();
-	for (uint32_t base = 0; base < n_blocks; base += 1024) {
-		uint32_t i = base + threadIdx.x;
-		uint64_t v = i < n_blocks ? counts[i] : 0, x = v;
+	for (uint32_t base = 0; base < n_blocks; base += 8192) {
+		const uint32_t i0 = base + threadIdx.x * 8;
+		uint64_t v[8], sum = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) { v[k] = i0 + k < n_blocks ? counts[i0 + k] : 0; sum += v[k]; }
+		uint64_t x = sum;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			uint32_t lo = __shfl_up((uint32_t)x, d, 64), hi = __shfl_up((uint32_t)(x >> 32), d, 64);
@@ -89,7 +94,9 @@ __global__ __launch_bounds__(1024) void k_scan_prefix(uint64_t *counts, uint32_t
 		__syncthreads();
 		uint64_t add = carry_s;
 		for (int k = 0; k < wave; k++) add += wave_tot[k];
-		if (i < n_blocks) counts[i] = add + x - v;           /* exclusive */
+		uint64_t run = add + x - sum;                        /* exclusive prefix of this lane's first entry */
+#pragma unroll
+		for (int k = 0; k < 8; k++) { if (i0 + k < n_blocks) counts[i0 + k] = run; run += v[k]; }
 		__syncthreads();
 		if (threadIdx.x == 1023) carry_s = add + x;
 		__syncthreads();
