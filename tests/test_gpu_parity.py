@@ -115,3 +115,30 @@ def test_randomised_sweep(hip_lib, libs):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "16", "3"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "16 cases, 0 mismatches" in out.stdout
+
+
+def test_cfg4_2160p_batch_at_scale(hip_lib, libs):
+    """SURVEY.md 8d cfg4 (3840x2160, high bitrate): 6 streams x 13 pictures in one batch, every frame hash against the
+    oracle (decoded on host threads)."""
+    import threading
+    streams, want = [], [None] * 6
+    for s in range(6):
+        es, _ = synth.generate_config("cfg4_2160p", n_frames=13, stream=s)
+        streams.append(es)
+
+    def ref(s):
+        frames, _, _ = cabi.decode_stream(libs["oracle"], streams[s], keep="planes")
+        want[s] = [hashing.frame_hash(*f) for f in frames]
+
+    ts = [threading.Thread(target=ref, args=(s,)) for s in range(6)]
+    [t.start() for t in ts]
+    with jb.Batch(3840, 2160, 6, 6 * 13 + 4, sum(len(s) for s in streams) + 8192) as b:
+        b.upload(streams)
+        assert b.decode() == 6 * 13
+        dev = b.frame_hashes()
+        per = {}
+        for p, info in enumerate(b.pictures()):
+            per.setdefault(info.stream, []).append(int(dev[p]))
+    [t.join() for t in ts]
+    for s in range(6):
+        assert per[s] == want[s], "stream %d" % s
