@@ -444,7 +444,12 @@ JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JM_EXP_NO_NT_STORE)
+		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
+		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);
+#else
 		o[0] = X.p[2 * r]; o[1] = X.p[2 * r + 1];
+#endif
 	}
 }
 
