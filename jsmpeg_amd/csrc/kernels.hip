@@ -495,8 +495,15 @@ __global__ __launch_bounds__(JM_WG) void k_rgba(JmRgbaBufs b, uint32_t lanes_per
 	uint8_t *out = b.rgba + (uint64_t)f * b.rgba_stride;
 	uint4 *o0 = reinterpret_cast<uint4 *>(out + ((size_t)(2 * rp) * b.width + x0) * 4);
 	uint4 *o1 = reinterpret_cast<uint4 *>(out + ((size_t)(2 * rp + 1) * b.width + x0) * 4);
+#ifndef JM_EXP_RGBA_NO_NT
+	/* written once, read by nobody on this GPU soon: streamed out past the L2 (5.50 -> 5.75 TB/s) */
+	typedef uint32_t jm_u4 __attribute__((ext_vector_type(4)));
+	const jm_u4 v0 = { px[0][0], px[0][1], px[0][2], px[0][3] }, v1 = { px[1][0], px[1][1], px[1][2], px[1][3] };
+	__builtin_nontemporal_store(v0, reinterpret_cast<jm_u4 *>(o0)); __builtin_nontemporal_store(v1, reinterpret_cast<jm_u4 *>(o1));
+#else
 	*o0 = make_uint4(px[0][0], px[0][1], px[0][2], px[0][3]);
 	*o1 = make_uint4(px[1][0], px[1][1], px[1][2], px[1][3]);
+#endif
 }
 
 /* Any size, one lane per OUTPUT pixel, following the reference's running indices exactly
