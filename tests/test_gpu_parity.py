@@ -142,3 +142,14 @@ def test_cfg4_2160p_batch_at_scale(hip_lib, libs):
     [t.join() for t in ts]
     for s in range(6):
         assert per[s] == want[s], "stream %d" % s
+
+
+def test_damaged_input_neither_faults_nor_hangs(hip_lib):
+    """tools/fuzz_corrupt.py, a short run: byte damage, truncation, spliced garbage, sprinkled start codes, damaged TS
+    packets.  Like the reference, no error is reported for bitstream content; unlike it, nothing is read or written out of bounds."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_corrupt.py"), "40", "2"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "40 damaged streams decoded without fault or hang" in out.stdout
