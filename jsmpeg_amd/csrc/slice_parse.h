@@ -314,33 +314,28 @@ JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 /* SLOW step: one symbol the 9-bit table does not resolve -- the escape
  * (mpeg1.js:767-780) and the codes of 10 to 16 bits. */
 JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
+	/* both forms are worked out for every lane and selected at the end: the lanes of a wave that are here hold a mix of
+	 * escapes and long codes, and a branch would run both sides anyway, plus its bookkeeping */
 	const uint32_t w = jm_bits32(L, L.bp);
-	bool bad = L.bp >= L.bp_end;
-	int run, level, used;
-	if ((w >> 26) == 1) {
-		/* escape: 6 + 6-bit run, 8- or 16-bit level */
-		run = (int)((w >> 20) & 63);
-		level = (int)((w >> 12) & 255);
-		used = 20;
-		if ((level & 127) == 0) {
-			const int low = (int)((w >> 4) & 255);
-			level = level ? low - 256 : low;
-			used = 28;
-		} else if (level > 128) level -= 256;
-	} else {
-		/* 6 .. 11 leading zeros, a 1, and 4 bits into the far table */
-		const int lz = __builtin_clz(w | 1u);
-		const uint32_t i2 = (uint32_t)((lz - 6) & 7) * 16u + ((w >> ((27 - lz) & 31)) & 15u);
-		const uint32_t f = c.lut->far_[i2 < 96 ? i2 : 0];
-		const int flen = (int)(f >> 11);
-		if (!flen || lz < 6 || lz > 11) bad = true;
-		run = (int)((f >> 6) & 31);
-		level = (int)(f & 63);
-		if ((w >> ((31 - flen) & 31)) & 1) level = -level;
-		used = flen + 1;
-	}
+	const bool esc = (w >> 26) == 1;
+	/* escape: 6 + 6-bit run, 8- or 16-bit level */
+	const int e_lv8 = (int)((w >> 12) & 255), e_low = (int)((w >> 4) & 255);
+	const bool e_long = (e_lv8 & 127) == 0;
+	const int e_level = e_long ? (e_lv8 ? e_low - 256 : e_low) : (e_lv8 > 128 ? e_lv8 - 256 : e_lv8);
+	/* 6 .. 11 leading zeros, a 1, and 4 bits into the far table */
+	const int lz = __builtin_clz(w | 1u);
+	const uint32_t i2 = (uint32_t)((lz - 6) & 7) * 16u + ((w >> ((27 - lz) & 31)) & 15u);
+	const uint32_t f = c.lut->far_[i2 < 96 ? i2 : 0];
+	const int flen = (int)(f >> 11);
+	const int f_mag = (int)(f & 63);
+	const int f_level = ((w >> ((31 - flen) & 31)) & 1) ? -f_mag : f_mag;
+	const bool f_bad = !flen || lz < 6 || lz > 11;
+
+	const int run = esc ? (int)((w >> 20) & 63) : (int)((f >> 6) & 31);
+	const int level = esc ? e_level : f_level;
+	const int used = esc ? (e_long ? 28 : 20) : flen + 1;
 	const int n = L.n + run;
-	if (n > 63) bad = true;
+	const bool bad = L.bp >= L.bp_end || n > 63 || (!esc && f_bad);
 	int st = JM_ST_DONE;
 	if (!bad) {
 		L.bp += (uint32_t)used;
