@@ -1,0 +1,31 @@
+"""The other configurations of SURVEY.md 8d as timings (not bench lines): one 1280x720 stream of 360 pictures through the
+batch interface (GOPs in parallel, 30 pictures per level), and the per-picture latency of the one-picture ABI (what the
+Node class sits on) at 720p and 1080p, planes copied to the host each time."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jsmpeg_amd import batch as jb, build, cabi, synth  # noqa: E402
+
+es, offs = synth.generate_config("cfg1_720p", n_frames=360)
+with jb.Batch(1280, 720, 1, 368, len(es) + 4096) as b:
+    b.upload([es])
+    b.decode()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b.decode()
+    dt = (time.perf_counter() - t0) / 5
+    print("cfg1 batch: one 1280x720 stream, 360 pictures: %.2f ms per pass = %.0f frames/s  %s" % (dt * 1e3, 360 / dt, b.timings()))
+for name, cfg, n in (("720p", "cfg1_720p", 60), ("1080p", "cfg2_1080p", 60)):
+    es, offs = synth.generate_config(cfg, n_frames=n)
+    with cabi.Mpeg1Decoder(build.LIB_HIP, len(es) + 1024, cabi.MODE_EXPAND) as d:
+        d.write(es)
+        d.decode()
+        t0 = time.perf_counter()
+        k = 1
+        while d.decode():
+            k += 1
+        dt = (time.perf_counter() - t0) / (k - 1)
+        print("one-picture ABI %s: %.3f ms per decode() incl. planes to the host (%d pictures) = %.0f frames/s" % (name, dt * 1e3, k, 1 / dt))
