@@ -39,7 +39,9 @@ typedef struct synth_params_t {
 	int32_t dc_size_max;     /* dct_dc_size ~ U[0, dc_size_max]                 */
 	int32_t coded_permille;  /* P pictures: probability a cbp bit is set         */
 	int32_t f_code_max;      /* P pictures: forward_f_code ~ U[1, f_code_max]   */
-	int32_t syntax_quirks;   /* 1: valid but unusual syntax -- slices that start / end mid-row or span rows,
+	int32_t syntax_quirks;   /* bit 1 (value 2): B / D pictures and P pictures with forward_f_code 0 between the
+	                            decoded ones (the reference consumes them without decoding);
+	                            bit 0 (value 1): valid but unusual syntax -- slices that start / end mid-row or span rows,
 	                            extra_information_slice / _picture, macroblock_stuffing, extension and
 	                            user_data start codes after the picture header (0: one plain slice per row) */
 } synth_params_t;
@@ -314,7 +316,7 @@ static void put_picture_header(gen_t *G, int temporal_ref, int type, int full_pe
 	bw_put(w, (uint32_t)type, 3);
 	bw_put(w, 0xffff, 16);     /* vbv_delay */
 	if (type == 2) { bw_put(w, (uint32_t)full_pel, 1); bw_put(w, (uint32_t)f_code, 3); }
-	if (G->p->syntax_quirks) {
+	if (G->p->syntax_quirks & 1) {
 		/* extra_information_picture, then extension_data and user_data: the reference skips all of it by
 		 * scanning for the next start code (mpeg1.c:961-966) */
 		for (int k = rng_range(&G->r, 0, 2); k > 0; k--) { bw_put(w, 1, 1); bw_put(w, (uint32_t)rng_range(&G->r, 0x11, 0xee), 8); }
@@ -324,6 +326,27 @@ static void put_picture_header(gen_t *G, int temporal_ref, int type, int full_pe
 		return;
 	}
 	bw_put(w, 0, 1);           /* extra_bit_picture */
+}
+
+/* A picture the reference consumes without decoding (mpeg1.c:955-960, 967-972): a B or D picture, or a P picture with
+ * forward_f_code 0 -- header, then a few "slices" of bytes that emulate no start code.  The plane sets do not rotate:
+ * the next P picture still predicts from the last decoded I / P picture. */
+static void put_skipped_picture(gen_t *G, int temporal_ref) {
+	bitw_t *w = &G->w;
+	const int kind = rng_range(&G->r, 0, 2);           /* 0: B, 1: D, 2: P with f_code 0 */
+	bw_align(w);
+	bw_start_code(w, 0x00);
+	bw_put(w, (uint32_t)temporal_ref & 1023, 10);
+	bw_put(w, kind == 0 ? 3u : (kind == 1 ? 4u : 2u), 3);
+	bw_put(w, 0xffff, 16);
+	if (kind == 0) { bw_put(w, 0, 1); bw_put(w, 1, 3); bw_put(w, 0, 1); bw_put(w, 1, 3); }
+	else if (kind == 2) { bw_put(w, 0, 1); bw_put(w, 0, 3); }
+	bw_put(w, 0, 1);
+	bw_align(w);
+	for (int sl = rng_range(&G->r, 1, 4), row = 1; sl > 0; sl--, row++) {
+		bw_start_code(w, row);
+		for (int k = rng_range(&G->r, 2, 60); k > 0; k--) bw_put(w, (uint32_t)rng_range(&G->r, 0x11, 0xee), 8);
+	}
 }
 
 static int has_aligned_start_code(const uint8_t *b, size_t from, size_t to) {
@@ -344,7 +367,7 @@ static void put_slice(gen_t *G, int a0, int a1, int type, int full_pel, int f_co
 		size_t payload = w->pos;
 		int qscale = rng_range(&G->r, p->qscale_lo, p->qscale_hi);
 		bw_put(w, (uint32_t)qscale, 5);
-		if (p->syntax_quirks)      /* extra_information_slice (mpeg1.c:1013-1016) */
+		if (p->syntax_quirks & 1)  /* extra_information_slice (mpeg1.c:1013-1016) */
 			for (int k = rng_range(&G->r, 0, 2); k > 0; k--) { bw_put(w, 1, 1); bw_put(w, (uint32_t)rng_range(&G->r, 1, 255), 8); }
 		bw_put(w, 0, 1); /* extra_bit_slice */
 
@@ -365,7 +388,7 @@ static void put_slice(gen_t *G, int a0, int a1, int type, int full_pel, int f_co
 			G->st.macroblocks++;
 			if (kind != 0) G->st.predicted++;
 			if (kind == 4) { pending_skip++; continue; }
-			if (p->syntax_quirks) for (int k = (rng_next(&G->r) % 8u) == 0 ? rng_range(&G->r, 1, 3) : 0; k > 0; k--) bw_put_code(w, N_MBA[34]);   /* macroblock_stuffing */
+			if (p->syntax_quirks & 1) for (int k = (rng_next(&G->r) % 8u) == 0 ? rng_range(&G->r, 1, 3) : 0; k > 0; k--) bw_put_code(w, N_MBA[34]);   /* macroblock_stuffing */
 			put_mba_increment(w, pending_skip + 1);
 			if (firstmb) pending_skip = 0;
 			if (pending_skip) {
@@ -472,7 +495,7 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 			f_code = rng_range(&G.r, 1, p->f_code_max < 1 ? 1 : p->f_code_max);
 		}
 		put_picture_header(&G, in_gop, type, full_pel, f_code);
-		if (!p->syntax_quirks)
+		if (!(p->syntax_quirks & 1))
 			for (int row = 0; row < G.g.mbh; row++) put_slice(&G, row * G.g.mbw, (row + 1) * G.g.mbw, type, full_pel, f_code);
 		else
 			for (int a = 0, n = G.g.mbw * G.g.mbh; a < n; ) {
@@ -481,6 +504,7 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 				put_slice(&G, a, a + len, type, full_pel, f_code);
 				a += len;
 			}
+		if ((p->syntax_quirks & 2) && rng_next(&G.r) % 3u == 0) put_skipped_picture(&G, in_gop);
 	}
 	bw_start_code(&G.w, 0xB7); /* sequence_end */
 	if (pic_offsets) pic_offsets[p->n_frames] = (uint32_t)(G.w.pos - 4);

@@ -28,12 +28,13 @@ def load_case(path):
 def test_oracle_matches_golden(path, libs):
     fx, es, offs = load_case(path)
     frames, idx, info = cabi.decode_stream(libs["oracle"], es)
-    assert frames == fx["frame_md5"]
+    # one entry per decode() == true; pictures the reference consumes without decoding (B / D / f_code 0) repeat the previous one
+    assert frames == fx.get("abi_frame_md5", fx["frame_md5"])
     assert idx == fx["bit_index_after_decode"]
     assert info["coded_size"] == fx["info"]["coded_size"] and info["width"] == fx["info"]["width"]
     # streaming-style feed (one write per picture, ts.js:205-210) must give the same pictures
     frames2, _, _ = cabi.decode_stream(libs["oracle"], es, offs)
-    assert frames2 == fx["frame_md5"]
+    assert frames2 == fx.get("abi_frame_md5", fx["frame_md5"])
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-5] for p in FIXTURES])
@@ -42,7 +43,7 @@ def test_reference_native_matches_golden(path, libs):
         pytest.skip("oracle/_ref not built (needs /root/reference once)")
     fx, es, offs = load_case(path)
     frames, idx, _ = cabi.decode_stream(libs["ref"], es)
-    assert frames == fx["frame_md5"]
+    assert frames == fx.get("abi_frame_md5", fx["frame_md5"])
     assert idx == fx["bit_index_after_decode"]
 
 
