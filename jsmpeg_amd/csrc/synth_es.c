@@ -39,7 +39,8 @@ typedef struct synth_params_t {
 	int32_t dc_size_max;     /* dct_dc_size ~ U[0, dc_size_max]                 */
 	int32_t coded_permille;  /* P pictures: probability a cbp bit is set         */
 	int32_t f_code_max;      /* P pictures: forward_f_code ~ U[1, f_code_max]   */
-	int32_t syntax_quirks;   /* bit 1 (value 2): B / D pictures and P pictures with forward_f_code 0 between the
+	int32_t syntax_quirks;   /* bit 2 (value 4, with bit 0): now and then ONE slice from where it starts to the end of the picture;
+	                            bit 1 (value 2): B / D pictures and P pictures with forward_f_code 0 between the
 	                            decoded ones (the reference consumes them without decoding);
 	                            bit 0 (value 1): valid but unusual syntax -- slices that start / end mid-row or span rows,
 	                            extra_information_slice / _picture, macroblock_stuffing, extension and
@@ -500,6 +501,7 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 		else
 			for (int a = 0, n = G.g.mbw * G.g.mbh; a < n; ) {
 				int len = rng_range(&G.r, 1, 2 * G.g.mbw + G.g.mbw / 2);
+				if ((p->syntax_quirks & 4) && rng_next(&G.r) % 4u == 0) len = n;   /* one slice to the end of the picture */
 				if (a + len > n) len = n - a;
 				put_slice(&G, a, a + len, type, full_pel, f_code);
 				a += len;

@@ -61,6 +61,7 @@ CASES = {
     # reference's JS class does not render -- the four runs are compared without those repeats, and the C ABI's full list
     # is kept beside (abi_frame_md5)
     "skipped_pictures_352x288": ("cfg1_720p", 20, dict(width=352, height=288, syntax_quirks=2)),
+    "long_slices_352x288": ("cfg1_720p", 16, dict(width=352, height=288, syntax_quirks=5)),
     "skipped_pictures_quirks_176x144": ("cfg1_720p", 20, dict(width=176, height=144, syntax_quirks=3, gop=5)),
 }
 
