@@ -40,7 +40,7 @@ def _csrc_headers():
 
 
 def build_synth(force=False):
-    src = [os.path.join(CSRC, "synth_es.c")]
+    src = [os.path.join(CSRC, "synth_es.c"), os.path.join(CSRC, "synth_mp2.c")]
     if force or _newer(LIB_SYNTH, src + _csrc_headers()):
         _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", LIB_SYNTH] + src)
     return LIB_SYNTH
@@ -103,9 +103,11 @@ def build_addon(force=False):
 
 def build_oracle(force=False):
     """CPU restatement (test infrastructure only)."""
-    src = [os.path.join(ORACLE, f) for f in ("mpeg1_oracle.c", "ycbcr_oracle.c", "ts_oracle.c")]
-    if force or _newer(LIB_ORACLE, src + [os.path.join(ORACLE, "mpeg1_oracle.h")]):
-        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", LIB_ORACLE] + src)
+    src = [os.path.join(ORACLE, f) for f in ("mpeg1_oracle.c", "ycbcr_oracle.c", "ts_oracle.c", "mp2_oracle.c")]
+    deps = [os.path.join(ORACLE, "mpeg1_oracle.h"), os.path.join(CSRC, "mp2_window.h")]
+    if force or _newer(LIB_ORACLE, src + deps):
+        # -ffp-contract=off: the MP2 restatement's float products must round as written (oracle/mp2_oracle.c header)
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-o", LIB_ORACLE] + src)
     return LIB_ORACLE
 
 

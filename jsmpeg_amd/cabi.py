@@ -195,3 +195,115 @@ def oracle_ts_demux(oracle_path, ts, stream_id=0xE0):
     if n < 0 or n > cap:
         raise RuntimeError("ts_oracle_demux failed (%d)" % n)
     return es[:n_es.value].copy(), [(writes[i].pts, writes[i].offset, writes[i].length) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MP2 audio: the reference's 10-function decoder ABI (reference src/wasm/mp2.h:10-20), exported by the same
+# three libraries.
+
+_MP2_SIGS = {
+    "mp2_decoder_create": (ctypes.c_void_p, [ctypes.c_uint, ctypes.c_int]),
+    "mp2_decoder_destroy": (None, [ctypes.c_void_p]),
+    "mp2_decoder_get_write_ptr": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint]),
+    "mp2_decoder_get_index": (ctypes.c_int, [ctypes.c_void_p]),
+    "mp2_decoder_set_index": (None, [ctypes.c_void_p, ctypes.c_uint]),
+    "mp2_decoder_did_write": (None, [ctypes.c_void_p, ctypes.c_uint]),
+    "mp2_decoder_get_left_channel_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mp2_decoder_get_right_channel_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "mp2_decoder_get_sample_rate": (ctypes.c_int, [ctypes.c_void_p]),
+    "mp2_decoder_decode": (ctypes.c_int, [ctypes.c_void_p]),
+}
+MP2_ABI_SYMBOLS = tuple(_MP2_SIGS)
+MP2_SAMPLES_PER_FRAME = 1152
+
+_mp2_libs = {}
+
+
+def load_mp2(path):
+    lib = _mp2_libs.get(path)
+    if lib is None:
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in _MP2_SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _mp2_libs[path] = lib
+    return lib
+
+
+class Mp2Decoder:
+    """One MP2 decoder handle of whichever library `path` names."""
+
+    def __init__(self, path, buffer_size=128 * 1024, mode=MODE_EXPAND):
+        self.lib = load_mp2(path)
+        self.h = self.lib.mp2_decoder_create(buffer_size, mode)
+        if not self.h:
+            raise RuntimeError("mp2_decoder_create failed (%s)" % path)
+
+    def close(self):
+        if self.h:
+            self.lib.mp2_decoder_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def write(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = int(data.size)
+        ptr = self.lib.mp2_decoder_get_write_ptr(self.h, n)
+        ctypes.memmove(ptr, data.ctypes.data, n)
+        self.lib.mp2_decoder_did_write(self.h, n)
+
+    def decode(self):
+        """Bytes of the frame that was decoded, 0 if none."""
+        return int(self.lib.mp2_decoder_decode(self.h))
+
+    @property
+    def index(self):
+        return self.lib.mp2_decoder_get_index(self.h)
+
+    @index.setter
+    def index(self, v):
+        self.lib.mp2_decoder_set_index(self.h, v)
+
+    @property
+    def sample_rate(self):
+        return self.lib.mp2_decoder_get_sample_rate(self.h)
+
+    def channels(self):
+        """Copies of the most recently decoded (left, right) float32[1152]."""
+        out = []
+        for getter in (self.lib.mp2_decoder_get_left_channel_ptr, self.lib.mp2_decoder_get_right_channel_ptr):
+            ptr = getter(self.h)
+            out.append(np.ctypeslib.as_array((ctypes.c_float * MP2_SAMPLES_PER_FRAME).from_address(ptr)).copy())
+        return tuple(out)
+
+
+def decode_mp2_stream(path, data, frame_offsets=None, buffer_size=None, mode=MODE_EXPAND, max_frames=None):
+    """Feeds `data` (one write, or one write per frame when `frame_offsets` is given, the way ts.js hands over PES
+    payloads) and pulls every frame.  Returns (pcm float32[n_frames, 2, 1152], [bit index after each decode()],
+    [frame bytes], sample rate after the last frame)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    pcm, indices, sizes = [], [], []
+    with Mp2Decoder(path, buffer_size or (len(data) + 1024), mode) as dec:
+        def pull():
+            while max_frames is None or len(pcm) < max_frames:
+                n = dec.decode()
+                if n == 0:
+                    break
+                sizes.append(n)
+                indices.append(dec.index)
+                pcm.append(np.stack(dec.channels()))
+        if frame_offsets is None:
+            dec.write(data)
+            pull()
+        else:
+            for k in range(len(frame_offsets) - 1):
+                dec.write(data[int(frame_offsets[k]):int(frame_offsets[k + 1])])
+                pull()
+        rate = dec.sample_rate
+    return (np.stack(pcm) if pcm else np.zeros((0, 2, MP2_SAMPLES_PER_FRAME), np.float32)), indices, sizes, rate

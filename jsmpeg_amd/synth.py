@@ -20,6 +20,12 @@ class SynthStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("macroblocks", "predicted", "coded_blocks", "coefficients")]
 
 
+class SynthMp2Params(ctypes.Structure):
+    _fields_ = [("n_frames", ctypes.c_int32), ("seed", ctypes.c_uint32)] + \
+               [(n, ctypes.c_int32) for n in ("sample_rate_index", "bitrate_index", "mode", "crc", "sf_lo", "sf_hi",
+                                               "alloc_permille", "vary", "quirks")]
+
+
 _lib = None
 
 
@@ -36,6 +42,8 @@ def lib():
         _lib.synth_ts_mux.restype = ctypes.c_size_t
         _lib.synth_ts_mux.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
                                       ctypes.c_void_p, ctypes.c_size_t]
+        _lib.synth_mp2_generate.restype = ctypes.c_size_t
+        _lib.synth_mp2_generate.argtypes = [ctypes.POINTER(SynthMp2Params), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     return _lib
 
 
@@ -93,3 +101,37 @@ def mux_ts(es, pic_offsets, fps=30.0):
     if n == 0:
         raise RuntimeError("TS mux overflowed its buffer")
     return out[:n].copy()
+
+
+# MP2 audio.  name -> generator parameters; bitrate_index is the header value (1..14:
+# 32 48 56 64 80 96 112 128 160 192 224 256 320 384 kbit/s), sample_rate_index 0 / 1 / 2 = 44.1 / 48 / 32 kHz.
+MP2_CONFIGS = {
+    "mp2_stereo_44k_192": dict(sample_rate_index=0, bitrate_index=10, mode=0, crc=0),
+    "mp2_joint_48k_128": dict(sample_rate_index=1, bitrate_index=8, mode=1, crc=1),
+    "mp2_mono_32k_48": dict(sample_rate_index=2, bitrate_index=2, mode=3, crc=0),
+    "mp2_dual_44k_384": dict(sample_rate_index=0, bitrate_index=14, mode=2, crc=1, alloc_permille=950, sf_lo=6),
+    "mp2_mono_48k_64": dict(sample_rate_index=1, bitrate_index=4, mode=3, crc=1),
+    "mp2_varying_44k": dict(sample_rate_index=0, bitrate_index=8, mode=0, crc=0, vary=1),
+    "mp2_varying_32k_quirks": dict(sample_rate_index=2, bitrate_index=8, mode=0, crc=0, vary=1, quirks=1),
+}
+
+
+def generate_mp2(n_frames, sample_rate_index=0, bitrate_index=10, mode=0, crc=0, sf_lo=9, sf_hi=62,
+                 alloc_permille=800, vary=0, quirks=0, seed=BASE_SEED + 0x4D5032):
+    """Returns (mp2 bytes: np.uint8[n], frame_offsets: np.uint32[n_frames + 1])."""
+    p = SynthMp2Params(n_frames, seed & 0xFFFFFFFF, sample_rate_index, bitrate_index, mode, crc, sf_lo, sf_hi,
+                       alloc_permille, vary, quirks)
+    cap = n_frames * 1800 + 64
+    buf = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n_frames + 1, dtype=np.uint32)
+    n = lib().synth_mp2_generate(ctypes.byref(p), buf.ctypes.data, cap, offs.ctypes.data)
+    if n == 0:
+        raise RuntimeError("synthetic MP2 generation failed")
+    return buf[:n].copy(), offs
+
+
+def generate_mp2_config(name, n_frames, stream=0, **overrides):
+    c = dict(MP2_CONFIGS[name])
+    c.update(overrides)
+    c.setdefault("seed", (BASE_SEED + 0x4D5032 + 7919 * stream) & 0xFFFFFFFF)
+    return generate_mp2(n_frames, **c)
