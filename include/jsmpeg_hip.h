@@ -1,5 +1,6 @@
 /*
- * jsmpeg_hip -- C ABI of the MI355X (gfx950) MPEG-1 video decode path.
+ * jsmpeg_hip -- C ABI of the MI355X (gfx950) MPEG-1 video decode path (parts 1, 2) and of its MP2 audio
+ * sibling (part 3).
  *
  * Drop-in boundary.  Part 1 is, symbol for symbol, the C ABI the reference
  * already defines for this path and that its JS wrapper binds through
@@ -174,6 +175,68 @@ int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
 /* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
  * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture. */
 int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[6]);
+
+/* ------------------------------------------------------------------ part 3
+ * MP2 audio (MPEG-1 Audio Layer II) -- the sibling decoder of the reference's
+ * wasm module.  First, symbol for symbol, the C ABI the
+ * reference defines for it (src/wasm/mp2.h:10-20, export list build.sh:68-77,
+ * binding src/mp2-wasm.js:21-104).  PCM is bit-identical to the reference's C /
+ * shipped wasm build (binary32, see jsmpeg_amd/csrc/mp2_dev.h for the
+ * arithmetic contract; the reference's pure-JS decoder rounds differently and
+ * agrees to ~5e-7 of full scale).                                            */
+
+typedef struct mp2_decoder_t mp2_decoder_t;
+
+/* mp2.h:10 -- buffer_size = initial byte capacity (JS option audioBufferSize) */
+mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffer_mode_t buffer_mode);
+/* mp2.h:11 */
+void mp2_decoder_destroy(mp2_decoder_t *self);
+/* mp2.h:12-15 -- as for the video decoder */
+void *mp2_decoder_get_write_ptr(mp2_decoder_t *self, unsigned int byte_size);
+int mp2_decoder_get_index(mp2_decoder_t *self);
+void mp2_decoder_set_index(mp2_decoder_t *self, unsigned int index);
+void mp2_decoder_did_write(mp2_decoder_t *self, unsigned int byte_size);
+/* mp2.h:17-18 -- HOST pointers to the 1152 float samples per channel of the
+ * most recently decoded frame; valid until the next decode. */
+void *mp2_decoder_get_left_channel_ptr(mp2_decoder_t *self);
+void *mp2_decoder_get_right_channel_ptr(mp2_decoder_t *self);
+/* mp2.h:19 -- of the most recently decoded frame; 44100 before the first */
+int mp2_decoder_get_sample_rate(mp2_decoder_t *self);
+/* mp2.h:20 -- decodes the frame at the cursor; returns its length in bytes,
+ * 0 if fewer than 16 bits are buffered or the header is not MPEG-1 Layer II
+ * with a valid bit rate / sampling frequency (mp2.c:275-302); the cursor then
+ * stays where it was.  Frames must be completely buffered (the reference never
+ * checks and decodes stale bytes; here the missing bytes read as 0). */
+int mp2_decoder_decode(mp2_decoder_t *self);
+
+/* Additive batch interface: N MP2 streams, every frame, PCM left in HBM. */
+typedef struct jsmpeg_hip_mp2_batch_t jsmpeg_hip_mp2_batch_t;
+
+/* max_bytes: total compressed bytes per batch (<= 256 MiB). device: HIP ordinal, -1 = current. */
+jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_streams, uint64_t max_bytes, int32_t device);
+void jsmpeg_hip_mp2_batch_destroy(jsmpeg_hip_mp2_batch_t *b);
+/* Copies n_streams host buffers of back-to-back Layer II frames into HBM.  Returns 0 or < 0. */
+int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
+                                const uint64_t *bytes);
+/* Decodes every frame of every stream -- per stream what `while (mp2_decoder_decode(d));` after one write of the
+ * whole buffer gives, except that a last frame that is not completely there is not decoded.  Work is enqueued on
+ * `hip_stream` (NULL = the batch's own); the call synchronises once internally (frame counts size the launches).
+ * Returns the total number of frames or < 0. */
+int jsmpeg_hip_mp2_batch_decode(jsmpeg_hip_mp2_batch_t *b, void *hip_stream);
+int jsmpeg_hip_mp2_batch_sync(jsmpeg_hip_mp2_batch_t *b);
+/* Frames of one stream, or of the whole batch with stream = -1. */
+uint32_t jsmpeg_hip_mp2_batch_frame_count(jsmpeg_hip_mp2_batch_t *b, int32_t stream);
+/* Where a frame starts in its stream, its length and sampling frequency (any pointer may be NULL). */
+int jsmpeg_hip_mp2_batch_frame_info(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, uint32_t frame,
+                                    uint32_t *byte_offset, uint32_t *byte_size, int32_t *sample_rate);
+/* DEVICE pointer: float[total frames][2][1152] (left, right), streams one after the other in upload order. */
+void *jsmpeg_hip_mp2_batch_pcm(jsmpeg_hip_mp2_batch_t *b);
+/* Device-to-host copy of `count` frames of one stream: out[count][2][1152]. */
+int jsmpeg_hip_mp2_batch_read_pcm(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, uint32_t first_frame, uint32_t count,
+                                  float *out);
+/* hipEvent timings of the last decode, milliseconds: [0] frame walk + count read-back, [1] host turn-around +
+ * side information, [2] sample read + matrixing, [3] windowing, [4] total. */
+int jsmpeg_hip_mp2_batch_timings(jsmpeg_hip_mp2_batch_t *b, float out_ms[5]);
 
 /* Last error of the calling thread ("" if none). */
 const char *jsmpeg_hip_last_error(void);

@@ -69,7 +69,7 @@ def check_kernel_resources():
     import re
     usage, name = {}, None
     out = ""
-    for f in ("kernels.hip", "ts_kernels.hip"):
+    for f in ("kernels.hip", "ts_kernels.hip", "mp2_stage.hip"):
         src = os.path.join(CSRC, f)
         out += subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                                "-I", CSRC, "--cuda-device-only", "-c", src, "-o", os.devnull,

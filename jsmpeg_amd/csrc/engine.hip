@@ -35,6 +35,9 @@ static int fail(const char *fmt, ...) {
 	} while (0)
 
 extern "C" const char *jsmpeg_hip_last_error(void) { return g_err; }
+/* for the other translation units of the library (mp2_stage.hip): same thread-local message */
+int jm_set_error(const char *msg) { return fail("%s", msg); }
+void jm_clear_error(void) { g_err[0] = 0; }
 extern "C" int jsmpeg_hip_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;

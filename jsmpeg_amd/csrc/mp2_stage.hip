@@ -1,0 +1,441 @@
+/*
+ * MP2 (MPEG-1 Audio Layer II) decode stage: gfx950 kernels and the host runtime behind part 3 of
+ * include/jsmpeg_hip.h -- the reference's 10-function MP2 decoder ABI (reference src/wasm/mp2.h:10-20) and an
+ * additive batch interface (many streams, every frame, PCM left in HBM).  SURVEY.md 8f row 4.
+ *
+ * Kernel plan and arithmetic contract: mp2_dev.h.  No audio arithmetic happens on the host: the host moves bytes,
+ * reads the frame length out of a header to advance the reference's byte cursor, and sizes launches.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "jsmpeg_hip.h"
+#include "mp2_dev.h"
+#include "mp2_window.h"
+
+int jm_set_error(const char *msg);      /* engine.hip: thread-local message behind jsmpeg_hip_last_error() */
+void jm_clear_error(void);
+
+static int mp2_fail(const char *fmt, const char *a = "", long b = 0) {
+	char buf[400];
+	snprintf(buf, sizeof(buf), fmt, a, b);
+	return jm_set_error(buf);
+}
+#define MP2_TRY(expr)                                                                                  \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if (e_ != hipSuccess) return mp2_fail(#expr ": %s (mp2_stage.hip:%ld)", hipGetErrorString(e_), __LINE__); \
+	} while (0)
+
+/* ================================================================================================ kernels */
+
+/* Bodies: mp2_dev.h (mp2_wg_*), shared with the test-only simulator. */
+
+__global__ void __launch_bounds__(64) k_mp2_walk(Mp2Bufs b) {
+	const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+	if (s < b.n_streams) mp2_wg_walk(b, s);
+}
+
+__global__ void __launch_bounds__(64) k_mp2_side(Mp2Bufs b) {
+	const uint32_t f = blockIdx.x * 64 + threadIdx.x;
+	if (f < b.n_frames) mp2_wg_side(b, f);
+}
+
+__global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
+	__shared__ int samples[72][33];
+	__shared__ float xs[72][33];
+	const int tid = (int)threadIdx.x;
+	mp2_wg_matrix_read(b, blockIdx.x, tid, samples);
+	__syncthreads();
+	mp2_wg_matrix_run(tid, samples, xs);
+	__syncthreads();
+	mp2_wg_matrix_store(b, blockIdx.x, tid, xs);
+}
+
+__global__ void __launch_bounds__(MP2_WINDOW_WG) k_mp2_window(Mp2Bufs b) {
+	__shared__ float xs[MP2_STAGED][MP2_VEC_FLOATS];
+	__shared__ float win[512];
+	const int tid = (int)threadIdx.x;
+	mp2_wg_window_stage(b, blockIdx.x, tid, xs, win);
+	__syncthreads();
+	mp2_wg_window_run(b, blockIdx.x, tid, xs, win);
+}
+
+/* ========================================================================================== shared state */
+
+template <class T>
+static hipError_t mp2_malloc(T **p, size_t bytes) {
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes ? bytes : 1);
+	static const int poison = [] { const char *v = getenv("JSMPEG_HIP_POISON"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
+	if (e == hipSuccess && poison >= 0 && bytes) { e = hipMemset(*p, poison, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+	return e;
+}
+
+static float *g_window_dev[16] = { nullptr };
+static int window_for_device(int dev, float **out) {
+	if (dev < 0 || dev >= 16) return mp2_fail("device ordinal %s%ld out of range", "", dev);
+	if (!g_window_dev[dev]) {
+		float host[512];
+		mp2_window_expand(host);
+		float *d = nullptr;
+		MP2_TRY(mp2_malloc(&d, sizeof(host)));
+		MP2_TRY(hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice));
+		MP2_TRY(hipDeviceSynchronize());
+		g_window_dev[dev] = d;
+	}
+	*out = g_window_dev[dev];
+	return 0;
+}
+
+static bool have_device(void) {
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+/* ========================================================================================== batch engine */
+
+struct jsmpeg_hip_mp2_batch_t {
+	int device;
+	hipStream_t own_stream;
+	uint32_t max_streams;
+	uint64_t max_bytes;
+	float *d_window;
+	uint8_t *d_in;
+	uint32_t *d_begin, *d_end, *d_cap_first, *d_count, *d_frame_first, *d_frame_pos;
+	uint32_t frame_pos_cap;
+	uint32_t *h_count;                 /* pinned */
+	Mp2Side *d_sides; float *d_w, *d_pcm;
+	uint32_t frames_cap;
+	uint32_t n_streams, n_frames;
+	std::vector<uint32_t> begin, end, cap_first, frame_first, h_frame_pos;
+	bool frame_pos_valid;
+	hipEvent_t ev[5];
+	hipStream_t last_stream;
+	bool decoded;
+};
+
+static void mp2_batch_free(jsmpeg_hip_mp2_batch_t *b) {
+	if (!b) return;
+	if (b->own_stream) hipStreamSynchronize(b->own_stream);
+	hipFree(b->d_in); hipFree(b->d_begin); hipFree(b->d_end); hipFree(b->d_cap_first); hipFree(b->d_count);
+	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipHostFree(b->h_count); hipFree(b->d_sides); hipFree(b->d_w);
+	hipFree(b->d_pcm);
+	for (hipEvent_t &e : b->ev) if (e) hipEventDestroy(e);
+	if (b->own_stream) hipStreamDestroy(b->own_stream);
+	delete b;
+}
+
+extern "C" jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_streams, uint64_t max_bytes, int32_t device) {
+	jm_clear_error();
+	if (!have_device()) { mp2_fail("no HIP device available: the MP2 decode stage has no CPU fallback"); return nullptr; }
+	if (max_streams == 0 || max_bytes == 0 || max_bytes > (1ull << 28)) { mp2_fail("bad MP2 batch configuration"); return nullptr; }
+	jsmpeg_hip_mp2_batch_t *b = new jsmpeg_hip_mp2_batch_t();
+	b->own_stream = nullptr; b->d_in = nullptr; b->d_begin = b->d_end = b->d_cap_first = b->d_count = b->d_frame_first = nullptr;
+	b->d_frame_pos = nullptr; b->h_count = nullptr; b->d_sides = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
+	b->frame_pos_cap = 0; b->frames_cap = 0; b->n_streams = 0; b->n_frames = 0; b->frame_pos_valid = false;
+	b->last_stream = nullptr; b->decoded = false;
+	for (hipEvent_t &e : b->ev) e = nullptr;
+	b->max_streams = max_streams; b->max_bytes = max_bytes;
+	bool ok = (device < 0 || hipSetDevice(device) == hipSuccess) && hipGetDevice(&b->device) == hipSuccess &&
+	          window_for_device(b->device, &b->d_window) == 0 &&
+	          hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) == hipSuccess &&
+	          mp2_malloc(&b->d_in, max_bytes + 4ull * max_streams + MP2_PAD) == hipSuccess &&
+	          mp2_malloc(&b->d_begin, 4ull * max_streams) == hipSuccess && mp2_malloc(&b->d_end, 4ull * max_streams) == hipSuccess &&
+	          mp2_malloc(&b->d_cap_first, 4ull * (max_streams + 1)) == hipSuccess &&
+	          mp2_malloc(&b->d_count, 4ull * max_streams) == hipSuccess &&
+	          mp2_malloc(&b->d_frame_first, 4ull * (max_streams + 1)) == hipSuccess &&
+	          hipHostMalloc(&b->h_count, 4ull * max_streams, hipHostMallocDefault) == hipSuccess;
+	for (hipEvent_t &e : b->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+	if (!ok) {
+		if (!jsmpeg_hip_last_error()[0]) mp2_fail("MP2 batch allocation failed: %s", hipGetErrorString(hipGetLastError()));
+		mp2_batch_free(b);
+		return nullptr;
+	}
+	return b;
+}
+
+extern "C" void jsmpeg_hip_mp2_batch_destroy(jsmpeg_hip_mp2_batch_t *b) { mp2_batch_free(b); }
+
+extern "C" int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
+                                           const uint64_t *bytes) {
+	if (!b) return mp2_fail("null MP2 batch");
+	if (n_streams == 0 || n_streams > b->max_streams) return mp2_fail("MP2 batch: %s%ld streams do not fit", "", n_streams);
+	MP2_TRY(hipSetDevice(b->device));
+	uint64_t at = 0, total = 0;
+	b->begin.assign(n_streams, 0); b->end.assign(n_streams, 0); b->cap_first.assign(n_streams + 1, 0);
+	for (uint32_t s = 0; s < n_streams; s++) {
+		total += bytes[s];
+		if (total > b->max_bytes) return mp2_fail("MP2 batch: %s%ld bytes do not fit", "", (long)total);
+		b->begin[s] = (uint32_t)at; b->end[s] = (uint32_t)(at + bytes[s]);
+		at = (at + bytes[s] + 3) & ~3ull;
+		/* the shortest Layer II frame: 32 kbit/s at 48 kHz = 96 bytes */
+		b->cap_first[s + 1] = b->cap_first[s] + (uint32_t)(bytes[s] / 96) + 1;
+	}
+	MP2_TRY(hipMemsetAsync(b->d_in, 0, at + MP2_PAD, b->own_stream));
+	for (uint32_t s = 0; s < n_streams; s++)
+		if (bytes[s]) MP2_TRY(hipMemcpyAsync(b->d_in + b->begin[s], data[s], bytes[s], hipMemcpyHostToDevice, b->own_stream));
+	MP2_TRY(hipMemcpyAsync(b->d_begin, b->begin.data(), 4ull * n_streams, hipMemcpyHostToDevice, b->own_stream));
+	MP2_TRY(hipMemcpyAsync(b->d_end, b->end.data(), 4ull * n_streams, hipMemcpyHostToDevice, b->own_stream));
+	MP2_TRY(hipMemcpyAsync(b->d_cap_first, b->cap_first.data(), 4ull * (n_streams + 1), hipMemcpyHostToDevice, b->own_stream));
+	if (b->frame_pos_cap < b->cap_first[n_streams]) {
+		MP2_TRY(hipStreamSynchronize(b->own_stream));
+		hipFree(b->d_frame_pos); b->d_frame_pos = nullptr;
+		b->frame_pos_cap = b->cap_first[n_streams] + b->cap_first[n_streams] / 4;
+		MP2_TRY(mp2_malloc(&b->d_frame_pos, 4ull * b->frame_pos_cap));
+	}
+	MP2_TRY(hipStreamSynchronize(b->own_stream));      /* the host buffers may go away after this call */
+	b->n_streams = n_streams; b->n_frames = 0; b->decoded = false; b->frame_pos_valid = false;
+	return 0;
+}
+
+static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {
+	Mp2Bufs k;
+	k.in = b->d_in; k.begin = b->d_begin; k.end = b->d_end; k.n_streams = b->n_streams; k.cap_first = b->d_cap_first;
+	k.frame_pos = b->d_frame_pos; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
+	k.sides = b->d_sides; k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.window = b->d_window; k.pcm = b->d_pcm;
+	return k;
+}
+
+extern "C" int jsmpeg_hip_mp2_batch_decode(jsmpeg_hip_mp2_batch_t *b, void *hip_stream) {
+	if (!b) return mp2_fail("null MP2 batch");
+	if (b->n_streams == 0) return mp2_fail("MP2 batch: nothing uploaded");
+	MP2_TRY(hipSetDevice(b->device));
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+	b->last_stream = st;
+	MP2_TRY(hipEventRecord(b->ev[0], st));
+	hipLaunchKernelGGL(k_mp2_walk, dim3((b->n_streams + 63) / 64), dim3(64), 0, st, batch_bufs(b));
+	MP2_TRY(hipGetLastError());
+	MP2_TRY(hipMemcpyAsync(b->h_count, b->d_count, 4ull * b->n_streams, hipMemcpyDeviceToHost, st));
+	MP2_TRY(hipEventRecord(b->ev[1], st));
+	MP2_TRY(hipStreamSynchronize(st));                 /* the one host turn-around: frame counts size everything below */
+	b->frame_first.assign(b->n_streams + 1, 0);
+	for (uint32_t s = 0; s < b->n_streams; s++) b->frame_first[s + 1] = b->frame_first[s] + b->h_count[s];
+	b->n_frames = b->frame_first[b->n_streams];
+	if (b->n_frames > b->frames_cap) {
+		hipFree(b->d_sides); hipFree(b->d_w); hipFree(b->d_pcm); b->d_sides = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
+		b->frames_cap = b->n_frames + b->n_frames / 8;
+		MP2_TRY(mp2_malloc(&b->d_sides, sizeof(Mp2Side) * (size_t)b->frames_cap));
+		MP2_TRY(mp2_malloc(&b->d_w, sizeof(float) * MP2_VEC_FLOATS * MP2_SUBBLOCKS_PER_FRAME * (size_t)b->frames_cap));
+		MP2_TRY(mp2_malloc(&b->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME * (size_t)b->frames_cap));
+	}
+	MP2_TRY(hipMemcpyAsync(b->d_frame_first, b->frame_first.data(), 4ull * (b->n_streams + 1), hipMemcpyHostToDevice, st));
+	if (b->n_frames) {
+		const Mp2Bufs k = batch_bufs(b);
+		hipLaunchKernelGGL(k_mp2_side, dim3((b->n_frames + 63) / 64), dim3(64), 0, st, k);
+		MP2_TRY(hipEventRecord(b->ev[2], st));
+		hipLaunchKernelGGL(k_mp2_matrix, dim3(b->n_frames), dim3(MP2_MATRIX_WG), 0, st, k);
+		MP2_TRY(hipEventRecord(b->ev[3], st));
+		hipLaunchKernelGGL(k_mp2_window, dim3(b->n_frames), dim3(MP2_WINDOW_WG), 0, st, k);
+		MP2_TRY(hipGetLastError());
+	} else {
+		MP2_TRY(hipEventRecord(b->ev[2], st));
+		MP2_TRY(hipEventRecord(b->ev[3], st));
+	}
+	MP2_TRY(hipEventRecord(b->ev[4], st));
+	b->decoded = true; b->frame_pos_valid = false;
+	return (int)b->n_frames;
+}
+
+extern "C" int jsmpeg_hip_mp2_batch_sync(jsmpeg_hip_mp2_batch_t *b) {
+	if (!b) return mp2_fail("null MP2 batch");
+	MP2_TRY(hipSetDevice(b->device));
+	MP2_TRY(hipStreamSynchronize(b->last_stream ? b->last_stream : b->own_stream));
+	return 0;
+}
+
+extern "C" uint32_t jsmpeg_hip_mp2_batch_frame_count(jsmpeg_hip_mp2_batch_t *b, int32_t stream) {
+	if (!b || !b->decoded) return 0;
+	if (stream < 0) return b->n_frames;
+	return (uint32_t)stream < b->n_streams ? b->frame_first[stream + 1] - b->frame_first[stream] : 0;
+}
+
+extern "C" int jsmpeg_hip_mp2_batch_frame_info(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, uint32_t frame,
+                                               uint32_t *byte_offset, uint32_t *byte_size, int32_t *sample_rate) {
+	if (!b || !b->decoded) return mp2_fail("MP2 batch: not decoded");
+	if (stream >= b->n_streams || frame >= b->frame_first[stream + 1] - b->frame_first[stream]) return mp2_fail("MP2 batch: no such frame");
+	MP2_TRY(hipSetDevice(b->device));
+	if (!b->frame_pos_valid) {
+		MP2_TRY(hipStreamSynchronize(b->last_stream ? b->last_stream : b->own_stream));
+		b->h_frame_pos.resize(b->cap_first[b->n_streams]);
+		MP2_TRY(hipMemcpy(b->h_frame_pos.data(), b->d_frame_pos, 4ull * b->cap_first[b->n_streams], hipMemcpyDeviceToHost));
+		b->frame_pos_valid = true;
+	}
+	const uint32_t pos = b->h_frame_pos[b->cap_first[stream] + frame];
+	uint8_t hdr[4];
+	MP2_TRY(hipMemcpy(hdr, b->d_in + pos, 4, hipMemcpyDeviceToHost));
+	Mp2Hdr H;
+	mp2_parse_header(hdr, 4, 0, H);
+	if (byte_offset) *byte_offset = pos - b->begin[stream];
+	if (byte_size) *byte_size = (uint32_t)H.frame_bytes;
+	if (sample_rate) *sample_rate = H.sample_rate;
+	return 0;
+}
+
+extern "C" void *jsmpeg_hip_mp2_batch_pcm(jsmpeg_hip_mp2_batch_t *b) { return b ? b->d_pcm : nullptr; }
+
+extern "C" int jsmpeg_hip_mp2_batch_read_pcm(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, uint32_t first_frame, uint32_t count,
+                                             float *out) {
+	if (!b || !b->decoded) return mp2_fail("MP2 batch: not decoded");
+	if (stream >= b->n_streams) return mp2_fail("MP2 batch: no such stream");
+	const uint32_t have = b->frame_first[stream + 1] - b->frame_first[stream];
+	if (first_frame > have || count > have - first_frame) return mp2_fail("MP2 batch: frame range outside the stream");
+	if (count == 0) return 0;
+	MP2_TRY(hipSetDevice(b->device));
+	MP2_TRY(hipStreamSynchronize(b->last_stream ? b->last_stream : b->own_stream));
+	const size_t frame_floats = 2 * MP2_SAMPLES_PER_FRAME;
+	MP2_TRY(hipMemcpy(out, b->d_pcm + (size_t)(b->frame_first[stream] + first_frame) * frame_floats,
+	                  sizeof(float) * frame_floats * count, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_mp2_batch_timings(jsmpeg_hip_mp2_batch_t *b, float out_ms[5]) {
+	if (!b || !b->decoded) return mp2_fail("MP2 batch: not decoded");
+	MP2_TRY(hipSetDevice(b->device));
+	MP2_TRY(hipEventSynchronize(b->ev[4]));
+	for (int i = 0; i < 4; i++) MP2_TRY(hipEventElapsedTime(&out_ms[i], b->ev[i], b->ev[i + 1]));
+	MP2_TRY(hipEventElapsedTime(&out_ms[4], b->ev[0], b->ev[4]));
+	return 0;
+}
+
+/* ================================================ the reference's one-frame-per-call ABI (src/wasm/mp2.h:10-20) */
+
+#define MP2_MAX_FRAME_BYTES 1792   /* 384 kbit/s at 32 kHz + padding = 1729 */
+#define MP2_RING_VECTORS 64        /* >= 36 written + 15 looked back on */
+
+struct mp2_decoder_t {
+	int device;
+	hipStream_t stream;
+	float *d_window;
+	/* compressed-data store: host mirror of bit_buffer_t (buffer.c:7-13) */
+	uint8_t *bytes;                /* pinned */
+	unsigned capacity, length, index /* bits */;
+	int mode;
+	int sample_rate;
+	uint32_t n_abs;                /* sub-blocks synthesised so far: the reference's v_pos is 64 * (-n_abs & 15) */
+	/* device state */
+	uint8_t *d_in; uint32_t *d_tables; /* begin, end, cap_first[2], frame_first[2], frame_pos, count */
+	Mp2Side *d_side; float *d_w, *d_pcm;
+	float *h_pcm;                  /* pinned: left[1152] | right[1152] of the last decoded frame */
+};
+
+static void mp2_dec_free(mp2_decoder_t *d) {
+	if (!d) return;
+	if (d->stream) hipStreamSynchronize(d->stream);
+	hipHostFree(d->bytes); hipFree(d->d_in); hipFree(d->d_tables); hipFree(d->d_side); hipFree(d->d_w); hipFree(d->d_pcm);
+	hipHostFree(d->h_pcm);
+	if (d->stream) hipStreamDestroy(d->stream);
+	delete d;
+}
+
+extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffer_mode_t buffer_mode) {
+	jm_clear_error();
+	if (!have_device()) { mp2_fail("no HIP device available: the MP2 decode stage has no CPU fallback"); return nullptr; }
+	mp2_decoder_t *d = new mp2_decoder_t();
+	d->stream = nullptr; d->bytes = nullptr; d->d_in = nullptr; d->d_tables = nullptr; d->d_side = nullptr; d->d_w = nullptr;
+	d->d_pcm = nullptr; d->h_pcm = nullptr;
+	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
+	d->sample_rate = 44100;        /* mp2.c:234 */
+	d->n_abs = 0;
+	const size_t ring_bytes = sizeof(float) * MP2_VEC_FLOATS * MP2_RING_VECTORS;
+	bool ok = hipGetDevice(&d->device) == hipSuccess && window_for_device(d->device, &d->d_window) == 0 &&
+	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipHostMalloc(&d->bytes, d->capacity, hipHostMallocDefault) == hipSuccess &&
+	          hipHostMalloc(&d->h_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME, hipHostMallocDefault) == hipSuccess &&
+	          mp2_malloc(&d->d_in, MP2_MAX_FRAME_BYTES + MP2_PAD) == hipSuccess && mp2_malloc(&d->d_tables, 4 * 8) == hipSuccess &&
+	          mp2_malloc(&d->d_side, sizeof(Mp2Side)) == hipSuccess && mp2_malloc(&d->d_w, ring_bytes) == hipSuccess &&
+	          mp2_malloc(&d->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME) == hipSuccess &&
+	          hipMemsetAsync(d->d_w, 0, ring_bytes, d->stream) == hipSuccess &&   /* V starts as zeros (mp2.c:231) */
+	          hipStreamSynchronize(d->stream) == hipSuccess;
+	if (!ok) {
+		if (!jsmpeg_hip_last_error()[0]) mp2_fail("MP2 decoder allocation failed: %s", hipGetErrorString(hipGetLastError()));
+		mp2_dec_free(d);
+		return nullptr;
+	}
+	memset(d->h_pcm, 0, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME);
+	return d;
+}
+
+extern "C" void mp2_decoder_destroy(mp2_decoder_t *d) { mp2_dec_free(d); }
+
+/* buffer.c:48-65, 167-190 */
+extern "C" void *mp2_decoder_get_write_ptr(mp2_decoder_t *d, unsigned int n) {
+	if (!d) return nullptr;
+	if (n > d->capacity - d->length) {
+		if (d->mode == BIT_BUFFER_MODE_EVICT) {
+			const unsigned byte_pos = d->index >> 3, available = d->capacity - d->length;
+			if (byte_pos == d->length || n > available + byte_pos) { d->length = 0; d->index = 0; }
+			else if (byte_pos) {
+				memmove(d->bytes, d->bytes + byte_pos, d->length - byte_pos);
+				d->length -= byte_pos;
+				d->index -= byte_pos << 3;
+			}
+		}
+		if (n > d->capacity - d->length) {
+			/* EXPAND; grows to fit where the reference's formula would under-allocate */
+			unsigned cap = d->capacity * 2;
+			if (cap < d->length + n) cap = d->length + n;
+			uint8_t *nb = nullptr;
+			if (hipHostMalloc(&nb, cap, hipHostMallocDefault) != hipSuccess) {
+				mp2_fail("cannot grow the MP2 store to %s%ld bytes", "", cap);
+				return nullptr;
+			}
+			memcpy(nb, d->bytes, d->length);
+			hipHostFree(d->bytes);
+			d->bytes = nb;
+			d->capacity = cap;
+			if (d->index > d->length << 3) d->index = d->length << 3;
+		}
+	}
+	return d->bytes + d->length;
+}
+extern "C" int mp2_decoder_get_index(mp2_decoder_t *d) { return d ? (int)d->index : 0; }
+extern "C" void mp2_decoder_set_index(mp2_decoder_t *d, unsigned int index) { if (d) d->index = index; }
+extern "C" void mp2_decoder_did_write(mp2_decoder_t *d, unsigned int n) { if (d) d->length += n; }
+extern "C" int mp2_decoder_get_sample_rate(mp2_decoder_t *d) { return d ? d->sample_rate : 0; }
+extern "C" void *mp2_decoder_get_left_channel_ptr(mp2_decoder_t *d) { return d ? d->h_pcm : nullptr; }
+extern "C" void *mp2_decoder_get_right_channel_ptr(mp2_decoder_t *d) { return d ? d->h_pcm + MP2_SAMPLES_PER_FRAME : nullptr; }
+
+static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_bytes) {
+	MP2_TRY(hipSetDevice(d->device));
+	const unsigned have = d->length - byte_pos;
+	const unsigned n = have < (unsigned)frame_bytes ? have : (unsigned)frame_bytes;   /* a frame that is not all there reads zeros (outside the contract) */
+	MP2_TRY(hipMemsetAsync(d->d_in, 0, MP2_MAX_FRAME_BYTES + MP2_PAD, d->stream));
+	MP2_TRY(hipMemcpyAsync(d->d_in, d->bytes + byte_pos, n, hipMemcpyHostToDevice, d->stream));
+	const uint32_t tables[8] = { 0u /* begin */, n /* end */, 0u, 1u /* cap_first */, 0u, 1u /* frame_first */, 0u /* frame_pos */, 1u /* count */ };
+	MP2_TRY(hipMemcpyAsync(d->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice, d->stream));
+	Mp2Bufs k;
+	k.in = d->d_in; k.begin = d->d_tables + 0; k.end = d->d_tables + 1; k.n_streams = 1; k.cap_first = d->d_tables + 2;
+	k.frame_first = d->d_tables + 4; k.frame_pos = d->d_tables + 6; k.count = d->d_tables + 7; k.n_frames = 1;
+	k.sides = d->d_side; k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = d->n_abs; k.window = d->d_window;
+	k.pcm = d->d_pcm;
+	hipLaunchKernelGGL(k_mp2_side, dim3(1), dim3(64), 0, d->stream, k);
+	hipLaunchKernelGGL(k_mp2_matrix, dim3(1), dim3(MP2_MATRIX_WG), 0, d->stream, k);
+	hipLaunchKernelGGL(k_mp2_window, dim3(1), dim3(MP2_WINDOW_WG), 0, d->stream, k);
+	MP2_TRY(hipGetLastError());
+	MP2_TRY(hipMemcpyAsync(d->h_pcm, d->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME, hipMemcpyDeviceToHost, d->stream));
+	MP2_TRY(hipStreamSynchronize(d->stream));
+	d->n_abs += MP2_SUBBLOCKS_PER_FRAME;
+	return 0;
+}
+
+/* mp2.c:275-286 */
+extern "C" int mp2_decoder_decode(mp2_decoder_t *d) {
+	if (!d) return 0;
+	const unsigned byte_pos = d->index >> 3;
+	if ((uint64_t)d->index + 16 > (uint64_t)d->length << 3) return 0;      /* bit_buffer_has(16) */
+	Mp2Hdr H;
+	/* the reference reads the header at the BIT cursor; every caller leaves it byte aligned (decode() itself sets
+	 * it to whole bytes, mp2.c:284), so the header is read at byte_pos */
+	mp2_parse_header(d->bytes, d->length, byte_pos, H);
+	int decoded = 0;
+	if (H.valid && mp2_dec_frame_gpu(d, byte_pos, H.frame_bytes) == 0) {
+		decoded = H.frame_bytes;
+		d->sample_rate = H.sample_rate;                                     /* mp2.c:482 */
+	}
+	d->index = (byte_pos + (unsigned)decoded) << 3;
+	return decoded;
+}

@@ -1,0 +1,127 @@
+"""ctypes front-end of the MP2 batch interface of include/jsmpeg_hip.h (part 3): many MPEG-1 Audio Layer II
+streams, every frame, PCM left in HBM.  Host-side plumbing only; the decode happens in libjsmpeg_hip.so on the
+GPU.  Loading fails loudly when the library is missing (there is no CPU decode in the product).
+
+The reference's one-frame-per-call MP2 decoder ABI (mp2_decoder_*) is driven through jsmpeg_amd.cabi.Mp2Decoder."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SAMPLES_PER_FRAME = 1152
+
+MP2_BATCH_SYMBOLS = ("jsmpeg_hip_mp2_batch_create", "jsmpeg_hip_mp2_batch_destroy", "jsmpeg_hip_mp2_batch_upload",
+                     "jsmpeg_hip_mp2_batch_decode", "jsmpeg_hip_mp2_batch_sync", "jsmpeg_hip_mp2_batch_frame_count",
+                     "jsmpeg_hip_mp2_batch_frame_info", "jsmpeg_hip_mp2_batch_pcm", "jsmpeg_hip_mp2_batch_read_pcm",
+                     "jsmpeg_hip_mp2_batch_timings")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.LIB_HIP
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: build it with `python -m jsmpeg_amd.build hip` "
+                               "(there is no CPU fallback for the MP2 decode stage)" % path)
+        L = ctypes.CDLL(path)
+        vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
+        L.jsmpeg_hip_mp2_batch_create.restype = vp
+        L.jsmpeg_hip_mp2_batch_create.argtypes = [u32, u64, i32]
+        L.jsmpeg_hip_mp2_batch_destroy.restype = None
+        L.jsmpeg_hip_mp2_batch_destroy.argtypes = [vp]
+        L.jsmpeg_hip_mp2_batch_upload.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_upload.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+        L.jsmpeg_hip_mp2_batch_decode.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_decode.argtypes = [vp, vp]
+        L.jsmpeg_hip_mp2_batch_sync.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_sync.argtypes = [vp]
+        L.jsmpeg_hip_mp2_batch_frame_count.restype = u32
+        L.jsmpeg_hip_mp2_batch_frame_count.argtypes = [vp, i32]
+        L.jsmpeg_hip_mp2_batch_frame_info.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_frame_info.argtypes = [vp, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32),
+                                                      ctypes.POINTER(i32)]
+        L.jsmpeg_hip_mp2_batch_pcm.restype = vp
+        L.jsmpeg_hip_mp2_batch_pcm.argtypes = [vp]
+        L.jsmpeg_hip_mp2_batch_read_pcm.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_read_pcm.argtypes = [vp, u32, u32, u32, vp]
+        L.jsmpeg_hip_mp2_batch_timings.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.jsmpeg_hip_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _err():
+    return (lib().jsmpeg_hip_last_error() or b"").decode()
+
+
+class Mp2Batch:
+    """One batch decoder: upload N streams, decode, read PCM (or take the device pointer)."""
+
+    def __init__(self, max_streams, max_bytes, device=-1):
+        self.L = lib()
+        self.h = self.L.jsmpeg_hip_mp2_batch_create(max_streams, max_bytes, device)
+        if not self.h:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_create failed: " + _err())
+        self.n_streams = 0
+
+    def close(self):
+        if self.h:
+            self.L.jsmpeg_hip_mp2_batch_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload(self, streams):
+        streams = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+        n = len(streams)
+        ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in streams])
+        lens = (ctypes.c_uint64 * n)(*[s.size for s in streams])
+        if self.L.jsmpeg_hip_mp2_batch_upload(self.h, n, ptrs, lens) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_upload failed: " + _err())
+        self.n_streams = n
+
+    def decode(self, hip_stream=None, sync=True):
+        n = self.L.jsmpeg_hip_mp2_batch_decode(self.h, hip_stream)
+        if n < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_decode failed: " + _err())
+        if sync and self.L.jsmpeg_hip_mp2_batch_sync(self.h) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_sync failed: " + _err())
+        return n
+
+    def frame_count(self, stream=-1):
+        return int(self.L.jsmpeg_hip_mp2_batch_frame_count(self.h, stream))
+
+    def frame_info(self, stream, frame):
+        off, size, rate = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int32()
+        if self.L.jsmpeg_hip_mp2_batch_frame_info(self.h, stream, frame, ctypes.byref(off), ctypes.byref(size),
+                                                  ctypes.byref(rate)) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_frame_info failed: " + _err())
+        return off.value, size.value, rate.value
+
+    def pcm_device_pointer(self):
+        return self.L.jsmpeg_hip_mp2_batch_pcm(self.h)
+
+    def read_pcm(self, stream, first=0, count=None):
+        """float32[count, 2, 1152] (left, right) of one stream."""
+        have = self.frame_count(stream)
+        if count is None:
+            count = have - first
+        out = np.empty((count, 2, SAMPLES_PER_FRAME), dtype=np.float32)
+        if self.L.jsmpeg_hip_mp2_batch_read_pcm(self.h, stream, first, count, out.ctypes.data) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_read_pcm failed: " + _err())
+        return out
+
+    def timings(self):
+        t = (ctypes.c_float * 5)()
+        if self.L.jsmpeg_hip_mp2_batch_timings(self.h, t) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_timings failed: " + _err())
+        return dict(zip(("walk_ms", "side_ms", "matrix_ms", "window_ms", "total_ms"), [float(x) for x in t]))

@@ -109,7 +109,7 @@ MP2_CONFIGS = {
     "mp2_stereo_44k_192": dict(sample_rate_index=0, bitrate_index=10, mode=0, crc=0),
     "mp2_joint_48k_128": dict(sample_rate_index=1, bitrate_index=8, mode=1, crc=1),
     "mp2_mono_32k_48": dict(sample_rate_index=2, bitrate_index=2, mode=3, crc=0),
-    "mp2_dual_44k_384": dict(sample_rate_index=0, bitrate_index=14, mode=2, crc=1, alloc_permille=950, sf_lo=6),
+    "mp2_dual_44k_384": dict(sample_rate_index=0, bitrate_index=14, mode=2, crc=1, alloc_permille=950),
     "mp2_mono_48k_64": dict(sample_rate_index=1, bitrate_index=4, mode=3, crc=1),
     "mp2_varying_44k": dict(sample_rate_index=0, bitrate_index=8, mode=0, crc=0, vary=1),
     "mp2_varying_32k_quirks": dict(sample_rate_index=2, bitrate_index=8, mode=0, crc=0, vary=1, quirks=1),

@@ -380,3 +380,33 @@ int mp2_decoder_decode(mp2_decoder_t *d) {                          /* mp2.c:275
 	d->index = (unsigned)(byte_pos + decoded) << 3;
 	return decoded;
 }
+
+/* ----- unit-level entry points for the table pin (not part of the reference ABI) ----- */
+
+/* The reference's lookup chain for one (header, subband, allocation code): mp2.c:339-345, 485-489.
+ * bitrate_index: header value 1..14; returns levels (0 = no bits), fills sblimit, nbal, bits, group. */
+int oracle_mp2_table(int bitrate_index, int sample_rate_index, int mono, int sb, int code,
+                     int *sblimit, int *nbal, int *bits, int *group) {
+	int tab2 = LUT_STEP1[mono ? 0 : 1][bitrate_index - 1];
+	int tab3 = LUT_STEP2[tab2][sample_rate_index];
+	*sblimit = tab3 & 63;
+	tab3 >>= 6;
+	int tab4 = LUT_STEP3[tab3][sb];
+	*nbal = tab4 >> 4;
+	int qtab = LUT_STEP4[tab4 & 15][code & ((1 << *nbal) - 1)];
+	*bits = *group = 0;
+	if (!qtab) return 0;
+	*bits = QUANT_TAB[qtab - 1].bits;
+	*group = QUANT_TAB[qtab - 1].group;
+	return QUANT_TAB[qtab - 1].levels;
+}
+/* mp2.c:510-517 */
+int oracle_mp2_scalefactor(int sf) {
+	if (sf == 63) return 0;
+	int shift = sf / 3;
+	return (SCALEFACTOR_BASE[sf % 3] + ((1 << shift) >> 1)) >> shift;
+}
+/* mp2.c:326-328 */
+int oracle_mp2_frame_size(int bitrate_index, int sample_rate_index, int padding) {
+	return 144000 * BIT_RATE[bitrate_index - 1] / SAMPLE_RATE[sample_rate_index] + padding;
+}

@@ -1,0 +1,64 @@
+"""Shared helpers of the MP2 tests."""
+import ctypes
+import glob
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT
+from jsmpeg_amd import synth
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "mp2_*.json")))
+FIXTURE_IDS = [os.path.basename(p)[4:-5] for p in FIXTURES]
+
+
+def load_case(path):
+    fx = json.load(open(path))
+    data, offs = synth.generate_mp2_config(fx["config"], fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(data.tobytes()).hexdigest() == fx["stream_md5"], "generator drifted from the fixture"
+    return fx, data, offs
+
+
+def frame_md5(pcm):
+    return [hashlib.md5(np.ascontiguousarray(f, dtype="<f4").tobytes()).hexdigest() for f in pcm]
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+_sim = None
+
+
+def sim_lib():
+    """tests/sim/sim_mp2.cpp: the device functions of the MP2 kernels compiled by g++ (TEST ONLY)."""
+    global _sim
+    if _sim is None:
+        so = os.path.join(ROOT, "tests", "sim", "libjsmpeg_sim_mp2.so")
+        src = os.path.join(ROOT, "tests", "sim", "sim_mp2.cpp")
+        csrc = os.path.join(ROOT, "jsmpeg_amd", "csrc")
+        deps = [src] + glob.glob(os.path.join(csrc, "mp2_*.h"))
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                                   "-I", csrc, "-o", so, src])
+        _sim = ctypes.CDLL(so)
+        _sim.sim_mp2_batch.restype = ctypes.c_int
+    return _sim
+
+
+def sim_batch(streams):
+    lib = sim_lib()
+    streams = [np.ascontiguousarray(s, dtype=np.uint8) for s in streams]
+    n = len(streams)
+    ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in streams])
+    lens = (ctypes.c_uint64 * n)(*[len(s) for s in streams])
+    cap = sum(len(s) // 96 + 1 for s in streams)
+    pcm = np.zeros((cap, 2, 1152), np.float32)
+    ff = np.zeros(n + 1, np.uint32)
+    r = lib.sim_mp2_batch(ptrs, lens, n, ctypes.c_void_p(pcm.ctypes.data), cap, ctypes.c_void_p(ff.ctypes.data))
+    assert r >= 0
+    return [pcm[ff[i]:ff[i + 1]] for i in range(n)]

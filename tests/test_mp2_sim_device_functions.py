@@ -1,0 +1,51 @@
+"""The workgroup bodies of the MP2 kernels (jsmpeg_amd/csrc/mp2_dev.h: mp2_wg_*), compiled by g++ into a TEST-ONLY
+simulator (tests/sim/sim_mp2.cpp), against the golden fixtures and the oracle -- so their logic AND their
+arithmetic (same source, -ffp-contract=off) are checked in the build container, which has no GPU.  The product
+never runs them on the CPU; launch shapes, LDS staging and the host runtime are covered by the `-m gpu` tests."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from jsmpeg_amd import cabi, synth
+from mp2_util import FIXTURES, FIXTURE_IDS, frame_md5, load_case, same_bits, sim_batch, sim_lib
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=FIXTURE_IDS)
+def test_batch_pipeline_matches_golden(path):
+    fx, data, offs = load_case(path)
+    (pcm,) = sim_batch([data])
+    assert frame_md5(pcm) == fx["frame_md5"]
+
+
+def test_batch_of_unequal_streams(libs):
+    """Several streams of different lengths and configurations in one batch: lookback never crosses a stream
+    boundary, every stream starts from a silent synthesis state."""
+    streams = [synth.generate_mp2_config(name, 5 + 7 * i, stream=40 + i)[0] for i, name in enumerate(synth.MP2_CONFIGS)]
+    streams.insert(2, np.zeros(0, np.uint8))                       # an empty stream
+    streams.append(streams[0][:len(streams[0]) - 100])             # last frame cut: not decoded
+    streams.append(np.frombuffer(b"\x00" * 300, dtype=np.uint8))   # no frame at all
+    got = sim_batch(streams)
+    for s, g in zip(streams, got):
+        want, _, sizes, _ = cabi.decode_mp2_stream(libs["oracle"], s)
+        if len(s) and len(want) and sum(sizes) > len(s):           # the oracle decodes a cut last frame (zeros), the batch does not
+            want = want[:-1]
+        assert same_bits(g, want)
+    assert len(got[2]) == 0 and len(got[-1]) == 0 and len(got[-2]) == len(got[0]) - 1
+
+
+@pytest.mark.parametrize("name", ["varying_44k", "dual_44k_384", "mono_32k_48"])
+def test_ring_mode_frame_by_frame(name, libs):
+    """The decoder ABI's path: one frame per launch through the 64-vector ring, state carried in the ring and the
+    sub-block count only."""
+    fx, data, offs = load_case(FIXTURES[FIXTURE_IDS.index(name)])
+    lib = sim_lib()
+    ring = np.zeros(64 * 64, np.float32)
+    n_abs = ctypes.c_uint32(0)
+    out = np.zeros((fx["n_frames"], 2, 1152), np.float32)
+    for k in range(fx["n_frames"]):
+        frame = np.ascontiguousarray(data[int(offs[k]):int(offs[k + 1])])
+        lib.sim_mp2_ring_frame(ctypes.c_void_p(frame.ctypes.data), len(frame), ctypes.c_void_p(ring.ctypes.data),
+                               ctypes.byref(n_abs), ctypes.c_void_p(out[k].ctypes.data))
+    assert n_abs.value == 36 * fx["n_frames"]
+    assert frame_md5(out) == fx["frame_md5"]
