@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU (default: the metric's 64)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STREAM)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-audio", action="store_true", help="skip the MP2 audio stage figure attached as audio_stage")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the multi-rank code path (RCCL scatter / all-gather) with the ranks present, even one")
     args = ap.parse_args()
@@ -401,6 +402,16 @@ def main():
         line["cpu_baseline"] = cpu_baseline(streams[:2], width, height)
     else:
         line["cpu_baseline"] = None
+    # the sibling stage: MP2 audio of the same batch, its own figure beside the headline metric;
+    # a reported extra, never fatal for the line
+    if world == 1 and not args.no_audio:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import mp2_bench
+            line["audio_stage"] = mp2_bench.measure(cpu_baseline=not args.no_cpu_baseline)
+        except Exception as e:
+            log("audio stage figure failed: %r" % (e,))
+            line["audio_stage"] = {"error": repr(e)}
     json_out.write(json.dumps(line) + "\n")
     json_out.flush()
     if multi:

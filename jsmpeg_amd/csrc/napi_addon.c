@@ -35,6 +35,16 @@
  *   batchReadRGBA(handle, p, Uint8ClampedArray)                      jsmpeg_hip_batch_read_rgba
  *   batchGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
  *   batchTimings(handle) -> {indexMs, hostMs, parseMs, reconMs, totalMs}
+ *
+ * MP2 audio (include/jsmpeg_hip.h part 3; what module.instance.exports._mp2_decoder_* is for the reference's
+ * src/mp2-wasm.js:21-104), used by jsmpeg_amd/js/mp2-hip.js:
+ *   mp2Create(bufferSize, mode) -> handle | throws   mp2_decoder_create
+ *   mp2Destroy / mp2GetIndex / mp2SetIndex / mp2GetSampleRate        the same-named ABI calls
+ *   mp2BufferWrite(handle, [Uint8Array, ...]) -> bytes               get_write_ptr + memcpy + did_write
+ *   mp2Decode(handle) -> bytes of the decoded frame, 0 if none       mp2_decoder_decode
+ *   mp2GetChannels(handle) -> {left, right}          Float32Array(1152) views over the decoder's host PCM
+ *                                                    (get_left/right_channel_ptr), like the heapF32.subarray
+ *                                                    views of mp2-wasm.js:91-99
  */
 #include <node_api.h>
 #include <stdint.h>
@@ -437,6 +447,118 @@ static napi_value fn_last_error(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* ------------------------------------------------------------------ MP2 audio */
+
+static mp2_decoder_t *mp2_handle_arg(napi_env env, napi_value v) {
+	void *p = NULL;
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: bad MP2 decoder handle");
+		return NULL;
+	}
+	return (mp2_decoder_t *)p;
+}
+
+static napi_value fn_mp2_create(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	uint32_t size = 128 * 1024, mode = BIT_BUFFER_MODE_EXPAND;
+	if (argc > 0) napi_get_value_uint32(env, argv[0], &size);
+	if (argc > 1) napi_get_value_uint32(env, argv[1], &mode);
+	mp2_decoder_t *d = mp2_decoder_create(size, (bit_buffer_mode_t)mode);
+	if (!d) {
+		napi_throw_error(env, NULL, jsmpeg_hip_last_error());   /* no GPU: there is no CPU decoder behind this class */
+		return NULL;
+	}
+	NAPI_OK(napi_create_external(env, d, NULL, NULL, &out));
+	return out;
+}
+
+static napi_value fn_mp2_destroy(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
+	if (d) mp2_decoder_destroy(d);
+	return NULL;
+}
+
+static napi_value fn_mp2_buffer_write(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
+	if (!d) return NULL;
+	uint32_t n = 0;
+	NAPI_OK(napi_get_array_length(env, argv[1], &n));
+	size_t total = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		napi_value el;
+		void *data; size_t len; napi_typedarray_type t; napi_value ab; size_t off;
+		NAPI_OK(napi_get_element(env, argv[1], i, &el));
+		NAPI_OK(napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off));
+		total += len;
+	}
+	uint8_t *dst = (uint8_t *)mp2_decoder_get_write_ptr(d, (unsigned)total);
+	if (!dst) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	for (uint32_t i = 0; i < n; i++) {
+		napi_value el;
+		void *data; size_t len; napi_typedarray_type t; napi_value ab; size_t off;
+		NAPI_OK(napi_get_element(env, argv[1], i, &el));
+		NAPI_OK(napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off));
+		memcpy(dst, data, len);
+		dst += len;
+	}
+	mp2_decoder_did_write(d, (unsigned)total);
+	NAPI_OK(napi_create_uint32(env, (uint32_t)total, &out));
+	return out;
+}
+
+#define MP2_INT_GETTER(name, expr)                                           \
+	static napi_value name(napi_env env, napi_callback_info info) {          \
+		size_t argc = 1;                                                     \
+		napi_value argv[1], out;                                             \
+		NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));       \
+		mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);                     \
+		if (!d) return NULL;                                                 \
+		NAPI_OK(napi_create_int32(env, (int32_t)(expr), &out));              \
+		return out;                                                          \
+	}
+MP2_INT_GETTER(fn_mp2_get_index, mp2_decoder_get_index(d))
+MP2_INT_GETTER(fn_mp2_get_sample_rate, mp2_decoder_get_sample_rate(d))
+MP2_INT_GETTER(fn_mp2_decode, mp2_decoder_decode(d))
+
+static napi_value fn_mp2_set_index(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
+	uint32_t idx = 0;
+	if (!d) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &idx));
+	mp2_decoder_set_index(d, idx);
+	return NULL;
+}
+
+/* Views stay valid for the decoder's lifetime: the host PCM is one pinned allocation refreshed in place by
+ * every decode (the reference re-derives its heap views each call, mp2-wasm.js:91-99). */
+static napi_value fn_mp2_get_channels(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out, ab, left, right;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
+	if (!d) return NULL;
+	float *l = (float *)mp2_decoder_get_left_channel_ptr(d), *r = (float *)mp2_decoder_get_right_channel_ptr(d);
+	if (!l || r != l + 1152) { napi_throw_error(env, NULL, "jsmpeg_hip: no PCM buffer"); return NULL; }
+	NAPI_OK(napi_create_external_arraybuffer(env, l, 2 * 1152 * sizeof(float), NULL, NULL, &ab));
+	NAPI_OK(napi_create_typedarray(env, napi_float32_array, 1152, ab, 0, &left));
+	NAPI_OK(napi_create_typedarray(env, napi_float32_array, 1152, ab, 1152 * sizeof(float), &right));
+	NAPI_OK(napi_create_object(env, &out));
+	NAPI_OK(napi_set_named_property(env, out, "left", left));
+	NAPI_OK(napi_set_named_property(env, out, "right", right));
+	return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "create", fn_create }, { "destroy", fn_destroy }, { "bufferWrite", fn_buffer_write },
@@ -449,6 +571,9 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },
 		{ "batchGeometry", fn_batch_geometry }, { "batchTimings", fn_batch_timings },
+		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },
+		{ "mp2GetIndex", fn_mp2_get_index }, { "mp2SetIndex", fn_mp2_set_index }, { "mp2GetSampleRate", fn_mp2_get_sample_rate },
+		{ "mp2Decode", fn_mp2_decode }, { "mp2GetChannels", fn_mp2_get_channels },
 	};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
 		napi_value f;

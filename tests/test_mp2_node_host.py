@@ -1,0 +1,94 @@
+"""The Node.js host side of the MP2 stage: N-API addon (mp2* bindings) + JSMpeg.Decoder.MP2AudioHIP."""
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT, have_reference
+from jsmpeg_amd import build
+from mp2_util import FIXTURES, FIXTURE_IDS, load_case
+from ts_craft import Muxer
+
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
+
+
+def _audio_ts(case, frames_per_pes=2):
+    """The fixture's frames as an MPEG-TS file: audio PES packets (stream 0xC0, PES_packet_length set, pts from
+    the frame number), a video-looking PID and null packets in between."""
+    fx, data, offs = load_case(FIXTURES[FIXTURE_IDS.index(case)])
+    m = Muxer()
+    for k in range(0, fx["n_frames"], frames_per_pes):
+        hi = min(k + frames_per_pes, fx["n_frames"])
+        pts = 90000 + int(round(90000 * 1152 * k / fx["sample_rate"]))
+        m.pes(0x101, 0xC0, data[int(offs[k]):int(offs[hi])].tobytes(), pts=pts, with_length=True)
+        if k % 4 == 0:
+            m.packet(0x1fff, b"")
+    f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+    f.write(m.bytes().tobytes())
+    f.close()
+    return fx, f.name
+
+
+def test_addon_exports_the_mp2_abi():
+    addon = build.build_addon()
+    out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
+    assert {"mp2Create", "mp2Destroy", "mp2BufferWrite", "mp2GetIndex", "mp2SetIndex", "mp2GetSampleRate", "mp2Decode",
+            "mp2GetChannels"} <= set(json.loads(out))
+
+
+def test_class_fails_loudly_without_gpu():
+    from conftest import have_gpu
+    if have_gpu():
+        pytest.skip("a GPU is present")
+    build.build_addon()
+    script = ("const {install}=require(%r);const {MP2AudioHIP}=install();const d=new MP2AudioHIP({});"
+              "console.log(d.decode());"
+              "try{d.write(0,[new Uint8Array(8)]);console.log('NO THROW')}catch(e){console.log('THROWS:'+e.message)}"
+              % os.path.join(ROOT, "jsmpeg_amd", "js", "mp2-hip.js"))
+    out = subprocess.check_output([NODE, "-e", script]).decode().splitlines()
+    assert out[0] == "false" and out[1].startswith("THROWS:") and "no CPU fallback" in out[1]
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference")
+@pytest.mark.parametrize("mode", ["static", "streaming"])
+@pytest.mark.parametrize("case", ["varying_44k", "mono_32k_48"])
+def test_class_is_a_dropin_for_the_wasm_wrapper(case, mode):
+    """Same play / onAudioDecode / currentTime / index / seek event sequence as the reference's
+    JSMpeg.Decoder.MP2AudioWASM, driven by the reference's own TS demuxer (binding = the reference's wasm exports,
+    so only the class is under test)."""
+    fx, ts = _audio_ts(case)
+    try:
+        args = [NODE, os.path.join(ROOT, "tests", "js", "mp2_class_vs_reference.js"), ts]
+        if mode == "streaming":
+            args.append("streaming")
+        out = json.loads(subprocess.check_output(args))
+    finally:
+        os.unlink(ts)
+    assert out["same"], out
+    assert out["plays"] >= fx["n_frames"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["static", "streaming"])
+@pytest.mark.parametrize("case", ["varying_44k", "joint_48k_128"])
+def test_node_class_on_gpu_matches_golden(case, mode, hip_lib):
+    """TS file -> ts-demux -> MP2AudioHIP -> addon -> HIP kernels: every frame's samples bit for bit."""
+    build.build_addon()
+    fx, ts = _audio_ts(case, frames_per_pes=3)
+    try:
+        args = [NODE, os.path.join(ROOT, "tests", "js", "hip_mp2_decode.js"), ts]
+        if mode == "streaming":
+            args.append("streaming")
+        out = json.loads(subprocess.check_output(args))
+    finally:
+        os.unlink(ts)
+    assert out["frames"] == fx["frame_md5"]
+    assert out["sampleRate"] == (fx["sample_rate"] if case != "varying_44k" else 44100)
+    assert len(out["indices"]) == fx["n_frames"]
+    if mode == "static":
+        assert out["indices"] == fx["bit_index_after_decode"]
