@@ -218,6 +218,20 @@ void jsmpeg_hip_mp2_batch_destroy(jsmpeg_hip_mp2_batch_t *b);
 /* Copies n_streams host buffers of back-to-back Layer II frames into HBM.  Returns 0 or < 0. */
 int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
                                 const uint64_t *bytes);
+/* Ingest side on the device (reference src/ts.js:25-210), the audio twin of
+ * jsmpeg_hip_batch_upload_ts: n_streams MPEG-TS buffers (host) -> the payload of `stream_id` (0xC0 = the first
+ * audio stream, ts.js:212-222), demultiplexed by the same GPU kernels straight into the batch's HBM buffer; per
+ * stream the same bytes and the same destination.write(pts, buffers) boundaries as one JSMpeg.Demuxer.TS fed the
+ * buffer in one write().  Packet-aligned input only.  The same TS buffers can be handed to both batches
+ * (video with 0xE0, audio with 0xC0).  Returns 0 or < 0. */
+int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                                   const uint64_t *ts_bytes, uint32_t stream_id);
+/* The destination.write calls of stream `stream` of the last upload_ts: pts in seconds, byte range inside that
+ * stream's MP2 bytes.  Returns their number (fills at most `cap` entries; any array may be NULL) or < 0. */
+int jsmpeg_hip_mp2_batch_ts_writes(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, double *pts, uint32_t *offset,
+                                   uint32_t *length, uint32_t cap);
+/* Device-to-host copy of one stream's resident MP2 bytes; returns their number (copies at most `cap`) or < 0. */
+int64_t jsmpeg_hip_mp2_batch_read_bytes(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, void *out, uint64_t cap);
 /* Decodes every frame of every stream -- per stream what `while (mp2_decoder_decode(d));` after one write of the
  * whole buffer gives, except that a last frame that is not completely there is not decoded.  Work is enqueued on
  * `hip_stream` (NULL = the batch's own); the call synchronises once internally (frame counts size the launches).

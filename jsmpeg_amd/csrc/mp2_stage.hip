@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "jsmpeg_hip.h"
+#include "kernels.h"
 #include "mp2_dev.h"
 #include "mp2_window.h"
 
@@ -116,6 +117,11 @@ struct jsmpeg_hip_mp2_batch_t {
 	hipEvent_t ev[5];
 	hipStream_t last_stream;
 	bool decoded;
+	/* ingest side (jsmpeg_hip_mp2_batch_upload_ts): TS scratch of the device demux (ts_kernels.hip) */
+	uint8_t *d_ts; uint64_t ts_cap;
+	JmTsRec *d_ts_rec; uint32_t *d_ts_es_off; JmTsCand *d_ts_cand; JmTsWrite *d_ts_writes; uint32_t ts_pkt_cap;
+	uint64_t *d_ts_begin, *d_ts_len; uint32_t *d_ts_small;
+	std::vector<uint32_t> ts_pkt_first, ts_n_writes;
 };
 
 static void mp2_batch_free(jsmpeg_hip_mp2_batch_t *b) {
@@ -124,6 +130,8 @@ static void mp2_batch_free(jsmpeg_hip_mp2_batch_t *b) {
 	hipFree(b->d_in); hipFree(b->d_begin); hipFree(b->d_end); hipFree(b->d_cap_first); hipFree(b->d_count);
 	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipHostFree(b->h_count); hipFree(b->d_sides); hipFree(b->d_w);
 	hipFree(b->d_pcm);
+	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
+	hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	for (hipEvent_t &e : b->ev) if (e) hipEventDestroy(e);
 	if (b->own_stream) hipStreamDestroy(b->own_stream);
 	delete b;
@@ -138,6 +146,8 @@ extern "C" jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_stre
 	b->d_frame_pos = nullptr; b->h_count = nullptr; b->d_sides = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
 	b->frame_pos_cap = 0; b->frames_cap = 0; b->n_streams = 0; b->n_frames = 0; b->frame_pos_valid = false;
 	b->last_stream = nullptr; b->decoded = false;
+	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr;
+	b->ts_pkt_cap = 0; b->d_ts_begin = b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (hipEvent_t &e : b->ev) e = nullptr;
 	b->max_streams = max_streams; b->max_bytes = max_bytes;
 	bool ok = (device < 0 || hipSetDevice(device) == hipSuccess) && hipGetDevice(&b->device) == hipSuccess &&
@@ -160,11 +170,8 @@ extern "C" jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_stre
 
 extern "C" void jsmpeg_hip_mp2_batch_destroy(jsmpeg_hip_mp2_batch_t *b) { mp2_batch_free(b); }
 
-extern "C" int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
-                                           const uint64_t *bytes) {
-	if (!b) return mp2_fail("null MP2 batch");
-	if (n_streams == 0 || n_streams > b->max_streams) return mp2_fail("MP2 batch: %s%ld streams do not fit", "", n_streams);
-	MP2_TRY(hipSetDevice(b->device));
+/* Lays the streams out in d_in (4-byte aligned starts), sizes the frame-position table, uploads the small tables. */
+static int mp2_batch_layout(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint64_t *bytes) {
 	uint64_t at = 0, total = 0;
 	b->begin.assign(n_streams, 0); b->end.assign(n_streams, 0); b->cap_first.assign(n_streams + 1, 0);
 	for (uint32_t s = 0; s < n_streams; s++) {
@@ -176,20 +183,137 @@ extern "C" int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n
 		b->cap_first[s + 1] = b->cap_first[s] + (uint32_t)(bytes[s] / 96) + 1;
 	}
 	MP2_TRY(hipMemsetAsync(b->d_in, 0, at + MP2_PAD, b->own_stream));
-	for (uint32_t s = 0; s < n_streams; s++)
-		if (bytes[s]) MP2_TRY(hipMemcpyAsync(b->d_in + b->begin[s], data[s], bytes[s], hipMemcpyHostToDevice, b->own_stream));
 	MP2_TRY(hipMemcpyAsync(b->d_begin, b->begin.data(), 4ull * n_streams, hipMemcpyHostToDevice, b->own_stream));
 	MP2_TRY(hipMemcpyAsync(b->d_end, b->end.data(), 4ull * n_streams, hipMemcpyHostToDevice, b->own_stream));
 	MP2_TRY(hipMemcpyAsync(b->d_cap_first, b->cap_first.data(), 4ull * (n_streams + 1), hipMemcpyHostToDevice, b->own_stream));
+	MP2_TRY(hipStreamSynchronize(b->own_stream));
 	if (b->frame_pos_cap < b->cap_first[n_streams]) {
-		MP2_TRY(hipStreamSynchronize(b->own_stream));
 		hipFree(b->d_frame_pos); b->d_frame_pos = nullptr;
 		b->frame_pos_cap = b->cap_first[n_streams] + b->cap_first[n_streams] / 4;
 		MP2_TRY(mp2_malloc(&b->d_frame_pos, 4ull * b->frame_pos_cap));
 	}
-	MP2_TRY(hipStreamSynchronize(b->own_stream));      /* the host buffers may go away after this call */
 	b->n_streams = n_streams; b->n_frames = 0; b->decoded = false; b->frame_pos_valid = false;
 	return 0;
+}
+
+extern "C" int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
+                                           const uint64_t *bytes) {
+	jm_clear_error();
+	if (!b || !data || !bytes) return mp2_fail("null MP2 batch argument");
+	if (n_streams == 0 || n_streams > b->max_streams) return mp2_fail("MP2 batch: %s%ld streams do not fit", "", n_streams);
+	MP2_TRY(hipSetDevice(b->device));
+	b->ts_n_writes.clear();
+	if (mp2_batch_layout(b, n_streams, bytes) != 0) return -1;
+	for (uint32_t s = 0; s < n_streams; s++)
+		if (bytes[s]) MP2_TRY(hipMemcpyAsync(b->d_in + b->begin[s], data[s], bytes[s], hipMemcpyHostToDevice, b->own_stream));
+	MP2_TRY(hipStreamSynchronize(b->own_stream));      /* the host buffers may go away after this call */
+	return 0;
+}
+
+/* Ingest side on the device (reference src/ts.js:25-210), the audio twin of jsmpeg_hip_batch_upload_ts: the same
+ * k_ts_parse / k_ts_walk / k_ts_gather kernels, stream id 0xC0 by default, payloads gathered straight into the
+ * MP2 batch buffer. */
+extern "C" int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                                              const uint64_t *ts_bytes, uint32_t stream_id) {
+	jm_clear_error();
+	if (!b || !ts || !ts_bytes) return mp2_fail("null MP2 batch argument");
+	if (n_streams == 0 || n_streams > b->max_streams) return mp2_fail("MP2 batch: %s%ld streams do not fit", "", n_streams);
+	if (stream_id == 0 || stream_id > 255) return mp2_fail("stream id %s%ld out of range", "", stream_id);
+	MP2_TRY(hipSetDevice(b->device));
+	std::vector<uint64_t> begin(n_streams), len(n_streams);
+	b->ts_pkt_first.assign(n_streams + 1, 0);
+	uint64_t off = 0;
+	uint32_t max_packets = 0;
+	for (uint32_t i = 0; i < n_streams; i++) {
+		begin[i] = off; len[i] = ts_bytes[i];
+		off += (ts_bytes[i] + 16 + 15) & ~15ull;              /* 16-byte aligned regions, 16 readable bytes behind each */
+		const uint64_t pk = ts_bytes[i] / 188;
+		if (b->ts_pkt_first[i] + pk > 0x3fffffffull) return mp2_fail("too many TS packets in one batch");
+		b->ts_pkt_first[i + 1] = b->ts_pkt_first[i] + (uint32_t)pk;
+		if ((uint32_t)pk > max_packets) max_packets = (uint32_t)pk;
+	}
+	const uint32_t n_packets = b->ts_pkt_first[n_streams];
+	if (off > b->ts_cap) {
+		hipFree(b->d_ts); b->d_ts = nullptr; b->ts_cap = 0;
+		MP2_TRY(mp2_malloc(&b->d_ts, off));
+		b->ts_cap = off;
+	}
+	if (n_packets > b->ts_pkt_cap) {
+		hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
+		b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
+		MP2_TRY(mp2_malloc(&b->d_ts_rec, sizeof(JmTsRec) * (size_t)n_packets));
+		MP2_TRY(mp2_malloc(&b->d_ts_es_off, sizeof(uint32_t) * (size_t)n_packets));
+		MP2_TRY(mp2_malloc(&b->d_ts_cand, sizeof(JmTsCand) * (size_t)n_packets));
+		MP2_TRY(mp2_malloc(&b->d_ts_writes, sizeof(JmTsWrite) * 2 * (size_t)n_packets));
+		b->ts_pkt_cap = n_packets;
+	}
+	const uint32_t ms = b->max_streams;
+	if (!b->d_ts_begin) {
+		MP2_TRY(mp2_malloc(&b->d_ts_begin, sizeof(uint64_t) * ms));
+		MP2_TRY(mp2_malloc(&b->d_ts_len, sizeof(uint64_t) * ms));
+		MP2_TRY(mp2_malloc(&b->d_ts_small, sizeof(uint32_t) * (6 * (size_t)ms + 1)));
+	}
+	uint32_t *d_pkt_first = b->d_ts_small, *d_n_writes = d_pkt_first + ms + 1, *d_es_total = d_n_writes + ms,
+	         *d_es_given = d_es_total + ms, *d_status = d_es_given + ms, *d_es_begin = d_status + ms;
+	for (uint32_t i = 0; i < n_streams; i++)
+		if (ts_bytes[i]) MP2_TRY(hipMemcpy(b->d_ts + begin[i], ts[i], ts_bytes[i], hipMemcpyHostToDevice));
+	MP2_TRY(hipMemcpy(b->d_ts_begin, begin.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
+	MP2_TRY(hipMemcpy(b->d_ts_len, len.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
+	MP2_TRY(hipMemcpy(d_pkt_first, b->ts_pkt_first.data(), sizeof(uint32_t) * (n_streams + 1), hipMemcpyHostToDevice));
+	MP2_TRY(hipDeviceSynchronize());
+	JmTsBufs tb;
+	tb.ts = b->d_ts; tb.ts_begin = b->d_ts_begin; tb.ts_len = b->d_ts_len; tb.pkt_first = d_pkt_first;
+	tb.n_streams = n_streams; tb.stream_id = stream_id;
+	tb.rec = b->d_ts_rec; tb.es_off = b->d_ts_es_off; tb.cand = b->d_ts_cand; tb.writes = b->d_ts_writes;
+	tb.n_writes = d_n_writes; tb.es_total = d_es_total; tb.es_given = d_es_given; tb.status = d_status;
+	tb.es = b->d_in; tb.es_begin = d_es_begin;
+	MP2_TRY(jm_launch_ts_parse_walk(tb, max_packets, nullptr));
+	std::vector<uint32_t> small(4 * (size_t)ms);
+	MP2_TRY(hipMemcpy(small.data(), d_n_writes, sizeof(uint32_t) * 4 * (size_t)ms, hipMemcpyDeviceToHost));
+	const uint32_t *h_n_writes = small.data(), *h_es_given = small.data() + 2 * ms, *h_status = small.data() + 3 * ms;
+	std::vector<uint64_t> es_len(n_streams);
+	for (uint32_t i = 0; i < n_streams; i++) {
+		if (h_status[i] == 1) return mp2_fail("stream %s%ld: a TS packet does not start with the sync byte: the device demux needs "
+		                                      "packet-aligned input (feed unaligned input through the reference's ts.js, which resyncs)", "", i);
+		if (h_status[i] == 3) return mp2_fail("stream %s%ld: a PES / adaptation-field header runs past the end of its TS packet", "", i);
+		if (h_status[i]) return mp2_fail("stream %s%ld: more than 16 PIDs carry PES headers", "", i);
+		es_len[i] = h_es_given[i];     /* what the destination received; a PES still open at the end stays pending, like in ts.js */
+	}
+	if (mp2_batch_layout(b, n_streams, es_len.data()) != 0) return -1;
+	b->ts_n_writes.assign(h_n_writes, h_n_writes + n_streams);
+	MP2_TRY(hipMemcpy(d_es_begin, b->begin.data(), sizeof(uint32_t) * n_streams, hipMemcpyHostToDevice));
+	MP2_TRY(hipDeviceSynchronize());
+	MP2_TRY(jm_launch_ts_gather(tb, max_packets, nullptr));
+	MP2_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+/* The destination.write(pts, buffers) calls of stream `stream` of the last upload_ts (ts.js:205-210): pts in
+ * seconds, byte range inside that stream's MP2 bytes.  Returns their number (fills at most `cap`) or < 0. */
+extern "C" int jsmpeg_hip_mp2_batch_ts_writes(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, double *pts, uint32_t *offset,
+                                              uint32_t *length, uint32_t cap) {
+	jm_clear_error();
+	if (!b || stream >= b->ts_n_writes.size()) return mp2_fail("no TS upload for stream %s%ld", "", stream);
+	MP2_TRY(hipSetDevice(b->device));
+	const uint32_t n = b->ts_n_writes[stream], k = n < cap ? n : cap;
+	std::vector<JmTsWrite> w(k);
+	if (k) MP2_TRY(hipMemcpy(w.data(), b->d_ts_writes + 2 * (size_t)b->ts_pkt_first[stream], sizeof(JmTsWrite) * k, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < k; i++) {
+		if (pts) pts[i] = (double)(((uint64_t)w[i].pts_hi << 32) | w[i].pts_lo) / 90000.0;
+		if (offset) offset[i] = w[i].begin;
+		if (length) length[i] = w[i].length;
+	}
+	return (int)n;
+}
+
+/* Device-to-host copy of one stream's resident MP2 bytes; returns their number (copies at most `cap`) or < 0. */
+extern "C" int64_t jsmpeg_hip_mp2_batch_read_bytes(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, void *out, uint64_t cap) {
+	jm_clear_error();
+	if (!b || stream >= b->n_streams) return mp2_fail("MP2 batch: no such stream");
+	MP2_TRY(hipSetDevice(b->device));
+	const uint64_t n = b->end[stream] - b->begin[stream], k = n < cap ? n : cap;
+	if (k && out) MP2_TRY(hipMemcpy(out, b->d_in + b->begin[stream], k, hipMemcpyDeviceToHost));
+	return (int64_t)n;
 }
 
 static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {

@@ -45,6 +45,17 @@
  *   mp2GetChannels(handle) -> {left, right}          Float32Array(1152) views over the decoder's host PCM
  *                                                    (get_left/right_channel_ptr), like the heapF32.subarray
  *                                                    views of mp2-wasm.js:91-99
+ *
+ * MP2 batch (include/jsmpeg_hip.h part 3, additive), used by JSMpeg.HIPBatch for the audio of its streams:
+ *   mp2BatchCreate(maxStreams, maxBytes) -> handle | throws
+ *   mp2BatchDestroy(handle)
+ *   mp2BatchUpload(handle, [Uint8Array MP2, ...])                     jsmpeg_hip_mp2_batch_upload
+ *   mp2BatchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xC0)   jsmpeg_hip_mp2_batch_upload_ts
+ *   mp2BatchDecode(handle) -> frames                                   jsmpeg_hip_mp2_batch_decode + _sync
+ *   mp2BatchFrameCount(handle, stream) -> frames of the stream
+ *   mp2BatchFrameInfo(handle, stream, frame) -> {byteOffset, byteSize, sampleRate}
+ *   mp2BatchTsWrites(handle, stream) -> [{pts, offset, length}, ...]
+ *   mp2BatchReadPCM(handle, stream, firstFrame, count, Float32Array(count * 2304))   [frame][left 1152 | right 1152]
  */
 #include <node_api.h>
 #include <stdint.h>
@@ -559,6 +570,155 @@ static napi_value fn_mp2_get_channels(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* ------------------------------------------------------------------ MP2 batch */
+
+static jsmpeg_hip_mp2_batch_t *mp2_batch_arg(napi_env env, napi_value v) {
+	void *p = NULL;
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: bad MP2 batch handle");
+		return NULL;
+	}
+	return (jsmpeg_hip_mp2_batch_t *)p;
+}
+
+static napi_value fn_mp2_batch_create(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	if (argc < 2) { napi_throw_type_error(env, NULL, "jsmpeg_hip: mp2BatchCreate(maxStreams, maxBytes)"); return NULL; }
+	uint32_t streams = 0;
+	double bytes = 0;
+	NAPI_OK(napi_get_value_uint32(env, argv[0], &streams));
+	NAPI_OK(napi_get_value_double(env, argv[1], &bytes));
+	jsmpeg_hip_mp2_batch_t *b = jsmpeg_hip_mp2_batch_create(streams, (uint64_t)bytes, -1);
+	if (!b) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }   /* no GPU: loud, never a CPU decode */
+	NAPI_OK(napi_create_external(env, b, NULL, NULL, &out));
+	return out;
+}
+
+static napi_value fn_mp2_batch_destroy(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	if (b) jsmpeg_hip_mp2_batch_destroy(b);
+	return NULL;
+}
+
+static napi_value mp2_batch_upload_common(napi_env env, napi_callback_info info, int ts) {
+	size_t argc = 3;
+	napi_value argv[3], out;
+	static const uint8_t *ptrs[JM_MAX_JS_STREAMS];
+	static uint64_t lens[JM_MAX_JS_STREAMS];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	uint32_t n = 0, sid = 0xC0;
+	if (argc < 2 || collect_buffers(env, argv[1], ptrs, lens, &n) != 0) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: expected an array of Uint8Arrays");
+		return NULL;
+	}
+	if (ts && argc > 2) napi_get_value_uint32(env, argv[2], &sid);
+	const int rc = ts ? jsmpeg_hip_mp2_batch_upload_ts(b, n, ptrs, lens, sid) : jsmpeg_hip_mp2_batch_upload(b, n, ptrs, lens);
+	if (rc < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_uint32(env, n, &out));
+	return out;
+}
+static napi_value fn_mp2_batch_upload(napi_env env, napi_callback_info info) { return mp2_batch_upload_common(env, info, 0); }
+static napi_value fn_mp2_batch_upload_ts(napi_env env, napi_callback_info info) { return mp2_batch_upload_common(env, info, 1); }
+
+static napi_value fn_mp2_batch_decode(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	const int n = jsmpeg_hip_mp2_batch_decode(b, NULL);
+	if (n < 0 || jsmpeg_hip_mp2_batch_sync(b) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_int32(env, n, &out));
+	return out;
+}
+
+static napi_value fn_mp2_batch_frame_count(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	int32_t stream = -1;
+	if (!b) return NULL;
+	if (argc > 1) NAPI_OK(napi_get_value_int32(env, argv[1], &stream));
+	NAPI_OK(napi_create_uint32(env, jsmpeg_hip_mp2_batch_frame_count(b, stream), &out));
+	return out;
+}
+
+static napi_value fn_mp2_batch_frame_info(napi_env env, napi_callback_info info) {
+	size_t argc = 3;
+	napi_value argv[3], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	uint32_t stream = 0, frame = 0, off = 0, size = 0;
+	int32_t rate = 0;
+	if (!b) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &stream));
+	NAPI_OK(napi_get_value_uint32(env, argv[2], &frame));
+	if (jsmpeg_hip_mp2_batch_frame_info(b, stream, frame, &off, &size, &rate) < 0) { napi_throw_range_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_object(env, &out));
+	if (!set_u32(env, out, "byteOffset", off) || !set_u32(env, out, "byteSize", size) || !set_u32(env, out, "sampleRate", (uint32_t)rate)) {
+		napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the frame info"); return NULL;
+	}
+	return out;
+}
+
+static napi_value fn_mp2_batch_ts_writes(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	uint32_t stream = 0;
+	if (!b) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &stream));
+	const int n = jsmpeg_hip_mp2_batch_ts_writes(b, stream, NULL, NULL, NULL, 0);
+	if (n < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	double *pts = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+	uint32_t *off = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1)), *len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+	napi_value result = NULL;
+	if (pts && off && len && jsmpeg_hip_mp2_batch_ts_writes(b, stream, pts, off, len, (uint32_t)n) == n &&
+	    napi_create_array_with_length(env, (size_t)n, &out) == napi_ok) {
+		result = out;
+		for (int i = 0; i < n && result; i++) {
+			napi_value o, v;
+			if (napi_create_object(env, &o) != napi_ok || napi_create_double(env, pts[i], &v) != napi_ok ||
+			    napi_set_named_property(env, o, "pts", v) != napi_ok || !set_u32(env, o, "offset", off[i]) ||
+			    !set_u32(env, o, "length", len[i]) || napi_set_element(env, out, (uint32_t)i, o) != napi_ok) result = NULL;
+		}
+	}
+	free(pts); free(off); free(len);
+	if (!result) napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the write list");
+	return result;
+}
+
+static napi_value fn_mp2_batch_read_pcm(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_mp2_batch_t *b = mp2_batch_arg(env, argv[0]);
+	uint32_t stream = 0, first = 0, count = 0;
+	if (!b) return NULL;
+	if (argc < 5) { napi_throw_type_error(env, NULL, "jsmpeg_hip: mp2BatchReadPCM(handle, stream, firstFrame, count, Float32Array)"); return NULL; }
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &stream));
+	NAPI_OK(napi_get_value_uint32(env, argv[2], &first));
+	NAPI_OK(napi_get_value_uint32(env, argv[3], &count));
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (napi_get_typedarray_info(env, argv[4], &t, &len, &data, &ab, &off) != napi_ok || t != napi_float32_array ||
+	    len < (size_t)count * 2304) {
+		napi_throw_range_error(env, NULL, "jsmpeg_hip: mp2BatchReadPCM needs a Float32Array of count * 2304 samples");
+		return NULL;
+	}
+	if (jsmpeg_hip_mp2_batch_read_pcm(b, stream, first, count, (float *)data) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_uint32(env, count, &out));
+	return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "create", fn_create }, { "destroy", fn_destroy }, { "bufferWrite", fn_buffer_write },
@@ -574,6 +734,10 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },
 		{ "mp2GetIndex", fn_mp2_get_index }, { "mp2SetIndex", fn_mp2_set_index }, { "mp2GetSampleRate", fn_mp2_get_sample_rate },
 		{ "mp2Decode", fn_mp2_decode }, { "mp2GetChannels", fn_mp2_get_channels },
+		{ "mp2BatchCreate", fn_mp2_batch_create }, { "mp2BatchDestroy", fn_mp2_batch_destroy }, { "mp2BatchUpload", fn_mp2_batch_upload },
+		{ "mp2BatchUploadTS", fn_mp2_batch_upload_ts }, { "mp2BatchDecode", fn_mp2_batch_decode },
+		{ "mp2BatchFrameCount", fn_mp2_batch_frame_count }, { "mp2BatchFrameInfo", fn_mp2_batch_frame_info },
+		{ "mp2BatchTsWrites", fn_mp2_batch_ts_writes }, { "mp2BatchReadPCM", fn_mp2_batch_read_pcm },
 	};
 	for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
 		napi_value f;

@@ -13,6 +13,12 @@
 //       onFrame(frame) { /* frame.stream, .index, .pts, .width, .height, .rgba | .y/.cr/.cb (valid during the call) */ },
 //     });
 //     batch.destroy();
+//
+// Audio (the MP2 stream 0xC0 of the same TS buffers, reference src/mp2.js / mp2-wasm.js) rides along when the batch is
+// created with `audio: true`: decodeTS() also demultiplexes and decodes every MP2 frame on the GPU, and
+//     batch.forEachAudioFrame((a) => { /* a.stream, .index, .pts, .sampleRate, .left, .right (Float32Array(1152), valid during the call) */ });
+// hands the PCM out per stream -- bit-identical to the reference's wasm decoder, with the time stamps its
+// Decoder.Base would have assigned (a PES's pts for the first frame that starts in it, + 1152 / rate from there on).
 'use strict';
 const path = require('path');
 
@@ -37,10 +43,63 @@ function install(JSMpeg, options) {
     this.lumaBytes = g.lumaBytes; this.chromaBytes = g.chromaBytes;
     this.pictures = 0;
     this.writes = null;
+    this.audio = null;
+    if (opts.audio) {
+      this.audio = { handle: this.native.mp2BatchCreate(this.maxStreams, opts.maxAudioBytes || Math.min(this.maxBytes, 256 * 1024 * 1024)),
+                     frames: 0, streams: 0, writes: null };
+    }
   }
 
   HIPBatch.prototype.destroy = function () {
     if (this.handle) { this.native.batchDestroy(this.handle); this.handle = null; }
+    if (this.audio && this.audio.handle) { this.native.mp2BatchDestroy(this.audio.handle); this.audio.handle = null; }
+  };
+
+  // ---- audio of the batch (needs {audio: true}) ----
+  HIPBatch.prototype.uploadAudioTS = function (buffers, streamId) {
+    if (!this.audio) throw new Error('HIPBatch: created without {audio: true}');
+    this.native.mp2BatchUploadTS(this.audio.handle, buffers, streamId || 0xC0);
+    this.audio.streams = buffers.length;
+    this.audio.writes = buffers.map((_, s) => this.native.mp2BatchTsWrites(this.audio.handle, s));
+    return this;
+  };
+  HIPBatch.prototype.uploadAudio = function (buffers) {      // raw MP2 streams, already demultiplexed
+    if (!this.audio) throw new Error('HIPBatch: created without {audio: true}');
+    this.native.mp2BatchUpload(this.audio.handle, buffers);
+    this.audio.streams = buffers.length;
+    this.audio.writes = null;
+    return this;
+  };
+  HIPBatch.prototype.decodeAudio = function () {
+    this.audio.frames = this.native.mp2BatchDecode(this.audio.handle);
+    return this.audio.frames;
+  };
+  HIPBatch.prototype.forEachAudioFrame = function (cb) {
+    const a = this.audio;
+    if (!a) return 0;
+    const CHUNK = 64, pcm = new Float32Array(CHUNK * 2304);
+    let n = 0;
+    for (let stream = 0; stream < a.streams; stream++) {
+      const count = this.native.mp2BatchFrameCount(a.handle, stream);
+      const writes = a.writes && a.writes[stream];
+      let w = 0, time = 0, lastWrite = -1;
+      for (let first = 0; first < count; first += CHUNK) {
+        const k = Math.min(CHUNK, count - first);
+        this.native.mp2BatchReadPCM(a.handle, stream, first, k, pcm);
+        for (let i = 0; i < k; i++) {
+          const info = this.native.mp2BatchFrameInfo(a.handle, stream, first + i);
+          if (writes) {       // reference src/decoder.js:73-93: decodedTime snaps to the newest pts the cursor has passed
+            while (w + 1 < writes.length && writes[w + 1].offset <= info.byteOffset) w++;
+            if (writes.length && w !== lastWrite && writes[w].offset <= info.byteOffset) { time = writes[w].pts; lastWrite = w; }
+          }
+          cb({ stream, index: first + i, pts: time, sampleRate: info.sampleRate, byteOffset: info.byteOffset,
+               left: pcm.subarray(i * 2304, i * 2304 + 1152), right: pcm.subarray(i * 2304 + 1152, i * 2304 + 2304) });
+          time += 1152 / info.sampleRate;
+          n++;
+        }
+      }
+    }
+    return n;
   };
 
   // MPEG-TS buffers (packet aligned) -> device demux with ts.js semantics -> decode.  Returns the picture count.
@@ -108,6 +167,11 @@ function install(JSMpeg, options) {
     opts = opts || {};
     this.uploadTS(buffers, opts.streamId);
     this.decode();
+    if (this.audio) {
+      this.uploadAudioTS(buffers, opts.audioStreamId);
+      this.decodeAudio();
+      if (opts.onAudio) this.forEachAudioFrame(opts.onAudio);
+    }
     return opts.onFrame ? this.forEachFrame(opts, opts.onFrame) : this.pictures;
   };
 

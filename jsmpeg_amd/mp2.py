@@ -15,7 +15,8 @@ SAMPLES_PER_FRAME = 1152
 MP2_BATCH_SYMBOLS = ("jsmpeg_hip_mp2_batch_create", "jsmpeg_hip_mp2_batch_destroy", "jsmpeg_hip_mp2_batch_upload",
                      "jsmpeg_hip_mp2_batch_decode", "jsmpeg_hip_mp2_batch_sync", "jsmpeg_hip_mp2_batch_frame_count",
                      "jsmpeg_hip_mp2_batch_frame_info", "jsmpeg_hip_mp2_batch_pcm", "jsmpeg_hip_mp2_batch_read_pcm",
-                     "jsmpeg_hip_mp2_batch_timings")
+                     "jsmpeg_hip_mp2_batch_timings", "jsmpeg_hip_mp2_batch_upload_ts", "jsmpeg_hip_mp2_batch_ts_writes",
+                     "jsmpeg_hip_mp2_batch_read_bytes")
 
 _lib = None
 
@@ -50,6 +51,12 @@ def lib():
         L.jsmpeg_hip_mp2_batch_read_pcm.argtypes = [vp, u32, u32, u32, vp]
         L.jsmpeg_hip_mp2_batch_timings.restype = ctypes.c_int
         L.jsmpeg_hip_mp2_batch_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.jsmpeg_hip_mp2_batch_upload_ts.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_upload_ts.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), u32]
+        L.jsmpeg_hip_mp2_batch_ts_writes.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_ts_writes.argtypes = [vp, u32, vp, vp, vp, u32]
+        L.jsmpeg_hip_mp2_batch_read_bytes.restype = ctypes.c_int64
+        L.jsmpeg_hip_mp2_batch_read_bytes.argtypes = [vp, u32, vp, u64]
         L.jsmpeg_hip_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -88,6 +95,35 @@ class Mp2Batch:
         if self.L.jsmpeg_hip_mp2_batch_upload(self.h, n, ptrs, lens) < 0:
             raise RuntimeError("jsmpeg_hip_mp2_batch_upload failed: " + _err())
         self.n_streams = n
+
+    def upload_ts(self, ts_buffers, stream_id=0xC0):
+        """MPEG-TS buffers in; the audio stream's payload is demultiplexed on the device (reference ts.js semantics)."""
+        bufs = [np.ascontiguousarray(s, dtype=np.uint8) for s in ts_buffers]
+        n = len(bufs)
+        ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in bufs])
+        lens = (ctypes.c_uint64 * n)(*[s.size for s in bufs])
+        if self.L.jsmpeg_hip_mp2_batch_upload_ts(self.h, n, ptrs, lens, stream_id) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_upload_ts failed: " + _err())
+        self.n_streams = n
+
+    def ts_writes(self, stream):
+        """[(pts seconds, offset, length)] -- the destination.write calls ts.js would have made."""
+        n = self.L.jsmpeg_hip_mp2_batch_ts_writes(self.h, stream, None, None, None, 0)
+        if n < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_ts_writes failed: " + _err())
+        pts = np.zeros(n, np.float64); off = np.zeros(n, np.uint32); ln = np.zeros(n, np.uint32)
+        if n:
+            self.L.jsmpeg_hip_mp2_batch_ts_writes(self.h, stream, pts.ctypes.data, off.ctypes.data, ln.ctypes.data, n)
+        return [(float(pts[i]), int(off[i]), int(ln[i])) for i in range(n)]
+
+    def read_bytes(self, stream):
+        n = self.L.jsmpeg_hip_mp2_batch_read_bytes(self.h, stream, None, 0)
+        if n < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_read_bytes failed: " + _err())
+        out = np.zeros(int(n), np.uint8)
+        if n:
+            self.L.jsmpeg_hip_mp2_batch_read_bytes(self.h, stream, out.ctypes.data, int(n))
+        return out
 
     def decode(self, hip_stream=None, sync=True):
         n = self.L.jsmpeg_hip_mp2_batch_decode(self.h, hip_stream)

@@ -116,3 +116,58 @@ def test_batch_full_size_vs_oracle(hip_lib, libs):
         assert b.decode() == 11 * 154
         a = b.read_pcm(0)
         assert same_bits(a, b.read_pcm(1)) and same_bits(a, b.read_pcm(2)) and same_bits(a, b.read_pcm(3 + 5))
+
+
+def _av_ts(video_case_frames, audio_fixture, seed_stream):
+    """A TS with a video stream (0xE0), an audio stream (0xC0, PES_packet_length set, two frames per PES) and null
+    packets, interleaved."""
+    from ts_craft import Muxer
+    es, voffs = synth.generate_config("cfg1_720p", n_frames=video_case_frames, width=176, height=144, stream=seed_stream)
+    fx, data, aoffs = load_case(FIXTURES[FIXTURE_IDS.index(audio_fixture)])
+    m = Muxer()
+    a = 0
+    for k in range(video_case_frames):
+        end = len(es) if k == video_case_frames - 1 else int(voffs[k + 1])
+        m.pes(0x100, 0xE0, es[int(voffs[k]):end].tobytes(), pts=90000 + 3000 * k)
+        while a < fx["n_frames"] and a * 1152 / fx["sample_rate"] <= (k + 1) / 30.0:
+            hi = min(a + 2, fx["n_frames"])
+            m.pes(0x101, 0xC0, data[int(aoffs[a]):int(aoffs[hi])].tobytes(), pts=90000 + int(90000 * 1152 * a / fx["sample_rate"]),
+                  with_length=True)
+            a = hi
+        m.packet(0x1fff, b"")
+    while a < fx["n_frames"]:
+        hi = min(a + 2, fx["n_frames"])
+        m.pes(0x101, 0xC0, data[int(aoffs[a]):int(aoffs[hi])].tobytes(), pts=90000 + int(90000 * 1152 * a / fx["sample_rate"]),
+              with_length=True)
+        a = hi
+    return m.bytes(), es, fx, data
+
+
+def test_batch_ts_in_audio_and_video_from_the_same_buffers(hip_lib, libs):
+    """The same MPEG-TS buffers handed to the video batch (stream 0xE0) and to the MP2 batch (stream 0xC0): the
+    device demux delivers exactly what the ts.js restatement delivers, and both decode bit-exactly."""
+    from jsmpeg_amd import batch as jb
+    from jsmpeg_amd import hashing
+    cases = [_av_ts(9, "stereo_44k_192", 3), _av_ts(6, "mono_32k_48", 4), _av_ts(12, "varying_44k", 5)]
+    ts = [c[0] for c in cases]
+    with mp2.Mp2Batch(len(ts), sum(len(t) for t in ts)) as ab, \
+            jb.Batch(176, 144, len(ts), 40, sum(len(t) for t in ts) + 4096) as vb:
+        ab.upload_ts(ts)                       # 0xC0
+        vb.upload_ts(ts)                       # 0xE0
+        assert ab.decode() == sum(c[2]["n_frames"] for c in cases)
+        n_pics = vb.decode()
+        assert n_pics == 9 + 6 + 12
+        dev = vb.frame_hashes()
+        per_stream = {}
+        for p, info in enumerate(vb.pictures()):
+            per_stream.setdefault(info.stream, []).append(int(dev[p]))
+        for s, (tsb, es, fx, data) in enumerate(cases):
+            want_bytes, want_writes = cabi.oracle_ts_demux(libs["oracle"], tsb, 0xC0)
+            got_writes = ab.ts_writes(s)
+            assert [(w[1], w[2]) for w in got_writes] == [(w[1], w[2]) for w in want_writes]
+            assert all(abs(g[0] - w[0]) < 1e-9 for g, w in zip(got_writes, want_writes))
+            delivered = sum(w[2] for w in want_writes)
+            assert np.array_equal(ab.read_bytes(s), want_bytes[:delivered]) and delivered == len(data)
+            assert frame_md5(ab.read_pcm(s)) == fx["frame_md5"]
+            frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+            assert per_stream[s] == [hashing.frame_hash(*f) for f in frames]

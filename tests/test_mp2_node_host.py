@@ -37,7 +37,8 @@ def test_addon_exports_the_mp2_abi():
     addon = build.build_addon()
     out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
     assert {"mp2Create", "mp2Destroy", "mp2BufferWrite", "mp2GetIndex", "mp2SetIndex", "mp2GetSampleRate", "mp2Decode",
-            "mp2GetChannels"} <= set(json.loads(out))
+            "mp2GetChannels", "mp2BatchCreate", "mp2BatchDestroy", "mp2BatchUpload", "mp2BatchUploadTS", "mp2BatchDecode",
+            "mp2BatchFrameCount", "mp2BatchFrameInfo", "mp2BatchTsWrites", "mp2BatchReadPCM"} <= set(json.loads(out))
 
 
 def test_class_fails_loudly_without_gpu():
@@ -92,3 +93,35 @@ def test_node_class_on_gpu_matches_golden(case, mode, hip_lib):
     assert len(out["indices"]) == fx["n_frames"]
     if mode == "static":
         assert out["indices"] == fx["bit_index_after_decode"]
+
+
+@pytest.mark.gpu
+def test_node_batch_audio_and_video_from_the_same_ts(hip_lib, libs):
+    """TS files with a video and an MP2 audio stream -> JSMpeg.HIPBatch({audio: true}): pictures against the oracle,
+    PCM against the audio fixtures, audio time stamps as the reference's Decoder.Base assigns them (pts of the PES a
+    frame starts in for the first such frame, + 1152 / rate after that)."""
+    import hashlib
+    from jsmpeg_amd import cabi
+    from test_mp2_gpu import _av_ts
+    build.build_addon()
+    cases = [_av_ts(9, "stereo_44k_192", 3), _av_ts(6, "mono_32k_48", 4)]
+    paths = []
+    try:
+        for c in cases:
+            f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+            f.write(c[0].tobytes())
+            f.close()
+            paths.append(f.name)
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_batch_av.js"), "176", "144"] + paths))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["pictures"] == 15 and out["audioFrames"] == sum(c[2]["n_frames"] for c in cases)
+    for s, (ts, es, fx, data) in enumerate(cases):
+        assert out["streams"][s]["planes"] == cabi.decode_stream(libs["oracle"], es)[0]
+        assert out["streams"][s]["audio"] == fx["frame_md5"]
+        assert out["streams"][s]["sampleRate"] == fx["sample_rate"]
+        pts = out["streams"][s]["audioPts"]
+        for k in range(fx["n_frames"]):            # two frames per PES, pts of the PES = 1 + 1152 k / rate
+            base = 1.0 + int(90000 * 1152 * (k - k % 2) / fx["sample_rate"]) / 90000.0
+            assert abs(pts[k] - (base + (k % 2) * 1152 / fx["sample_rate"])) < 1e-9, (s, k)

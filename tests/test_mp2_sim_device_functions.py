@@ -49,3 +49,23 @@ def test_ring_mode_frame_by_frame(name, libs):
                                ctypes.byref(n_abs), ctypes.c_void_p(out[k].ctypes.data))
     assert n_abs.value == 36 * fx["n_frames"]
     assert frame_md5(out) == fx["frame_md5"]
+
+
+def test_randomised_sweep_against_the_oracle(libs):
+    """150 random generator configurations (every sampling frequency, bit rates / modes / CRC / padding changing from
+    frame to frame, forbidden-but-decodable codes, sparse and dense allocations, quiet and loud scalefactors) through
+    the device functions in one batch each; every sample against the oracle."""
+    rng = np.random.RandomState(20260923)
+    checked = 0
+    for case in range(150):
+        kw = dict(sample_rate_index=int(rng.randint(0, 3)), bitrate_index=int(rng.randint(1, 15)), mode=int(rng.randint(0, 4)),
+                  crc=int(rng.randint(0, 2)), vary=int(rng.rand() < 0.5), quirks=int(rng.rand() < 0.3),
+                  alloc_permille=int(rng.choice([150, 500, 800, 1000])), sf_lo=int(rng.choice([8, 12, 30])), sf_hi=62,
+                  seed=int(rng.randint(1, 2 ** 31 - 1)))
+        n_frames = int(rng.randint(1, 9))
+        data, _ = synth.generate_mp2(n_frames, **kw)
+        want = cabi.decode_mp2_stream(libs["oracle"], data)[0]
+        (got,) = sim_batch([data])
+        assert len(want) == n_frames and same_bits(got, want), (case, kw)
+        checked += n_frames
+    assert checked > 400
