@@ -171,3 +171,25 @@ def test_batch_ts_in_audio_and_video_from_the_same_buffers(hip_lib, libs):
             assert frame_md5(ab.read_pcm(s)) == fx["frame_md5"]
             frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
             assert per_stream[s] == [hashing.frame_hash(*f) for f in frames]
+
+
+def test_randomised_sweep(hip_lib, libs):
+    """120 random generator configurations in ONE batch (every sampling frequency, bit rates / modes / CRC / padding
+    changing from frame to frame, forbidden-but-decodable codes, sparse and dense allocations), every sample against
+    the oracle; a dozen of them also through the one-frame ABI."""
+    rng = np.random.RandomState(777)
+    streams = []
+    for case in range(120):
+        kw = dict(sample_rate_index=int(rng.randint(0, 3)), bitrate_index=int(rng.randint(1, 15)), mode=int(rng.randint(0, 4)),
+                  crc=int(rng.randint(0, 2)), vary=int(rng.rand() < 0.5), quirks=int(rng.rand() < 0.3),
+                  alloc_permille=int(rng.choice([150, 500, 800, 1000])), sf_lo=int(rng.choice([8, 12, 30])), sf_hi=62,
+                  seed=int(rng.randint(1, 2 ** 31 - 1)))
+        streams.append(synth.generate_mp2(int(rng.randint(1, 12)), **kw)[0])
+    want = [cabi.decode_mp2_stream(libs["oracle"], s)[0] for s in streams]
+    with mp2.Mp2Batch(len(streams), sum(len(s) for s in streams) + 64) as b:
+        b.upload(streams)
+        assert b.decode() == sum(len(w) for w in want)
+        bad = [i for i in range(len(streams)) if not same_bits(b.read_pcm(i), want[i])]
+        assert not bad, bad
+    for i in range(0, 120, 10):
+        assert same_bits(cabi.decode_mp2_stream(hip_lib, streams[i])[0], want[i]), i
