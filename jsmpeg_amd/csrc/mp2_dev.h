@@ -8,13 +8,15 @@
  * are closed-form once the allocation is known (every granule of a frame has the same number of bits), so here:
  *
  *   k_mp2_walk    one lane per stream    frame chain: header -> frame length -> next header   (mp2.c:275-328)
- *   k_mp2_side    one lane per frame     allocation, scfsi, scalefactors -> Mp2Side: per (channel, subband)
- *                                        steps, scalefactor indices, bit offset inside a granule (mp2.c:339-412)
- *   k_mp2_matrix  one workgroup / frame  768 (granule, channel, subband) triples read + requantised in parallel
- *                                        (mp2.c:491-549), then 72 matrixings (mp2.c:551-687), stored as the 32
- *                                        distinct values x[] of each (the reference's 64-entry V block is +-x)
+ *   k_mp2_matrix  one workgroup / frame  side information by 64 lanes, one per (subband, channel) pair: allocation,
+ *                                        scfsi, scalefactors -- every field's position is a prefix sum over the
+ *                                        pairs before it (mp2.c:339-412); then 768 (granule, pair) triples read +
+ *                                        requantised in parallel (mp2.c:491-549), then 72 matrixings
+ *                                        (mp2.c:551-687), stored as the 32 distinct values x[] of each (the
+ *                                        reference's 64-entry V block is +-x)
  *   k_mp2_window  one workgroup / frame  2304 output samples, each the reference's 16 accumulate-and-truncate
- *                                        steps over the last 16 vectors (mp2.c:449-480)
+ *                                        steps over the last 16 vectors (mp2.c:449-480); what depends on the
+ *                                        sub-block alone is wave-uniform (scalar registers)
  *
  * Arithmetic is the reference C's, operation by operation (see oracle/mp2_oracle.c's header for the contract):
  * integer requantisation; binary32 sums; products (float)((double)x * constant); accumulator
@@ -33,21 +35,20 @@
 
 #pragma clang fp contract(off)
 
-/* What k_mp2_side leaves per frame.  `steps == 0`: no bits for that subband. */
-struct Mp2Side {
-	uint32_t sample_bit;        /* bit position (inside the batch buffer) of the first sample code */
-	uint32_t end_byte;          /* first byte past the stream: reads beyond return 0 bits           */
-	uint32_t w_first;           /* index (in 64-float units: [channel][32]) of the frame's first vector in the W buffer */
-	uint32_t n_abs0;            /* sub-blocks of this stream before this frame (vector age test, v_pos)  */
-	uint32_t pcm_frame;         /* frame slot in the PCM buffer                                       */
-	uint16_t granule_bits;      /* bits of one granule (all 12 are alike)                             */
-	uint8_t sblimit, bound;     /* subbands coded; first subband whose samples both channels share    */
-	uint8_t channels, valid, pad_[2];
-	uint16_t steps[2][32];      /* quantisation steps per (channel, subband)                          */
-	uint16_t bit_in_granule[2][32]; /* where the (channel, subband) triple starts inside a granule   */
-	uint8_t scalefactor[2][32][3];  /* 6-bit indices, one per part (4 granules each)                  */
-	uint8_t scfsi[2][32];       /* scalefactor selection as read (kept in the record so that the parsing lane indexes
-	                               memory, not a private array: no scratch)                            */
+/* Side information of one frame, built in LDS by the first 64 lanes of the frame's workgroup (lane q = subband * 2 +
+ * channel) -- see mp2_side_* below.  `steps == 0`: no bits for that subband. */
+struct Mp2Frame {
+	uint32_t pos, end;          /* first byte of the frame; first byte past its stream (reads beyond return 0 bits) */
+	uint32_t alloc_bit;         /* bit position of the first allocation code                                       */
+	uint32_t scfsi_bit, sf_bit, sample_bit;   /* ... of the first scfsi, scalefactor, sample code                  */
+	int32_t granule_bits;       /* bits of one granule (all 12 are alike)                                           */
+	int32_t sblimit, bound, channels, high, valid;
+	uint16_t steps[64];         /* [q] quantisation steps                                                           */
+	uint16_t bit_in_granule[64];/* [q] where the triple starts inside a granule                                     */
+	uint16_t gbits[64];         /* [q] bits the pair occupies in a granule (0 where channel 1 shares channel 0's)   */
+	uint8_t coded[64];          /* [q] transmits its own scfsi / scalefactors                                       */
+	uint8_t sel[64], nsf[64];   /* [q] scfsi as read; scalefactors transmitted (3 2 1 2)                            */
+	uint8_t sf[64][4];          /* [q] scalefactor index per part (three used)                                      */
 };
 
 /* What k_mp2_walk leaves per frame: where it starts; the header is parsed again by k_mp2_side. */
@@ -69,10 +70,10 @@ MP2_HD uint32_t mp2_bits_at(const uint8_t *p, uint32_t end, uint64_t bitpos, int
 	return (w >> (32 - (int)(bitpos & 7) - n)) & ((1u << n) - 1u);
 }
 
-/* Frame header at byte `pos` (mp2.c:275-328).  The reference reads an 11-bit sync, 2-bit version, 2-bit layer. */
-MP2_HD void mp2_parse_header(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Hdr &H) {
-	const uint64_t b = (uint64_t)pos << 3;
-	const uint32_t w = mp2_bits_at(p, end, b, 16), w2 = mp2_bits_at(p, end, b + 16, 16);
+/* Frame header (mp2.c:275-328) from its four bytes, big endian in `h`.  The reference reads an 11-bit sync, 2-bit
+ * version, 2-bit layer. */
+MP2_HD void mp2_parse_header_word(uint32_t h, Mp2Hdr &H) {
+	const uint32_t w = h >> 16, w2 = h & 0xffffu;
 	const int sync = (int)(w >> 5), version = (int)((w >> 3) & 3), layer = (int)((w >> 1) & 3);
 	H.has_crc = !(w & 1);
 	H.bitrate_index = (int)(w2 >> 12);                 /* header value: 0 = free format, 15 = forbidden */
@@ -90,97 +91,122 @@ MP2_HD void mp2_parse_header(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Hd
 		H.sample_rate = mp2_sample_rate(H.sample_rate_index);
 	}
 }
-
-/* Allocation, scalefactor selection and scalefactors of the frame at byte `pos` (mp2.c:339-412).  Fills everything
- * of S except w_first / n_abs0 / pcm_frame (the caller's).  S may live in device global memory: every array
- * access below is to it, never to a private copy. */
-MP2_HD void mp2_parse_side(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Side &S) {
-	Mp2Hdr H;
-	mp2_parse_header(p, end, pos, H);
-	S.valid = (uint8_t)H.valid; S.end_byte = end;
-	S.pad_[0] = S.pad_[1] = 0;
-	if (!H.valid) { S.sblimit = S.bound = S.channels = 0; S.granule_bits = 0; S.sample_bit = 0; return; }
-	const int mono = H.mode == MP2_MODE_MONO;
-	int high;
-	const int sblimit = mp2_table_select(H.bitrate_index, H.sample_rate_index, mono, &high);
-	int bound = H.mode == MP2_MODE_JOINT ? (H.mode_ext + 1) << 2 : (mono ? 0 : 32);   /* mp2.c:311-318 */
-	if (bound > sblimit) bound = sblimit;                                              /* mp2.c:347-349 */
-	const int channels = mono ? 1 : 2;
-	uint64_t bit = ((uint64_t)pos << 3) + (uint64_t)H.header_bits;
-	for (int sb = 0; sb < 32; sb++) S.steps[0][sb] = S.steps[1][sb] = 0;
-	/* bit allocation (mp2.c:352-361): both channels below `bound`, one shared code from there on */
-	for (int sb = 0; sb < sblimit; sb++) {
-		const int nbal = mp2_nbal(high, sb);
-		const int a = mp2_steps(high, sb, (int)mp2_bits_at(p, end, bit, nbal));
-		bit += (uint64_t)nbal;
-		int c = a;
-		if (sb < bound) { c = mp2_steps(high, sb, (int)mp2_bits_at(p, end, bit, nbal)); bit += (uint64_t)nbal; }
-		S.steps[0][sb] = (uint16_t)a; S.steps[1][sb] = (uint16_t)c;
-	}
-	/* scalefactor selection (mp2.c:364-375): only the coded channels read theirs */
-	for (int sb = 0; sb < 32; sb++) S.scfsi[0][sb] = S.scfsi[1][sb] = 0;
-	for (int sb = 0; sb < sblimit; sb++) {
-		for (int ch = 0; ch < channels; ch++)
-			if (S.steps[ch][sb]) { S.scfsi[ch][sb] = (uint8_t)mp2_bits_at(p, end, bit, 2); bit += 2; }
-		if (mono) S.scfsi[1][sb] = S.scfsi[0][sb];
-	}
-	/* scalefactors (mp2.c:378-412).  A subband without bits keeps whatever the reference's arrays held from
-	 * earlier frames, but never uses it (read_samples returns before, mp2.c:499-503): 0 here. */
-	for (int sb = 0; sb < 32; sb++)
-		for (int k = 0; k < 3; k++) S.scalefactor[0][sb][k] = S.scalefactor[1][sb][k] = 0;
-	for (int sb = 0; sb < sblimit; sb++) {
-		for (int ch = 0; ch < channels; ch++) {
-			if (!S.steps[ch][sb]) continue;
-			const int sel = S.scfsi[ch][sb];
-			const int a = (int)mp2_bits_at(p, end, bit, 6); bit += 6;
-			int b1 = a, c = a;
-			if (sel == 0) { b1 = (int)mp2_bits_at(p, end, bit, 6); bit += 6; c = (int)mp2_bits_at(p, end, bit, 6); bit += 6; }
-			else if (sel == 1) { c = (int)mp2_bits_at(p, end, bit, 6); bit += 6; }                  /* a a c */
-			else if (sel == 3) { b1 = c = (int)mp2_bits_at(p, end, bit, 6); bit += 6; }             /* a b b */
-			S.scalefactor[ch][sb][0] = (uint8_t)a; S.scalefactor[ch][sb][1] = (uint8_t)b1; S.scalefactor[ch][sb][2] = (uint8_t)c;
-		}
-		if (mono)
-			for (int k = 0; k < 3; k++) S.scalefactor[1][sb][k] = S.scalefactor[0][sb][k];
-	}
-	/* where every (channel, subband) triple sits inside a granule (order of mp2.c:421-430) */
-	int g = 0;
-	for (int sb = 0; sb < sblimit; sb++) {
-		S.bit_in_granule[0][sb] = (uint16_t)g;
-		g += mp2_granule_bits(S.steps[0][sb]);
-		if (sb < bound) {
-			S.bit_in_granule[1][sb] = (uint16_t)g;
-			g += mp2_granule_bits(S.steps[1][sb]);
-		} else {
-			/* shared samples: channel 1 gets channel 0's REQUANTISED values (mp2.c:426-430 copies sample[0] after its
-			 * scalefactor was applied) -- so it reads with channel 0's parameters */
-			S.bit_in_granule[1][sb] = S.bit_in_granule[0][sb];
-			S.steps[1][sb] = S.steps[0][sb];
-			for (int k = 0; k < 3; k++) S.scalefactor[1][sb][k] = S.scalefactor[0][sb][k];
-		}
-	}
-	for (int sb = sblimit; sb < 32; sb++) S.bit_in_granule[0][sb] = S.bit_in_granule[1][sb] = 0;
-	S.granule_bits = (uint16_t)g;
-	S.sample_bit = (uint32_t)bit;
-	S.sblimit = (uint8_t)sblimit; S.bound = (uint8_t)bound; S.channels = (uint8_t)channels;
+/* ... at byte `pos` of a buffer whose bytes at or past `end` read as 0 */
+MP2_HD void mp2_parse_header(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Hdr &H) {
+	const uint64_t b = (uint64_t)pos << 3;
+	mp2_parse_header_word((mp2_bits_at(p, end, b, 16) << 16) | mp2_bits_at(p, end, b + 16, 16), H);
 }
 
-/* The three requantised samples of (granule 0..11, channel, subband) (mp2.c:491-549). */
-MP2_HD void mp2_read_triple(const uint8_t *p, const Mp2Side &S, int granule, int ch, int sb, int out[3]) {
-	const int steps = S.steps[ch][sb];
+/* ---------------------------------------------------------------------------------------------------------
+ * Side information in five lane-parallel phases (a barrier between each): the reference reads allocation, scfsi and
+ * scalefactors one after the other (mp2.c:339-412), but where each field sits follows from the fields before it by
+ * prefix sums over the 64 (subband, channel) pairs in bitstream order q = subband * 2 + channel:
+ *   phase 0  lane 0         header, table choice, joint-stereo bound                       (mp2.c:275-349)
+ *   phase 1  lane q         allocation code: its position depends on the header alone      (mp2.c:352-361)
+ *   phase 2  lane q         scfsi: 2 bits x (coded pairs before q)                         (mp2.c:364-375)
+ *   phase 3  lane q         scalefactors: 6 bits x (scalefactors transmitted before q)     (mp2.c:378-412)
+ *   phase 4  lane q         start of the pair's triple inside a granule, shared-channel copies, sample start
+ * A lane's prefix is a loop over the entries before it in LDS (every lane reads the same address: a broadcast). */
+MP2_HD int mp2_alloc_bits_before(int high, int bound, int sb) {       /* allocation bits of subbands 0 .. sb - 1 */
+	int n = 0;
+	for (int s = 0; s < sb; s++) n += mp2_nbal(high, s) * (s < bound ? 2 : 1);
+	return n;
+}
+
+MP2_HD void mp2_side_phase0(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Frame &F) {
+	Mp2Hdr H;
+	mp2_parse_header(p, end, pos, H);
+	F.pos = pos; F.end = end; F.valid = H.valid;
+	const int mono = H.mode == MP2_MODE_MONO;
+	int high = 0;
+	const int sblimit = H.valid ? mp2_table_select(H.bitrate_index, H.sample_rate_index, mono, &high) : 0;
+	int bound = H.mode == MP2_MODE_JOINT ? (H.mode_ext + 1) << 2 : (mono ? 0 : 32);      /* mp2.c:311-318 */
+	if (bound > sblimit) bound = sblimit;                                                 /* mp2.c:347-349 */
+	F.sblimit = sblimit; F.bound = bound; F.high = high; F.channels = mono ? 1 : 2;
+	F.alloc_bit = (pos << 3) + (uint32_t)H.header_bits;
+	F.scfsi_bit = F.alloc_bit + (uint32_t)mp2_alloc_bits_before(high, bound, sblimit);
+}
+
+MP2_HD void mp2_side_phase1(const uint8_t *p, Mp2Frame &F, int q) {
+	const int sb = q >> 1, ch = q & 1;
+	int steps = 0;
+	if (sb < F.sblimit) {
+		const int nbal = mp2_nbal(F.high, sb);
+		/* below the bound both channels have a code; from the bound on channel 1 uses channel 0's (same position) */
+		const uint32_t bit = F.alloc_bit + (uint32_t)mp2_alloc_bits_before(F.high, F.bound, sb) + (uint32_t)((ch && sb < F.bound) ? nbal : 0);
+		steps = mp2_steps(F.high, sb, (int)mp2_bits_at(p, F.end, bit, nbal));
+	}
+	F.steps[q] = (uint16_t)steps;
+	F.coded[q] = (uint8_t)(steps != 0 && ch < F.channels);
+	/* samples of the pair inside a granule: channel 1 from the bound on has none of its own (mp2.c:424-430) */
+	F.gbits[q] = (uint16_t)((ch == 0 || sb < F.bound) ? mp2_granule_bits(steps) : 0);
+}
+
+MP2_HD void mp2_side_phase2(const uint8_t *p, Mp2Frame &F, int q) {
+	int before = 0;
+	for (int k = 0; k < q; k++) before += F.coded[k];
+	int sel = 0, nsf = 0;
+	if (F.coded[q]) {
+		sel = (int)mp2_bits_at(p, F.end, F.scfsi_bit + 2u * (uint32_t)before, 2);
+		nsf = sel == 0 ? 3 : (sel == 2 ? 1 : 2);
+	}
+	F.sel[q] = (uint8_t)sel; F.nsf[q] = (uint8_t)nsf;
+	if (q == 63) F.sf_bit = F.scfsi_bit + 2u * (uint32_t)(before + F.coded[63]);
+}
+
+MP2_HD void mp2_side_phase3(const uint8_t *p, Mp2Frame &F, int q) {
+	int before = 0;
+	for (int k = 0; k < q; k++) before += F.nsf[k];
+	int a = 0, b1 = 0, c = 0;
+	if (F.coded[q]) {
+		uint32_t bit = F.sf_bit + 6u * (uint32_t)before;
+		const int sel = F.sel[q];
+		a = (int)mp2_bits_at(p, F.end, bit, 6); bit += 6;
+		b1 = c = a;                                                                       /* case 2: a a a */
+		if (sel == 0) { b1 = (int)mp2_bits_at(p, F.end, bit, 6); c = (int)mp2_bits_at(p, F.end, bit + 6, 6); }   /* a b c */
+		else if (sel == 1) c = (int)mp2_bits_at(p, F.end, bit, 6);                       /* a a c */
+		else if (sel == 3) b1 = c = (int)mp2_bits_at(p, F.end, bit, 6);                  /* a b b */
+	}
+	F.sf[q][0] = (uint8_t)a; F.sf[q][1] = (uint8_t)b1; F.sf[q][2] = (uint8_t)c; F.sf[q][3] = 0;
+	if (q == 63) F.sample_bit = F.sf_bit + 6u * (uint32_t)(before + F.nsf[63]);
+}
+
+MP2_HD void mp2_side_phase4(Mp2Frame &F, int q) {
+	const int sb = q >> 1, ch = q & 1;
+	const bool shared = ch == 1 && sb >= F.bound;      /* channel 1 gets channel 0's REQUANTISED samples (mp2.c:426-430,
+	                                                       or the mono copy): it reads with channel 0's parameters */
+	const int upto = shared ? q - 1 : q;
+	int g = 0;
+	for (int k = 0; k < upto; k++) g += F.gbits[k];
+	F.bit_in_granule[q] = (uint16_t)g;
+	if (shared) {
+		F.steps[q] = F.steps[q - 1];
+		F.sf[q][0] = F.sf[q - 1][0]; F.sf[q][1] = F.sf[q - 1][1]; F.sf[q][2] = F.sf[q - 1][2];
+	}
+	if (q == 63) {
+		int total = 0;
+		for (int k = 0; k < 64; k++) total += F.gbits[k];
+		F.granule_bits = total;
+	}
+}
+
+/* The three requantised samples of (granule 0..11, pair q) (mp2.c:491-549). */
+MP2_HD void mp2_read_triple(const uint8_t *p, const Mp2Frame &F, int granule, int q, int out[3]) {
+	const int steps = F.steps[q];
 	if (steps == 0) { out[0] = out[1] = out[2] = 0; return; }                      /* also every sb >= sblimit (mp2.c:431-438) */
-	const int sf = mp2_scalefactor(S.scalefactor[ch][sb][granule >> 2]);
-	const uint64_t bit = (uint64_t)S.sample_bit + (uint64_t)granule * S.granule_bits + S.bit_in_granule[ch][sb];
+	const int sf = mp2_scalefactor(F.sf[q][granule >> 2]);
+	const uint64_t bit = (uint64_t)F.sample_bit + (uint64_t)granule * (uint64_t)F.granule_bits + F.bit_in_granule[q];
 	const int nb = mp2_code_bits(steps);
 	int c0, c1, c2;
 	if (mp2_grouped(steps)) {                                                      /* mp2.c:521-528 */
-		int v = (int)mp2_bits_at(p, S.end_byte, bit, nb);
+		int v = (int)mp2_bits_at(p, F.end, bit, nb);
 		c0 = v % steps; v /= steps;
 		c1 = v % steps;
 		c2 = v / steps;
 	} else {                                                                       /* mp2.c:529-534 */
-		c0 = (int)mp2_bits_at(p, S.end_byte, bit, nb);
-		c1 = (int)mp2_bits_at(p, S.end_byte, bit + (uint64_t)nb, nb);
-		c2 = (int)mp2_bits_at(p, S.end_byte, bit + 2 * (uint64_t)nb, nb);
+		c0 = (int)mp2_bits_at(p, F.end, bit, nb);
+		c1 = (int)mp2_bits_at(p, F.end, bit + (uint64_t)nb, nb);
+		c2 = (int)mp2_bits_at(p, F.end, bit + 2 * (uint64_t)nb, nb);
 	}
 	out[0] = mp2_requantise(c0, steps, sf);
 	out[1] = mp2_requantise(c1, steps, sf);
@@ -257,41 +283,29 @@ MP2_HD void mp2_matrix(const int *s, int stride, float (&x)[32]) {
 	for (int k = 0; k < 16; k++) x[2 * k + 1] = o[k];
 }
 
-/* Entry o (0..63) of the reference's V block for a matrixing whose distinct values are x[] (mp2.c:658-691):
- * V[0..15] = x[16..31], V[16] = 0, V[17..32] = -x[31..16], V[33..48] = -x[15..0], V[49..63] = -x[1..15]. */
-MP2_HD float mp2_v_from_x(const float *x, int o) {
-	if (o < 16) return x[16 + o];
-	if (o == 16) return 0.0f;
-	if (o <= 32) return -x[48 - o];
-	if (o <= 48) return -x[48 - o];
-	return -x[o - 48];
+/* Entry o (0..63) of the reference's V block in terms of a matrixing's distinct values x[] (mp2.c:658-691):
+ * V[0..15] = x[16..31], V[16] = 0, V[17..32] = -x[31..16], V[33..48] = -x[15..0], V[49..63] = -x[1..15].
+ * Returned as an index into x, a sign mask to XOR into the binary32 pattern (negation is exact) and a keep mask
+ * (0 for the one entry that is zero). */
+struct Mp2VMap { int idx; uint32_t sign, keep; };
+MP2_HD Mp2VMap mp2_v_map(int o) {
+	Mp2VMap m;
+	m.keep = 0xffffffffu; m.sign = 0x80000000u;
+	if (o < 16) { m.idx = 16 + o; m.sign = 0; }
+	else if (o == 16) { m.idx = 0; m.keep = 0; m.sign = 0; }
+	else if (o <= 48) m.idx = 48 - o;
+	else m.idx = o - 48;
+	return m;
 }
+MP2_HD float mp2_bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+MP2_HD uint32_t mp2_float_to_bits(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
 
-/* One output sample (mp2.c:449-480): sub-block number n_abs (0-based count of sub-blocks the stream has
- * synthesised before this one), output index i (0..31).  `vec(age)` must return the x[] of the matrixing done
- * `age` sub-blocks earlier for this channel (age 0 = this sub-block), or nullptr where the reference's V ring
- * still holds its initial zeros.  `window(i)` = D[i], i = 0..511. */
-template <class Vec, class Win>
-MP2_HD float mp2_window_sample(uint32_t n_abs, int i, Vec vec, Win window) {
-	const int k = (int)((0u - (n_abs + 1u)) & 15u);          /* v_pos = 64 k after this sub-block's shift (mp2.c:445) */
-	int U = 0;
-#pragma unroll
-	for (int pass = 0; pass < 2; pass++) {
-		const int d0 = (pass == 0 ? 512 : 544) - 32 * k;     /* mp2.c:453, 466 */
-		const int v0 = pass == 0 ? 32 * (k & 1) : 96 - 32 * (k & 1);   /* mp2.c:454, 465 */
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int d_index = d0 + 64 * j + i, v_index = v0 + 128 * j + i;
-			const int slot = v_index >> 6, o = v_index & 63;
-			const float *x = vec((slot - k) & 15);
-			const float v = x ? mp2_v_from_x(x, o) : 0.0f;
-			const float prod = window(d_index & 511) * v;
-			const float acc = (float)U + prod;
-			U = (int)acc;                                    /* truncation at every step: U is an int in the reference (mp2.c:213, 458) */
-		}
-	}
-	return (float)((double)(float)U / 2147418112.0);          /* mp2.c:477-479 */
-}
+/* wave-uniform values: on the device they are moved to scalar registers */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MP2_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define MP2_UNIFORM(x) (x)
+#endif
 
 /* ---------------------------------------------------------------------------------------------------------
  * Workgroup bodies.  The kernels (mp2_stage.hip) are these functions called with their thread index, with a
@@ -313,7 +327,6 @@ struct Mp2Bufs {
 	uint32_t *count;               /* [n_streams] frames found */
 	const uint32_t *frame_first;   /* [n_streams + 1] prefix sums of count (host) */
 	uint32_t n_frames;
-	Mp2Side *sides;                /* [n_frames] */
 	float *w;                      /* vectors of MP2_VEC_FLOATS floats; index masked with w_mask */
 	uint32_t w_mask;               /* 0xffffffff: one vector per sub-block of the batch; 63: the decoder ABI's ring */
 	uint32_t n_abs_base;           /* sub-blocks the stream synthesised before this launch (decoder ABI), 0 for a batch */
@@ -321,47 +334,90 @@ struct Mp2Bufs {
 	float *pcm;                    /* [n_frames][2][1152] */
 };
 
-/* k_mp2_walk, lane = stream: the reference's decode() loop without the decoding (mp2.c:275-286: has 16 bits ->
- * header -> frame length -> next).  Stops where the reference stops (invalid header) and at a frame that is not
- * completely there. */
-MP2_HD void mp2_wg_walk(const Mp2Bufs &b, uint32_t s) {
-	uint32_t pos = b.begin[s];
-	const uint32_t end = b.end[s], first = b.cap_first[s], cap = b.cap_first[s + 1] - first;
-	uint32_t n = 0;
-	while (pos + 2 <= end && n < cap) {
+/* k_mp2_walk, workgroup (one wavefront) = stream: the reference's decode() loop without the decoding (mp2.c:275-286:
+ * has 16 bits -> header -> frame length -> next).  Stops where the reference stops (invalid header) and at a frame
+ * that is not completely there.  The chain of headers is serial by nature; what is not serial is fetching the bytes:
+ * the 64 lanes stage 4 KiB of the stream in LDS with 16-byte loads (fill), lane 0 hops from header to header inside
+ * it at LDS latency (hop), and only a hop that leaves the staged window costs another round trip to HBM. */
+#define MP2_WALK_WG 64
+#define MP2_WALK_CHUNK 4096
+struct Mp2Walk {
+	uint32_t pos, n, base, done;
+	uint32_t chunk[MP2_WALK_CHUNK / 4];
+};
+MP2_HD void mp2_wg_walk_init(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
+	W.pos = b.begin[s]; W.n = 0; W.done = 0; W.base = b.begin[s] & ~15u;
+}
+MP2_HD void mp2_wg_walk_fill(const Mp2Bufs &b, uint32_t s, int tid, Mp2Walk &W) {
+	const uint32_t end = b.end[s], base = W.base;
+	for (int piece = tid; piece < MP2_WALK_CHUNK / 16; piece += MP2_WALK_WG) {
+		const uint32_t a = base + 16u * (uint32_t)piece;
+		uint32_t v[4] = { 0u, 0u, 0u, 0u };
+		if (a < end) {                                /* the batch buffer is readable (and zero) MP2_PAD bytes past its last stream */
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(b.in + a);
+			v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) W.chunk[4 * piece + k] = v[k];
+	}
+}
+MP2_HD void mp2_wg_walk_hop(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
+	const uint32_t end = b.end[s], first = b.cap_first[s], cap = b.cap_first[s + 1] - first, base = W.base;
+	const uint8_t *bytes = reinterpret_cast<const uint8_t *>(W.chunk);
+	uint32_t pos = W.pos, n = W.n;
+	for (;;) {
+		if (pos + 2 > end || n >= cap) { W.done = 1; break; }          /* bit_buffer_has(16), mp2.c:278 */
+		if (pos + 4 > base + MP2_WALK_CHUNK) { W.base = pos & ~15u; break; }   /* header outside the staged window: refill */
+		uint32_t h = 0;
+#pragma unroll
+		for (int k = 0; k < 4; k++) h = (h << 8) | (pos + k < end ? bytes[pos - base + k] : 0u);
 		Mp2Hdr H;
-		mp2_parse_header(b.in, end, pos, H);
-		if (!H.valid || pos + (uint32_t)H.frame_bytes > end) break;
+		mp2_parse_header_word(h, H);
+		if (!H.valid || pos + (uint32_t)H.frame_bytes > end) { W.done = 1; break; }
 		b.frame_pos[first + n] = pos;
 		n++;
 		pos += (uint32_t)H.frame_bytes;
 	}
-	b.count[s] = n;
+	W.pos = pos; W.n = n;
+	if (W.done) b.count[s] = n;
 }
 
-/* k_mp2_side, lane = frame */
-MP2_HD void mp2_wg_side(const Mp2Bufs &b, uint32_t f) {
-	uint32_t lo = 0, hi = b.n_streams;          /* stream s with frame_first[s] <= f < frame_first[s + 1] */
+/* Which stream a frame of the batch belongs to and its number inside it (frame_first = prefix sums of the counts). */
+MP2_HD void mp2_frame_place(const Mp2Bufs &b, uint32_t f, uint32_t &s, uint32_t &n) {
+	uint32_t lo = 0, hi = b.n_streams;
 	while (hi - lo > 1) {
 		const uint32_t mid = (lo + hi) >> 1;
 		if (b.frame_first[mid] <= f) lo = mid; else hi = mid;
 	}
-	const uint32_t s = lo, n = f - b.frame_first[s];
-	Mp2Side &S = b.sides[f];
-	mp2_parse_side(b.in, b.end[s], b.frame_pos[b.cap_first[s] + n], S);
-	S.n_abs0 = b.n_abs_base + 36u * n;
-	S.w_first = b.n_abs_base + 36u * f;
-	S.pcm_frame = f;
+	s = lo; n = f - b.frame_first[lo];
 }
+/* index of the frame's first vector in W (masked at use) and sub-blocks of its stream before it */
+MP2_HD uint32_t mp2_frame_w_first(const Mp2Bufs &b, uint32_t f) { return b.n_abs_base + 36u * f; }
+MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t n) { return b.n_abs_base + 36u * n; }
 
-/* k_mp2_matrix, workgroup = frame.  samples / xs: [sub-block * 2 + channel][subband], rows padded to 33 words
- * (the matrixing lanes all read the same column). */
-MP2_HD void mp2_wg_matrix_read(const Mp2Bufs &b, uint32_t f, int tid, int (&samples)[72][33]) {
-	const Mp2Side &S = b.sides[f];
+/* k_mp2_matrix, workgroup = frame.  Phases 0-4: side information (first 64 lanes; see mp2_side_*); then
+ * samples / xs: [sub-block * 2 + channel][subband], rows padded to 33 words (the matrixing lanes all read the
+ * same column). */
+MP2_HD void mp2_wg_side(const Mp2Bufs &b, uint32_t f, int tid, int phase, Mp2Frame &F) {
+	if (phase == 0) {
+		if (tid == 0) {
+			uint32_t s, n;
+			mp2_frame_place(b, f, s, n);
+			mp2_side_phase0(b.in, b.end[s], b.frame_pos[b.cap_first[s] + n], F);
+		}
+		return;
+	}
+	if (tid >= 64) return;
+	if (phase == 1) mp2_side_phase1(b.in, F, tid);
+	else if (phase == 2) mp2_side_phase2(b.in, F, tid);
+	else if (phase == 3) mp2_side_phase3(b.in, F, tid);
+	else mp2_side_phase4(F, tid);
+}
+MP2_HD void mp2_wg_matrix_read(const Mp2Bufs &b, int tid, const Mp2Frame &F, int (&samples)[72][33]) {
 	for (int item = tid; item < 768; item += MP2_MATRIX_WG) {
-		const int gr = item >> 6, ch = (item >> 5) & 1, sb = item & 31;
+		const int gr = item >> 6, q = item & 63, ch = q & 1, sb = q >> 1;
 		int t[3];
-		mp2_read_triple(b.in, S, gr, ch, sb, t);
+		mp2_read_triple(b.in, F, gr, q, t);
 		samples[(gr * 3 + 0) * 2 + ch][sb] = t[0];
 		samples[(gr * 3 + 1) * 2 + ch][sb] = t[1];
 		samples[(gr * 3 + 2) * 2 + ch][sb] = t[2];
@@ -375,7 +431,7 @@ MP2_HD void mp2_wg_matrix_run(int tid, const int (&samples)[72][33], float (&xs)
 	for (int k = 0; k < 32; k++) xs[tid][k] = x[k];
 }
 MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const float (&xs)[72][33]) {
-	const uint32_t w_first = b.sides[f].w_first;
+	const uint32_t w_first = mp2_frame_w_first(b, f);
 	for (int idx = tid; idx < 72 * 32; idx += MP2_MATRIX_WG) {
 		const int v = idx >> 5, k = idx & 31;       /* v = sub-block * 2 + channel */
 		const uint32_t vec = (w_first + (uint32_t)(v >> 1)) & b.w_mask;
@@ -383,10 +439,14 @@ MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const flo
 	}
 }
 
-/* k_mp2_window, workgroup = frame: the 51 vectors its 36 sub-blocks look back on are staged, then every lane
- * runs the reference's 16 accumulate-and-truncate steps for its output samples. */
+/* k_mp2_window, workgroup = frame: the 51 vectors its 36 sub-blocks look back on are staged, then every
+ * wavefront takes sub-blocks p = wave, wave + 4, ..: lane = channel * 32 + output sample.  Everything that depends on
+ * the sub-block alone -- the ring position k, which vector a tap reads, where in the window -- is wave-uniform; a
+ * lane keeps only where its two V entries (o = i and o = 32 + i) sit in x[] and their signs. */
 MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&xs)[MP2_STAGED][MP2_VEC_FLOATS], float (&win)[512]) {
-	const uint32_t w_first = b.sides[f].w_first, n_abs0 = b.sides[f].n_abs0;
+	uint32_t s, n;
+	mp2_frame_place(b, f, s, n);
+	const uint32_t w_first = mp2_frame_w_first(b, f), n_abs0 = mp2_frame_n_abs0(b, n);
 	for (int idx = tid; idx < 512; idx += MP2_WINDOW_WG) win[idx] = b.window[idx];
 	for (int idx = tid; idx < MP2_STAGED * MP2_VEC_FLOATS; idx += MP2_WINDOW_WG) {
 		const int v = idx >> 6, e = idx & 63, rel = v - MP2_LOOKBACK;
@@ -398,13 +458,33 @@ MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&x
 }
 MP2_HD void mp2_wg_window_run(const Mp2Bufs &b, uint32_t f, int tid, const float (&xs)[MP2_STAGED][MP2_VEC_FLOATS],
                               const float (&win)[512]) {
-	const uint32_t n_abs0 = b.sides[f].n_abs0, pcm_frame = b.sides[f].pcm_frame;
-	for (int item = tid; item < MP2_SUBBLOCKS_PER_FRAME * 64; item += MP2_WINDOW_WG) {
-		const int i = item & 31, ch = (item >> 5) & 1, p = item >> 6;
-		const float out = mp2_window_sample(n_abs0 + (uint32_t)p, i,
-			[&](int age) -> const float * { return &xs[MP2_LOOKBACK + p - age][ch * 32]; },
-			[&](int d) -> float { return win[d]; });
-		b.pcm[((size_t)pcm_frame * 2 + (size_t)ch) * MP2_SAMPLES_PER_FRAME + (size_t)(p * 32 + i)] = out;
+	uint32_t s, n;
+	mp2_frame_place(b, f, s, n);
+	const uint32_t n_abs0 = mp2_frame_n_abs0(b, n);
+	const int wave = MP2_UNIFORM(tid >> 6), lane = tid & 63, ch = lane >> 5, i = lane & 31;
+	const Mp2VMap lo = mp2_v_map(i), hi = mp2_v_map(32 + i);
+	float *out = b.pcm + ((size_t)f * 2 + (size_t)ch) * MP2_SAMPLES_PER_FRAME + (size_t)i;
+	for (int p = wave; p < MP2_SUBBLOCKS_PER_FRAME; p += MP2_WINDOW_WG / 64) {
+		const int k = (int)((0u - (n_abs0 + (uint32_t)p + 1u)) & 15u);   /* v_pos = 64 k after this sub-block's shift (mp2.c:445) */
+		const int odd = k & 1;
+		int U = 0;
+#pragma unroll
+		for (int pass = 0; pass < 2; pass++) {
+			/* mp2.c:453-471: pass 0 reads V at 32 (k & 1) + 128 j + i, D at 512 - 32 k + 64 j + i;
+			 * pass 1 reads V at 96 - 32 (k & 1) + 128 j + i, D at 544 - 32 k + 64 j + i */
+			const Mp2VMap m = (pass == 0) == (odd == 0) ? lo : hi;
+			const int d0 = (pass == 0 ? 512 : 544) - 32 * k;
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const int slot = 2 * j + pass;                    /* 64-entry block of the V ring the tap falls into */
+				const int vec = MP2_LOOKBACK + p - ((slot - k) & 15); /* the matrixing done (slot - k) mod 16 sub-blocks ago */
+				const uint32_t xv = (mp2_float_to_bits(xs[vec][ch * 32 + m.idx]) & m.keep) ^ m.sign;
+				const float prod = win[((d0 + 64 * j) & 511) + i] * mp2_bits_to_float(xv);
+				const float acc = (float)U + prod;
+				U = (int)acc;                                     /* truncation at every tap: U is an int in the reference (mp2.c:213, 458) */
+			}
+		}
+		out[p * 32] = (float)((double)(float)U / 2147418112.0);   /* mp2.c:477-479 */
 	}
 }
 

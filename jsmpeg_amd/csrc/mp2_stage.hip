@@ -36,21 +36,30 @@ static int mp2_fail(const char *fmt, const char *a = "", long b = 0) {
 
 /* Bodies: mp2_dev.h (mp2_wg_*), shared with the test-only simulator. */
 
-__global__ void __launch_bounds__(64) k_mp2_walk(Mp2Bufs b) {
-	const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-	if (s < b.n_streams) mp2_wg_walk(b, s);
-}
-
-__global__ void __launch_bounds__(64) k_mp2_side(Mp2Bufs b) {
-	const uint32_t f = blockIdx.x * 64 + threadIdx.x;
-	if (f < b.n_frames) mp2_wg_side(b, f);
+__global__ void __launch_bounds__(MP2_WALK_WG) k_mp2_walk(Mp2Bufs b) {
+	__shared__ Mp2Walk W;
+	const uint32_t s = blockIdx.x;
+	const int tid = (int)threadIdx.x;
+	if (tid == 0) mp2_wg_walk_init(b, s, W);
+	__syncthreads();
+	while (!W.done) {
+		mp2_wg_walk_fill(b, s, tid, W);
+		__syncthreads();
+		if (tid == 0) mp2_wg_walk_hop(b, s, W);
+		__syncthreads();
+	}
 }
 
 __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
+	__shared__ Mp2Frame F;
 	__shared__ int samples[72][33];
 	__shared__ float xs[72][33];
 	const int tid = (int)threadIdx.x;
-	mp2_wg_matrix_read(b, blockIdx.x, tid, samples);
+	for (int phase = 0; phase < 5; phase++) {
+		mp2_wg_side(b, blockIdx.x, tid, phase, F);
+		__syncthreads();
+	}
+	mp2_wg_matrix_read(b, tid, F, samples);
 	__syncthreads();
 	mp2_wg_matrix_run(tid, samples, xs);
 	__syncthreads();
@@ -109,7 +118,7 @@ struct jsmpeg_hip_mp2_batch_t {
 	uint32_t *d_begin, *d_end, *d_cap_first, *d_count, *d_frame_first, *d_frame_pos;
 	uint32_t frame_pos_cap;
 	uint32_t *h_count;                 /* pinned */
-	Mp2Side *d_sides; float *d_w, *d_pcm;
+	float *d_w, *d_pcm;
 	uint32_t frames_cap;
 	uint32_t n_streams, n_frames;
 	std::vector<uint32_t> begin, end, cap_first, frame_first, h_frame_pos;
@@ -128,7 +137,7 @@ static void mp2_batch_free(jsmpeg_hip_mp2_batch_t *b) {
 	if (!b) return;
 	if (b->own_stream) hipStreamSynchronize(b->own_stream);
 	hipFree(b->d_in); hipFree(b->d_begin); hipFree(b->d_end); hipFree(b->d_cap_first); hipFree(b->d_count);
-	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipHostFree(b->h_count); hipFree(b->d_sides); hipFree(b->d_w);
+	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipHostFree(b->h_count); hipFree(b->d_w);
 	hipFree(b->d_pcm);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
 	hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
@@ -143,7 +152,7 @@ extern "C" jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_stre
 	if (max_streams == 0 || max_bytes == 0 || max_bytes > (1ull << 28)) { mp2_fail("bad MP2 batch configuration"); return nullptr; }
 	jsmpeg_hip_mp2_batch_t *b = new jsmpeg_hip_mp2_batch_t();
 	b->own_stream = nullptr; b->d_in = nullptr; b->d_begin = b->d_end = b->d_cap_first = b->d_count = b->d_frame_first = nullptr;
-	b->d_frame_pos = nullptr; b->h_count = nullptr; b->d_sides = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
+	b->d_frame_pos = nullptr; b->h_count = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
 	b->frame_pos_cap = 0; b->frames_cap = 0; b->n_streams = 0; b->n_frames = 0; b->frame_pos_valid = false;
 	b->last_stream = nullptr; b->decoded = false;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr;
@@ -320,7 +329,7 @@ static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {
 	Mp2Bufs k;
 	k.in = b->d_in; k.begin = b->d_begin; k.end = b->d_end; k.n_streams = b->n_streams; k.cap_first = b->d_cap_first;
 	k.frame_pos = b->d_frame_pos; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
-	k.sides = b->d_sides; k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.window = b->d_window; k.pcm = b->d_pcm;
+	k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.window = b->d_window; k.pcm = b->d_pcm;
 	return k;
 }
 
@@ -331,7 +340,7 @@ extern "C" int jsmpeg_hip_mp2_batch_decode(jsmpeg_hip_mp2_batch_t *b, void *hip_
 	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
 	b->last_stream = st;
 	MP2_TRY(hipEventRecord(b->ev[0], st));
-	hipLaunchKernelGGL(k_mp2_walk, dim3((b->n_streams + 63) / 64), dim3(64), 0, st, batch_bufs(b));
+	hipLaunchKernelGGL(k_mp2_walk, dim3(b->n_streams), dim3(MP2_WALK_WG), 0, st, batch_bufs(b));
 	MP2_TRY(hipGetLastError());
 	MP2_TRY(hipMemcpyAsync(b->h_count, b->d_count, 4ull * b->n_streams, hipMemcpyDeviceToHost, st));
 	MP2_TRY(hipEventRecord(b->ev[1], st));
@@ -340,16 +349,14 @@ extern "C" int jsmpeg_hip_mp2_batch_decode(jsmpeg_hip_mp2_batch_t *b, void *hip_
 	for (uint32_t s = 0; s < b->n_streams; s++) b->frame_first[s + 1] = b->frame_first[s] + b->h_count[s];
 	b->n_frames = b->frame_first[b->n_streams];
 	if (b->n_frames > b->frames_cap) {
-		hipFree(b->d_sides); hipFree(b->d_w); hipFree(b->d_pcm); b->d_sides = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
+		hipFree(b->d_w); hipFree(b->d_pcm); b->d_w = nullptr; b->d_pcm = nullptr;
 		b->frames_cap = b->n_frames + b->n_frames / 8;
-		MP2_TRY(mp2_malloc(&b->d_sides, sizeof(Mp2Side) * (size_t)b->frames_cap));
 		MP2_TRY(mp2_malloc(&b->d_w, sizeof(float) * MP2_VEC_FLOATS * MP2_SUBBLOCKS_PER_FRAME * (size_t)b->frames_cap));
 		MP2_TRY(mp2_malloc(&b->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME * (size_t)b->frames_cap));
 	}
 	MP2_TRY(hipMemcpyAsync(b->d_frame_first, b->frame_first.data(), 4ull * (b->n_streams + 1), hipMemcpyHostToDevice, st));
 	if (b->n_frames) {
 		const Mp2Bufs k = batch_bufs(b);
-		hipLaunchKernelGGL(k_mp2_side, dim3((b->n_frames + 63) / 64), dim3(64), 0, st, k);
 		MP2_TRY(hipEventRecord(b->ev[2], st));
 		hipLaunchKernelGGL(k_mp2_matrix, dim3(b->n_frames), dim3(MP2_MATRIX_WG), 0, st, k);
 		MP2_TRY(hipEventRecord(b->ev[3], st));
@@ -442,14 +449,14 @@ struct mp2_decoder_t {
 	uint32_t n_abs;                /* sub-blocks synthesised so far: the reference's v_pos is 64 * (-n_abs & 15) */
 	/* device state */
 	uint8_t *d_in; uint32_t *d_tables; /* begin, end, cap_first[2], frame_first[2], frame_pos, count */
-	Mp2Side *d_side; float *d_w, *d_pcm;
+	float *d_w, *d_pcm;
 	float *h_pcm;                  /* pinned: left[1152] | right[1152] of the last decoded frame */
 };
 
 static void mp2_dec_free(mp2_decoder_t *d) {
 	if (!d) return;
 	if (d->stream) hipStreamSynchronize(d->stream);
-	hipHostFree(d->bytes); hipFree(d->d_in); hipFree(d->d_tables); hipFree(d->d_side); hipFree(d->d_w); hipFree(d->d_pcm);
+	hipHostFree(d->bytes); hipFree(d->d_in); hipFree(d->d_tables); hipFree(d->d_w); hipFree(d->d_pcm);
 	hipHostFree(d->h_pcm);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
@@ -459,7 +466,7 @@ extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffe
 	jm_clear_error();
 	if (!have_device()) { mp2_fail("no HIP device available: the MP2 decode stage has no CPU fallback"); return nullptr; }
 	mp2_decoder_t *d = new mp2_decoder_t();
-	d->stream = nullptr; d->bytes = nullptr; d->d_in = nullptr; d->d_tables = nullptr; d->d_side = nullptr; d->d_w = nullptr;
+	d->stream = nullptr; d->bytes = nullptr; d->d_in = nullptr; d->d_tables = nullptr; d->d_w = nullptr;
 	d->d_pcm = nullptr; d->h_pcm = nullptr;
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->sample_rate = 44100;        /* mp2.c:234 */
@@ -470,7 +477,7 @@ extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffe
 	          hipHostMalloc(&d->bytes, d->capacity, hipHostMallocDefault) == hipSuccess &&
 	          hipHostMalloc(&d->h_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME, hipHostMallocDefault) == hipSuccess &&
 	          mp2_malloc(&d->d_in, MP2_MAX_FRAME_BYTES + MP2_PAD) == hipSuccess && mp2_malloc(&d->d_tables, 4 * 8) == hipSuccess &&
-	          mp2_malloc(&d->d_side, sizeof(Mp2Side)) == hipSuccess && mp2_malloc(&d->d_w, ring_bytes) == hipSuccess &&
+	          mp2_malloc(&d->d_w, ring_bytes) == hipSuccess &&
 	          mp2_malloc(&d->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME) == hipSuccess &&
 	          hipMemsetAsync(d->d_w, 0, ring_bytes, d->stream) == hipSuccess &&   /* V starts as zeros (mp2.c:231) */
 	          hipStreamSynchronize(d->stream) == hipSuccess;
@@ -534,9 +541,8 @@ static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_byte
 	Mp2Bufs k;
 	k.in = d->d_in; k.begin = d->d_tables + 0; k.end = d->d_tables + 1; k.n_streams = 1; k.cap_first = d->d_tables + 2;
 	k.frame_first = d->d_tables + 4; k.frame_pos = d->d_tables + 6; k.count = d->d_tables + 7; k.n_frames = 1;
-	k.sides = d->d_side; k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = d->n_abs; k.window = d->d_window;
+	k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = d->n_abs; k.window = d->d_window;
 	k.pcm = d->d_pcm;
-	hipLaunchKernelGGL(k_mp2_side, dim3(1), dim3(64), 0, d->stream, k);
 	hipLaunchKernelGGL(k_mp2_matrix, dim3(1), dim3(MP2_MATRIX_WG), 0, d->stream, k);
 	hipLaunchKernelGGL(k_mp2_window, dim3(1), dim3(MP2_WINDOW_WG), 0, d->stream, k);
 	MP2_TRY(hipGetLastError());

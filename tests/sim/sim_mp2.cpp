@@ -34,19 +34,27 @@ int sim_mp2_batch(const uint8_t *const *data, const uint64_t *bytes, uint32_t n_
 	memset(&b, 0, sizeof(b));
 	b.in = in.data(); b.begin = begin.data(); b.end = end.data(); b.n_streams = n_streams; b.cap_first = cap_first.data();
 	b.frame_pos = frame_pos.data(); b.count = count.data(); b.window = window; b.w_mask = 0xffffffffu; b.n_abs_base = 0;
-	for (uint32_t s = 0; s < n_streams; s++) mp2_wg_walk(b, s);
+	for (uint32_t s = 0; s < n_streams; s++) {
+		static Mp2Walk W;
+		mp2_wg_walk_init(b, s, W);
+		while (!W.done) {
+			for (int t = 0; t < MP2_WALK_WG; t++) mp2_wg_walk_fill(b, s, t, W);
+			mp2_wg_walk_hop(b, s, W);
+		}
+	}
 	for (uint32_t s = 0; s < n_streams; s++) frame_first[s + 1] = frame_first[s] + count[s];
 	const uint32_t n_frames = frame_first[n_streams];
 	memcpy(frame_first_out, frame_first.data(), 4 * (n_streams + 1));
 	if (n_frames > pcm_cap_frames) return -1;
-	std::vector<Mp2Side> sides(n_frames ? n_frames : 1);
 	std::vector<float> w((size_t)n_frames * MP2_SUBBLOCKS_PER_FRAME * MP2_VEC_FLOATS + 1, -12345.0f);   /* poison: every read must have been written */
-	b.frame_first = frame_first.data(); b.n_frames = n_frames; b.sides = sides.data(); b.w = w.data(); b.pcm = pcm_out;
-	for (uint32_t f = 0; f < n_frames; f++) mp2_wg_side(b, f);
+	b.frame_first = frame_first.data(); b.n_frames = n_frames; b.w = w.data(); b.pcm = pcm_out;
 	static int samples[72][33];
 	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
 	for (uint32_t f = 0; f < n_frames; f++) {
-		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, f, t, samples);
+		static Mp2Frame F;
+		for (int phase = 0; phase < 5; phase++)
+			for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(b, f, t, phase, F);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, t, F, samples);
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, xs);
 	}
@@ -68,16 +76,17 @@ void sim_mp2_ring_frame(const uint8_t *frame, uint32_t n, float *ring, uint32_t 
 	memcpy(rw, tables, sizeof(rw));
 	float window[512];
 	mp2_window_expand(window);
-	Mp2Side side;
 	Mp2Bufs b;
 	memset(&b, 0, sizeof(b));
 	b.in = in.data(); b.begin = rw + 0; b.end = rw + 1; b.n_streams = 1; b.cap_first = rw + 2; b.frame_first = rw + 4;
-	b.frame_pos = rw + 6; b.count = rw + 7; b.n_frames = 1; b.sides = &side; b.w = ring; b.w_mask = 63; b.n_abs_base = *n_abs;
+	b.frame_pos = rw + 6; b.count = rw + 7; b.n_frames = 1; b.w = ring; b.w_mask = 63; b.n_abs_base = *n_abs;
 	b.window = window; b.pcm = pcm_out;
 	static int samples[72][33];
 	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
-	mp2_wg_side(b, 0);
-	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, 0, t, samples);
+	static Mp2Frame F;
+	for (int phase = 0; phase < 5; phase++)
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(b, 0, t, phase, F);
+	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, t, F, samples);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, 0, t, xs);
 	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, 0, t, staged, win);
