@@ -37,7 +37,11 @@
 
 /* Side information of one frame, built in LDS by the first 64 lanes of the frame's workgroup (lane q = subband * 2 +
  * channel) -- see mp2_side_* below.  `steps == 0`: no bits for that subband. */
+#define MP2_FRAME_STAGE 1792       /* bytes of a frame staged in LDS: the longest frame (384 kbit/s at 32 kHz, padded) is
+                                      1729 bytes, + up to 15 for the 16-byte aligned start of the window */
 struct Mp2Frame {
+	uint32_t bytes[MP2_FRAME_STAGE / 4];   /* the frame's bytes from `base` (16-byte aligned, <= its first byte) on   */
+	uint32_t base;              /* all positions below are relative to it                                            */
 	uint32_t pos, end;          /* first byte of the frame; first byte past its stream (reads beyond return 0 bits) */
 	uint32_t alloc_bit;         /* bit position of the first allocation code                                       */
 	uint32_t scfsi_bit, sf_bit, sample_bit;   /* ... of the first scfsi, scalefactor, sample code                  */
@@ -113,10 +117,12 @@ MP2_HD int mp2_alloc_bits_before(int high, int bound, int sb) {       /* allocat
 	return n;
 }
 
-MP2_HD void mp2_side_phase0(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Frame &F) {
+MP2_HD void mp2_side_phase0(Mp2Frame &F) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
+	const uint32_t pos = F.pos, end = F.end;
 	Mp2Hdr H;
 	mp2_parse_header(p, end, pos, H);
-	F.pos = pos; F.end = end; F.valid = H.valid;
+	F.valid = H.valid;
 	const int mono = H.mode == MP2_MODE_MONO;
 	int high = 0;
 	const int sblimit = H.valid ? mp2_table_select(H.bitrate_index, H.sample_rate_index, mono, &high) : 0;
@@ -127,7 +133,8 @@ MP2_HD void mp2_side_phase0(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Fra
 	F.scfsi_bit = F.alloc_bit + (uint32_t)mp2_alloc_bits_before(high, bound, sblimit);
 }
 
-MP2_HD void mp2_side_phase1(const uint8_t *p, Mp2Frame &F, int q) {
+MP2_HD void mp2_side_phase1(Mp2Frame &F, int q) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	const int sb = q >> 1, ch = q & 1;
 	int steps = 0;
 	if (sb < F.sblimit) {
@@ -142,7 +149,8 @@ MP2_HD void mp2_side_phase1(const uint8_t *p, Mp2Frame &F, int q) {
 	F.gbits[q] = (uint16_t)((ch == 0 || sb < F.bound) ? mp2_granule_bits(steps) : 0);
 }
 
-MP2_HD void mp2_side_phase2(const uint8_t *p, Mp2Frame &F, int q) {
+MP2_HD void mp2_side_phase2(Mp2Frame &F, int q) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	int before = 0;
 	for (int k = 0; k < q; k++) before += F.coded[k];
 	int sel = 0, nsf = 0;
@@ -154,7 +162,8 @@ MP2_HD void mp2_side_phase2(const uint8_t *p, Mp2Frame &F, int q) {
 	if (q == 63) F.sf_bit = F.scfsi_bit + 2u * (uint32_t)(before + F.coded[63]);
 }
 
-MP2_HD void mp2_side_phase3(const uint8_t *p, Mp2Frame &F, int q) {
+MP2_HD void mp2_side_phase3(Mp2Frame &F, int q) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	int before = 0;
 	for (int k = 0; k < q; k++) before += F.nsf[k];
 	int a = 0, b1 = 0, c = 0;
@@ -191,7 +200,8 @@ MP2_HD void mp2_side_phase4(Mp2Frame &F, int q) {
 }
 
 /* The three requantised samples of (granule 0..11, pair q) (mp2.c:491-549). */
-MP2_HD void mp2_read_triple(const uint8_t *p, const Mp2Frame &F, int granule, int q, int out[3]) {
+MP2_HD void mp2_read_triple(const Mp2Frame &F, int granule, int q, int out[3]) {
+	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	const int steps = F.steps[q];
 	if (steps == 0) { out[0] = out[1] = out[2] = 0; return; }                      /* also every sb >= sblimit (mp2.c:431-438) */
 	const int sf = mp2_scalefactor(F.sf[q][granule >> 2]);
@@ -340,13 +350,16 @@ struct Mp2Bufs {
  * the 64 lanes stage 4 KiB of the stream in LDS with 16-byte loads (fill), lane 0 hops from header to header inside
  * it at LDS latency (hop), and only a hop that leaves the staged window costs another round trip to HBM. */
 #define MP2_WALK_WG 64
-#define MP2_WALK_CHUNK 4096
+#define MP2_WALK_CHUNK 16384
 struct Mp2Walk {
 	uint32_t pos, n, base, done;
+	uint16_t frame_bytes[4][16];   /* [sampling_frequency][bitrate_index] -> unpadded frame length, 0 = the reference refuses the header */
 	uint32_t chunk[MP2_WALK_CHUNK / 4];
 };
-MP2_HD void mp2_wg_walk_init(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
-	W.pos = b.begin[s]; W.n = 0; W.done = 0; W.base = b.begin[s] & ~15u;
+MP2_HD void mp2_wg_walk_init(const Mp2Bufs &b, uint32_t s, int tid, Mp2Walk &W) {
+	if (tid == 0) { W.pos = b.begin[s]; W.n = 0; W.done = 0; W.base = b.begin[s] & ~15u; }
+	const int sr = tid >> 4, br = tid & 15;           /* 64 lanes = the 4 x 16 table */
+	W.frame_bytes[sr][br] = (uint16_t)((sr < 3 && br >= 1 && br <= 14) ? mp2_frame_bytes(br, sr, 0) : 0);
 }
 MP2_HD void mp2_wg_walk_fill(const Mp2Bufs &b, uint32_t s, int tid, Mp2Walk &W) {
 	const uint32_t end = b.end[s], base = W.base;
@@ -371,12 +384,14 @@ MP2_HD void mp2_wg_walk_hop(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
 		uint32_t h = 0;
 #pragma unroll
 		for (int k = 0; k < 4; k++) h = (h << 8) | (pos + k < end ? bytes[pos - base + k] : 0u);
-		Mp2Hdr H;
-		mp2_parse_header_word(h, H);
-		if (!H.valid || pos + (uint32_t)H.frame_bytes > end) { W.done = 1; break; }
+		/* sync (11 ones), MPEG-1 (11), Layer II (10) = the top 15 bits; then bit rate, sampling frequency, padding
+		 * (mp2_parse_header_word is the long form of the same test) */
+		const uint32_t unpadded = W.frame_bytes[(h >> 10) & 3][(h >> 12) & 15];
+		const uint32_t frame_bytes = unpadded + ((h >> 9) & 1);
+		if ((h >> 17) != 0x7ffeu || unpadded == 0 || pos + frame_bytes > end) { W.done = 1; break; }
 		b.frame_pos[first + n] = pos;
 		n++;
-		pos += (uint32_t)H.frame_bytes;
+		pos += frame_bytes;
 	}
 	W.pos = pos; W.n = n;
 	if (W.done) b.count[s] = n;
@@ -398,26 +413,39 @@ MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t n) { return b.n_abs_
 /* k_mp2_matrix, workgroup = frame.  Phases 0-4: side information (first 64 lanes; see mp2_side_*); then
  * samples / xs: [sub-block * 2 + channel][subband], rows padded to 33 words (the matrixing lanes all read the
  * same column). */
-MP2_HD void mp2_wg_side(const Mp2Bufs &b, uint32_t f, int tid, int phase, Mp2Frame &F) {
-	if (phase == 0) {
-		if (tid == 0) {
-			uint32_t s, n;
-			mp2_frame_place(b, f, s, n);
-			mp2_side_phase0(b.in, b.end[s], b.frame_pos[b.cap_first[s] + n], F);
+/* all lanes: the frame's bytes into LDS with one 16-byte load each -- every bit field after this comes from LDS */
+MP2_HD void mp2_wg_stage_frame(const Mp2Bufs &b, uint32_t f, int tid, Mp2Frame &F) {
+	uint32_t s, n;
+	mp2_frame_place(b, f, s, n);
+	const uint32_t pos = b.frame_pos[b.cap_first[s] + n], end = b.end[s], base = pos & ~15u;
+	for (int piece = tid; piece < MP2_FRAME_STAGE / 16; piece += MP2_MATRIX_WG) {
+		const uint32_t a = base + 16u * (uint32_t)piece;
+		uint32_t v[4] = { 0u, 0u, 0u, 0u };
+		if (a < end) {                                /* the batch buffer is readable (and zero) MP2_PAD bytes past its last stream */
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(b.in + a);
+			v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
 		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) F.bytes[4 * piece + k] = v[k];
+	}
+	if (tid == 0) { F.base = base; F.pos = pos - base; F.end = end - base; }
+}
+MP2_HD void mp2_wg_side(int tid, int phase, Mp2Frame &F) {
+	if (phase == 0) {
+		if (tid == 0) mp2_side_phase0(F);
 		return;
 	}
 	if (tid >= 64) return;
-	if (phase == 1) mp2_side_phase1(b.in, F, tid);
-	else if (phase == 2) mp2_side_phase2(b.in, F, tid);
-	else if (phase == 3) mp2_side_phase3(b.in, F, tid);
+	if (phase == 1) mp2_side_phase1(F, tid);
+	else if (phase == 2) mp2_side_phase2(F, tid);
+	else if (phase == 3) mp2_side_phase3(F, tid);
 	else mp2_side_phase4(F, tid);
 }
-MP2_HD void mp2_wg_matrix_read(const Mp2Bufs &b, int tid, const Mp2Frame &F, int (&samples)[72][33]) {
+MP2_HD void mp2_wg_matrix_read(int tid, const Mp2Frame &F, int (&samples)[72][33]) {
 	for (int item = tid; item < 768; item += MP2_MATRIX_WG) {
 		const int gr = item >> 6, q = item & 63, ch = q & 1, sb = q >> 1;
 		int t[3];
-		mp2_read_triple(b.in, F, gr, q, t);
+		mp2_read_triple(F, gr, q, t);
 		samples[(gr * 3 + 0) * 2 + ch][sb] = t[0];
 		samples[(gr * 3 + 1) * 2 + ch][sb] = t[1];
 		samples[(gr * 3 + 2) * 2 + ch][sb] = t[2];

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(MP2_WALK_WG) k_mp2_walk(Mp2Bufs b) {
 	__shared__ Mp2Walk W;
 	const uint32_t s = blockIdx.x;
 	const int tid = (int)threadIdx.x;
-	if (tid == 0) mp2_wg_walk_init(b, s, W);
+	mp2_wg_walk_init(b, s, tid, W);
 	__syncthreads();
 	while (!W.done) {
 		mp2_wg_walk_fill(b, s, tid, W);
@@ -55,11 +55,13 @@ __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
 	__shared__ int samples[72][33];
 	__shared__ float xs[72][33];
 	const int tid = (int)threadIdx.x;
+	mp2_wg_stage_frame(b, blockIdx.x, tid, F);
+	__syncthreads();
 	for (int phase = 0; phase < 5; phase++) {
-		mp2_wg_side(b, blockIdx.x, tid, phase, F);
+		mp2_wg_side(tid, phase, F);
 		__syncthreads();
 	}
-	mp2_wg_matrix_read(b, tid, F, samples);
+	mp2_wg_matrix_read(tid, F, samples);
 	__syncthreads();
 	mp2_wg_matrix_run(tid, samples, xs);
 	__syncthreads();

@@ -36,7 +36,7 @@ int sim_mp2_batch(const uint8_t *const *data, const uint64_t *bytes, uint32_t n_
 	b.frame_pos = frame_pos.data(); b.count = count.data(); b.window = window; b.w_mask = 0xffffffffu; b.n_abs_base = 0;
 	for (uint32_t s = 0; s < n_streams; s++) {
 		static Mp2Walk W;
-		mp2_wg_walk_init(b, s, W);
+		for (int t = 0; t < MP2_WALK_WG; t++) mp2_wg_walk_init(b, s, t, W);
 		while (!W.done) {
 			for (int t = 0; t < MP2_WALK_WG; t++) mp2_wg_walk_fill(b, s, t, W);
 			mp2_wg_walk_hop(b, s, W);
@@ -52,9 +52,10 @@ int sim_mp2_batch(const uint8_t *const *data, const uint64_t *bytes, uint32_t n_
 	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
 	for (uint32_t f = 0; f < n_frames; f++) {
 		static Mp2Frame F;
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_stage_frame(b, f, t, F);
 		for (int phase = 0; phase < 5; phase++)
-			for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(b, f, t, phase, F);
-		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, t, F, samples);
+			for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(t, phase, F);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, xs);
 	}
@@ -84,9 +85,10 @@ void sim_mp2_ring_frame(const uint8_t *frame, uint32_t n, float *ring, uint32_t 
 	static int samples[72][33];
 	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
 	static Mp2Frame F;
+	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_stage_frame(b, 0, t, F);
 	for (int phase = 0; phase < 5; phase++)
-		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(b, 0, t, phase, F);
-	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(b, t, F, samples);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(t, phase, F);
+	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, 0, t, xs);
 	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, 0, t, staged, win);
