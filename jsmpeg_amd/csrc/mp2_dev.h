@@ -310,6 +310,20 @@ MP2_HD Mp2VMap mp2_v_map(int o) {
 MP2_HD float mp2_bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 MP2_HD uint32_t mp2_float_to_bits(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
 
+/* float -> int of the accumulator (mp2.c:458).  In range: truncation, like the reference.  Out of range (a damaged
+ * stream: undefined in C, a trap in wasm, outside the contract) all three of device, simulator and oracle saturate:
+ * the device through the conversion instruction itself (v_cvt_i32_f32 saturates; written as such because the
+ * language-level cast is undefined there and free to be optimised on that assumption). */
+MP2_HD int mp2_f2i(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	int r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(a));
+	return r;
+#else
+	return a >= 2147483648.0f ? 2147483647 : (a < -2147483648.0f ? (-2147483647 - 1) : (int)a);
+#endif
+}
+
 /* wave-uniform values: on the device they are moved to scalar registers */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MP2_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -509,7 +523,7 @@ MP2_HD void mp2_wg_window_run(const Mp2Bufs &b, uint32_t f, int tid, const float
 				const uint32_t xv = (mp2_float_to_bits(xs[vec][ch * 32 + m.idx]) & m.keep) ^ m.sign;
 				const float prod = win[((d0 + 64 * j) & 511) + i] * mp2_bits_to_float(xv);
 				const float acc = (float)U + prod;
-				U = (int)acc;                                     /* truncation at every tap: U is an int in the reference (mp2.c:213, 458) */
+				U = mp2_f2i(acc);                                 /* truncation at every tap: U is an int in the reference (mp2.c:213, 458) */
 			}
 		}
 		out[p * 32] = (float)((double)(float)U / 2147418112.0);   /* mp2.c:477-479 */

@@ -29,3 +29,15 @@ for name, cfg, n in (("720p", "cfg1_720p", 60), ("1080p", "cfg2_1080p", 60)):
             k += 1
         dt = (time.perf_counter() - t0) / (k - 1)
         print("one-picture ABI %s: %.3f ms per decode() incl. planes to the host (%d pictures) = %.0f frames/s" % (name, dt * 1e3, k, 1 / dt))
+# MP2 audio: the one-frame ABI (what JSMpeg.Decoder.MP2AudioHIP sits on), one decode() at a time with the PCM copied to the host
+data, _ = synth.generate_mp2_config("mp2_stereo_44k_192", 400)
+with cabi.Mp2Decoder(build.LIB_HIP, len(data) + 1024, cabi.MODE_EXPAND) as d:
+    d.write(data)
+    d.decode()
+    t0 = time.perf_counter()
+    k = 1
+    while d.decode():
+        k += 1
+    dt = (time.perf_counter() - t0) / (k - 1)
+    print("one-frame MP2 ABI: %.3f ms per decode() incl. PCM to the host (%d frames) = %.0f frames/s = %.0f x real time at 44.1 kHz"
+          % (dt * 1e3, k, 1 / dt, 1152 / 44100 / dt))
