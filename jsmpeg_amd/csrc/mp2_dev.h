@@ -348,6 +348,7 @@ struct Mp2Bufs {
 	uint32_t n_streams;
 	const uint32_t *cap_first;     /* [n_streams + 1] prefix sums of the per-stream frame capacity */
 	uint32_t *frame_pos;           /* [cap_first[n_streams]] byte position of every frame found */
+	uint32_t *frame_hdr;           /* [cap_first[n_streams]] its four header bytes, big endian (frame length, sampling rate for the host), or null */
 	uint32_t *count;               /* [n_streams] frames found */
 	const uint32_t *frame_first;   /* [n_streams + 1] prefix sums of count (host) */
 	uint32_t n_frames;
@@ -404,6 +405,7 @@ MP2_HD void mp2_wg_walk_hop(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
 		const uint32_t frame_bytes = unpadded + ((h >> 9) & 1);
 		if ((h >> 17) != 0x7ffeu || unpadded == 0 || pos + frame_bytes > end) { W.done = 1; break; }
 		b.frame_pos[first + n] = pos;
+		if (b.frame_hdr) b.frame_hdr[first + n] = h;
 		n++;
 		pos += frame_bytes;
 	}

@@ -117,13 +117,13 @@ struct jsmpeg_hip_mp2_batch_t {
 	uint64_t max_bytes;
 	float *d_window;
 	uint8_t *d_in;
-	uint32_t *d_begin, *d_end, *d_cap_first, *d_count, *d_frame_first, *d_frame_pos;
+	uint32_t *d_begin, *d_end, *d_cap_first, *d_count, *d_frame_first, *d_frame_pos, *d_frame_hdr;
 	uint32_t frame_pos_cap;
 	uint32_t *h_count;                 /* pinned */
 	float *d_w, *d_pcm;
 	uint32_t frames_cap;
 	uint32_t n_streams, n_frames;
-	std::vector<uint32_t> begin, end, cap_first, frame_first, h_frame_pos;
+	std::vector<uint32_t> begin, end, cap_first, frame_first, h_frame_pos, h_frame_hdr;
 	bool frame_pos_valid;
 	hipEvent_t ev[5];
 	hipStream_t last_stream;
@@ -139,7 +139,7 @@ static void mp2_batch_free(jsmpeg_hip_mp2_batch_t *b) {
 	if (!b) return;
 	if (b->own_stream) hipStreamSynchronize(b->own_stream);
 	hipFree(b->d_in); hipFree(b->d_begin); hipFree(b->d_end); hipFree(b->d_cap_first); hipFree(b->d_count);
-	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipHostFree(b->h_count); hipFree(b->d_w);
+	hipFree(b->d_frame_first); hipFree(b->d_frame_pos); hipFree(b->d_frame_hdr); hipHostFree(b->h_count); hipFree(b->d_w);
 	hipFree(b->d_pcm);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes);
 	hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
@@ -154,7 +154,7 @@ extern "C" jsmpeg_hip_mp2_batch_t *jsmpeg_hip_mp2_batch_create(uint32_t max_stre
 	if (max_streams == 0 || max_bytes == 0 || max_bytes > (1ull << 28)) { mp2_fail("bad MP2 batch configuration"); return nullptr; }
 	jsmpeg_hip_mp2_batch_t *b = new jsmpeg_hip_mp2_batch_t();
 	b->own_stream = nullptr; b->d_in = nullptr; b->d_begin = b->d_end = b->d_cap_first = b->d_count = b->d_frame_first = nullptr;
-	b->d_frame_pos = nullptr; b->h_count = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
+	b->d_frame_pos = nullptr; b->d_frame_hdr = nullptr; b->h_count = nullptr; b->d_w = nullptr; b->d_pcm = nullptr;
 	b->frame_pos_cap = 0; b->frames_cap = 0; b->n_streams = 0; b->n_frames = 0; b->frame_pos_valid = false;
 	b->last_stream = nullptr; b->decoded = false;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr;
@@ -199,9 +199,10 @@ static int mp2_batch_layout(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const
 	MP2_TRY(hipMemcpyAsync(b->d_cap_first, b->cap_first.data(), 4ull * (n_streams + 1), hipMemcpyHostToDevice, b->own_stream));
 	MP2_TRY(hipStreamSynchronize(b->own_stream));
 	if (b->frame_pos_cap < b->cap_first[n_streams]) {
-		hipFree(b->d_frame_pos); b->d_frame_pos = nullptr;
+		hipFree(b->d_frame_pos); hipFree(b->d_frame_hdr); b->d_frame_pos = nullptr; b->d_frame_hdr = nullptr;
 		b->frame_pos_cap = b->cap_first[n_streams] + b->cap_first[n_streams] / 4;
 		MP2_TRY(mp2_malloc(&b->d_frame_pos, 4ull * b->frame_pos_cap));
+		MP2_TRY(mp2_malloc(&b->d_frame_hdr, 4ull * b->frame_pos_cap));
 	}
 	b->n_streams = n_streams; b->n_frames = 0; b->decoded = false; b->frame_pos_valid = false;
 	return 0;
@@ -330,7 +331,7 @@ extern "C" int64_t jsmpeg_hip_mp2_batch_read_bytes(jsmpeg_hip_mp2_batch_t *b, ui
 static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {
 	Mp2Bufs k;
 	k.in = b->d_in; k.begin = b->d_begin; k.end = b->d_end; k.n_streams = b->n_streams; k.cap_first = b->d_cap_first;
-	k.frame_pos = b->d_frame_pos; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
+	k.frame_pos = b->d_frame_pos; k.frame_hdr = b->d_frame_hdr; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
 	k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.window = b->d_window; k.pcm = b->d_pcm;
 	return k;
 }
@@ -394,14 +395,14 @@ extern "C" int jsmpeg_hip_mp2_batch_frame_info(jsmpeg_hip_mp2_batch_t *b, uint32
 	if (!b->frame_pos_valid) {
 		MP2_TRY(hipStreamSynchronize(b->last_stream ? b->last_stream : b->own_stream));
 		b->h_frame_pos.resize(b->cap_first[b->n_streams]);
+		b->h_frame_hdr.resize(b->cap_first[b->n_streams]);
 		MP2_TRY(hipMemcpy(b->h_frame_pos.data(), b->d_frame_pos, 4ull * b->cap_first[b->n_streams], hipMemcpyDeviceToHost));
+		MP2_TRY(hipMemcpy(b->h_frame_hdr.data(), b->d_frame_hdr, 4ull * b->cap_first[b->n_streams], hipMemcpyDeviceToHost));
 		b->frame_pos_valid = true;
 	}
 	const uint32_t pos = b->h_frame_pos[b->cap_first[stream] + frame];
-	uint8_t hdr[4];
-	MP2_TRY(hipMemcpy(hdr, b->d_in + pos, 4, hipMemcpyDeviceToHost));
 	Mp2Hdr H;
-	mp2_parse_header(hdr, 4, 0, H);
+	mp2_parse_header_word(b->h_frame_hdr[b->cap_first[stream] + frame], H);
 	if (byte_offset) *byte_offset = pos - b->begin[stream];
 	if (byte_size) *byte_size = (uint32_t)H.frame_bytes;
 	if (sample_rate) *sample_rate = H.sample_rate;
@@ -542,7 +543,7 @@ static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_byte
 	MP2_TRY(hipMemcpyAsync(d->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice, d->stream));
 	Mp2Bufs k;
 	k.in = d->d_in; k.begin = d->d_tables + 0; k.end = d->d_tables + 1; k.n_streams = 1; k.cap_first = d->d_tables + 2;
-	k.frame_first = d->d_tables + 4; k.frame_pos = d->d_tables + 6; k.count = d->d_tables + 7; k.n_frames = 1;
+	k.frame_first = d->d_tables + 4; k.frame_pos = d->d_tables + 6; k.frame_hdr = nullptr; k.count = d->d_tables + 7; k.n_frames = 1;
 	k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = d->n_abs; k.window = d->d_window;
 	k.pcm = d->d_pcm;
 	hipLaunchKernelGGL(k_mp2_matrix, dim3(1), dim3(MP2_MATRIX_WG), 0, d->stream, k);
