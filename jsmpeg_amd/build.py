@@ -14,7 +14,7 @@ REFERENCE = os.environ.get("JSMPEG_REFERENCE", "/root/reference")
 NODE_INCLUDE = "/usr/include/node"
 
 LIB_SYNTH = os.path.join(PKG, "libjsmpeg_synth.so")
-LIB_HIP = os.path.join(PKG, "libjsmpeg_hip.so")
+LIB_HIP = os.environ.get("JSMPEG_HIP_LIB") or os.path.join(PKG, "libjsmpeg_hip.so")   # the override: tuning experiments only (tools/variants.sh)
 ADDON_NODE = os.path.join(PKG, "js", "jsmpeg_hip.node")
 LIB_ORACLE = os.path.join(ORACLE, "libmpeg1_oracle.so")
 REF_DIR = os.path.join(ORACLE, "_ref")

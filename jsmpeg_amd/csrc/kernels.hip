@@ -308,8 +308,12 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	__shared__ uint32_t lds_pad[JM_EXP_LDS_PAD / 4];   /* experiment: fewer workgroups per CU */
 	if (blocks_per_pic == 0xffffffffu) lds_pad[threadIdx.x] = 1;
 #endif
+#ifdef JM_EXP_NO_XCD   /* experiment: plain mapping, a picture's workgroups spread over all eight XCDs */
+	const uint32_t blk = blockIdx.x % blocks_per_pic, k = blockIdx.x / blocks_per_pic;
+#else
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t blk = q % blocks_per_pic, k = (q / blocks_per_pic) * 8 + xcd;
+#endif
 	if (k >= b.n_level_pics) return;
 	JM_STAMP(0)
 	const JmReconDesc D = b.desc[k];                 /* uniform: one scalar load */

@@ -265,6 +265,8 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = 0;   /* experiment: two dwords per row (wrong pixels) */
 #elif defined(JM_EXP_PRED_X1)
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = 0; B.R[3 * r + 2] = 0;
+#elif defined(JM_EXP_NT_PRED) && defined(__HIP_DEVICE_COMPILE__)
+			B.R[3 * r] = __builtin_nontemporal_load(wr); B.R[3 * r + 1] = __builtin_nontemporal_load(wr + 1); B.R[3 * r + 2] = __builtin_nontemporal_load(wr + 2);   /* experiment: streaming hint on the prediction rows */
 #else
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
 #endif
