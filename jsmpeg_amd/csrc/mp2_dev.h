@@ -355,6 +355,7 @@ struct Mp2Bufs {
 	float *w;                      /* vectors of MP2_VEC_FLOATS floats; index masked with w_mask */
 	uint32_t w_mask;               /* 0xffffffff: one vector per sub-block of the batch; 63: the decoder ABI's ring */
 	uint32_t n_abs_base;           /* sub-blocks the stream synthesised before this launch (decoder ABI), 0 for a batch */
+	const uint32_t *n_abs_ptr;     /* if not null, n_abs_base is read from here instead (decoder ABI: a replayed hipGraph has fixed arguments) */
 	const float *window;           /* D[0..511] */
 	float *pcm;                    /* [n_frames][2][1152] */
 };
@@ -423,8 +424,9 @@ MP2_HD void mp2_frame_place(const Mp2Bufs &b, uint32_t f, uint32_t &s, uint32_t 
 	s = lo; n = f - b.frame_first[lo];
 }
 /* index of the frame's first vector in W (masked at use) and sub-blocks of its stream before it */
-MP2_HD uint32_t mp2_frame_w_first(const Mp2Bufs &b, uint32_t f) { return b.n_abs_base + 36u * f; }
-MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t n) { return b.n_abs_base + 36u * n; }
+MP2_HD uint32_t mp2_n_abs_base(const Mp2Bufs &b) { return b.n_abs_ptr ? *b.n_abs_ptr : b.n_abs_base; }
+MP2_HD uint32_t mp2_frame_w_first(const Mp2Bufs &b, uint32_t f) { return mp2_n_abs_base(b) + 36u * f; }
+MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t n) { return mp2_n_abs_base(b) + 36u * n; }
 
 /* k_mp2_matrix, workgroup = frame.  Phases 0-4: side information (first 64 lanes; see mp2_side_*); then
  * samples / xs: [sub-block * 2 + channel][subband], rows padded to 33 words (the matrixing lanes all read the

@@ -332,7 +332,7 @@ static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {
 	Mp2Bufs k;
 	k.in = b->d_in; k.begin = b->d_begin; k.end = b->d_end; k.n_streams = b->n_streams; k.cap_first = b->d_cap_first;
 	k.frame_pos = b->d_frame_pos; k.frame_hdr = b->d_frame_hdr; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
-	k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.window = b->d_window; k.pcm = b->d_pcm;
+	k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.n_abs_ptr = nullptr; k.window = b->d_window; k.pcm = b->d_pcm;
 	return k;
 }
 
@@ -450,16 +450,26 @@ struct mp2_decoder_t {
 	int mode;
 	int sample_rate;
 	uint32_t n_abs;                /* sub-blocks synthesised so far: the reference's v_pos is 64 * (-n_abs & 15) */
-	/* device state */
-	uint8_t *d_in; uint32_t *d_tables; /* begin, end, cap_first[2], frame_first[2], frame_pos, count */
+	/* device state.  One staging block per frame: MP2_STAGE_WORDS little tables (begin, end, cap_first[2],
+	 * frame_first[2], frame_pos, count, n_abs) followed by the frame's bytes -- pinned on the host, mirrored on the device
+	 * by ONE copy, so that a frame is a fixed sequence {copy in, k_mp2_matrix, k_mp2_window, copy out} with fixed
+	 * arguments: captured once as a hipGraph and replayed per decode() (the call is launch-bound: ~0.05 ms of which
+	 * the kernels are a few microseconds). */
+	uint8_t *h_stage, *d_stage;    /* MP2_STAGE_BYTES each */
 	float *d_w, *d_pcm;
 	float *h_pcm;                  /* pinned: left[1152] | right[1152] of the last decoded frame */
+	hipGraph_t graph; hipGraphExec_t graph_exec;
+	int use_graph;                 /* 1: replay; 0: plain launches (JSMPEG_HIP_NO_GRAPH=1, or capture not available) */
 };
+#define MP2_STAGE_WORDS 16
+#define MP2_STAGE_BYTES (4 * MP2_STAGE_WORDS + MP2_MAX_FRAME_BYTES + MP2_PAD)
 
 static void mp2_dec_free(mp2_decoder_t *d) {
 	if (!d) return;
 	if (d->stream) hipStreamSynchronize(d->stream);
-	hipHostFree(d->bytes); hipFree(d->d_in); hipFree(d->d_tables); hipFree(d->d_w); hipFree(d->d_pcm);
+	if (d->graph_exec) hipGraphExecDestroy(d->graph_exec);
+	if (d->graph) hipGraphDestroy(d->graph);
+	hipHostFree(d->bytes); hipHostFree(d->h_stage); hipFree(d->d_stage); hipFree(d->d_w); hipFree(d->d_pcm);
 	hipHostFree(d->h_pcm);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
@@ -469,8 +479,9 @@ extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffe
 	jm_clear_error();
 	if (!have_device()) { mp2_fail("no HIP device available: the MP2 decode stage has no CPU fallback"); return nullptr; }
 	mp2_decoder_t *d = new mp2_decoder_t();
-	d->stream = nullptr; d->bytes = nullptr; d->d_in = nullptr; d->d_tables = nullptr; d->d_w = nullptr;
-	d->d_pcm = nullptr; d->h_pcm = nullptr;
+	d->stream = nullptr; d->bytes = nullptr; d->h_stage = nullptr; d->d_stage = nullptr; d->d_w = nullptr;
+	d->d_pcm = nullptr; d->h_pcm = nullptr; d->graph = nullptr; d->graph_exec = nullptr;
+	{ const char *v = getenv("JSMPEG_HIP_NO_GRAPH"); d->use_graph = !(v && v[0] == '1'); }
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->sample_rate = 44100;        /* mp2.c:234 */
 	d->n_abs = 0;
@@ -479,7 +490,8 @@ extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffe
 	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipHostMalloc(&d->bytes, d->capacity, hipHostMallocDefault) == hipSuccess &&
 	          hipHostMalloc(&d->h_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME, hipHostMallocDefault) == hipSuccess &&
-	          mp2_malloc(&d->d_in, MP2_MAX_FRAME_BYTES + MP2_PAD) == hipSuccess && mp2_malloc(&d->d_tables, 4 * 8) == hipSuccess &&
+	          hipHostMalloc(&d->h_stage, MP2_STAGE_BYTES, hipHostMallocDefault) == hipSuccess &&
+	          mp2_malloc(&d->d_stage, MP2_STAGE_BYTES) == hipSuccess &&
 	          mp2_malloc(&d->d_w, ring_bytes) == hipSuccess &&
 	          mp2_malloc(&d->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME) == hipSuccess &&
 	          hipMemsetAsync(d->d_w, 0, ring_bytes, d->stream) == hipSuccess &&   /* V starts as zeros (mp2.c:231) */
@@ -533,23 +545,51 @@ extern "C" int mp2_decoder_get_sample_rate(mp2_decoder_t *d) { return d ? d->sam
 extern "C" void *mp2_decoder_get_left_channel_ptr(mp2_decoder_t *d) { return d ? d->h_pcm : nullptr; }
 extern "C" void *mp2_decoder_get_right_channel_ptr(mp2_decoder_t *d) { return d ? d->h_pcm + MP2_SAMPLES_PER_FRAME : nullptr; }
 
-static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_bytes) {
-	MP2_TRY(hipSetDevice(d->device));
-	const unsigned have = d->length - byte_pos;
-	const unsigned n = have < (unsigned)frame_bytes ? have : (unsigned)frame_bytes;   /* a frame that is not all there reads zeros (outside the contract) */
-	MP2_TRY(hipMemsetAsync(d->d_in, 0, MP2_MAX_FRAME_BYTES + MP2_PAD, d->stream));
-	MP2_TRY(hipMemcpyAsync(d->d_in, d->bytes + byte_pos, n, hipMemcpyHostToDevice, d->stream));
-	const uint32_t tables[8] = { 0u /* begin */, n /* end */, 0u, 1u /* cap_first */, 0u, 1u /* frame_first */, 0u /* frame_pos */, 1u /* count */ };
-	MP2_TRY(hipMemcpyAsync(d->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice, d->stream));
+/* the fixed sequence of one frame on d->stream */
+static int mp2_dec_enqueue(mp2_decoder_t *d) {
+	uint32_t *t = reinterpret_cast<uint32_t *>(d->d_stage);
+	MP2_TRY(hipMemcpyAsync(d->d_stage, d->h_stage, MP2_STAGE_BYTES, hipMemcpyHostToDevice, d->stream));
 	Mp2Bufs k;
-	k.in = d->d_in; k.begin = d->d_tables + 0; k.end = d->d_tables + 1; k.n_streams = 1; k.cap_first = d->d_tables + 2;
-	k.frame_first = d->d_tables + 4; k.frame_pos = d->d_tables + 6; k.frame_hdr = nullptr; k.count = d->d_tables + 7; k.n_frames = 1;
-	k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = d->n_abs; k.window = d->d_window;
+	k.in = d->d_stage + 4 * MP2_STAGE_WORDS; k.begin = t + 0; k.end = t + 1; k.n_streams = 1; k.cap_first = t + 2;
+	k.frame_first = t + 4; k.frame_pos = t + 6; k.frame_hdr = nullptr; k.count = t + 7; k.n_frames = 1;
+	k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = 0; k.n_abs_ptr = t + 8; k.window = d->d_window;
 	k.pcm = d->d_pcm;
 	hipLaunchKernelGGL(k_mp2_matrix, dim3(1), dim3(MP2_MATRIX_WG), 0, d->stream, k);
 	hipLaunchKernelGGL(k_mp2_window, dim3(1), dim3(MP2_WINDOW_WG), 0, d->stream, k);
 	MP2_TRY(hipGetLastError());
 	MP2_TRY(hipMemcpyAsync(d->h_pcm, d->d_pcm, sizeof(float) * 2 * MP2_SAMPLES_PER_FRAME, hipMemcpyDeviceToHost, d->stream));
+	return 0;
+}
+
+static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_bytes) {
+	MP2_TRY(hipSetDevice(d->device));
+	const unsigned have = d->length - byte_pos;
+	const unsigned n = have < (unsigned)frame_bytes ? have : (unsigned)frame_bytes;   /* a frame that is not all there reads zeros (outside the contract) */
+	uint32_t *t = reinterpret_cast<uint32_t *>(d->h_stage);
+	const uint32_t tables[MP2_STAGE_WORDS] = { 0u /* begin */, n /* end */, 0u, 1u /* cap_first */, 0u, 1u /* frame_first */,
+	                                           0u /* frame_pos */, 1u /* count */, d->n_abs };
+	memcpy(t, tables, sizeof(tables));
+	memcpy(d->h_stage + 4 * MP2_STAGE_WORDS, d->bytes + byte_pos, n);
+	memset(d->h_stage + 4 * MP2_STAGE_WORDS + n, 0, MP2_MAX_FRAME_BYTES + MP2_PAD - n);
+	if (d->use_graph && !d->graph_exec) {
+		/* first frame: capture the sequence instead of running it; any failure falls back to plain launches for good */
+		hipGraph_t g = nullptr;
+		bool ok = hipStreamBeginCapture(d->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+		if (ok) {
+			const bool enq = mp2_dec_enqueue(d) == 0;
+			ok = hipStreamEndCapture(d->stream, &g) == hipSuccess && enq && g;
+		}
+		if (ok) ok = hipGraphInstantiate(&d->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+		if (ok) d->graph = g;
+		else {
+			if (g) hipGraphDestroy(g);
+			d->graph_exec = nullptr; d->use_graph = 0;
+			(void)hipGetLastError();
+			jm_clear_error();
+		}
+	}
+	if (d->use_graph) MP2_TRY(hipGraphLaunch(d->graph_exec, d->stream));
+	else if (mp2_dec_enqueue(d) != 0) return -1;
 	MP2_TRY(hipStreamSynchronize(d->stream));
 	d->n_abs += MP2_SUBBLOCKS_PER_FRAME;
 	return 0;
