@@ -453,13 +453,15 @@ struct mp2_decoder_t {
 	/* device state.  One staging block per frame: MP2_STAGE_WORDS little tables (begin, end, cap_first[2],
 	 * frame_first[2], frame_pos, count, n_abs) followed by the frame's bytes -- pinned on the host, mirrored on the device
 	 * by ONE copy, so that a frame is a fixed sequence {copy in, k_mp2_matrix, k_mp2_window, copy out} with fixed
-	 * arguments: captured once as a hipGraph and replayed per decode() (the call is launch-bound: ~0.05 ms of which
-	 * the kernels are a few microseconds). */
+	 * arguments.  The call is launch-bound (~0.04 ms, of which the kernels are a few microseconds), so the sequence
+	 * can be captured once as a hipGraph and replayed per decode() (JSMPEG_HIP_GRAPH=1) -- measured on the MI355X box
+	 * (tools/latency_probe.py): 0.047 ms per decode() replayed against 0.042 ms with the four plain enqueues, so plain
+	 * launches are the default (the one staged copy instead of memset + two copies is what took 0.047 to 0.042). */
 	uint8_t *h_stage, *d_stage;    /* MP2_STAGE_BYTES each */
 	float *d_w, *d_pcm;
 	float *h_pcm;                  /* pinned: left[1152] | right[1152] of the last decoded frame */
 	hipGraph_t graph; hipGraphExec_t graph_exec;
-	int use_graph;                 /* 1: replay; 0: plain launches (JSMPEG_HIP_NO_GRAPH=1, or capture not available) */
+	int use_graph;                 /* 1: replay (JSMPEG_HIP_GRAPH=1 and capture worked); 0: plain launches */
 };
 #define MP2_STAGE_WORDS 16
 #define MP2_STAGE_BYTES (4 * MP2_STAGE_WORDS + MP2_MAX_FRAME_BYTES + MP2_PAD)
@@ -481,7 +483,7 @@ extern "C" mp2_decoder_t *mp2_decoder_create(unsigned int buffer_size, bit_buffe
 	mp2_decoder_t *d = new mp2_decoder_t();
 	d->stream = nullptr; d->bytes = nullptr; d->h_stage = nullptr; d->d_stage = nullptr; d->d_w = nullptr;
 	d->d_pcm = nullptr; d->h_pcm = nullptr; d->graph = nullptr; d->graph_exec = nullptr;
-	{ const char *v = getenv("JSMPEG_HIP_NO_GRAPH"); d->use_graph = !(v && v[0] == '1'); }
+	{ const char *v = getenv("JSMPEG_HIP_GRAPH"); d->use_graph = v && v[0] == '1'; }
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->sample_rate = 44100;        /* mp2.c:234 */
 	d->n_abs = 0;
