@@ -218,6 +218,10 @@ void jsmpeg_hip_mp2_batch_destroy(jsmpeg_hip_mp2_batch_t *b);
 /* Copies n_streams host buffers of back-to-back Layer II frames into HBM.  Returns 0 or < 0. */
 int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *data,
                                 const uint64_t *bytes);
+/* Same, from ONE packed DEVICE buffer (`begin[i]`, `end[i]` byte ranges inside it) -- what a rank holds after the
+ * RCCL scatter of its shard.  Copied device-to-device on `hip_stream` (void* hipStream_t, NULL = the batch's own). */
+int jsmpeg_hip_mp2_batch_upload_device(jsmpeg_hip_mp2_batch_t *b, const void *dev_bytes, uint64_t total_bytes,
+                                       uint32_t n_streams, const uint32_t *begin, const uint32_t *end, void *hip_stream);
 /* Ingest side on the device (reference src/ts.js:25-210), the audio twin of
  * jsmpeg_hip_batch_upload_ts: n_streams MPEG-TS buffers (host) -> the payload of `stream_id` (0xC0 = the first
  * audio stream, ts.js:212-222), demultiplexed by the same GPU kernels straight into the batch's HBM buffer; per

@@ -222,6 +222,29 @@ extern "C" int jsmpeg_hip_mp2_batch_upload(jsmpeg_hip_mp2_batch_t *b, uint32_t n
 	return 0;
 }
 
+/* Same, from ONE packed DEVICE buffer (`begin[i]`, `end[i]` byte ranges inside it): what a rank holds after the RCCL
+ * scatter of its shard (bench.py does this for the video streams).  Device-to-device copies on `hip_stream`
+ * (NULL = the batch's own); the call returns when they are enqueued and the small tables are in place. */
+extern "C" int jsmpeg_hip_mp2_batch_upload_device(jsmpeg_hip_mp2_batch_t *b, const void *dev_bytes, uint64_t total_bytes,
+                                                  uint32_t n_streams, const uint32_t *begin, const uint32_t *end, void *hip_stream) {
+	jm_clear_error();
+	if (!b || !dev_bytes || !begin || !end) return mp2_fail("null MP2 batch argument");
+	if (n_streams == 0 || n_streams > b->max_streams) return mp2_fail("MP2 batch: %s%ld streams do not fit", "", n_streams);
+	MP2_TRY(hipSetDevice(b->device));
+	std::vector<uint64_t> len(n_streams);
+	for (uint32_t s = 0; s < n_streams; s++) {
+		if (end[s] < begin[s] || end[s] > total_bytes) return mp2_fail("MP2 batch: stream %s%ld range outside the buffer", "", s);
+		len[s] = end[s] - begin[s];
+	}
+	b->ts_n_writes.clear();
+	if (mp2_batch_layout(b, n_streams, len.data()) != 0) return -1;
+	hipStream_t st = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+	for (uint32_t s = 0; s < n_streams; s++)
+		if (len[s]) MP2_TRY(hipMemcpyAsync(b->d_in + b->begin[s], (const uint8_t *)dev_bytes + begin[s], len[s], hipMemcpyDeviceToDevice, st));
+	if (st != b->own_stream) MP2_TRY(hipStreamSynchronize(st));   /* decode may be enqueued on another stream */
+	return 0;
+}
+
 /* Ingest side on the device (reference src/ts.js:25-210), the audio twin of jsmpeg_hip_batch_upload_ts: the same
  * k_ts_parse / k_ts_walk / k_ts_gather kernels, stream id 0xC0 by default, payloads gathered straight into the
  * MP2 batch buffer. */

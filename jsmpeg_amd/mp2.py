@@ -16,7 +16,7 @@ MP2_BATCH_SYMBOLS = ("jsmpeg_hip_mp2_batch_create", "jsmpeg_hip_mp2_batch_destro
                      "jsmpeg_hip_mp2_batch_decode", "jsmpeg_hip_mp2_batch_sync", "jsmpeg_hip_mp2_batch_frame_count",
                      "jsmpeg_hip_mp2_batch_frame_info", "jsmpeg_hip_mp2_batch_pcm", "jsmpeg_hip_mp2_batch_read_pcm",
                      "jsmpeg_hip_mp2_batch_timings", "jsmpeg_hip_mp2_batch_upload_ts", "jsmpeg_hip_mp2_batch_ts_writes",
-                     "jsmpeg_hip_mp2_batch_read_bytes")
+                     "jsmpeg_hip_mp2_batch_read_bytes", "jsmpeg_hip_mp2_batch_upload_device")
 
 _lib = None
 
@@ -57,6 +57,8 @@ def lib():
         L.jsmpeg_hip_mp2_batch_ts_writes.argtypes = [vp, u32, vp, vp, vp, u32]
         L.jsmpeg_hip_mp2_batch_read_bytes.restype = ctypes.c_int64
         L.jsmpeg_hip_mp2_batch_read_bytes.argtypes = [vp, u32, vp, u64]
+        L.jsmpeg_hip_mp2_batch_upload_device.restype = ctypes.c_int
+        L.jsmpeg_hip_mp2_batch_upload_device.argtypes = [vp, vp, u64, u32, vp, vp, vp]
         L.jsmpeg_hip_last_error.restype = ctypes.c_char_p
         _lib = L
     return _lib
@@ -95,6 +97,15 @@ class Mp2Batch:
         if self.L.jsmpeg_hip_mp2_batch_upload(self.h, n, ptrs, lens) < 0:
             raise RuntimeError("jsmpeg_hip_mp2_batch_upload failed: " + _err())
         self.n_streams = n
+
+    def upload_device(self, dev_ptr, total_bytes, begin, end, hip_stream=None):
+        """Streams already in device memory: one packed buffer, byte ranges [begin[i], end[i])."""
+        begin = np.ascontiguousarray(begin, dtype=np.uint32)
+        end = np.ascontiguousarray(end, dtype=np.uint32)
+        if self.L.jsmpeg_hip_mp2_batch_upload_device(self.h, dev_ptr, total_bytes, len(begin), begin.ctypes.data, end.ctypes.data,
+                                                     hip_stream) < 0:
+            raise RuntimeError("jsmpeg_hip_mp2_batch_upload_device failed: " + _err())
+        self.n_streams = len(begin)
 
     def upload_ts(self, ts_buffers, stream_id=0xC0):
         """MPEG-TS buffers in; the audio stream's payload is demultiplexed on the device (reference ts.js semantics)."""

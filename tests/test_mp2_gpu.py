@@ -219,3 +219,29 @@ def test_damaged_streams_still_equal_the_oracle(hip_lib, libs):
     for i in range(0, 240, 12):
         pcm, idx, _, _ = cabi.decode_mp2_stream(hip_lib, streams[i])
         assert idx == full[i][1] and same_bits(pcm, full[i][0]), i
+
+
+def test_batch_upload_from_device_memory(hip_lib, libs):
+    """Streams that are already in HBM (one packed buffer + byte ranges, the layout a rank holds after the RCCL
+    scatter of its shard): same PCM as the host upload."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = [synth.generate_mp2_config(name, 7 + 3 * i, stream=80 + i)[0] for i, name in enumerate(synth.MP2_CONFIGS)]
+    packed, begin, end = [], [], []
+    at = 0
+    for s in streams:
+        gap = np.full(5 + len(begin) % 3, 0xFF, np.uint8)      # ranges need not be aligned or adjacent
+        packed.append(gap); at += len(gap)
+        begin.append(at); packed.append(s); at += len(s); end.append(at)
+    packed = np.concatenate(packed)
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(len(packed))) == 0
+    try:
+        assert hip.hipMemcpy(dptr, ctypes.c_void_p(packed.ctypes.data), ctypes.c_size_t(len(packed)), 1) == 0
+        with mp2.Mp2Batch(len(streams), len(packed) + 64) as b:
+            b.upload_device(dptr, len(packed), begin, end)
+            assert b.decode() == sum(7 + 3 * i for i in range(len(streams)))
+            for i, s in enumerate(streams):
+                assert same_bits(b.read_pcm(i), cabi.decode_mp2_stream(libs["oracle"], s)[0]), i
+    finally:
+        hip.hipFree(dptr)
