@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.argv = sys.argv[:1] + sys.argv[1:]
 import bench  # noqa: E402  (generate_streams only)
+bench.CONFIG = os.environ.get("JSMPEG_KBENCH_CONFIG", bench.CONFIG)   # e.g. cfg1_720p, cfg4_2160p: the other configurations as timings
 from jsmpeg_amd import batch as jb, synth  # noqa: E402
 
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -26,4 +27,7 @@ with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, to
         if r:
             acc = t if acc is None else {k: acc[k] + t[k] for k in t}
     lv = b.counters()["levels"]
-    print({k: round(v / (reps - 1), 3) for k, v in acc.items()}, "recon per level %.3f" % (acc["recon_ms"] / (reps - 1) / lv))
+    ms = acc["total_ms"] / (reps - 1)
+    print({k: round(v / (reps - 1), 3) for k, v in acc.items()}, "recon per level %.3f" % (acc["recon_ms"] / (reps - 1) / lv),
+          "| %s %d x %d: %.0f frames/s, %.0f Mpixel/s" % (bench.CONFIG, n_streams, frames, n_streams * frames / ms * 1e3,
+                                                         n_streams * frames / ms * 1e3 * cfg["width"] * cfg["height"] / 1e6))
