@@ -125,3 +125,36 @@ def test_node_batch_audio_and_video_from_the_same_ts(hip_lib, libs):
         for k in range(fx["n_frames"]):            # two frames per PES, pts of the PES = 1 + 1152 k / rate
             base = 1.0 + int(90000 * 1152 * (k - k % 2) / fx["sample_rate"]) / 90000.0
             assert abs(pts[k] - (base + (k % 2) * 1152 / fx["sample_rate"])) < 1e-9, (s, k)
+
+
+def test_batch_audio_time_stamps_follow_decoder_base():
+    """HIPBatch.forEachAudioFrame over a stand-in binding (no GPU): a frame that starts a PES gets that PES's pts, the
+    frames after it 1152 / rate each (what Decoder.Base.advanceDecodedTime does, src/decoder.js:73-93); a PES that
+    starts in the middle of a frame does not restamp that frame."""
+    script = r"""
+const { install } = require(%r);
+const frames = [ {byteOffset: 0}, {byteOffset: 600}, {byteOffset: 1200}, {byteOffset: 1800}, {byteOffset: 2400} ];
+const writes = [ {pts: 1.0, offset: 0, length: 1200}, {pts: 2.0, offset: 1200, length: 900}, {pts: 3.0, offset: 2100, length: 900} ];
+const binding = {
+  batchCreate: () => ({}), batchGeometry: () => ({ codedWidth: 16, codedHeight: 16, lumaBytes: 256, chromaBytes: 64 }), batchDestroy() {},
+  mp2BatchCreate: () => ({}), mp2BatchDestroy() {}, mp2BatchUploadTS() {}, mp2BatchTsWrites: () => writes, mp2BatchDecode: () => frames.length,
+  mp2BatchFrameCount: () => frames.length, mp2BatchFrameInfo: (h, s, f) => ({ byteOffset: frames[f].byteOffset, byteSize: 600, sampleRate: 48000 }),
+  mp2BatchReadPCM: (h, s, first, count, pcm) => { for (let i = 0; i < count * 2304; i++) pcm[i] = first + i / 2304; return count; },
+};
+const { HIPBatch } = install(null, { binding });
+const b = new HIPBatch({ width: 16, height: 16, audio: true });
+b.uploadAudioTS([new Uint8Array(188)]);
+b.decodeAudio();
+const out = [];
+b.forEachAudioFrame((a) => out.push([a.stream, a.index, +a.pts.toFixed(6), a.sampleRate, a.left.length, a.right.length, Math.floor(a.left[0]), Math.floor(a.right[0])]));
+console.log(JSON.stringify(out));
+""" % os.path.join(ROOT, "jsmpeg_amd", "js", "batch-hip.js")
+    out = json.loads(subprocess.check_output([NODE, "-e", script]))
+    d = 1152 / 48000
+    # frames 0 and 2 start a PES; the third PES begins inside frame 3 (1800 < 2100 < 2400), so frame 3 runs on from
+    # frame 2 and frame 4 -- the first to start inside that PES -- takes its pts
+    want_pts = [1.0, 1.0 + d, 2.0, 2.0 + d, 3.0]
+    assert [o[:2] for o in out] == [[0, i] for i in range(5)]
+    assert all(o[3] == 48000 and o[4] == 1152 and o[5] == 1152 for o in out)
+    assert [o[2] for o in out] == [round(x, 6) for x in want_pts]
+    assert [o[6] for o in out] == [0, 1, 2, 3, 4]
