@@ -37,8 +37,11 @@
 
 /* Side information of one frame, built in LDS by the first 64 lanes of the frame's workgroup (lane q = subband * 2 +
  * channel) -- see mp2_side_* below.  `steps == 0`: no bits for that subband. */
-#define MP2_FRAME_STAGE 1792       /* bytes of a frame staged in LDS: the longest frame (384 kbit/s at 32 kHz, padded) is
-                                      1729 bytes, + up to 15 for the 16-byte aligned start of the window */
+#define MP2_FRAME_STAGE 4608       /* bytes staged in LDS from the frame's start on.  Not the frame length (at most 1729) but as
+                                      far as its fields can REACH: a frame's allocation may promise more sample bits than
+                                      its length holds (48 header + 188 allocation + 120 scfsi + 1080 scalefactor + 12 x
+                                      2880 sample bits = 4497 bytes, + 15 for the aligned start), and the reference then
+                                      reads on into the bytes that follow (tests: "promises more bits than it has") */
 struct Mp2Frame {
 	uint32_t bytes[MP2_FRAME_STAGE / 4];   /* the frame's bytes from `base` (16-byte aligned, <= its first byte) on   */
 	uint32_t base;              /* all positions below are relative to it                                            */
@@ -52,6 +55,11 @@ struct Mp2Frame {
 	uint16_t gbits[64];         /* [q] bits the pair occupies in a granule (0 where channel 1 shares channel 0's)   */
 	uint8_t coded[64];          /* [q] transmits its own scfsi / scalefactors                                       */
 	uint8_t sel[64], nsf[64];   /* [q] scfsi as read; scalefactors transmitted (3 2 1 2)                            */
+	/* The prefix sums over the pairs, as bit planes: plane b has bit q set when bit b of the pair's value is set, so
+	 * "sum over the pairs before q" = sum_b 2^b * popcount(plane_b & below(q)).  Lanes OR their bits in (LDS atomics). */
+	uint64_t coded_mask;        /* value: coded (1 bit)                                                             */
+	uint64_t nsf_plane[2];      /* value: scalefactors transmitted, 0..3                                            */
+	uint64_t gbits_plane[6];    /* value: bits in a granule, 0..48                                                  */
 	uint8_t sf[64][4];          /* [q] scalefactor index per part (three used)                                      */
 };
 
@@ -111,10 +119,49 @@ MP2_HD void mp2_parse_header(const uint8_t *p, uint32_t end, uint32_t pos, Mp2Hd
  *   phase 3  lane q         scalefactors: 6 bits x (scalefactors transmitted before q)     (mp2.c:378-412)
  *   phase 4  lane q         start of the pair's triple inside a granule, shared-channel copies, sample start
  * A lane's prefix is a loop over the entries before it in LDS (every lane reads the same address: a broadcast). */
-MP2_HD int mp2_alloc_bits_before(int high, int bound, int sb) {       /* allocation bits of subbands 0 .. sb - 1 */
-	int n = 0;
-	for (int s = 0; s < sb; s++) n += mp2_nbal(high, s) * (s < bound ? 2 : 1);
-	return n;
+/* MSB-first bit field (n <= 24) of the staged frame: two aligned dwords and a funnel shift.  Bytes at or past the end of
+ * the stream were staged as 0; nothing a frame's fields can reach lies past the staged window (MP2_FRAME_STAGE). */
+MP2_HD uint32_t mp2_bswap32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_bswap32(v);
+#else
+	return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+#endif
+}
+MP2_HD uint32_t mp2_frame_bits(const Mp2Frame &F, uint64_t bitpos, int n) {
+	const uint32_t idx = (uint32_t)(bitpos >> 5);
+	if (n == 0 || idx + 1 >= MP2_FRAME_STAGE / 4) return 0;
+	const uint64_t w = ((uint64_t)mp2_bswap32(F.bytes[idx]) << 32) | mp2_bswap32(F.bytes[idx + 1]);
+	return (uint32_t)((w << (bitpos & 31)) >> (64 - n));
+}
+
+/* allocation bits of subbands 0 .. x - 1 of one channel (Tables 3-B.2a-d column nbal, summed) */
+MP2_HD int mp2_nbal_before(int high, int x) {
+	if (high) return x <= 11 ? 4 * x : (x <= 23 ? 44 + 3 * (x - 11) : 80 + 2 * (x - 23));
+	return x <= 2 ? 4 * x : 8 + 3 * (x - 2);
+}
+/* ... of both channels: two codes per subband below the bound, one from there on */
+MP2_HD int mp2_alloc_bits_before(int high, int bound, int sb) {
+	return mp2_nbal_before(high, sb) + mp2_nbal_before(high, sb < bound ? sb : bound);
+}
+
+/* bit q of a 64-bit plane in LDS: an atomic OR on the device (the 64 lanes of the phase run together), a plain one in
+ * the simulator (they run one after the other) */
+MP2_HD void mp2_plane_set(uint64_t &plane, int q, int bit) {
+	if (!bit) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+	atomicOr(reinterpret_cast<unsigned int *>(&plane) + (q >> 5), 1u << (q & 31));
+#else
+	plane |= 1ull << q;
+#endif
+}
+MP2_HD int mp2_plane_before(uint64_t plane, int q) {       /* how many of the pairs before q have the bit */
+	const uint64_t below = plane & ((1ull << q) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __popcll(below);
+#else
+	return __builtin_popcountll(below);
+#endif
 }
 
 MP2_HD void mp2_side_phase0(Mp2Frame &F) {
@@ -131,92 +178,98 @@ MP2_HD void mp2_side_phase0(Mp2Frame &F) {
 	F.sblimit = sblimit; F.bound = bound; F.high = high; F.channels = mono ? 1 : 2;
 	F.alloc_bit = (pos << 3) + (uint32_t)H.header_bits;
 	F.scfsi_bit = F.alloc_bit + (uint32_t)mp2_alloc_bits_before(high, bound, sblimit);
+	F.coded_mask = 0; F.nsf_plane[0] = F.nsf_plane[1] = 0;
+	for (int k = 0; k < 6; k++) F.gbits_plane[k] = 0;
 }
 
 MP2_HD void mp2_side_phase1(Mp2Frame &F, int q) {
-	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	const int sb = q >> 1, ch = q & 1;
 	int steps = 0;
 	if (sb < F.sblimit) {
 		const int nbal = mp2_nbal(F.high, sb);
 		/* below the bound both channels have a code; from the bound on channel 1 uses channel 0's (same position) */
 		const uint32_t bit = F.alloc_bit + (uint32_t)mp2_alloc_bits_before(F.high, F.bound, sb) + (uint32_t)((ch && sb < F.bound) ? nbal : 0);
-		steps = mp2_steps(F.high, sb, (int)mp2_bits_at(p, F.end, bit, nbal));
+		steps = mp2_steps(F.high, sb, (int)mp2_frame_bits(F, bit, nbal));
 	}
-	F.steps[q] = (uint16_t)steps;
-	F.coded[q] = (uint8_t)(steps != 0 && ch < F.channels);
+	const int coded = steps != 0 && ch < F.channels;
 	/* samples of the pair inside a granule: channel 1 from the bound on has none of its own (mp2.c:424-430) */
-	F.gbits[q] = (uint16_t)((ch == 0 || sb < F.bound) ? mp2_granule_bits(steps) : 0);
+	const int gbits = (ch == 0 || sb < F.bound) ? mp2_granule_bits(steps) : 0;
+	F.steps[q] = (uint16_t)steps;
+	F.coded[q] = (uint8_t)coded;
+	F.gbits[q] = (uint16_t)gbits;
+	mp2_plane_set(F.coded_mask, q, coded);
+#pragma unroll
+	for (int k = 0; k < 6; k++) mp2_plane_set(F.gbits_plane[k], q, (gbits >> k) & 1);
 }
 
 MP2_HD void mp2_side_phase2(Mp2Frame &F, int q) {
-	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
-	int before = 0;
-	for (int k = 0; k < q; k++) before += F.coded[k];
+	const uint64_t coded_mask = F.coded_mask;
 	int sel = 0, nsf = 0;
 	if (F.coded[q]) {
-		sel = (int)mp2_bits_at(p, F.end, F.scfsi_bit + 2u * (uint32_t)before, 2);
+		sel = (int)mp2_frame_bits(F, F.scfsi_bit + 2u * (uint32_t)mp2_plane_before(coded_mask, q), 2);
 		nsf = sel == 0 ? 3 : (sel == 2 ? 1 : 2);
 	}
 	F.sel[q] = (uint8_t)sel; F.nsf[q] = (uint8_t)nsf;
-	if (q == 63) F.sf_bit = F.scfsi_bit + 2u * (uint32_t)(before + F.coded[63]);
+	mp2_plane_set(F.nsf_plane[0], q, nsf & 1);
+	mp2_plane_set(F.nsf_plane[1], q, nsf >> 1);
+	if (q == 63) F.sf_bit = F.scfsi_bit + 2u * (uint32_t)(mp2_plane_before(coded_mask, 63) + (int)((coded_mask >> 63) & 1));
 }
 
 MP2_HD void mp2_side_phase3(Mp2Frame &F, int q) {
-	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
-	int before = 0;
-	for (int k = 0; k < q; k++) before += F.nsf[k];
+	const uint64_t n0 = F.nsf_plane[0], n1 = F.nsf_plane[1];
+	const int before = mp2_plane_before(n0, q) + 2 * mp2_plane_before(n1, q);
 	int a = 0, b1 = 0, c = 0;
 	if (F.coded[q]) {
 		uint32_t bit = F.sf_bit + 6u * (uint32_t)before;
 		const int sel = F.sel[q];
-		a = (int)mp2_bits_at(p, F.end, bit, 6); bit += 6;
+		const uint32_t three = mp2_frame_bits(F, bit, 18);                               /* up to three 6-bit indices in one look */
+		a = (int)(three >> 12);
+		const int second = (int)((three >> 6) & 63), third = (int)(three & 63);
 		b1 = c = a;                                                                       /* case 2: a a a */
-		if (sel == 0) { b1 = (int)mp2_bits_at(p, F.end, bit, 6); c = (int)mp2_bits_at(p, F.end, bit + 6, 6); }   /* a b c */
-		else if (sel == 1) c = (int)mp2_bits_at(p, F.end, bit, 6);                       /* a a c */
-		else if (sel == 3) b1 = c = (int)mp2_bits_at(p, F.end, bit, 6);                  /* a b b */
+		if (sel == 0) { b1 = second; c = third; }                                         /* a b c */
+		else if (sel == 1) c = second;                                                    /* a a c */
+		else if (sel == 3) b1 = c = second;                                               /* a b b */
 	}
 	F.sf[q][0] = (uint8_t)a; F.sf[q][1] = (uint8_t)b1; F.sf[q][2] = (uint8_t)c; F.sf[q][3] = 0;
-	if (q == 63) F.sample_bit = F.sf_bit + 6u * (uint32_t)(before + F.nsf[63]);
+	if (q == 63) F.sample_bit = F.sf_bit + 6u * (uint32_t)(before + (int)F.nsf[63]);
 }
 
+MP2_HD int mp2_gbits_before(const Mp2Frame &F, int q) {
+	int g = 0;
+#pragma unroll
+	for (int k = 0; k < 6; k++) g += mp2_plane_before(F.gbits_plane[k], q) << k;
+	return g;
+}
 MP2_HD void mp2_side_phase4(Mp2Frame &F, int q) {
 	const int sb = q >> 1, ch = q & 1;
 	const bool shared = ch == 1 && sb >= F.bound;      /* channel 1 gets channel 0's REQUANTISED samples (mp2.c:426-430,
 	                                                       or the mono copy): it reads with channel 0's parameters */
-	const int upto = shared ? q - 1 : q;
-	int g = 0;
-	for (int k = 0; k < upto; k++) g += F.gbits[k];
-	F.bit_in_granule[q] = (uint16_t)g;
+	F.bit_in_granule[q] = (uint16_t)mp2_gbits_before(F, shared ? q - 1 : q);
 	if (shared) {
 		F.steps[q] = F.steps[q - 1];
 		F.sf[q][0] = F.sf[q - 1][0]; F.sf[q][1] = F.sf[q - 1][1]; F.sf[q][2] = F.sf[q - 1][2];
 	}
-	if (q == 63) {
-		int total = 0;
-		for (int k = 0; k < 64; k++) total += F.gbits[k];
-		F.granule_bits = total;
-	}
+	if (q == 63) F.granule_bits = mp2_gbits_before(F, 63) + (int)F.gbits[63];
 }
 
 /* The three requantised samples of (granule 0..11, pair q) (mp2.c:491-549). */
 MP2_HD void mp2_read_triple(const Mp2Frame &F, int granule, int q, int out[3]) {
-	const uint8_t *p = reinterpret_cast<const uint8_t *>(F.bytes);
 	const int steps = F.steps[q];
 	if (steps == 0) { out[0] = out[1] = out[2] = 0; return; }                      /* also every sb >= sblimit (mp2.c:431-438) */
 	const int sf = mp2_scalefactor(F.sf[q][granule >> 2]);
 	const uint64_t bit = (uint64_t)F.sample_bit + (uint64_t)granule * (uint64_t)F.granule_bits + F.bit_in_granule[q];
 	const int nb = mp2_code_bits(steps);
 	int c0, c1, c2;
-	if (mp2_grouped(steps)) {                                                      /* mp2.c:521-528 */
-		int v = (int)mp2_bits_at(p, F.end, bit, nb);
-		c0 = v % steps; v /= steps;
-		c1 = v % steps;
-		c2 = v / steps;
+	if (mp2_grouped(steps)) {                                                      /* mp2.c:521-528: v % steps, (v / steps) % steps, v / steps^2 */
+		const int v = (int)mp2_frame_bits(F, bit, nb);
+		/* the divisor is one of three constants: multiplications instead of a division by a variable */
+		if (steps == 3) { const int t = v / 3; c0 = v - 3 * t; c2 = t / 3; c1 = t - 3 * c2; }
+		else if (steps == 5) { const int t = v / 5; c0 = v - 5 * t; c2 = t / 5; c1 = t - 5 * c2; }
+		else { const int t = v / 9; c0 = v - 9 * t; c2 = t / 9; c1 = t - 9 * c2; }
 	} else {                                                                       /* mp2.c:529-534 */
-		c0 = (int)mp2_bits_at(p, F.end, bit, nb);
-		c1 = (int)mp2_bits_at(p, F.end, bit + (uint64_t)nb, nb);
-		c2 = (int)mp2_bits_at(p, F.end, bit + 2 * (uint64_t)nb, nb);
+		c0 = (int)mp2_frame_bits(F, bit, nb);
+		c1 = (int)mp2_frame_bits(F, bit + (uint64_t)nb, nb);
+		c2 = (int)mp2_frame_bits(F, bit + 2 * (uint64_t)nb, nb);
 	}
 	out[0] = mp2_requantise(c0, steps, sf);
 	out[1] = mp2_requantise(c1, steps, sf);
@@ -442,6 +495,13 @@ MP2_HD void mp2_wg_stage_frame(const Mp2Bufs &b, uint32_t f, int tid, Mp2Frame &
 		if (a < end) {                                /* the batch buffer is readable (and zero) MP2_PAD bytes past its last stream */
 			const uint32_t *src = reinterpret_cast<const uint32_t *>(b.in + a);
 			v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+			if (a + 16 > end) {                       /* the piece that straddles the end of the stream: bytes past it read as 0 */
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const int keep = (int)(end - a) - 4 * k;      /* bytes of dword k that belong to the stream */
+					v[k] = keep >= 4 ? v[k] : (keep <= 0 ? 0u : (v[k] & (0xffffffffu >> (8 * (4 - keep)))));   /* little endian: low bytes first */
+				}
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) F.bytes[4 * piece + k] = v[k];
@@ -449,6 +509,11 @@ MP2_HD void mp2_wg_stage_frame(const Mp2Bufs &b, uint32_t f, int tid, Mp2Frame &
 	if (tid == 0) { F.base = base; F.pos = pos - base; F.end = end - base; }
 }
 MP2_HD void mp2_wg_side(int tid, int phase, Mp2Frame &F) {
+#ifdef MP2_EXP_NO_SIDE     /* experiment: what the side-information phases cost (wrong samples) */
+	if (phase == 0 && tid < 64) { F.steps[tid] = 15; F.bit_in_granule[tid] = (uint16_t)(12 * tid); F.sf[tid][0] = F.sf[tid][1] = F.sf[tid][2] = 20; }
+	if (phase == 0 && tid == 0) { F.sample_bit = (F.pos << 3) + 32; F.granule_bits = 768; F.valid = 1; }
+	return;
+#endif
 	if (phase == 0) {
 		if (tid == 0) mp2_side_phase0(F);
 		return;
@@ -463,7 +528,11 @@ MP2_HD void mp2_wg_matrix_read(int tid, const Mp2Frame &F, int (&samples)[72][33
 	for (int item = tid; item < 768; item += MP2_MATRIX_WG) {
 		const int gr = item >> 6, q = item & 63, ch = q & 1, sb = q >> 1;
 		int t[3];
+#ifdef MP2_EXP_NO_TRIPLES   /* experiment: what reading + requantising the samples costs (wrong samples) */
+		t[0] = t[1] = t[2] = F.steps[q] + gr;
+#else
 		mp2_read_triple(F, gr, q, t);
+#endif
 		samples[(gr * 3 + 0) * 2 + ch][sb] = t[0];
 		samples[(gr * 3 + 1) * 2 + ch][sb] = t[1];
 		samples[(gr * 3 + 2) * 2 + ch][sb] = t[2];
@@ -471,6 +540,10 @@ MP2_HD void mp2_wg_matrix_read(int tid, const Mp2Frame &F, int (&samples)[72][33
 }
 MP2_HD void mp2_wg_matrix_run(int tid, const int (&samples)[72][33], float (&xs)[72][33]) {
 	if (tid >= 72) return;
+#ifdef MP2_EXP_NO_MATRIX   /* experiment: what the matrixings cost (wrong samples) */
+	for (int k = 0; k < 32; k++) xs[tid][k] = (float)samples[tid][k];
+	return;
+#endif
 	float x[32];
 	mp2_matrix(&samples[tid][0], 1, x);
 #pragma unroll

@@ -460,7 +460,7 @@ extern "C" int jsmpeg_hip_mp2_batch_timings(jsmpeg_hip_mp2_batch_t *b, float out
 
 /* ================================================ the reference's one-frame-per-call ABI (src/wasm/mp2.h:10-20) */
 
-#define MP2_MAX_FRAME_BYTES 1792   /* 384 kbit/s at 32 kHz + padding = 1729 */
+#define MP2_MAX_FRAME_BYTES MP2_FRAME_STAGE   /* not the longest frame (1729 bytes) but as far as a frame's fields can reach (mp2_dev.h) */
 #define MP2_RING_VECTORS 64        /* >= 36 written + 15 looked back on */
 
 struct mp2_decoder_t {
@@ -588,8 +588,11 @@ static int mp2_dec_enqueue(mp2_decoder_t *d) {
 
 static int mp2_dec_frame_gpu(mp2_decoder_t *d, unsigned byte_pos, int frame_bytes) {
 	MP2_TRY(hipSetDevice(d->device));
-	const unsigned have = d->length - byte_pos;
-	const unsigned n = have < (unsigned)frame_bytes ? have : (unsigned)frame_bytes;   /* a frame that is not all there reads zeros (outside the contract) */
+	const unsigned have = d->length - byte_pos, reach = MP2_FRAME_STAGE - 16;
+	/* everything the frame's fields can reach: a frame whose allocation promises more bits than its length holds reads on
+	 * into the bytes buffered behind it, like the reference; bytes that are not buffered read as 0 (outside the contract) */
+	const unsigned n = have < reach ? have : reach;
+	(void)frame_bytes;
 	uint32_t *t = reinterpret_cast<uint32_t *>(d->h_stage);
 	const uint32_t tables[MP2_STAGE_WORDS] = { 0u /* begin */, n /* end */, 0u, 1u /* cap_first */, 0u, 1u /* frame_first */,
 	                                           0u /* frame_pos */, 1u /* count */, d->n_abs };

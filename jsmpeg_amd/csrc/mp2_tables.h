@@ -112,8 +112,12 @@ MP2_HD int mp2_code_bits(int steps) {
 	if (steps == 3) return 5;
 	if (steps == 5) return 7;
 	if (steps == 9) return 10;
-	int n = 0;
-	while ((1 << n) - 1 < steps) n++;
+	int n = 0, v = steps;                        /* steps = 2^n - 1: n = its bit length */
+#if defined(__HIP_DEVICE_COMPILE__)
+	n = v ? 32 - __builtin_clz((unsigned)v) : 0;
+#else
+	while (v) { n++; v >>= 1; }
+#endif
 	return n;
 }
 /* bits one subband of one channel takes per granule (three samples) */
@@ -132,8 +136,15 @@ MP2_HD int mp2_scalefactor(int index) {
 }
 
 /* Requantisation of one sample code (mp2.c:537-548): fixed point, all 32-bit integer. */
+/* 65536 / (steps + 1) without a division: steps + 1 is 4, 6, 10 for the groups and a power of two otherwise */
+MP2_HD int mp2_requantise_scale(int steps) {
+	if (steps == 3) return 16384;
+	if (steps == 5) return 10922;
+	if (steps == 9) return 6553;
+	return 65536 >> mp2_code_bits(steps);
+}
 MP2_HD int mp2_requantise(int code, int steps, int sf) {
-	const int scale = 65536 / (steps + 1);
+	const int scale = mp2_requantise_scale(steps);
 	const int mid = ((steps + 1) >> 1) - 1;
 	const int val = (mid - code) * scale;
 	return (val * (sf >> 12) + ((val * (sf & 4095) + 2048) >> 12)) >> 12;

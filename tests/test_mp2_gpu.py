@@ -245,3 +245,19 @@ def test_batch_upload_from_device_memory(hip_lib, libs):
                 assert same_bits(b.read_pcm(i), cabi.decode_mp2_stream(libs["oracle"], s)[0]), i
     finally:
         hip.hipFree(dptr)
+
+
+def test_frame_that_promises_more_bits_than_it_has(hip_lib, libs):
+    """An allocation that claims more sample bits than the frame's length holds: the reference reads on into the bytes
+    behind the frame, so do the batch and the one-frame ABI (the kernels stage what a frame's fields can reach, not
+    its length)."""
+    from test_mp2_sim_device_functions import _overcommitted_stream
+    streams = [_overcommitted_stream(seed) for seed in range(6)]
+    want = [cabi.decode_mp2_stream(libs["oracle"], s, max_frames=1)[0] for s in streams]
+    with mp2.Mp2Batch(len(streams), sum(len(s) for s in streams) + 64) as b:
+        b.upload(streams)
+        b.decode()
+        for i in range(len(streams)):
+            assert b.frame_count(i) >= 1 and same_bits(b.read_pcm(i, 0, 1), want[i]), i
+    for i, s in enumerate(streams):
+        assert same_bits(cabi.decode_mp2_stream(hip_lib, s, max_frames=1)[0], want[i]), i

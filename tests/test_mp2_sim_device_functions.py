@@ -44,7 +44,7 @@ def test_ring_mode_frame_by_frame(name, libs):
     n_abs = ctypes.c_uint32(0)
     out = np.zeros((fx["n_frames"], 2, 1152), np.float32)
     for k in range(fx["n_frames"]):
-        frame = np.ascontiguousarray(data[int(offs[k]):int(offs[k + 1])])
+        frame = np.ascontiguousarray(data[int(offs[k]):int(offs[k]) + 4592])      # what the frame's fields can reach, like the ABI stages it
         lib.sim_mp2_ring_frame(ctypes.c_void_p(frame.ctypes.data), len(frame), ctypes.c_void_p(ring.ctypes.data),
                                ctypes.byref(n_abs), ctypes.c_void_p(out[k].ctypes.data))
     assert n_abs.value == 36 * fx["n_frames"]
@@ -107,3 +107,23 @@ def test_damaged_streams_still_equal_the_oracle(libs):
     assert sum(len(w) for w in want) > 200
     for i in range(len(streams)):
         assert same_bits(got[i], want[i]), i
+
+
+def _overcommitted_stream(seed):
+    """A frame whose allocation promises far more sample bits than its length holds (every subband 16-bit samples at
+    112 kbit/s): the reference reads on into the bytes that follow; 6 KB of random bytes follow."""
+    rng = np.random.RandomState(seed)
+    bits = [1] * 11 + [1, 1] + [1, 0] + [1]            # sync, MPEG-1, Layer II, no CRC
+    bits += [0, 1, 1, 1] + [0, 0] + [0] + [0] + [0, 0] + [0, 0] + [0, 0, 0, 0]   # 112 kbit/s, 44.1 kHz, stereo
+    bits += [1] * (2 * (11 * 4 + 12 * 3 + 7 * 2))      # allocation: every code all ones -> 65535 steps everywhere
+    body = np.packbits(np.array(bits, np.uint8))
+    return np.concatenate([body, rng.randint(0, 256, 6000).astype(np.uint8)])
+
+
+def test_frame_that_promises_more_bits_than_it_has(libs):
+    for seed in range(6):
+        data = _overcommitted_stream(seed)
+        want, _, sizes, _ = cabi.decode_mp2_stream(libs["oracle"], data, max_frames=1)
+        assert len(want) == 1 and sizes[0] == 365
+        (got,) = sim_batch([data])
+        assert len(got) >= 1 and same_bits(got[:1], want), seed
