@@ -538,23 +538,25 @@ MP2_HD void mp2_wg_matrix_read(int tid, const Mp2Frame &F, int (&samples)[72][33
 		samples[(gr * 3 + 2) * 2 + ch][sb] = t[2];
 	}
 }
-MP2_HD void mp2_wg_matrix_run(int tid, const int (&samples)[72][33], float (&xs)[72][33]) {
+/* in place: lane t reads row t completely (mp2_matrix loads its 32 inputs first), then writes the 32 outputs over
+ * it as binary32 bit patterns -- one LDS array for both (15 KB per workgroup instead of 24) */
+MP2_HD void mp2_wg_matrix_run(int tid, int (&samples)[72][33]) {
 	if (tid >= 72) return;
-#ifdef MP2_EXP_NO_MATRIX   /* experiment: what the matrixings cost (wrong samples) */
-	for (int k = 0; k < 32; k++) xs[tid][k] = (float)samples[tid][k];
-	return;
-#endif
 	float x[32];
+#ifdef MP2_EXP_NO_MATRIX   /* experiment: what the matrixings cost (wrong samples) */
+	for (int k = 0; k < 32; k++) x[k] = (float)samples[tid][k];
+#else
 	mp2_matrix(&samples[tid][0], 1, x);
+#endif
 #pragma unroll
-	for (int k = 0; k < 32; k++) xs[tid][k] = x[k];
+	for (int k = 0; k < 32; k++) samples[tid][k] = (int)mp2_float_to_bits(x[k]);
 }
-MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const float (&xs)[72][33]) {
+MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const int (&samples)[72][33]) {
 	const uint32_t w_first = mp2_frame_w_first(b, f);
 	for (int idx = tid; idx < 72 * 32; idx += MP2_MATRIX_WG) {
 		const int v = idx >> 5, k = idx & 31;       /* v = sub-block * 2 + channel */
 		const uint32_t vec = (w_first + (uint32_t)(v >> 1)) & b.w_mask;
-		b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)((v & 1) * 32 + k)] = xs[v][k];
+		b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)((v & 1) * 32 + k)] = mp2_bits_to_float((uint32_t)samples[v][k]);
 	}
 }
 

@@ -52,8 +52,7 @@ __global__ void __launch_bounds__(MP2_WALK_WG) k_mp2_walk(Mp2Bufs b) {
 
 __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
 	__shared__ Mp2Frame F;
-	__shared__ int samples[72][33];
-	__shared__ float xs[72][33];
+	__shared__ int samples[72][33];          /* requantised samples, then (in place) the matrixing outputs */
 	const int tid = (int)threadIdx.x;
 	mp2_wg_stage_frame(b, blockIdx.x, tid, F);
 	__syncthreads();
@@ -63,9 +62,9 @@ __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
 	}
 	mp2_wg_matrix_read(tid, F, samples);
 	__syncthreads();
-	mp2_wg_matrix_run(tid, samples, xs);
+	mp2_wg_matrix_run(tid, samples);
 	__syncthreads();
-	mp2_wg_matrix_store(b, blockIdx.x, tid, xs);
+	mp2_wg_matrix_store(b, blockIdx.x, tid, samples);
 }
 
 __global__ void __launch_bounds__(MP2_WINDOW_WG) k_mp2_window(Mp2Bufs b) {

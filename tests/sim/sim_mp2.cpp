@@ -49,15 +49,15 @@ int sim_mp2_batch(const uint8_t *const *data, const uint64_t *bytes, uint32_t n_
 	std::vector<float> w((size_t)n_frames * MP2_SUBBLOCKS_PER_FRAME * MP2_VEC_FLOATS + 1, -12345.0f);   /* poison: every read must have been written */
 	b.frame_first = frame_first.data(); b.n_frames = n_frames; b.w = w.data(); b.pcm = pcm_out;
 	static int samples[72][33];
-	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
+	static float staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
 	for (uint32_t f = 0; f < n_frames; f++) {
 		static Mp2Frame F;
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_stage_frame(b, f, t, F);
 		for (int phase = 0; phase < 5; phase++)
 			for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(t, phase, F);
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
-		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
-		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, xs);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, samples);
 	}
 	for (uint32_t f = 0; f < n_frames; f++) {
 		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win);
@@ -83,14 +83,14 @@ void sim_mp2_ring_frame(const uint8_t *frame, uint32_t n, float *ring, uint32_t 
 	b.frame_pos = rw + 6; b.count = rw + 7; b.n_frames = 1; b.w = ring; b.w_mask = 63; b.n_abs_base = *n_abs;
 	b.window = window; b.pcm = pcm_out;
 	static int samples[72][33];
-	static float xs[72][33], staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
+	static float staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
 	static Mp2Frame F;
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_stage_frame(b, 0, t, F);
 	for (int phase = 0; phase < 5; phase++)
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(t, phase, F);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
-	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples, xs);
-	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, 0, t, xs);
+	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples);
+	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, 0, t, samples);
 	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, 0, t, staged, win);
 	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, 0, t, staged, win);
 	*n_abs += MP2_SUBBLOCKS_PER_FRAME;
