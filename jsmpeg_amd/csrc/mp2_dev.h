@@ -389,8 +389,12 @@ MP2_HD int mp2_f2i(float a) {
  * barrier between the phases; the test-only simulator calls the same functions in plain loops. */
 
 #define MP2_PAD 16                 /* bytes kept readable (zero) after the last stream */
-#define MP2_MATRIX_WG 128
-#define MP2_WINDOW_WG 256
+#ifndef MP2_MATRIX_WG
+#define MP2_MATRIX_WG 128          /* k_mp2_matrix on the benchmark batch (tools/variants.sh): 64 lanes 114 us, 128 lanes 94, 256 lanes 100 */
+#endif
+#ifndef MP2_WINDOW_WG
+#define MP2_WINDOW_WG 256          /* k_mp2_window: 128 lanes 135 us, 256 lanes 114, 512 lanes 122 */
+#endif
 #define MP2_VEC_FLOATS 64          /* one sub-block's matrixing output for both channels: [2][32] */
 #define MP2_LOOKBACK 15            /* vectors before a frame's first that its windowing reads (16 taps) */
 #define MP2_STAGED (MP2_LOOKBACK + MP2_SUBBLOCKS_PER_FRAME)   /* 51 */
