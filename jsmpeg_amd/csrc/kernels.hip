@@ -345,7 +345,12 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, uint32_t b
 	/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the loads) */
 	JmBlk B;
 	B.idct = false; B.k00 = false; B.live = false;
+#ifndef JM_EXP_COND_LOADS   /* no branch around the loads (recon_block.h): lanes past the picture look at block 0 and are masked after */
+	jm_recon_front(c, Q, B);
+	if (!valid) { B.idct = false; B.lowf = false; B.k00 = false; B.live = false; B.pred = false; B.cnt = 0; B.konst = 0; }
+#else
 	if (valid) jm_recon_front(c, Q, B);
+#endif
 	JM_STAMP(1)
 #ifdef JM_EXP_NO_PRED
 	B.pred = false;
