@@ -577,8 +577,11 @@ MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&x
 		const int v = idx >> 6, e = idx & 63, rel = v - MP2_LOOKBACK;
 		/* vectors from before the stream's first sub-block: the reference's V ring still holds its zeros (mp2.c:231) */
 		const bool there = rel >= 0 || (uint32_t)(-rel) <= n_abs0;
-		const uint32_t vec = (w_first + (uint32_t)rel) & b.w_mask;
-		xs[v][e] = there ? b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)e] : 0.0f;
+		/* no branch around the load (a lane without a vector reads the frame's first one): the thirteen loads of a lane
+		 * are issued back to back and awaited one by one */
+		const uint32_t vec = (w_first + (uint32_t)(there ? rel : 0)) & b.w_mask;
+		const float val = b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)e];
+		xs[v][e] = there ? val : 0.0f;
 	}
 }
 MP2_HD void mp2_wg_window_run(const Mp2Bufs &b, uint32_t f, int tid, const float (&xs)[MP2_STAGED][MP2_VEC_FLOATS],
