@@ -63,7 +63,7 @@ struct Mp2Frame {
 	uint8_t sf[64][4];          /* [q] scalefactor index per part (three used)                                      */
 };
 
-/* What k_mp2_walk leaves per frame: where it starts; the header is parsed again by k_mp2_side. */
+/* A frame header, parsed (k_mp2_walk finds where the frames start; k_mp2_matrix parses each header again). */
 struct Mp2Hdr {
 	int valid;                  /* 0: the reference's decode_frame returns 0 here (mp2.c:283-302)     */
 	int has_crc, bitrate_index, sample_rate_index, padding, mode, mode_ext;
