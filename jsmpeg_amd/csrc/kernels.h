@@ -57,35 +57,31 @@ struct JmParseBufs {
 };
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);
 
-/* One picture of a reconstruct launch: everything a workgroup needs to start, in one 32-byte scalar
- * load (the picture / order / offset tables cost a chain of dependent loads per workgroup). */
-struct alignas(32) JmReconDesc {
-	uint64_t tok_off;            /* first token slot of the picture */
-	uint32_t mb_first;           /* index of its first macroblock record */
-	uint32_t stream;             /* whose quantiser matrices apply */
-	uint32_t dst;                /* frame number (frame f at pool + f * frame_bytes) the picture is written to */
-	uint32_t fwd;                /* ... of its forward reference, JM_NO_FRAME if none */
-	uint32_t stale;              /* ... of what the reference's plane set held before this picture -- the decoded picture
-	                                before last of the stream (the reference rotates two plane sets, mpeg1.c:986-994):
-	                                macroblocks the picture never writes keep showing it.  JM_NO_FRAME: zeros (the JS
-	                                typed arrays start zeroed, mpeg1.js:131-152) */
-	uint32_t pad_;
+/* One picture of a reconstruct launch: everything a workgroup needs to start, as device addresses, in two scalar
+ * loads (no pointer arithmetic on picture / stream numbers in the kernel, and fewer scalar registers held). */
+struct alignas(64) JmReconDesc {
+	const uint16_t *tok;         /* the picture's token base */
+	const JmMbRec *mb;           /* its first macroblock record */
+	uint8_t *dst;                /* the frame the picture is written to */
+	const uint8_t *fwd;          /* the frame of its forward reference, null if none */
+	const uint8_t *stale;        /* the frame of what the reference's plane set held before this picture -- the decoded
+	                                picture before last of the stream (the reference rotates two plane sets,
+	                                mpeg1.c:986-994): macroblocks the picture never writes keep showing it.  Null: zeros
+	                                (the JS typed arrays start zeroed, mpeg1.js:131-152) */
+	const uint8_t *qm;           /* the stream's quantiser matrices: intra | non-intra, 128 bytes (JmStream::intra_q) */
+	uint64_t pad_[2];
 };
-#define JM_NO_FRAME 0xffffffffu
 
 struct JmReconBufs {
 	JmGeom g;
 	const JmReconDesc *desc;     /* the pictures of this level */
 	uint32_t n_level_pics;
-	const JmStream *streams;
-	const JmMbRec *mb;
-	const uint16_t *tokens;
 	const JmVlcLuts *luts;       /* device global copy (zig-zag order) */
-	uint8_t *pool;
+	uint32_t *tickets;           /* eight zeroed counters that belong to this launch alone (tile hand-out, one per XCD class) */
 	uint8_t epoch;
 	int zero_uncovered;
-	uint64_t *dbg;               /* diagnostics only (builds with -DJM_EXP_TIMING): phase timestamps, or null */
 };
+#define JM_TICKET_GROUPS 1024    /* groups of eight counters a decoder keeps; zeroed together, used one per launch */
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 
 /* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */

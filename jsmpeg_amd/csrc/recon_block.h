@@ -50,13 +50,27 @@ static constexpr int JM_PREMULT[64] = MPEG1_PREMULTIPLIER_INIT;
 /* ---- instructions the path leans on, with their plain-C meaning (the C forms
  * are what the test-only simulator compiles) ---- */
 #if defined(__HIP_DEVICE_COMPILE__)
-/* a * b and a * k + acc on the low 24 bits of the operands, low 32 bits of the result.  Spelled as
- * instructions: the compiler only selects the 24-bit forms when it can prove the operand ranges, and
- * falls back to the quarter-rate v_mul_lo_u32 for the data-dependent IDCT values. */
-JM_D int jm_mul24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-JM_D int jm_mad24(int a, int k, int acc) {
-	if (__builtin_constant_p(a) && a == 0) return acc;   /* the low-frequency transform passes literal zeros: nothing to multiply */
-	int d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(acc)); return d;
+/* a * b and a * k + acc on the low 24 bits of the operands, low 32 bits of the result (v_mul_i32_i24 /
+ * v_mad_i32_i24: full rate, v_mul_lo_u32 is quarter rate).  Through the intrinsic, so that the compiler
+ * encodes constants as inline operands / literals / scalar registers as it sees fit (the round-1 asm forms
+ * pinned every constant into a vector register: a v_mov per use, or -- inside the persistent loop --
+ * dozens of registers of hoisted constants). */
+JM_D int jm_mul24(int a, int b) { return __mul24(a, b); }
+JM_D int jm_mad24(int a, int k, int acc) { return __mul24(a, k) + acc; }
+/* sign-extended 16-bit half HI of `w`, times the constant K (an inline operand, 0..64), plus `add`: unpacking a
+ * coefficient and premultiplying it in ONE instruction (v_mad_i32_i16 with op_sel picking the half) */
+template <int HI>
+JM_D int jm_mad16(uint32_t w, int k) {
+	int d;
+	if (HI) asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "v"(k));
+	else asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[0,0,0,0]" : "=v"(d) : "v"(w), "v"(k));
+	return d;
+}
+/* the two lanes of a pair (lane j and lane j + 32 of a wavefront) trade a register each: the upper lane's `up`
+ * for the lower lane's `lo` (v_permlane32_swap_b32) */
+JM_D void jm_pair_swap(int &up, int &lo) {
+	const auto r = __builtin_amdgcn_permlane32_swap((unsigned)up, (unsigned)lo, false, false);
+	up = (int)r[0]; lo = (int)r[1];
 }
 /* per byte (a + b + (c & 1)) >> 1 */
 JM_D uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp(a, b, c); }
@@ -73,6 +87,8 @@ JM_HD int jm_mul24(int a, int b) {
 	return (int)(uint32_t)(uint64_t)(x * y);
 }
 JM_HD int jm_mad24(int a, int k, int acc) { return (int)((uint32_t)jm_mul24(a, k) + (uint32_t)acc); }
+template <int HI>
+JM_HD int jm_mad16(uint32_t w, int k) { return (int)(int16_t)(HI ? (w >> 16) : (w & 0xffffu)) * k; }
 JM_HD uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) {
 	uint32_t r = 0;
 	for (int i = 0; i < 32; i += 8) r |= ((((a >> i) & 255u) + ((b >> i) & 255u) + ((c >> i) & 1u)) >> 1) << i;
@@ -234,31 +250,20 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)(((rec_cnt >> (8 * j)) & 0xff) + 1) & ~1u;
 	B.tkw = reinterpret_cast<const uint32_t *>(c.tok + t0);
 	B.tw[0] = B.tw[1] = B.tw[2] = B.tw[3] = 0;
-#ifndef JM_EXP_COND_LOADS   /* every lane loads -- blocks without tokens read the picture's first slots, blocks without prediction
-                               the first bytes of the frame (one address for all of them) -- so that there is no branch around
-                               the loads and the wait for the tokens is a counted one (s_waitcnt vmcnt(9)): the nine prediction
-                               rows stay in flight across the set-up barrier and are only awaited where they are used.
-                               Measured against the branchy form (JM_EXP_COND_LOADS): 13.3 against 13.6 ms of reconstruct */
+	/* every lane loads -- blocks without tokens read the picture's first slots, blocks without prediction
+	 * the first bytes of the frame (one address for all of them) -- so that there is no branch around
+	 * the loads and the wait for the tokens is a counted one (s_waitcnt vmcnt(9)): the nine prediction
+	 * rows stay in flight across the set-up barrier and are only awaited where they are used
+	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
 		const uint32_t *tk = B.cnt > 0 ? B.tkw : reinterpret_cast<const uint32_t *>(c.tok);
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
 	}
-#else
-	if (B.cnt > 0) { B.tw[0] = B.tkw[0]; B.tw[1] = B.tkw[1]; B.tw[2] = B.tkw[2]; B.tw[3] = B.tkw[3]; }
-#endif
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
 	B.m = B.oh = B.ov = 0;
-#ifndef JM_EXP_COND_LOADS
 	{
 		int mh = B.pred ? rec_mvh : 0, mv = B.pred ? rec_mvv : 0;
-#else
-	if (B.pred) {
-		int mh = rec_mvh, mv = rec_mvv;
-#endif
-#ifdef JM_EXP_ZERO_MV
-		mh = mh & 1; mv = mv & 1;   /* experiment: coherent vectors (keeps the half-pel work) */
-#endif
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
 		const int H = mh >> 1, V = mv >> 1;
 		B.oh = (uint32_t)(mh & 1); B.ov = (uint32_t)(mv & 1);
@@ -270,29 +275,15 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		if (sx + 8 + (int)B.oh > stride) sx = stride - 8 - (int)B.oh;
 		if (sy + 8 + (int)B.ov > ph) sy = ph - 8 - (int)B.ov;
 		const uint32_t off = (uint32_t)(sy * stride + sx);
-#ifndef JM_EXP_COND_LOADS
 		const uint32_t *w = reinterpret_cast<const uint32_t *>(B.pred ? c.fwd + plane_off + (off & ~3u) : c.fwd);
 		B.m = B.pred ? off & 3u : 0u;
 		const int wstride = B.pred ? stride >> 2 : 0;
 		if (!B.pred) { B.oh = B.ov = 0; }
-#else
-		const uint32_t *w = reinterpret_cast<const uint32_t *>(c.fwd + plane_off + (off & ~3u));
-		B.m = off & 3u;
-		const int wstride = stride >> 2;
-#endif
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
 			const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
-#if defined(JM_EXP_PRED_X2)
-			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = 0;   /* experiment: two dwords per row (wrong pixels) */
-#elif defined(JM_EXP_PRED_X1)
-			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = 0; B.R[3 * r + 2] = 0;
-#elif defined(JM_EXP_NT_PRED) && defined(__HIP_DEVICE_COMPILE__)
-			B.R[3 * r] = __builtin_nontemporal_load(wr); B.R[3 * r + 1] = __builtin_nontemporal_load(wr + 1); B.R[3 * r + 2] = __builtin_nontemporal_load(wr + 2);   /* experiment: streaming hint on the prediction rows */
-#else
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
-#endif
 		}
 	}
 
@@ -326,7 +317,9 @@ JM_HD void jm_recon_konst(const JmReconCtx &c, JmBlk &B) {
 
 /* PHASE 1b (lanes whose block needs the transform): dequantise the tokens into a slot
  * (mpeg1.c:1535-1548).  `Slot`: 72 int16 in LDS, all zero on entry; [0, 64) raster coefficients,
- * [64] the intra dc.  zero(), put(pos, v), get8(i, out[8]) / put8(i, in[8]) = entries 8i .. 8i+7. */
+ * [64] the intra dc.  zero(), put(pos, v); for the transform get_cols(r, h, low, w) = columns 4h..4h+3
+ * (low: 2h, 2h+1) of row r as packed pairs, get_dc(), put_row(r, h, pk) = row r as four packed pairs;
+ * get8p(i, pk) = entries 8i .. 8i+7 as packed pairs. */
 template <class Slot>
 JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	const uint8_t *q = c.qm + (B.intra ? 0 : 64);
@@ -349,47 +342,86 @@ JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	}
 }
 
-/* PHASE 2 (one lane per block that needs it, blocks packed to the front of the workgroup's slots):
- * premultiply + 8x8 integer IDCT (mpeg1.c:1551, 1673-1740), in place: levels in, residual out
- * (saturated to int16). */
+/* PHASE 2: premultiply + 8x8 integer IDCT (mpeg1.c:1551, 1673-1740), in place in the block's slot: levels in,
+ * residual out (int16).  TWO LANES PER BLOCK -- lane j and lane j + 32 of a wavefront, `h` = 0 / 1 -- so that a
+ * lane holds 32 (not 64) live values: the kernel's register peak used to be this transform, and the registers it
+ * frees are what lets the persistent loop keep the next tile's records in flight at four wavefronts per SIMD.
+ *   columns: lane h transforms columns 4h .. 4h+3 over all eight rows          v[r * 4 + c], r = 0..7, c = 0..3
+ *   trade  : the upper lane's rows 0..3 for the lower lane's rows 4..7         (16 v_permlane32_swap_b32)
+ *            -> row 4h + i = ( v[i * 4 + 0..3] , v[(i + 4) * 4 + 0..3] ) on both lanes
+ *   rows   : lane h transforms rows 4h .. 4h+3 and writes them back packed to int16
+ * LOW: only rows 0..3 x columns 0..3 can be non-zero: lane h takes columns 2h, 2h+1 (v[r * 2 + c]); the very same
+ * network with literal zeros for the rest -- the compiler drops what they feed; results are identical by
+ * construction.  Premultipliers differ between the two lanes of a pair (they hold different columns): one select
+ * per coefficient between two inline constants. */
+template <bool LOW> struct JmIdctRegs { int v[LOW ? 16 : 32]; };
+
 template <bool LOW, class Slot>
-JM_HD void jm_recon_idct(Slot &s) {
-	/* LOW: only rows 0..3 x columns 0..3 can be non-zero.  The very same network with literal zeros for the
-	 * rest -- the compiler drops what they feed (4 of the 8 column transforms, a third of every row
-	 * transform); results are identical by construction. */
-	int v[64];
+JM_HD void jm_recon_idct_cols(Slot &s, int h, JmIdctRegs<LOW> &R) {
+	constexpr int NC = LOW ? 2 : 4, NR = LOW ? 4 : 8;
+	int (&v)[LOW ? 16 : 32] = R.v;
 #pragma unroll
-	for (int i = 0; i < 64; i++) v[i] = 0;
+	for (int r = 0; r < NR; r++) {
+		uint32_t w[2];
+		s.get_cols(r, h, LOW, w);                        /* the NC columns of row r as packed int16 pairs */
 #pragma unroll
-	for (int i = 0; i < (LOW ? 4 : 8); i++) {
-		int16_t t[8];
-		s.get8(i, t);
-#pragma unroll
-		for (int k = 0; k < (LOW ? 4 : 8); k++) v[8 * i + k] = (int)t[k] * JM_PREMULT[8 * i + k];   /* mpeg1.c:1551 */
+		for (int c = 0; c < NC; c++) {
+			const int k = h ? JM_PREMULT[8 * r + NC + c] : JM_PREMULT[8 * r + c];   /* mpeg1.c:1551 */
+			v[r * NC + c] = (c & 1) ? jm_mad16<1>(w[c >> 1], k) : jm_mad16<0>(w[c >> 1], k);
+		}
 	}
-	{
-		int16_t t[8];
-		s.get8(8, t);
-		v[0] += (int)((uint32_t)(int)t[0] << 8);             /* intra: dc << 8 (zero otherwise) */
-	}
+#pragma unroll
+	for (int i = NR * NC; i < 8 * NC; i++) v[i] = 0;
+	v[0] += h ? 0 : (int)((uint32_t)s.get_dc() << 8);    /* intra: dc << 8 (zero otherwise) */
 	const int c128 = 128;
-	/* columns, then rows with the final rounding (mpeg1.c:1682-1739) */
 #pragma unroll
-	for (int i = 0; i < (LOW ? 4 : 8); i++)
-		JM_IDCT_1D(v[i], v[8 + i], v[16 + i], v[24 + i], v[32 + i], v[40 + i], v[48 + i], v[56 + i], 0, JM_FIN_NONE)
+	for (int c = 0; c < NC; c++)
+		JM_IDCT_1D(v[c], v[NC + c], v[2 * NC + c], v[3 * NC + c], v[4 * NC + c], v[5 * NC + c], v[6 * NC + c], v[7 * NC + c], 0, JM_FIN_NONE)
+}
+
+template <bool LOW, class Slot>
+JM_HD void jm_recon_idct_rows(Slot &s, int h, JmIdctRegs<LOW> &R) {
+	int (&v)[LOW ? 16 : 32] = R.v;
+	const int c128 = 128;
 #pragma unroll
-	for (int i = 0; i < 64; i += 8)
-		JM_IDCT_1D(v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6], v[i + 7], 128, JM_FIN_NONE)
-	/* the final >> 8 and the int16 pair in one v_perm: bytes 1..2 of each value.  No saturation is
-	 * needed: |output| <= 18473 for any levels in [-2048, 2047] (tools/idct_bounds.py). */
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
+	for (int i = 0; i < 4; i++) {
+		/* the final >> 8 and the int16 pair in one v_perm: bytes 1..2 of each value.  No saturation is
+		 * needed: |output| <= 18473 for any levels in [-2048, 2047] (tools/idct_bounds.py). */
 		uint32_t pk[4];
-#pragma unroll
-		for (int k = 0; k < 4; k++) pk[k] = jm_perm((uint32_t)v[8 * i + 2 * k + 1], (uint32_t)v[8 * i + 2 * k], 0x06050201u);
-		s.put8p(i, pk);
+		if (LOW) {
+			int a0 = v[i * 2], a1 = v[i * 2 + 1], a2 = v[(i + 4) * 2], a3 = v[(i + 4) * 2 + 1], a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+			JM_IDCT_1D(a0, a1, a2, a3, a4, a5, a6, a7, 128, JM_FIN_NONE)
+			pk[0] = jm_perm((uint32_t)a1, (uint32_t)a0, 0x06050201u); pk[1] = jm_perm((uint32_t)a3, (uint32_t)a2, 0x06050201u);
+			pk[2] = jm_perm((uint32_t)a5, (uint32_t)a4, 0x06050201u); pk[3] = jm_perm((uint32_t)a7, (uint32_t)a6, 0x06050201u);
+		} else {
+			int *a = v + i * 4, *e = v + (i + 4) * 4;
+			JM_IDCT_1D(a[0], a[1], a[2], a[3], e[0], e[1], e[2], e[3], 128, JM_FIN_NONE)
+			pk[0] = jm_perm((uint32_t)a[1], (uint32_t)a[0], 0x06050201u); pk[1] = jm_perm((uint32_t)a[3], (uint32_t)a[2], 0x06050201u);
+			pk[2] = jm_perm((uint32_t)e[1], (uint32_t)e[0], 0x06050201u); pk[3] = jm_perm((uint32_t)e[3], (uint32_t)e[2], 0x06050201u);
+		}
+		s.put_row(4 * h + i, h, pk);
 	}
 }
+
+/* the trade between the two stages, on the device: rows 0..3 of the upper lane for rows 4..7 of the lower */
+#if defined(__HIPCC__)
+#if !defined(__HIP_DEVICE_COMPILE__)
+JM_D void jm_pair_swap(int &, int &) {}   /* host pass of the kernel source: never runs */
+#endif
+template <bool LOW>
+JM_D void jm_recon_idct_trade(JmIdctRegs<LOW> &R) {
+	constexpr int NC = LOW ? 2 : 4;
+#pragma unroll
+	for (int i = 0; i < 4 * NC; i++) jm_pair_swap(R.v[i], R.v[4 * NC + i]);
+}
+template <bool LOW, class Slot>
+JM_D void jm_recon_idct_pair(Slot &s, int h) {
+	JmIdctRegs<LOW> R;
+	jm_recon_idct_cols<LOW>(s, h, R);
+	jm_recon_idct_trade<LOW>(R);
+	jm_recon_idct_rows<LOW>(s, h, R);
+}
+#endif
 
 /* PHASE 1c (every lane, its own block, once the raw rows have arrived): half-pel prediction
  * (mpeg1.c:1208-1437).  P = (A + B + C + D + 2) >> 2 with B = A shifted by oh bytes, C/D = the
@@ -469,7 +501,9 @@ JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(JM_EXP_NO_NT_STORE)
+#if defined(JM_TMP_NO_STORE)
+		if (X.p[0] == 0x12345678u && X.p[3] == 0x9abcdef0u) { o[0] = 1; }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(JM_TMP_PLAIN_STORE)
 		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
 		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);
 #else

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "index_tables.h"
@@ -18,10 +19,23 @@ struct HostSlot {
 	int16_t v[72];
 	void zero() { memset(v, 0, sizeof(v)); }
 	void put(int pos, int level) { v[pos] = (int16_t)level; }
-	void get8(int i, int16_t (&t)[8]) { memcpy(t, v + 8 * i, 16); }
-	void put8p(int i, const uint32_t (&pk)[4]) { memcpy(v + 8 * i, pk, 16); }
+	void get_cols(int r, int h, bool low, uint32_t (&w)[2]) { w[0] = w[1] = 0; memcpy(w, v + 8 * r + (low ? 2 : 4) * h, low ? 4 : 8); }
+	int get_dc() { return v[64]; }
+	void put_row(int row, int, const uint32_t (&pk)[4]) { memcpy(v + 8 * row, pk, 16); }
 	void get8p(int i, uint32_t (&pk)[4]) { memcpy(pk, v + 8 * i, 16); }
 };
+
+// the two lanes of a pair, one after the other; the register trade is a swap of array entries
+template <bool LOW>
+static void sim_idct_pair(HostSlot &s) {
+	JmIdctRegs<LOW> A, B;
+	jm_recon_idct_cols<LOW>(s, 0, A);
+	jm_recon_idct_cols<LOW>(s, 1, B);
+	const int nc = LOW ? 2 : 4;
+	for (int i = 0; i < 4 * nc; i++) std::swap(B.v[i], A.v[4 * nc + i]);   // upper lane's rows 0..3 <-> lower lane's rows 4..7
+	jm_recon_idct_rows<LOW>(s, 0, A);
+	jm_recon_idct_rows<LOW>(s, 1, B);
+}
 
 // Step counters of the emulated wavefront scheduler (cost model of k_parse): turns taken per step
 // kind, and lanes that were served in those turns.
@@ -206,9 +220,11 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 				g_idct[0] += (uint64_t)totalA; g_idct[1] += (uint64_t)totalB; g_idct[2] += (uint64_t)(totalA / 64); g_idct[3] += (uint64_t)((total + 63) / 64);
 				for (int l = 0; l < 256; l++) if (B[l].idct) jm_recon_scatter(c, B[l], slots[rank[l]]);
 				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_predict(B[l]);
+				// the pair transform: lane j and lane j + 32 of a wavefront share a slot; a wavefront's 32 slots run the
+				// cheap transform when all of them are low-frequency blocks (same rule as the kernel)
 				for (int l = 0; l < total; l++) {
-					if ((l | 63) < totalA) jm_recon_idct<true>(slots[l]);   // wavefronts that hold only low-frequency blocks
-					else jm_recon_idct<false>(slots[l]);
+					const bool low = (l / 32) * 32 + 32 <= totalA;
+					if (low) sim_idct_pair<true>(slots[l]); else sim_idct_pair<false>(slots[l]);
 				}
 				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_back(c, B[l], slots[rank[l]]);
 			}
