@@ -75,18 +75,6 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 
 static void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g, width, height); }
 
-/* One reconstruct launch with its own zeroed group of tile hand-out counters: the pool of groups is zeroed
- * whenever `group` is 0 (stream-ordered behind the launches that used it last). */
-static hipError_t recon_launch(JmReconBufs &rb, uint32_t *ticket_pool, uint32_t &group, hipStream_t st) {
-	if (group == 0) {
-		hipError_t e = hipMemsetAsync(ticket_pool, 0, sizeof(uint32_t) * 8 * JM_TICKET_GROUPS, st);
-		if (e != hipSuccess) return e;
-	}
-	rb.tickets = ticket_pool + 8 * group;
-	group = (group + 1) % JM_TICKET_GROUPS;
-	return jm_launch_recon(rb, st);
-}
-
 #define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
 
 /* =========================================================================
@@ -115,7 +103,6 @@ struct jsmpeg_hip_batch_t {
 	hipEvent_t ev_cov;
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
-	uint32_t *d_tickets; uint32_t ticket_group;   /* k_recon's tile hand-out counters: JM_TICKET_GROUPS groups of eight, one group per launch */
 	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
 	/* ingest side (jsmpeg_hip_batch_upload_ts): scratch sized to the largest upload so far */
 	uint8_t *d_ts; uint64_t ts_cap;
@@ -136,7 +123,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
-	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba); hipFree(b->d_tickets);
+	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	if (b->h_covered) hipHostFree(b->h_covered);
@@ -176,7 +163,6 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_pool_alloc, pool_bytes));
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
-	HIP_TRY(jm_malloc(&b->d_tickets, sizeof(uint32_t) * 8 * JM_TICKET_GROUPS));
 	HIP_TRY(hipHostMalloc(&b->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault));
 	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
 	return 0;
@@ -198,7 +184,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
-	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr; b->d_tickets = nullptr; b->ticket_group = 0;
+	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (auto &e : b->ev) e = nullptr;
@@ -497,11 +483,10 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
-	b->ticket_group = 0;
 	for (uint32_t l = 0; l < b->n_levels; l++) {
 		rb.desc = b->d_desc + b->level_off[l];
 		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
-		HIP_TRY(recon_launch(rb, b->d_tickets, b->ticket_group, st));
+		HIP_TRY(jm_launch_recon(rb, st));
 	}
 
 	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4 meanwhile).
@@ -534,7 +519,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 			for (size_t i = 0; i < again.size(); i++) {
 				rb.desc = b->d_desc + b->n_decoded + i;
 				rb.n_level_pics = 1;
-				HIP_TRY(recon_launch(rb, b->d_tickets, b->ticket_group, st));
+				HIP_TRY(jm_launch_recon(rb, st));
 			}
 		}
 	}
@@ -708,7 +693,6 @@ struct mpeg1_decoder_t {
 	int cur;                         /* frame index being written next (planes_current) */
 	uint8_t *h_frame;                /* pinned: last decoded Y | Cr | Cb */
 	uint8_t *d_rgba; size_t rgba_cap; /* renderer stage scratch (jsmpeg_hip_decoder_render_rgba) */
-	uint32_t *d_tickets; uint32_t ticket_group;   /* k_recon's tile hand-out counters */
 	uint8_t epoch;
 	std::vector<uint32_t> stage_pos; std::vector<uint8_t> stage_code;
 };
@@ -727,7 +711,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	d->d_sc_owner = nullptr; d->d_pic_sc = nullptr; d->d_counters = nullptr; d->h_scan_pos = nullptr;
 	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_desc = nullptr;
 	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr;
-	d->h_frame = nullptr; d->stream = nullptr; d->d_rgba = nullptr; d->rgba_cap = 0; d->d_tickets = nullptr; d->ticket_group = 0;
+	d->h_frame = nullptr; d->stream = nullptr; d->d_rgba = nullptr; d->rgba_cap = 0;
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->d_es_cap = 0; d->mirrored = 0; d->scan_cap = 0; d->tokens_cap = 0;
 	d->has_sequence_header = 0; d->frame_rate = 0; d->width = d->height = 0; d->cur = 0; d->epoch = 0;
@@ -738,8 +722,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	          hipHostMalloc(&d->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
 	          jm_malloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
 	          jm_malloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && jm_malloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
-	          jm_malloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess &&
-	          jm_malloc(&d->d_tickets, sizeof(uint32_t) * 8 * JM_TICKET_GROUPS) == hipSuccess;
+	          jm_malloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess;
 	if (!ok) {
 		if (!g_err[0]) fail("decoder allocation failed: %s", hipGetErrorString(hipGetLastError()));
 		dec_fail_cleanup(d);
@@ -754,7 +737,7 @@ static int dec_fail_cleanup(mpeg1_decoder_t *d) {
 	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
 	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
 	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_desc);
-	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_rgba); hipFree(d->d_tickets); hipHostFree(d->h_frame);
+	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_rgba); hipHostFree(d->h_frame);
 	if (d->stream) hipStreamDestroy(d->stream);
 	delete d;
 	return -1;
@@ -1034,7 +1017,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
-	HIP_TRY(recon_launch(rb, d->d_tickets, d->ticket_group, st));
+	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));

@@ -77,11 +77,9 @@ struct JmReconBufs {
 	const JmReconDesc *desc;     /* the pictures of this level */
 	uint32_t n_level_pics;
 	const JmVlcLuts *luts;       /* device global copy (zig-zag order) */
-	uint32_t *tickets;           /* eight zeroed counters that belong to this launch alone (tile hand-out, one per XCD class) */
 	uint8_t epoch;
 	int zero_uncovered;
 };
-#define JM_TICKET_GROUPS 1024    /* groups of eight counters a decoder keeps; zeroed together, used one per launch */
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 
 /* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */

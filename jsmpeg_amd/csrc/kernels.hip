@@ -263,27 +263,22 @@ hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
 }
 
 /* ------------------------------------------------------------------------
- * Reconstruct: one lane per 8x8 block, 256 blocks (a tile) per workgroup pass.
+ * Reconstruct: one lane per 8x8 block, one workgroup per tile of TW x 4 blocks
+ * of one plane (recon_block.h, JmTiles), one wavefront per block row of it.
+ * All tiles of a picture are dispatched to the same XCD (workgroup b runs on
+ * XCD b % 8) so the forward frame's prediction reads hit one L2.
  *
- * PERSISTENT workgroups: the launch holds as many workgroups as the GPU keeps
- * resident (4 per CU) and each walks tiles  vb = blockIdx.x, + gridDim.x, ...
- * A tile's life is a chain of dependent loads -- picture descriptor ->
- * macroblock record -> tokens and prediction rows -- which a one-tile
- * workgroup pays in full (36 % of its life, profiles/r01_recon_notes.md).
- * Here the descriptor of tile i + 2 (scalar registers) and the records of
- * tile i + 1 (four vector registers) are requested while tile i is worked on,
- * so a tile starts with its record in hand and only the token / row latency
- * is left, most of it behind the set-up barrier and the coefficient scatter.
- *
- * Tile -> picture mapping is XCD-aware: gridDim.x is a multiple of 8, so
- * vb % 8 == blockIdx.x % 8 == the XCD the workgroup runs on, and all tiles of
- * a picture (and the forward frame's reads) stay on one XCD's L2.
+ * What bounds it (round 2, profiles/r02_recon_notes.md): with the synthetic
+ * streams' random vectors the P levels run at the speed of a kernel that does
+ * nothing but this kernel's loads and stores (tools/ubench_pred.hip) -- L1
+ * misses in flight per CU, not HBM bandwidth and not the arithmetic.  A
+ * persistent-workgroup form (tile tickets, records prefetched a tile ahead,
+ * stores deferred a tile) was built and measured slower: a wavefront that
+ * loops pays for its own store acknowledgements (one in-order counter for
+ * loads and stores), which a workgroup that simply ends never waits for.
  * ---------------------------------------------------------------------- */
 #ifndef JM_RECON_WG
-#define JM_RECON_WG 256   /* lanes = 8x8 blocks per tile; LDS: 144 bytes per lane */
-#endif
-#ifndef JM_RECON_CHUNK
-#define JM_RECON_CHUNK 4  /* consecutive tiles per ticket */
+#define JM_RECON_WG 256   /* 4 wavefronts = 4 block rows of a tile; LDS: 144 bytes per lane */
 #endif
 #define JM_SLOT_HALVES 72 /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
 
@@ -309,218 +304,86 @@ struct LdsSlot {
 	}
 };
 
-/* The picture descriptor by scalar loads.  Inside the persistent loop the compiler will not select scalar loads by
- * itself (the planes are stored to between two descriptor reads, so it cannot prove the table unchanged and falls
- * back to vector loads + readfirstlane); the table is read-only for the kernel, so the loads are spelled out.  The
- * compiler does not see them in flight: jm_desc_wait() before the first use. */
-typedef uint32_t jm_u8v __attribute__((ext_vector_type(8)));
-typedef uint32_t jm_u4v __attribute__((ext_vector_type(4)));
-struct JmDescRegs { jm_u8v a; jm_u4v b; };
-static __device__ __forceinline__ JmDescRegs jm_desc_request(const JmReconDesc *p) {
-	JmDescRegs r;
-	asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(r.a), "=&s"(r.b) : "s"(p));
-	return r;
-}
-/* only the record pointer (for the record prefetch of the NEXT tile: twelve scalar registers fewer held across a tile;
- * the rest of that descriptor is asked for when its tile starts and comes out of the scalar cache) */
-typedef uint32_t jm_u2v __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ jm_u2v jm_desc_request_mb(const JmReconDesc *p) {
-	jm_u2v r;
-	asm volatile("s_load_dwordx2 %0, %1, 0x8" : "=s"(r) : "s"(p));
-	return r;
-}
-static __device__ __forceinline__ const JmMbRec *jm_desc_wait_mb(jm_u2v r) {
-	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
-	return reinterpret_cast<const JmMbRec *>((uint64_t)r[0] | ((uint64_t)r[1] << 32));
-}
-static __device__ __forceinline__ uint64_t jm_u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
-static __device__ __forceinline__ JmReconDesc jm_desc_wait(JmDescRegs r) {
-	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b));
-	JmReconDesc D;
-	D.tok = reinterpret_cast<const uint16_t *>(jm_u64(r.a[0], r.a[1]));
-	D.mb = reinterpret_cast<const JmMbRec *>(jm_u64(r.a[2], r.a[3]));
-	D.dst = reinterpret_cast<uint8_t *>(jm_u64(r.a[4], r.a[5]));
-	D.fwd = reinterpret_cast<const uint8_t *>(jm_u64(r.a[6], r.a[7]));
-	D.stale = reinterpret_cast<const uint8_t *>(jm_u64(r.b[0], r.b[1]));
-	D.qm = reinterpret_cast<const uint8_t *>(jm_u64(r.b[2], r.b[3]));
-	D.pad_[0] = D.pad_[1] = 0;
-	return D;
-}
-static_assert(offsetof(JmReconDesc, tok) == 0 && offsetof(JmReconDesc, fwd) == 24 && offsetof(JmReconDesc, stale) == 32 && offsetof(JmReconDesc, qm) == 40 && sizeof(JmReconDesc) == 64, "JmReconDesc layout");
-
-/* tile vb -> (picture k of the level, 256-block piece blk of it) */
-static __device__ __forceinline__ void recon_tile(uint32_t vb, uint32_t bpp, uint32_t &blk, uint32_t &k) {
-	const uint32_t q = vb >> 3, pq = q / bpp;
-	blk = q - pq * bpp;
-	k = pq * 8 + (vb & 7);
-}
-/* the macroblock record of this lane's block of tile (D, blk); lanes past the picture look at block 0 */
-static __device__ __forceinline__ uint4_like_t recon_record(const JmReconBufs &b, const JmMbRec *mb, uint32_t blk) {
-	const int g = (int)(blk * JM_RECON_WG + threadIdx.x);
-	JmLoc Q;
-	jm_recon_locate(b.g, mb, g < 6 * b.g.mb_size ? g : 0, Q);
-	return Q.rw;
-}
-
-__global__ __launch_bounds__(JM_RECON_WG, 4) void k_recon(JmReconBufs b, uint32_t bpp) {
+__global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_WG];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
-	__shared__ uint32_t next_ticket;
-	/* Tiles are handed out in chunks of JM_RECON_CHUNK consecutive tiles of one XCD class (blockIdx.x % 8: tile
-	 * 8 s + x is number s of class x) by eight counters, one per class: a workgroup that gets through its tiles
-	 * faster simply takes more chunks (a static stride measured 9 % slower: the slowest workgroup sets the time; one
-	 * ticket per TILE measured slower still: 15 k atomics per counter and launch serialise at ~90 per microsecond).
-	 * A workgroup's first two chunks come from blockIdx / gridDim; thread 0 draws the ticket for the chunk after
-	 * the next at the first tile of every chunk and the workgroup reads it behind that tile's last barrier. */
-	const uint32_t xcd = blockIdx.x & 7, per_class = gridDim.x >> 3;
-	uint32_t *const ticket = b.tickets + xcd;
-	uint32_t seq = (blockIdx.x >> 3) * JM_RECON_CHUNK, in_chunk = 0;
-	uint32_t next_chunk = per_class + (blockIdx.x >> 3), after_next = 0;
-	uint32_t blk, k;
-	recon_tile(seq * 8 + xcd, bpp, blk, k);
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t tile = q % (uint32_t)T.per_picture, k = (q / (uint32_t)T.per_picture) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
-	uint4_like_t rw = recon_record(b, jm_desc_wait_mb(jm_desc_request_mb(b.desc + k)), blk);
+	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
+	JmLoc Q;
+	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
+	Q.rw = *reinterpret_cast<const uint4_like_t *>(D.mb + Q.mbaddr);
+	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
+	uint4 tq = make_uint4(0, 0, 0, 0);
+	if (threadIdx.x < 8) tq = reinterpret_cast<const uint4 *>(D.qm)[threadIdx.x];
+	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
 	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
-	own.zero();                                      /* once: whoever reads a slot back leaves it zeroed (phase 3) */
-	if (threadIdx.x < 4) reinterpret_cast<uint4 *>(qm + 128)[threadIdx.x] = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x];   /* once: the zig-zag order */
-	/* The pixels of a tile are stored one tile LATE, behind the next tile's loads: gfx950 counts loads and stores
-	 * in one in-order counter, so a wait for the next tile's tokens is also a wait for every store issued before them
-	 * -- with the stores at the end of a tile each tile paid the write latency of the one before (measured: the
-	 * longer a workgroup's chain of tiles, the slower; without stores the longer the faster).  Issued after the next
-	 * tile's rows have been used they have a whole tile's time before anything younger is waited for. */
-	JmPix Xlate;
-	JmBlk Blate;
-	Xlate.store = false;
+	own.zero();
+	JmReconCtx c;
+	c.g = b.g;
+	c.mb = D.mb;
+	c.tok = D.tok;
+	c.has_fwd = D.fwd != nullptr;
+	c.dst = D.dst;
+	c.fwd = c.has_fwd ? D.fwd : D.dst;
+	c.stale = D.stale;
+	c.qm = qm; c.zz = qm + 128;
+	c.epoch = b.epoch;
+	c.zero_uncovered = b.zero_uncovered;
+
+	/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the loads;
+	 * no branch around them, see recon_block.h -- lanes without a block look at block 0 and are masked after) */
+	JmBlk B;
+	jm_recon_front(c, Q, B);
+	if (!valid) { B.idct = false; B.lowf = false; B.k00 = false; B.live = false; B.pred = false; B.cnt = 0; B.konst = 0; }
+	/* the blocks that need the transform, packed to the front of the workgroup's slots: first the ones
+	 * whose coefficients all lie in the top-left 4x4 (wavefronts that hold only those run the cheap
+	 * transform), then the rest */
+	const uint64_t needA = __ballot(B.idct && B.lowf), needB = __ballot(B.idct && !B.lowf);
+	const uint32_t beforeA = __builtin_amdgcn_mbcnt_hi((uint32_t)(needA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needA, 0));
+	const uint32_t beforeB = __builtin_amdgcn_mbcnt_hi((uint32_t)(needB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needB, 0));
+	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(needA) | ((uint32_t)__popcll(needB) << 16);
+	if (threadIdx.x < 12) reinterpret_cast<uint4 *>(qm)[threadIdx.x] = tq;
+	__syncthreads();
+	uint32_t prior = 0, sum = 0;
 #pragma unroll
-	for (int i = 0; i < 16; i++) Xlate.p[i] = 0;
-	Blate.out = nullptr; Blate.stride = 0;
-
-	for (;;) {
-		/* the thread number, opaque per tile: what derives from it (lane, wavefront, LDS addresses) is recomputed with
-		 * a few instructions instead of living in registers across the whole loop (one of them was spilled) */
-		uint32_t tid = threadIdx.x;
-		asm volatile("" : "+v"(tid));
-		const uint32_t lane = tid & 63, wave = tid >> 6;
-		/* ---- this tile's descriptor; of the tile after this one the record pointer is requested now, its records
-		 * once this tile's own loads are out (below) ---- */
-		const JmDescRegs dr = jm_desc_request(b.desc + k);
-		const bool first = in_chunk == 0;
-		const uint32_t seqn = in_chunk + 1 < JM_RECON_CHUNK ? seq + 1 : next_chunk * JM_RECON_CHUNK;
-		uint32_t nblk, nk;
-		recon_tile(seqn * 8 + xcd, bpp, nblk, nk);
-		const bool more = nk < b.n_level_pics;
-		const jm_u2v dn = jm_desc_request_mb(b.desc + (more ? nk : k));
-		const JmReconDesc D = jm_desc_wait(dr);      /* (waits for both requests) */
-
-		/* ---- this tile ---- */
-		const int g = (int)(blk * JM_RECON_WG + tid);
-		const bool valid = g < 6 * b.g.mb_size;
-		JmLoc Q;
-		jm_recon_where(b.g, valid ? g : 0, Q);
-		Q.rw = rw;
-		/* the stream's quantiser matrices: 128 contiguous bytes, eight 16-byte loads */
-		uint4 tq = make_uint4(0, 0, 0, 0);
-		if (tid < 8) tq = reinterpret_cast<const uint4 *>(D.qm)[tid];
-		JmReconCtx c;
-		c.g = b.g;
-		c.mb = D.mb;
-		c.tok = D.tok;
-		c.has_fwd = D.fwd != nullptr;
-		c.dst = D.dst;
-		c.fwd = c.has_fwd ? D.fwd : D.dst;
-		c.stale = D.stale;
-		c.qm = qm; c.zz = qm + 128;
-		c.epoch = b.epoch;
-		c.zero_uncovered = b.zero_uncovered;
-
-		/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the
-		 * loads; no branch around them, see recon_block.h -- lanes past the picture look at block 0 and are masked after) */
-		JmBlk B;
-		jm_recon_front(c, Q, B);
-		if (!valid) { B.idct = false; B.lowf = false; B.k00 = false; B.live = false; B.pred = false; B.cnt = 0; B.konst = 0; }
-		/* the next tile's records: in flight from here until just before this tile's stores; and, at the first tile of
-		 * a chunk, thread 0's ticket for the chunk after the next (spelled out: the compiler's wave-level atomic
-		 * optimisation would wait for the result on the spot) */
-		uint4_like_t rwn = recon_record(b, jm_desc_wait_mb(dn), more ? nblk : blk);
-		uint32_t drawn = 0;
-#ifndef JM_RECON_STATIC
-		if (first && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ticket), "v"(1u) : "memory");
-#endif
-		/* the blocks that need the transform, packed to the front of the workgroup's slots: first the ones
-		 * whose coefficients all lie in the top-left 4x4 (wavefronts that hold only those run the cheap
-		 * transform), then the rest */
-		const uint64_t needA = __ballot(B.idct && B.lowf), needB = __ballot(B.idct && !B.lowf);
-		const uint32_t beforeA = __builtin_amdgcn_mbcnt_hi((uint32_t)(needA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needA, 0));
-		const uint32_t beforeB = __builtin_amdgcn_mbcnt_hi((uint32_t)(needB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needB, 0));
-		if (lane == 0) wave_total[wave] = (uint32_t)__popcll(needA) | ((uint32_t)__popcll(needB) << 16);
-		if (tid < 8) reinterpret_cast<uint4 *>(qm)[tid] = tq;
-		__syncthreads();
-		uint32_t prior = 0, sum = 0;
-#pragma unroll
-		for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
-		const uint32_t totalA = __builtin_amdgcn_readfirstlane(sum & 0xffffu), total = totalA + __builtin_amdgcn_readfirstlane(sum >> 16);
-		const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : totalA + (prior >> 16) + beforeB;
-		LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
-		jm_recon_konst(c, B);
-		if (B.idct) jm_recon_scatter(c, B, mine);
-		if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
-		/* every load of this tile has been used: the next tile's records are taken out of flight (a load still pending
-		 * at the loop's back edge would make the compiler wait for everything at its first use) and the stores of the
-		 * tile before go out */
-		asm volatile("" : "+v"(rwn.x), "+v"(rwn.y), "+v"(rwn.z), "+v"(rwn.w));
-		rw = rwn;
-		if (Xlate.store) jm_recon_store(Blate, Xlate);
-		__syncthreads();
-		/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the
-		 * workgroup 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past
-		 * the last packed block skip it altogether */
-		for (uint32_t r0 = 0; r0 < total; r0 += JM_RECON_WG / 2) {
-			const uint32_t s0 = r0 + wave * 32;
-			if (s0 < total) {
-				int h = (int)(lane >> 5);
-				asm volatile("" : "+v"(h));      /* opaque: the per-lane premultiplier selects are made where they are used, not hoisted into 32 registers */
-				LdsSlot sl = { coef + (s0 + (lane & 31)) * JM_SLOT_HALVES };
-				if (s0 + 32 <= totalA) jm_recon_idct_pair<true>(sl, h);      /* wave-uniform */
-				else jm_recon_idct_pair<false>(sl, h);
-			}
+	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
+	const uint32_t totalA = sum & 0xffffu, total = totalA + (sum >> 16);
+	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : totalA + (prior >> 16) + beforeB;
+	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
+	jm_recon_konst(c, B);
+	if (B.idct) jm_recon_scatter(c, B, mine);
+	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
+	__syncthreads();
+	/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the workgroup
+	 * 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past the last
+	 * packed block skip it altogether */
+	for (uint32_t r0 = 0; r0 < total; r0 += JM_RECON_WG / 2) {
+		const uint32_t s0 = r0 + wave * 32;
+		if (s0 < total) {
+			LdsSlot sl = { coef + (s0 + (lane & 31)) * JM_SLOT_HALVES };
+			if (s0 + 32 <= totalA) jm_recon_idct_pair<true>(sl, (int)(lane >> 5));      /* wave-uniform */
+			else jm_recon_idct_pair<false>(sl, (int)(lane >> 5));
 		}
-#ifndef JM_RECON_STATIC
-		if (first && tid == 0) {
-			asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn));
-			next_ticket = drawn;
-		}
-#endif
-		__syncthreads();
-#ifndef JM_RECON_STATIC
-		if (first) after_next = __builtin_amdgcn_readfirstlane(next_ticket) + 2 * per_class;   /* rewritten only after two more barriers */
-#else
-		if (first) after_next = next_chunk + per_class;
-#endif
-		/* phase 3 */
-		JmPix X;
-		X.store = false;
-		if (valid) X = jm_recon_pixels(c, B, mine);
-		if (B.idct) mine.zero();             /* the slot is free again: the next tile's scatter comes after its set-up barrier */
-		if (!more) { if (X.store) jm_recon_store(B, X); break; }
-		Xlate = X; Blate.out = B.out; Blate.stride = B.stride;
-		blk = nblk; k = nk; seq = seqn;
-		if (++in_chunk == JM_RECON_CHUNK) { in_chunk = 0; next_chunk = after_next; }
 	}
+	__syncthreads();
+	/* phase 3 */
+	JmPix X;
+	X.store = false;
+	if (valid) X = jm_recon_pixels(c, B, mine);
+	if (X.store) jm_recon_store(B, X);
 }
-
-/* workgroups the GPU keeps resident: 4 per CU (LDS 37 KB, 121 VGPRs), 256 CUs */
-#define JM_RECON_RESIDENT 1024
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	if (b.n_level_pics == 0) return hipSuccess;
-	const uint32_t bpp = (uint32_t)(6 * b.g.mb_size + JM_RECON_WG - 1) / JM_RECON_WG;
+	JmTiles T;
+	jm_tiles_init(T, b.g);
 	const uint32_t groups = (b.n_level_pics + 7) / 8;
-	const uint64_t tiles = (uint64_t)groups * 8 * bpp;
-	static const uint32_t resident = getenv("JSMPEG_HIP_RECON_GRID") ? (uint32_t)atoi(getenv("JSMPEG_HIP_RECON_GRID")) & ~7u : JM_RECON_RESIDENT;   /* tuning only */
-	const uint64_t chunks = (tiles / 8 + JM_RECON_CHUNK - 1) / JM_RECON_CHUNK * 8;
-	const uint32_t grid = chunks < resident ? (uint32_t)chunks : resident;   /* both multiples of 8 */
-	hipLaunchKernelGGL(k_recon, dim3(grid), dim3(JM_RECON_WG), 0, st, b, bpp);
+	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), 0, st, b, T);
 	return hipGetLastError();
 }
 

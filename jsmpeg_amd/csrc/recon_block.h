@@ -224,6 +224,58 @@ JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) 
 	Q.rw = *reinterpret_cast<const uint4_like_t *>(mb + Q.mbaddr);
 }
 
+/* TILES.  A workgroup reconstructs a tile of TW x 4 blocks of ONE plane -- wavefront w takes block row 4 ty + w,
+ * lane l the block tx TW + l of it -- rather than 256 consecutive blocks of the block raster (one block row):
+ * the forward windows of four block rows overlap (vectors reach +-8 .. +-64 pixels, a block row is 8), so the
+ * cache lines one wavefront pulls into the CU's L1 serve the other three; with random vectors the kernel is bound
+ * by L1 misses in flight, not by HBM (tools/ubench_pred.hip: the 256 x 1 shape 0.73 ms, 60 x 4 0.62 ms for the
+ * luma of 640 pictures at +-32).  A wavefront still stores whole row pieces: TW x 8 contiguous bytes.
+ * TW = the plane's width in blocks split into the fewest pieces of at most 64. */
+#define JM_TILE_ROWS 4         /* block rows per tile: 4 (a wavefront per row; measured 1.09 ms per level) or 2 (two wavefronts side by side per row: 1.11) */
+struct JmTiles {
+	int tw_y, cols_y, rows_y;      /* luma: a wavefront's width in blocks, tile columns, tile rows */
+	int tw_c, cols_c, rows_c;      /* each chroma plane */
+	int per_picture;               /* cols_y * rows_y + 2 * cols_c * rows_c */
+};
+JM_HD void jm_tiles_init(JmTiles &T, const JmGeom &G) {
+	const int bw = 2 * G.mb_width, bh = 2 * G.mb_height, bwc = G.mb_width, bhc = G.mb_height;
+	const int wpr = 4 / JM_TILE_ROWS;                                  /* wavefronts side by side in a tile */
+	T.cols_y = (bw + 64 * wpr - 1) / (64 * wpr); T.tw_y = (bw + T.cols_y * wpr - 1) / (T.cols_y * wpr); T.rows_y = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
+	T.cols_c = (bwc + 64 * wpr - 1) / (64 * wpr); T.tw_c = (bwc + T.cols_c * wpr - 1) / (T.cols_c * wpr); T.rows_c = (bhc + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
+	T.per_picture = T.cols_y * T.rows_y + 2 * T.cols_c * T.rows_c;
+}
+/* lane `lane` of wavefront `wave` of tile `tile` of a picture: where its block is; false: no block (past the
+ * plane's edge or the wavefront's width) -- Q then describes a neighbouring block, so that every lane has loads to issue */
+JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int wave, int lane, JmLoc &Q) {
+	const int ny = T.cols_y * T.rows_y, nc = T.cols_c * T.rows_c;
+	const int wpr = 4 / JM_TILE_ROWS;
+	int pl = 0, t = tile, cols = T.cols_y, tw = T.tw_y;       /* pl: 0 luma, 1 / 2 the chroma planes in block-number order (block 4, block 5) */
+	if (tile >= ny) { pl = tile >= ny + nc ? 2 : 1; t = tile - ny - (pl - 1) * nc; cols = T.cols_c; tw = T.tw_c; }
+	const int ty = t / cols, tx = t - ty * cols;
+	int bx = (tx * wpr + wave % wpr) * tw + lane, by = ty * JM_TILE_ROWS + wave / wpr;
+	const int bw = pl ? G.mb_width : 2 * G.mb_width, bh = pl ? G.mb_height : 2 * G.mb_height;
+	const bool ok = lane < tw && bx < bw && by < bh;
+	/* a lane without a block looks at the nearest block that exists (its loads then coalesce with that lane's; all of
+	 * them looking at block 0 of the picture made one hot spot of it: 1.5 instead of 1.1 ms per level) */
+	if (lane >= tw) bx -= lane - (tw - 1);
+	if (bx >= bw) bx = bw - 1;
+	if (by >= bh) by = bh - 1;
+	if (pl == 0) {
+		Q.mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
+		Q.bnum = ((by & 1) << 1) | (bx & 1);
+		Q.stride = G.coded_width; Q.ph = G.coded_height;
+		Q.plane_off = 0;
+	} else {
+		Q.mbaddr = by * G.mb_width + bx;
+		Q.bnum = 3 + pl;
+		Q.stride = G.coded_width >> 1; Q.ph = G.coded_height >> 1;
+		/* frame layout Y | Cr | Cb; block 4 goes to the Cb plane, block 5 to Cr (mpeg1.c:1571) */
+		Q.plane_off = G.luma_bytes + (pl == 1 ? G.chroma_bytes : 0u);
+	}
+	Q.x0 = bx << 3; Q.y0 = by << 3;
+	return ok;
+}
+
 /* PHASE 1 (every lane, its own block): what the block holds, the token and prediction loads. */
 JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	const int bnum = Q.bnum, x0 = Q.x0, y0 = Q.y0, stride = Q.stride, ph = Q.ph;
@@ -344,8 +396,9 @@ JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 
 /* PHASE 2: premultiply + 8x8 integer IDCT (mpeg1.c:1551, 1673-1740), in place in the block's slot: levels in,
  * residual out (int16).  TWO LANES PER BLOCK -- lane j and lane j + 32 of a wavefront, `h` = 0 / 1 -- so that a
- * lane holds 32 (not 64) live values: the kernel's register peak used to be this transform, and the registers it
- * frees are what lets the persistent loop keep the next tile's records in flight at four wavefronts per SIMD.
+ * lane holds 32 (not 64) live values and a workgroup's transform is spread over all four wavefronts (with one lane
+ * per block the packed blocks fill the first wavefronts and the others wait at the barrier): on the 4-row tiles
+ * 1.09 ms per level against 1.19 for the one-lane form (round 2).
  *   columns: lane h transforms columns 4h .. 4h+3 over all eight rows          v[r * 4 + c], r = 0..7, c = 0..3
  *   trade  : the upper lane's rows 0..3 for the lower lane's rows 4..7         (16 v_permlane32_swap_b32)
  *            -> row 4h + i = ( v[i * 4 + 0..3] , v[(i + 4) * 4 + 0..3] ) on both lanes
@@ -501,9 +554,7 @@ JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
-#if defined(JM_TMP_NO_STORE)
-		if (X.p[0] == 0x12345678u && X.p[3] == 0x9abcdef0u) { o[0] = 1; }
-#elif defined(__HIP_DEVICE_COMPILE__) && !defined(JM_TMP_PLAIN_STORE)
+#if defined(__HIP_DEVICE_COMPILE__)
 		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
 		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);
 #else

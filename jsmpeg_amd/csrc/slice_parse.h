@@ -136,6 +136,15 @@ JM_HD void jm_lane_refill(JmLane &L) {
 		const uint32_t ch = L.fillc + (uint32_t)i;
 		v[i] = L.es16[ch < target ? ch : target - 1];   /* unconditional (a chunk not needed re-reads the last one): no branch between the loads */
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* every loaded register is "used" here, on every path: the compiler places its wait for the loads HERE.  Without
+	 * it the waits sit inside the conditional ring writes below, the loads count as possibly pending ever after, and
+	 * every step of the turn loop starts with s_waitcnt vmcnt(0) -- which, loads and stores sharing one in-order
+	 * counter, also waits for every token / record store still on its way (measured in round 2: the wavefronts spent
+	 * 45 % of their time in waits) */
+#pragma unroll
+	for (int i = 0; i < JM_ES_RING_DW / 4; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+#endif
 #pragma unroll
 	for (int i = 0; i < JM_ES_RING_DW / 4; i++) {
 		const uint32_t ch = L.fillc + (uint32_t)i;

@@ -41,6 +41,7 @@ static void sim_idct_pair(HostSlot &s) {
 // kind, and lanes that were served in those turns.
 static int g_thr[JM_ST_KINDS] = { JM_T_COLD, 1, 1, 1, 1, 0 };   // experiments: the scheduler's COLD threshold
 static uint64_t g_idct[4];         // reconstruct: low-frequency / other blocks through the transform, wavefronts that run the cheap / any transform
+static uint64_t g_blocks_seen;
 static uint64_t g_picks;           // turns (scheduling decisions)
 static uint64_t g_cost;            // cost model: instructions issued by the wavefronts
 static int g_kcost[JM_ST_KINDS + 1] = { 430, 60, 95, 110, 270, 0, 50 };   // per handler; [KINDS] = per turn
@@ -198,20 +199,25 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			uint8_t qm[128];
 			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
 			c.qm = qm; c.zz = luts.zigzag; c.epoch = epoch; c.zero_uncovered = 1;
-			// k_recon, one emulated 256-lane workgroup at a time: front, rank the blocks that need the
-			// transform, scatter into the packed slots, transform slots [0, total), back
+			// k_recon, one emulated 256-lane workgroup (a tile of TW x 4 blocks of one plane) at a time: front, rank the
+			// blocks that need the transform, scatter into the packed slots, transform slots [0, total), back
 			static HostSlot slots[256];
 			static JmBlk B[256];
-			for (int g0 = 0; g0 < 6 * g.mb_size; g0 += 256) {
+			JmTiles T;
+			jm_tiles_init(T, g);
+			for (int tile = 0; tile < T.per_picture; tile++) {
 				int rank[256], totalA = 0, totalB = 0;
+				bool valid[256];
 				for (int l = 0; l < 256; l++) {
 					slots[l].zero();
 					B[l].idct = false; B[l].lowf = false; B[l].k00 = false; B[l].live = false;
-					if (g0 + l < 6 * g.mb_size) {
-						JmLoc Q;
-						jm_recon_locate(c.g, c.mb, g0 + l, Q);
+					JmLoc Q;
+					valid[l] = jm_recon_where_tile(c.g, T, tile, l >> 6, l & 63, Q);
+					if (valid[l]) {
+						Q.rw = *reinterpret_cast<const uint4_like_t *>(c.mb + Q.mbaddr);
 						jm_recon_front(c, Q, B[l]);
 						jm_recon_konst(c, B[l]);
+						g_blocks_seen++;
 					}
 					if (B[l].idct && B[l].lowf) totalA++; else if (B[l].idct) totalB++;
 				}
@@ -219,15 +225,17 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 				const int total = totalA + totalB;
 				g_idct[0] += (uint64_t)totalA; g_idct[1] += (uint64_t)totalB; g_idct[2] += (uint64_t)(totalA / 64); g_idct[3] += (uint64_t)((total + 63) / 64);
 				for (int l = 0; l < 256; l++) if (B[l].idct) jm_recon_scatter(c, B[l], slots[rank[l]]);
-				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_predict(B[l]);
+				for (int l = 0; l < 256; l++) if (valid[l]) jm_recon_predict(B[l]);
 				// the pair transform: lane j and lane j + 32 of a wavefront share a slot; a wavefront's 32 slots run the
 				// cheap transform when all of them are low-frequency blocks (same rule as the kernel)
 				for (int l = 0; l < total; l++) {
 					const bool low = (l / 32) * 32 + 32 <= totalA;
 					if (low) sim_idct_pair<true>(slots[l]); else sim_idct_pair<false>(slots[l]);
 				}
-				for (int l = 0; l < 256; l++) if (g0 + l < 6 * g.mb_size) jm_recon_back(c, B[l], slots[rank[l]]);
+				for (int l = 0; l < 256; l++) if (valid[l]) jm_recon_back(c, B[l], slots[rank[l]]);
 			}
+			if (g_blocks_seen != (uint64_t)6 * g.mb_size) return -3;   // the tiles cover every block of the picture exactly once
+			g_blocks_seen = 0;
 		}
 	int out = 0;
 	const size_t fb = (size_t)g.luma_bytes + 2 * g.chroma_bytes;

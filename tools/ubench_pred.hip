@@ -1,0 +1,94 @@
+/*
+ * Micro-benchmark of k_recon's prediction-row access pattern: one lane per 8x8 luma block of a 1920x1088 plane, 9 rows x
+ * 12 bytes from a dword-aligned address at (x0 + mvx, y0 + mvy), pseudo-random vectors per macroblock; the loads of a
+ * lane are issued (a) in row order, (b) rotated so that instruction j only touches absolute rows = j (mod 9) -- no two
+ * instructions of a wavefront touch the same cache line -- and (c) with all vectors zero.  Output: 8 bytes per lane per
+ * row (so the kernel has recon's read / write mix).  hipcc --offload-arch=gfx950 -O3 -o tools/ubench_pred tools/ubench_pred.hip
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE, bool STORE, int TW>
+__global__ __launch_bounds__(256) void k_pred(const uint8_t *src, uint8_t *dst, uint32_t frame_bytes, uint32_t n_frames, uint32_t range) {
+	const int W = 1920, H = 1088, BW = W / 8;
+	/* TW == 0: a workgroup is 256 consecutive blocks of the block raster (one block row); else: TW blocks wide x 4 block rows, one row per wavefront */
+	const uint32_t bpf = TW ? (uint32_t)((BW / TW) * (H / 8 / 4)) : (BW * (H / 8) + 255) / 256;
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t blk = q % bpf, f = (q / bpf) * 8 + xcd;
+	if (f >= n_frames) return;
+	int by, bx;
+	if (TW) {
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		if (lane >= TW) return;
+		const int tcols = BW / TW, ty = blk / tcols, tx = blk - ty * tcols;
+		by = ty * 4 + wave; bx = tx * TW + lane;
+	} else {
+		const int g = blk * 256 + threadIdx.x;
+		if (g >= BW * (H / 8)) return;
+		by = g / BW; bx = g - by * BW;
+	}
+	const uint32_t h = hash32((uint32_t)(f * 8160 + (by >> 1) * 120 + (bx >> 1)));
+	int mvx = MODE == 2 ? 0 : (int)(h % (2 * range + 1)) - (int)range, mvy = MODE == 2 ? 0 : (int)((h >> 12) % (2 * range + 1)) - (int)range;
+	int sx = bx * 8 + mvx, sy = by * 8 + mvy;
+	sx = sx < 0 ? 0 : (sx > W - 12 ? W - 12 : sx);
+	sy = sy < 0 ? 0 : (sy > H - 9 ? H - 9 : sy);
+	const uint8_t *fs = src + (size_t)f * frame_bytes;
+	const uint32_t off = (uint32_t)(sy * W + sx);
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(fs + (off & ~3u));
+	const int rot = MODE == 1 ? sy % 9 : 0;
+	uint32_t a0 = 0, a1 = 0;
+	uint32_t R[27];
+#pragma unroll
+	for (int j = 0; j < 9; j++) {
+		int r = j - rot; r += r < 0 ? 9 : 0;              /* MODE 1: absolute row sy + r = j (mod 9) */
+		const uint32_t *wr = w + r * (W / 4);
+		R[3 * j] = wr[0]; R[3 * j + 1] = wr[1]; R[3 * j + 2] = wr[2];
+	}
+#pragma unroll
+	for (int j = 0; j < 9; j++) { a0 ^= R[3 * j] + R[3 * j + 2]; a1 += R[3 * j + 1]; }
+	uint8_t *o = dst + (size_t)f * frame_bytes + (size_t)(by * 8) * W + bx * 8;
+	if (STORE) {
+#pragma unroll
+		for (int r = 0; r < 8; r++) { uint2 v = make_uint2(a0 + r, a1 ^ r); __builtin_nontemporal_store(v.x, (uint32_t *)(o + r * W)); __builtin_nontemporal_store(v.y, (uint32_t *)(o + r * W) + 1); }
+	} else if (a0 == 0x12345678u && a1 == 0x9abcdef0u) *(uint32_t *)o = 1;
+}
+
+template <int MODE, bool STORE, int TW>
+static void run(const char *name, const uint8_t *src, uint8_t *dst, uint32_t fb, uint32_t n, uint32_t range) {
+	const uint32_t bpf = TW ? (240 / TW) * (136 / 4) : (240 * 136 + 255) / 256, grid = ((n + 7) / 8) * 8 * bpf;
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	float best = 1e9f;
+	for (int rep = 0; rep < 3; rep++) {
+		CK(hipEventRecord(e0));
+		hipLaunchKernelGGL((k_pred<MODE, STORE, TW>), dim3(grid), dim3(256), 0, 0, src, dst, fb, n, range);
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+	}
+	printf("%-40s range %2u: %.3f ms  (%u luma planes: %.2f GB read-alg + %.2f GB written)\n", name, range, best, n, n * 2088960.0 / 1e9, STORE ? n * 2088960.0 / 1e9 : 0.0);
+}
+
+int main() {
+	const uint32_t fb = 1920 * 1088, n = 640;
+	uint8_t *src, *dst;
+	CK(hipMalloc(&src, (size_t)fb * n + 4096)); CK(hipMalloc(&dst, (size_t)fb * n + 4096));
+	CK(hipMemset(src, 7, (size_t)fb * n + 4096)); CK(hipMemset(dst, 0, (size_t)fb * n + 4096));
+	for (uint32_t range : { 8u, 16u, 32u }) {
+		run<0, true, 0>("256x1 row order, stores", src, dst, fb, n, range);
+		run<1, true, 0>("256x1 rotated, stores", src, dst, fb, n, range);
+		run<0, true, 60>("60x4 row order, stores", src, dst, fb, n, range);
+		run<1, true, 60>("60x4 rotated, stores", src, dst, fb, n, range);
+		run<0, false, 0>("256x1 row order, no stores", src, dst, fb, n, range);
+		run<1, false, 0>("256x1 rotated, no stores", src, dst, fb, n, range);
+		run<0, false, 60>("60x4 row order, no stores", src, dst, fb, n, range);
+		run<1, false, 60>("60x4 rotated, no stores", src, dst, fb, n, range);
+	}
+	run<2, true, 0>("256x1 zero vectors, stores", src, dst, fb, n, 0);
+	run<2, true, 60>("60x4 zero vectors, stores", src, dst, fb, n, 0);
+	run<2, false, 0>("256x1 zero vectors, no stores", src, dst, fb, n, 0);
+	return 0;
+}
