@@ -748,7 +748,9 @@ extern "C" void mpeg1_decoder_destroy(mpeg1_decoder_t *d) { dec_fail_cleanup(d);
 /* buffer.c:167-190 */
 static void store_evict(mpeg1_decoder_t *d, unsigned needed) {
 	unsigned byte_pos = d->index >> 3, available = d->capacity - d->length;
-	if (byte_pos == d->length || needed > available + byte_pos) {
+	/* a cursor at OR PAST the data (set_index with any value; the reference has the same arithmetic, buffer.c:167-190,
+	 * but only traps inside the wasm sandbox): nothing to keep */
+	if (byte_pos >= d->length || needed > available + byte_pos) {
 		d->length = 0; d->index = 0; d->codes.clear(); d->mirrored = 0;
 		return;
 	}
@@ -1035,14 +1037,15 @@ extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
 	if (k == d->codes.size()) { d->index = d->length << 3; return false; }
 	uint64_t bit = ((uint64_t)d->codes[k].pos + 4) * 8 + 10;
 	int type = (int)host_bits(d, bit, 3); bit += 3 + 16;
-	d->index = (unsigned)bit;
+	const uint64_t end_bits = (uint64_t)d->length << 3;          /* a chunk that ends inside a picture header: the cursor never passes the data (store_evict's arithmetic relies on it) */
+	d->index = (unsigned)std::min(bit, end_bits);
 	if (type <= 0 || type >= 3) return true;                       /* B, D, unknown: skipped */
 	int full_pel = 0, f_code = 0;
 	if (type == JM_PIC_PREDICTIVE) {
 		full_pel = (int)host_bits(d, bit, 1);
 		f_code = (int)host_bits(d, bit + 1, 3);
 		bit += 4;
-		d->index = (unsigned)bit;
+		d->index = (unsigned)std::min(bit, end_bits);
 		if (f_code == 0) return true;
 	}
 	/* next start code from the cursor; skip extension / user data; take the run of slices */
@@ -1052,8 +1055,11 @@ extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
 	while (j < d->codes.size() && d->codes[j].code >= JM_CODE_SLICE_FIRST && d->codes[j].code <= JM_CODE_SLICE_LAST) j++;
 	if (j > first) {
 		if (dec_picture_gpu(d, k, first, j, type, full_pel, f_code) != 0) {
-			fprintf(stderr, "jsmpeg_hip: decode failed: %s\n", g_err);
-			abort(); /* never silently hand back a stale picture */
+			/* a HIP error (allocation, device reset ...): never hand back a stale picture, never take the host process
+			 * down either.  false + the message in jsmpeg_hip_last_error(); the cursor goes back onto the picture's
+			 * start code so that the picture is not lost to a caller that can retry (the addon throws) */
+			d->index = d->codes[k].pos << 3;
+			return false;
 		}
 	} else d->cur ^= 1; /* a picture without slices still rotates the planes (mpeg1.c:986-994) */
 	/* cursor: rewound onto the code that ended the picture, or end of data (mpeg1.c:980-984) */

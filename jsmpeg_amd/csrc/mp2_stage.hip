@@ -537,7 +537,7 @@ extern "C" void *mp2_decoder_get_write_ptr(mp2_decoder_t *d, unsigned int n) {
 	if (n > d->capacity - d->length) {
 		if (d->mode == BIT_BUFFER_MODE_EVICT) {
 			const unsigned byte_pos = d->index >> 3, available = d->capacity - d->length;
-			if (byte_pos == d->length || n > available + byte_pos) { d->length = 0; d->index = 0; }
+			if (byte_pos >= d->length || n > available + byte_pos) { d->length = 0; d->index = 0; }   /* >= : a cursor past the data (set_index) must not reach the memmove below */
 			else if (byte_pos) {
 				memmove(d->bytes, d->bytes + byte_pos, d->length - byte_pos);
 				d->length -= byte_pos;

@@ -72,13 +72,53 @@
 		}                                                                    \
 	} while (0)
 
-static mpeg1_decoder_t *handle_arg(napi_env env, napi_value v) {
+/* What a decoder handle points at: the decoder and the plane views handed to JS.  The views are made ONCE per
+ * plane allocation and cached (a new external ArrayBuffer per decoded picture would pile up finalizers), they are
+ * detached when the decoder is destroyed (the pinned host planes are freed then: a late read by a renderer must
+ * see an empty view, not freed memory), and where the host forbids external buffers (V8 sandbox builds, Electron
+ * >= 21: napi_no_external_buffers_allowed) they are JS-owned buffers that every getPlanes() refreshes by a copy. */
+typedef struct {
+	mpeg1_decoder_t *d;
+	napi_ref views;              /* {y, cr, cb} or NULL */
+	void *views_ptr;             /* the Y pointer the cached views were made for */
+	size_t views_n;
+	int copied;                  /* the cached views own their memory: refresh by memcpy */
+	void *copy_dst[3];
+} dec_wrap_t;
+
+static dec_wrap_t *wrap_arg(napi_env env, napi_value v) {
 	void *p = NULL;
-	if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((dec_wrap_t *)p)->d) {
 		napi_throw_type_error(env, NULL, "jsmpeg_hip: bad decoder handle");
 		return NULL;
 	}
-	return (mpeg1_decoder_t *)p;
+	return (dec_wrap_t *)p;
+}
+static mpeg1_decoder_t *handle_arg(napi_env env, napi_value v) {
+	dec_wrap_t *w = wrap_arg(env, v);
+	return w ? w->d : NULL;
+}
+static void wrap_finalize(napi_env env, void *data, void *hint) {
+	(void)env; (void)hint;
+	dec_wrap_t *w = (dec_wrap_t *)data;
+	if (w->d) mpeg1_decoder_destroy(w->d);   /* a handle dropped without destroy() */
+	free(w);
+}
+/* forget the cached views; detach their buffers when they look at decoder memory */
+static void wrap_drop_views(napi_env env, dec_wrap_t *w) {
+	if (!w->views) return;
+	napi_value obj;
+	if (napi_get_reference_value(env, w->views, &obj) == napi_ok && obj && !w->copied) {
+		static const char *names[3] = { "y", "cr", "cb" };
+		for (int i = 0; i < 3; i++) {
+			napi_value view, ab;
+			void *data; size_t len, off; napi_typedarray_type t;
+			if (napi_get_named_property(env, obj, names[i], &view) == napi_ok &&
+			    napi_get_typedarray_info(env, view, &t, &len, &data, &ab, &off) == napi_ok) napi_detach_arraybuffer(env, ab);
+		}
+	}
+	napi_delete_reference(env, w->views);
+	w->views = NULL; w->views_ptr = NULL; w->views_n = 0; w->copied = 0;
 }
 
 static napi_value fn_create(napi_env env, napi_callback_info info) {
@@ -94,7 +134,14 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
 		napi_throw_error(env, NULL, jsmpeg_hip_last_error());
 		return NULL;
 	}
-	NAPI_OK(napi_create_external(env, d, NULL, NULL, &out));
+	dec_wrap_t *w = (dec_wrap_t *)calloc(1, sizeof(dec_wrap_t));
+	if (!w) { mpeg1_decoder_destroy(d); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
+	w->d = d;
+	if (napi_create_external(env, w, wrap_finalize, NULL, &out) != napi_ok) {
+		mpeg1_decoder_destroy(d); free(w);
+		napi_throw_error(env, NULL, "jsmpeg_hip: N-API call failed: napi_create_external");
+		return NULL;
+	}
 	return out;
 }
 
@@ -102,8 +149,11 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1];
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	mpeg1_decoder_t *d = handle_arg(env, argv[0]);
-	if (d) mpeg1_decoder_destroy(d);
+	dec_wrap_t *w = wrap_arg(env, argv[0]);
+	if (!w) return NULL;
+	wrap_drop_views(env, w);
+	mpeg1_decoder_destroy(w->d);
+	w->d = NULL;                 /* the wrapper itself goes with the handle (wrap_finalize) */
 	return NULL;
 }
 
@@ -182,37 +232,63 @@ static napi_value fn_decode(napi_env env, napi_callback_info info) {
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
 	mpeg1_decoder_t *d = handle_arg(env, argv[0]);
 	if (!d) return NULL;
-	NAPI_OK(napi_get_boolean(env, mpeg1_decoder_decode(d), &out));
+	const bool got = mpeg1_decoder_decode(d);
+	if (!got && jsmpeg_hip_last_error()[0]) {   /* a HIP failure, not "no complete picture buffered": loud, never a stale picture */
+		napi_throw_error(env, NULL, jsmpeg_hip_last_error());
+		return NULL;
+	}
+	NAPI_OK(napi_get_boolean(env, got, &out));
 	return out;
 }
 
-static napi_value plane_view(napi_env env, void *ptr, size_t len) {
+/* one plane as a Uint8Array: over the decoder's pinned host memory, or (external buffers forbidden) over a JS-owned
+ * copy whose address comes back in *copy_dst */
+static napi_value plane_view(napi_env env, void *ptr, size_t len, int *copied, void **copy_dst) {
 	napi_value ab, view;
-	if (napi_create_external_arraybuffer(env, ptr, len, NULL, NULL, &ab) != napi_ok) return NULL;
+	if (*copied || napi_create_external_arraybuffer(env, ptr, len, NULL, NULL, &ab) != napi_ok) {
+		napi_value pending;
+		bool is_pending = false;
+		if (napi_is_exception_pending(env, &is_pending) == napi_ok && is_pending) napi_get_and_clear_last_exception(env, &pending);
+		void *dst = NULL;
+		if (napi_create_arraybuffer(env, len, &dst, &ab) != napi_ok || !dst) return NULL;
+		memcpy(dst, ptr, len);
+		*copied = 1;
+		*copy_dst = dst;
+	}
 	if (napi_create_typedarray(env, napi_uint8_array, len, ab, 0, &view) != napi_ok) return NULL;
 	return view;
 }
 
-/* Views stay valid for the decoder's lifetime: the host planes are one pinned
- * allocation made when the sequence header is parsed and are refreshed in place
- * by every decode (the reference re-derives its heap views each call because
- * memory.grow can move them, mpeg1-wasm.js:109-116). */
+/* The views are cached for as long as the planes stay where they are: one pinned allocation made when the
+ * sequence header is parsed, refreshed in place by every decode (the reference re-derives its heap views each call
+ * because memory.grow can move them, mpeg1-wasm.js:109-116). */
 static napi_value fn_get_planes(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1], out, y, cr, cb;
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	mpeg1_decoder_t *d = handle_arg(env, argv[0]);
-	if (!d) return NULL;
+	dec_wrap_t *w = wrap_arg(env, argv[0]);
+	if (!w) return NULL;
+	mpeg1_decoder_t *d = w->d;
 	size_t n = (size_t)mpeg1_decoder_get_coded_size(d);
-	if (!n || !mpeg1_decoder_get_y_ptr(d)) { napi_get_null(env, &out); return out; }
-	y = plane_view(env, mpeg1_decoder_get_y_ptr(d), n);
-	cr = plane_view(env, mpeg1_decoder_get_cr_ptr(d), n >> 2);
-	cb = plane_view(env, mpeg1_decoder_get_cb_ptr(d), n >> 2);
+	void *py = mpeg1_decoder_get_y_ptr(d), *pcr = mpeg1_decoder_get_cr_ptr(d), *pcb = mpeg1_decoder_get_cb_ptr(d);
+	if (!n || !py) { napi_get_null(env, &out); return out; }
+	if (w->views && w->views_ptr == py && w->views_n == n && napi_get_reference_value(env, w->views, &out) == napi_ok && out) {
+		if (w->copied) { memcpy(w->copy_dst[0], py, n); memcpy(w->copy_dst[1], pcr, n >> 2); memcpy(w->copy_dst[2], pcb, n >> 2); }
+		return out;
+	}
+	wrap_drop_views(env, w);
+	int copied = 0;
+	y = plane_view(env, py, n, &copied, &w->copy_dst[0]);
+	cr = y ? plane_view(env, pcr, n >> 2, &copied, &w->copy_dst[1]) : NULL;
+	cb = cr ? plane_view(env, pcb, n >> 2, &copied, &w->copy_dst[2]) : NULL;
+	if (copied && y && !w->copy_dst[0]) { w->copy_dst[0] = NULL; }
 	if (!y || !cr || !cb) { napi_throw_error(env, NULL, "jsmpeg_hip: cannot create plane views"); return NULL; }
 	NAPI_OK(napi_create_object(env, &out));
 	NAPI_OK(napi_set_named_property(env, out, "y", y));
 	NAPI_OK(napi_set_named_property(env, out, "cr", cr));
 	NAPI_OK(napi_set_named_property(env, out, "cb", cb));
+	NAPI_OK(napi_create_reference(env, out, 1, &w->views));
+	w->views_ptr = py; w->views_n = n; w->copied = copied;
 	return out;
 }
 
@@ -460,13 +536,41 @@ static napi_value fn_last_error(napi_env env, napi_callback_info info) {
 
 /* ------------------------------------------------------------------ MP2 audio */
 
-static mp2_decoder_t *mp2_handle_arg(napi_env env, napi_value v) {
+/* the MP2 handle: the decoder and its cached {left, right} views (same rules as dec_wrap_t) */
+typedef struct {
+	mp2_decoder_t *d;
+	napi_ref views;
+	void *views_ptr;
+	int copied;
+	void *copy_dst;
+} mp2_wrap_t;
+static mp2_wrap_t *mp2_wrap_arg(napi_env env, napi_value v) {
 	void *p = NULL;
-	if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((mp2_wrap_t *)p)->d) {
 		napi_throw_type_error(env, NULL, "jsmpeg_hip: bad MP2 decoder handle");
 		return NULL;
 	}
-	return (mp2_decoder_t *)p;
+	return (mp2_wrap_t *)p;
+}
+static mp2_decoder_t *mp2_handle_arg(napi_env env, napi_value v) {
+	mp2_wrap_t *w = mp2_wrap_arg(env, v);
+	return w ? w->d : NULL;
+}
+static void mp2_wrap_finalize(napi_env env, void *data, void *hint) {
+	(void)env; (void)hint;
+	mp2_wrap_t *w = (mp2_wrap_t *)data;
+	if (w->d) mp2_decoder_destroy(w->d);
+	free(w);
+}
+static void mp2_wrap_drop_views(napi_env env, mp2_wrap_t *w) {
+	if (!w->views) return;
+	napi_value obj, view, ab;
+	void *data; size_t len, off; napi_typedarray_type t;
+	if (!w->copied && napi_get_reference_value(env, w->views, &obj) == napi_ok && obj &&
+	    napi_get_named_property(env, obj, "left", &view) == napi_ok &&
+	    napi_get_typedarray_info(env, view, &t, &len, &data, &ab, &off) == napi_ok) napi_detach_arraybuffer(env, ab);
+	napi_delete_reference(env, w->views);
+	w->views = NULL; w->views_ptr = NULL; w->copied = 0;
 }
 
 static napi_value fn_mp2_create(napi_env env, napi_callback_info info) {
@@ -481,7 +585,14 @@ static napi_value fn_mp2_create(napi_env env, napi_callback_info info) {
 		napi_throw_error(env, NULL, jsmpeg_hip_last_error());   /* no GPU: there is no CPU decoder behind this class */
 		return NULL;
 	}
-	NAPI_OK(napi_create_external(env, d, NULL, NULL, &out));
+	mp2_wrap_t *w = (mp2_wrap_t *)calloc(1, sizeof(mp2_wrap_t));
+	if (!w) { mp2_decoder_destroy(d); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
+	w->d = d;
+	if (napi_create_external(env, w, mp2_wrap_finalize, NULL, &out) != napi_ok) {
+		mp2_decoder_destroy(d); free(w);
+		napi_throw_error(env, NULL, "jsmpeg_hip: N-API call failed: napi_create_external");
+		return NULL;
+	}
 	return out;
 }
 
@@ -489,8 +600,11 @@ static napi_value fn_mp2_destroy(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1];
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
-	if (d) mp2_decoder_destroy(d);
+	mp2_wrap_t *w = mp2_wrap_arg(env, argv[0]);
+	if (!w) return NULL;
+	mp2_wrap_drop_views(env, w);
+	mp2_decoder_destroy(w->d);
+	w->d = NULL;
 	return NULL;
 }
 
@@ -557,16 +671,32 @@ static napi_value fn_mp2_get_channels(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1], out, ab, left, right;
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	mp2_decoder_t *d = mp2_handle_arg(env, argv[0]);
-	if (!d) return NULL;
-	float *l = (float *)mp2_decoder_get_left_channel_ptr(d), *r = (float *)mp2_decoder_get_right_channel_ptr(d);
+	mp2_wrap_t *w = mp2_wrap_arg(env, argv[0]);
+	if (!w) return NULL;
+	float *l = (float *)mp2_decoder_get_left_channel_ptr(w->d), *r = (float *)mp2_decoder_get_right_channel_ptr(w->d);
 	if (!l || r != l + 1152) { napi_throw_error(env, NULL, "jsmpeg_hip: no PCM buffer"); return NULL; }
-	NAPI_OK(napi_create_external_arraybuffer(env, l, 2 * 1152 * sizeof(float), NULL, NULL, &ab));
+	const size_t bytes = 2 * 1152 * sizeof(float);
+	if (w->views && w->views_ptr == (void *)l && napi_get_reference_value(env, w->views, &out) == napi_ok && out) {
+		if (w->copied) memcpy(w->copy_dst, l, bytes);
+		return out;
+	}
+	mp2_wrap_drop_views(env, w);
+	int copied = 0;
+	if (napi_create_external_arraybuffer(env, l, bytes, NULL, NULL, &ab) != napi_ok) {
+		napi_value pending;
+		bool is_pending = false;
+		if (napi_is_exception_pending(env, &is_pending) == napi_ok && is_pending) napi_get_and_clear_last_exception(env, &pending);
+		NAPI_OK(napi_create_arraybuffer(env, bytes, &w->copy_dst, &ab));
+		memcpy(w->copy_dst, l, bytes);
+		copied = 1;
+	}
 	NAPI_OK(napi_create_typedarray(env, napi_float32_array, 1152, ab, 0, &left));
 	NAPI_OK(napi_create_typedarray(env, napi_float32_array, 1152, ab, 1152 * sizeof(float), &right));
 	NAPI_OK(napi_create_object(env, &out));
 	NAPI_OK(napi_set_named_property(env, out, "left", left));
 	NAPI_OK(napi_set_named_property(env, out, "right", right));
+	NAPI_OK(napi_create_reference(env, out, 1, &w->views));
+	w->views_ptr = l; w->copied = copied;
 	return out;
 }
 

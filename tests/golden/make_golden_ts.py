@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import ts_craft  # noqa: E402
 from jsmpeg_amd import build, cabi  # noqa: E402
+from oracle import checkers
 
 
 def main():
@@ -37,7 +38,7 @@ def main():
             ref = json.loads(subprocess.check_output(["node", os.path.join(ROOT, "oracle", "ref_node_ts.js"), f.name]))
         finally:
             os.unlink(f.name)
-        es, writes = cabi.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
+        es, writes = checkers.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
         mine = [dict(pts=p, length=int(n), md5=hashlib.md5(es[o:o + n].tobytes()).hexdigest()) for p, o, n in writes]
         assert len(mine) == len(ref["writes"]), (name, len(mine), len(ref["writes"]))
         for a, b in zip(mine, ref["writes"]):

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from jsmpeg_amd import cabi, mp2, synth
+from oracle import checkers
 from mp2_util import FIXTURES, FIXTURE_IDS, frame_md5, load_case, same_bits
 
 pytestmark = pytest.mark.gpu
@@ -162,7 +163,7 @@ def test_batch_ts_in_audio_and_video_from_the_same_buffers(hip_lib, libs):
         for p, info in enumerate(vb.pictures()):
             per_stream.setdefault(info.stream, []).append(int(dev[p]))
         for s, (tsb, es, fx, data) in enumerate(cases):
-            want_bytes, want_writes = cabi.oracle_ts_demux(libs["oracle"], tsb, 0xC0)
+            want_bytes, want_writes = checkers.oracle_ts_demux(libs["oracle"], tsb, 0xC0)
             got_writes = ab.ts_writes(s)
             assert [(w[1], w[2]) for w in got_writes] == [(w[1], w[2]) for w in want_writes]
             assert all(abs(g[0] - w[0]) < 1e-9 for g, w in zip(got_writes, want_writes))

@@ -12,6 +12,7 @@ import pytest
 
 from conftest import ROOT
 from jsmpeg_amd import cabi, synth
+from oracle import checkers
 
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "rgba_*.json")))
 IDS = [os.path.basename(p)[5:-5] for p in FIXTURES]
@@ -32,7 +33,7 @@ def md5(a):
 def test_oracle_matches_reference_fixture(path, libs):
     fx, es, _ = load_case(path)
     frames, _, info = cabi.decode_stream(libs["oracle"], es, keep="planes")
-    got = [md5(cabi.oracle_rgba(libs["oracle"], y, cr, cb, info["width"], info["height"])) for y, cr, cb in frames]
+    got = [md5(checkers.oracle_rgba(libs["oracle"], y, cr, cb, info["width"], info["height"])) for y, cr, cb in frames]
     assert got == fx["rgba_md5"]
 
 
@@ -45,7 +46,7 @@ def test_oracle_odd_width_is_sheared_like_the_reference(libs):
     y = rng.integers(0, 256, cw * ch, dtype=np.uint8)
     cr = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
     cb = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
-    out = cabi.oracle_rgba(libs["oracle"], y, cr, cb, w, h).reshape(-1, 4)
+    out = checkers.oracle_rgba(libs["oracle"], y, cr, cb, w, h).reshape(-1, 4)
     cols, rows = w >> 1, h >> 1
     S = 2 * cols + w
     assert (out[:, 3] == 255).all()
@@ -72,7 +73,7 @@ def test_decoder_abi_render_rgba(path, hip_lib, libs):
             rgba = dec.render_rgba()
             if len(got) < 2:   # also against the restatement on the very planes this decoder returned
                 y, cr, cb = dec.planes()
-                assert np.array_equal(rgba, cabi.oracle_rgba(libs["oracle"], y, cr, cb, dec.width, dec.height))
+                assert np.array_equal(rgba, checkers.oracle_rgba(libs["oracle"], y, cr, cb, dec.width, dec.height))
             got.append(md5(rgba))
     assert got == fx["rgba_md5"]
 

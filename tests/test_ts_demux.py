@@ -13,6 +13,7 @@ import pytest
 import ts_craft
 from conftest import ROOT
 from jsmpeg_amd import cabi, hashing, synth
+from oracle import checkers
 
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ts_*.json")))
 IDS = [os.path.basename(p)[3:-5] for p in FIXTURES]
@@ -34,7 +35,7 @@ def as_fixture_writes(es, writes):
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
 def test_oracle_matches_reference_fixture(path, libs):
     fx, ts = load_case(path)
-    es, writes = cabi.oracle_ts_demux(libs["oracle"], ts, fx["stream_id"])
+    es, writes = checkers.oracle_ts_demux(libs["oracle"], ts, fx["stream_id"])
     assert as_fixture_writes(es, writes) == fx["writes"]
 
 
@@ -42,7 +43,7 @@ def test_oracle_feeds_the_decoder_like_ts_js(libs):
     """The demuxed bytes are the elementary stream: decoding them gives the stream's golden frames."""
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_cfg0_240p_intra.json")))
     es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
-    got, writes = cabi.oracle_ts_demux(libs["oracle"], synth.mux_ts(es, offs), 0xE0)
+    got, writes = checkers.oracle_ts_demux(libs["oracle"], synth.mux_ts(es, offs), 0xE0)
     assert len(writes) == fx["n_frames"]
     frames, _, _ = cabi.decode_stream(libs["oracle"], got)
     assert frames == fx["frame_md5"]
@@ -78,7 +79,7 @@ def test_ts_in_planes_out(hip_lib, libs):
         es, offs = synth.generate_config("cfg1_720p", n_frames=13, stream=s, width=352, height=288)
         ts = synth.mux_ts(es, offs)
         streams.append(ts)
-        demuxed, writes = cabi.oracle_ts_demux(libs["oracle"], ts, 0xE0)
+        demuxed, writes = checkers.oracle_ts_demux(libs["oracle"], ts, 0xE0)
         assert len(writes) == 13
         frames, _, _ = cabi.decode_stream(libs["oracle"], demuxed, keep="planes")
         want.append([hashing.frame_hash(*f) for f in frames])

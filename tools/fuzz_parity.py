@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jsmpeg_amd import batch as jb, build, cabi, hashing, synth  # noqa: E402
+from oracle import checkers
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -49,7 +50,7 @@ for c in range(cases):
             if [int(dev[p]) for p in per.get(s, [])] != [hashing.frame_hash(*f) for f in want[s]]:
                 ok = False; why.append("batch stream %d" % s)
         p_last = per[0][-1]
-        if not np.array_equal(b.read_rgba(p_last), cabi.oracle_rgba(build.LIB_ORACLE, *want[0][-1], ov["width"], ov["height"])):
+        if not np.array_equal(b.read_rgba(p_last), checkers.oracle_rgba(build.LIB_ORACLE, *want[0][-1], ov["width"], ov["height"])):
             ok = False; why.append("rgba")
     got, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], keep="planes")
     if len(got) != len(want_abi[0]) or any(not all(np.array_equal(a, bb) for a, bb in zip(x, y)) for x, y in zip(got, want_abi[0])):
@@ -65,7 +66,7 @@ for c in range(cases):
     tss = [synth.mux_ts(g[0], g[1]) for g in gen]
     want_ts = []
     for ts in tss:
-        demuxed, writes = cabi.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
+        demuxed, writes = checkers.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
         given = demuxed[:sum(w[2] for w in writes)]
         fr = cabi.decode_stream(build.LIB_ORACLE, given, keep="planes")[0] if len(given) else []
         want_ts.append([hashing.frame_hash(*f) for i, f in enumerate(fr) if i == 0 or not (ov["syntax_quirks"] & 2) or not all(np.array_equal(a, bb) for a, bb in zip(f, fr[i - 1]))])

@@ -4,10 +4,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jsmpeg_amd import build, cabi, synth
+from oracle import checkers
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 es, offs = synth.generate_config("cfg2_1080p", n_frames=3)
 frames, _, info = cabi.decode_stream(build.LIB_ORACLE, es, keep="planes")
-want = [cabi.oracle_rgba(build.LIB_ORACLE, y, cr, cb, 1920, 1080) for y, cr, cb in frames]
+want = [checkers.oracle_rgba(build.LIB_ORACLE, y, cr, cb, 1920, 1080) for y, cr, cb in frames]
 bad = 0
 for r in range(reps):
     with cabi.Mpeg1Decoder(build.LIB_HIP, len(es) + 1024, cabi.MODE_EXPAND) as dec:
