@@ -173,8 +173,10 @@ int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *ho
  * [4] total.  Valid after jsmpeg_hip_batch_sync. */
 int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
 /* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
- * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture. */
-int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[6]);
+ * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture,
+ * [6] pictures with macroblocks the stream never writes (they keep the decoded
+ * picture before last, see part 4), [7] reserved. */
+int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]);
 
 /* ------------------------------------------------------------------ part 3
  * MP2 audio (MPEG-1 Audio Layer II) -- the sibling decoder of the reference's
@@ -255,6 +257,54 @@ int jsmpeg_hip_mp2_batch_read_pcm(jsmpeg_hip_mp2_batch_t *b, uint32_t stream, ui
 /* hipEvent timings of the last decode, milliseconds: [0] frame walk + count read-back, [1] host turn-around +
  * side information, [2] sample read + matrixing, [3] windowing, [4] total. */
 int jsmpeg_hip_mp2_batch_timings(jsmpeg_hip_mp2_batch_t *b, float out_ms[5]);
+
+/* ------------------------------------------------------------------ part 4
+ * (stream, GOP) shards across the GPUs of one node (additive: the reference is one single-threaded
+ * decoder, its nearest relative is the relay that fans a stream out, websocket-relay.js:42-48).  Closed GOPs decode
+ * independently -- an I picture is all intra, there are no B pictures, a P picture references the picture before it
+ * -- so the one exchange step of the path moves compressed bytes: the rank that holds the streams sends every rank
+ * the units it owns (RCCL over xGMI), each rank decodes its piece with its own jsmpeg_hip_batch_t as that many
+ * independent streams.
+ * One difference to decoding the whole stream in one piece exists and is inherent to the reference's plane rotation
+ * (mpeg1.c:986-994): a macroblock a picture never writes keeps showing the decoded picture BEFORE LAST; for the first
+ * two pictures of a unit that picture belongs to the GOP before, which the unit's decoder never saw (it shows zeros,
+ * like the reference fed the unit alone).  jsmpeg_hip_batch_counters()[6] counts the pictures with such macroblocks. */
+
+typedef struct jsmpeg_hip_gop_unit_t {
+	uint64_t offset, bytes;     /* byte range of the unit in the elementary stream */
+	uint32_t pictures;          /* picture start codes inside it */
+	uint32_t needs_header;      /* 1: the stream's first sequence header must go in front (only the first one counts for
+	                               the reference, mpeg1.js:32; a unit's own later header may differ and is ignored) */
+} jsmpeg_hip_gop_unit_t;
+
+/* Cuts one elementary stream (HOST memory) at its I pictures -- in front of the sequence / GOP headers glued to each.
+ * Returns the number of units (fills at most `cap`), >= 1; *header_offset / *header_bytes: the stream's first sequence
+ * header (0 / 0 if it has none: the stream is then one unit). */
+int jsmpeg_hip_split_gops(const uint8_t *es, uint64_t es_bytes, jsmpeg_hip_gop_unit_t *units, uint32_t cap,
+                          uint64_t *header_offset, uint64_t *header_bytes);
+/* Balanced assignment of n units (weights = compressed bytes) to `world` ranks: owner[i] = rank of unit i. */
+int jsmpeg_hip_plan_shards(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner);
+
+/* One RCCL communicator over the ranks of a job (one process per GPU).  The 128-byte id is made on one rank
+ * (jsmpeg_hip_dist_unique_id) and handed to the others by whatever launched them (torch.distributed, MPI, a file). */
+typedef struct jsmpeg_hip_dist_t jsmpeg_hip_dist_t;
+#define JSMPEG_HIP_DIST_ID_BYTES 128
+int jsmpeg_hip_dist_unique_id(void *id);
+jsmpeg_hip_dist_t *jsmpeg_hip_dist_create(int32_t rank, int32_t world, const void *id, int32_t device);   /* device: HIP ordinal, -1 = current */
+void jsmpeg_hip_dist_destroy(jsmpeg_hip_dist_t *d);
+int32_t jsmpeg_hip_dist_rank(jsmpeg_hip_dist_t *d);
+int32_t jsmpeg_hip_dist_world(jsmpeg_hip_dist_t *d);
+/* The exchange step: piece r (offset[r], bytes[r]; the same arrays on every rank) of the packed DEVICE buffer
+ * `src_dev` on rank `src_rank` lands in rank r's DEVICE buffer `dst_dev`.  Grouped sends: the source's xGMI links
+ * carry their pieces at once.  Enqueued on `hip_stream` (void* hipStream_t).  Returns 0 or < 0. */
+int jsmpeg_hip_dist_scatter(jsmpeg_hip_dist_t *d, int32_t src_rank, const void *src_dev, const uint64_t *offset,
+                            const uint64_t *bytes, void *dst_dev, void *hip_stream);
+/* The reverse (set-up: streams that arrived on several ranks are collected where they are distributed from). */
+int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, const void *src_dev, const uint64_t *offset,
+                           const uint64_t *bytes, void *dst_dev, void *hip_stream);
+/* `bytes_per_rank` bytes from every rank to every rank (reporting: the 8-byte plane hashes). */
+int jsmpeg_hip_dist_allgather(jsmpeg_hip_dist_t *d, const void *src_dev, void *dst_dev, uint64_t bytes_per_rank,
+                              void *hip_stream);
 
 /* Last error of the calling thread ("" if none). */
 const char *jsmpeg_hip_last_error(void);

@@ -209,9 +209,10 @@ class Batch:
         return dict(index_ms=ms[0], host_ms=ms[1], parse_ms=ms[2], recon_ms=ms[3], total_ms=ms[4])
 
     def counters(self):
-        c = (ctypes.c_uint64 * 6)()
+        c = (ctypes.c_uint64 * 8)()
         self._ok(self.L.jsmpeg_hip_batch_counters(self.h, c))
-        return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5])
+        return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5],
+                    uncovered_pictures=c[6])
 
     @property
     def frame_pool_ptr(self):

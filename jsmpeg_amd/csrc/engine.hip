@@ -625,10 +625,11 @@ extern "C" int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]) 
 	return 0;
 }
 
-extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[6]) {
+extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]) {
 	if (!b) return fail("null batch");
 	out[0] = b->n_sc; out[1] = b->n_pics; out[2] = b->n_decoded; out[3] = b->n_levels; out[4] = b->n_slices;
 	out[5] = (uint64_t)b->g.mb_size;
+	out[6] = b->n_uncovered; out[7] = 0;
 	return 0;
 }
 

@@ -1,13 +1,135 @@
 """Multi-GPU plumbing of the decode path: independent
-(stream, GOP) units shard across ranks, there is no pixel exchange.  Two
-exchange steps exist and both are here, backend-agnostic (RCCL = "nccl" on the
-GPUs, "gloo" in the CPU tests):
-  scatter_shards  -- the rank that holds the compressed streams sends every
-                     rank its packed shard
-  gather_hashes   -- all-gather of the 8-byte per-picture plane hashes
-plus the host-side cutting of one elementary stream into closed-GOP units."""
+(stream, GOP) units shard across ranks, there is no pixel exchange.  The work
+is done by part 4 of the C ABI (include/jsmpeg_hip.h, csrc/shard.hip) -- the
+cut of an elementary stream at its closed GOPs, the balanced plan, and the
+RCCL exchange steps (scatter of the compressed units over xGMI, all-gather of
+the 8-byte plane hashes) -- this module is its ctypes face, plus numpy
+restatements of the cut and the plan that the tests hold the C code against.
+Control traffic between the ranks (the communicator id, barriers, the max of
+the timings) is the launcher's business (torch.distributed, any backend)."""
+import ctypes
+
 import numpy as np
 
+from . import batch as _batch
+
+
+class GopUnit(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("bytes", ctypes.c_uint64), ("pictures", ctypes.c_uint32),
+                ("needs_header", ctypes.c_uint32)]
+
+
+DIST_ID_BYTES = 128
+SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_dist_unique_id", "jsmpeg_hip_dist_create",
+                 "jsmpeg_hip_dist_destroy", "jsmpeg_hip_dist_rank", "jsmpeg_hip_dist_world", "jsmpeg_hip_dist_scatter",
+                 "jsmpeg_hip_dist_gather", "jsmpeg_hip_dist_allgather")
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = _batch.lib()
+    if not _bound:
+        u64p, u32p, vp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p
+        L.jsmpeg_hip_split_gops.restype = ctypes.c_int
+        L.jsmpeg_hip_split_gops.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(GopUnit), ctypes.c_uint32, u64p, u64p]
+        L.jsmpeg_hip_plan_shards.restype = ctypes.c_int
+        L.jsmpeg_hip_plan_shards.argtypes = [u64p, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.jsmpeg_hip_dist_unique_id.restype = ctypes.c_int
+        L.jsmpeg_hip_dist_unique_id.argtypes = [vp]
+        L.jsmpeg_hip_dist_create.restype = vp
+        L.jsmpeg_hip_dist_create.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32]
+        L.jsmpeg_hip_dist_destroy.restype = None
+        L.jsmpeg_hip_dist_destroy.argtypes = [vp]
+        for name in ("jsmpeg_hip_dist_scatter", "jsmpeg_hip_dist_gather"):
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [vp, ctypes.c_int32, vp, u64p, u64p, vp, vp]
+        L.jsmpeg_hip_dist_allgather.restype = ctypes.c_int
+        L.jsmpeg_hip_dist_allgather.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
+        _bound = True
+    return L
+
+
+def gop_units(es):
+    """The closed-GOP units of one elementary stream (host bytes) as the C ABI cuts them:
+    ([(offset, bytes, pictures, needs_header)], (header_offset, header_bytes))."""
+    L = _lib()
+    es = np.ascontiguousarray(es, dtype=np.uint8)
+    ho, hb = ctypes.c_uint64(), ctypes.c_uint64()
+    n = L.jsmpeg_hip_split_gops(es.ctypes.data, len(es), None, 0, ctypes.byref(ho), ctypes.byref(hb))
+    if n < 0:
+        raise RuntimeError(_batch.last_error())
+    units = (GopUnit * n)()
+    L.jsmpeg_hip_split_gops(es.ctypes.data, len(es), units, n, ctypes.byref(ho), ctypes.byref(hb))
+    return [(u.offset, u.bytes, u.pictures, u.needs_header) for u in units], (ho.value, hb.value)
+
+
+def split_gops_c(es):
+    """split_gops() through the C ABI: a list of independently decodable byte arrays."""
+    es = np.ascontiguousarray(es, dtype=np.uint8)
+    units, (ho, hb) = gop_units(es)
+    header = es[ho:ho + hb]
+    return [np.concatenate([header, es[o:o + n]]) if needs else es[o:o + n] for o, n, _, needs in units]
+
+
+def plan_shards_c(weights, world):
+    """plan_shards() through the C ABI: owner rank per unit."""
+    L = _lib()
+    w = (ctypes.c_uint64 * len(weights))(*[int(x) for x in weights])
+    owner = (ctypes.c_uint32 * len(weights))()
+    if L.jsmpeg_hip_plan_shards(w, len(weights), world, owner) != 0:
+        raise RuntimeError(_batch.last_error())
+    return list(owner)
+
+
+def unique_id():
+    """128 bytes that name a new communicator: made on one rank, handed to the others by the launcher."""
+    buf = (ctypes.c_uint8 * DIST_ID_BYTES)()
+    if _lib().jsmpeg_hip_dist_unique_id(buf) != 0:
+        raise RuntimeError(_batch.last_error())
+    return bytes(buf)
+
+
+class Dist:
+    """One RCCL communicator (jsmpeg_hip_dist_t).  Buffers are device pointers (ints), streams hipStream_t (ints)."""
+
+    def __init__(self, rank, world, uid, device=-1):
+        self.L = _lib()
+        self.rank, self.world = rank, world
+        buf = (ctypes.c_uint8 * DIST_ID_BYTES).from_buffer_copy(uid)
+        self.h = self.L.jsmpeg_hip_dist_create(rank, world, buf, device)
+        if not self.h:
+            raise RuntimeError("jsmpeg_hip_dist_create failed: " + _batch.last_error())
+
+    def close(self):
+        if self.h:
+            self.L.jsmpeg_hip_dist_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _arr(self, v):
+        return (ctypes.c_uint64 * self.world)(*[int(x) for x in v])
+
+    def scatter(self, src_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
+        if self.L.jsmpeg_hip_dist_scatter(self.h, src_rank, src_ptr, self._arr(offsets), self._arr(sizes), dst_ptr, stream) != 0:
+            raise RuntimeError(_batch.last_error())
+
+    def gather(self, dst_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
+        if self.L.jsmpeg_hip_dist_gather(self.h, dst_rank, src_ptr, self._arr(offsets), self._arr(sizes), dst_ptr, stream) != 0:
+            raise RuntimeError(_batch.last_error())
+
+    def allgather(self, src_ptr, dst_ptr, bytes_per_rank, stream=None):
+        if self.L.jsmpeg_hip_dist_allgather(self.h, src_ptr, dst_ptr, int(bytes_per_rank), stream) != 0:
+            raise RuntimeError(_batch.last_error())
+
+
+# ---- numpy restatements (what tests/test_distributed.py holds the C code against) ----
 
 def plan_shards(weights, world):
     """Greedy balanced assignment of units (weights = compressed bytes) to ranks;
@@ -84,16 +206,45 @@ def split_gops(es):
     return units
 
 
-def scatter_shards(dist, local_out, shards, src=0):
-    """`shards`: on rank `src` a list (one uint8 tensor per rank, equal length), else None.
-    Fills `local_out` on every rank."""
-    dist.scatter(local_out, shards if dist.get_rank() == src else None, src=src)
-    return local_out
+# ---- the job-level bookkeeping every rank computes alike (bench.py; tests/test_distributed.py runs it over gloo) ----
+
+def unit_table(streams_units):
+    """streams_units: for every stream of the JOB (global stream order) the list of its units' byte sizes (header
+    included where one is prepended).  Returns [(stream, gop, bytes)] in global unit order."""
+    return [(s, g, int(n)) for s, units in enumerate(streams_units) for g, n in enumerate(units)]
 
 
-def gather_hashes(dist, torch, local_hashes):
-    """local_hashes: int64 tensor (one per local picture, equal count on every
-    rank) -> list of tensors, one per rank."""
-    out = [torch.empty_like(local_hashes) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, local_hashes)
-    return out
+def layout_pieces(table, owner, world, gap=16):
+    """Where every unit sits inside its owner's piece (the packed buffer that rank receives and hands to
+    jsmpeg_hip_batch_upload_device as that many independent streams): 16-byte aligned begins, `gap` bytes of 0xff
+    between units.  Returns per rank dict(units=[global unit numbers, in order], begin, end, size)."""
+    pieces = [dict(units=[], begin=[], end=[], size=gap) for _ in range(world)]
+    for u, (_, _, n) in enumerate(table):
+        p = pieces[owner[u]]
+        off = (p["size"] + 15) & ~15
+        p["units"].append(u)
+        p["begin"].append(off)
+        p["end"].append(off + n)
+        p["size"] = off + n + gap
+    for p in pieces:
+        p["size"] = (p["size"] + 64 + 15) & ~15
+        p["begin"] = np.array(p["begin"], np.uint32)
+        p["end"] = np.array(p["end"], np.uint32)
+    return pieces
+
+
+def piece_offsets(pieces):
+    """Offsets and sizes of the pieces inside the source rank's packed buffer (piece after piece, 256-byte aligned)."""
+    offs, off = [], 0
+    for p in pieces:
+        offs.append(off)
+        off += (p["size"] + 255) & ~255
+    return offs, [p["size"] for p in pieces], off
+
+
+def fill_source(buf, pieces, offsets, unit_bytes):
+    """Writes every unit (unit_bytes[u]: uint8 array) to its place in the source buffer `buf` (numpy uint8, preset to
+    0xff by the caller)."""
+    for p, base in zip(pieces, offsets):
+        for u, b, e in zip(p["units"], p["begin"], p["end"]):
+            buf[base + int(b):base + int(e)] = unit_bytes[u]

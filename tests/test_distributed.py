@@ -1,8 +1,9 @@
-"""The N > 1 path on CPU: 2 processes, gloo.  Rank 0 holds every rank's packed
-compressed shard, scatters them (the exchange step RCCL does over xGMI on the
-GPUs), each rank "decodes" its shard -- here with the oracle standing in for
-the GPU, as the checker -- and the per-picture hashes are all-gathered.  The
-assembled result must equal decoding every stream on one rank."""
+"""The N > 1 path on CPU: 2 processes, gloo.  Every rank cuts its streams into closed-GOP units and the ranks agree
+on the job's unit table; the plan (C ABI) gives every unit an owner; rank 0 collects the compressed units and packs
+one piece per rank; the pieces travel (here torch.distributed send / recv over gloo stands in for the library's RCCL
+scatter, which needs GPUs); each rank decodes its piece as that many independent streams -- here with the oracle
+standing in for the GPU, as the checker -- and the per-picture hashes are all-gathered.  The assembled result must
+equal decoding every stream, whole, on one rank.  bench.py runs the same bookkeeping functions."""
 import os
 import socket
 import sys
@@ -14,7 +15,8 @@ from conftest import ROOT
 
 WORLD = 2
 STREAMS_PER_RANK = 2
-FRAMES = 6
+FRAMES = 12
+GOP = 4
 
 
 def _free_port():
@@ -25,63 +27,103 @@ def _free_port():
     return p
 
 
+def _streams_of(rank):
+    from jsmpeg_amd import synth
+    return [synth.generate_config("cfg1_720p", n_frames=FRAMES, stream=rank * STREAMS_PER_RANK + k, width=176, height=144,
+                                  gop=GOP)[0] for k in range(STREAMS_PER_RANK)]
+
+
 def _worker(rank, port, oracle_path, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from jsmpeg_amd import cabi, distributed as jd, hashing, synth
+    from jsmpeg_amd import cabi, distributed as jd, hashing
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
-        def streams_of(r):
-            return [synth.generate_config("cfg1_720p", n_frames=FRAMES, stream=r * STREAMS_PER_RANK + k,
-                                          width=176, height=144)[0] for k in range(STREAMS_PER_RANK)]
-        packs = [jd.pack_streams(streams_of(r)) for r in range(WORLD)]       # deterministic: same on every rank
-        max_len = max(len(p[0]) for p in packs)
-        shards = None
+        mine = [jd.split_gops_c(es) for es in _streams_of(rank)]                  # this rank's streams, cut by the C ABI
+        sizes = [None] * WORLD
+        dist.all_gather_object(sizes, [[len(u) for u in units] for units in mine])
+        table = jd.unit_table([units for r in sizes for units in r])             # the job's units, same on every rank
+        owner = jd.plan_shards_c([n for _, _, n in table], WORLD)
+        pieces = jd.layout_pieces(table, owner, WORLD)
+        offsets, psizes, total = jd.piece_offsets(pieces)
+        # collect on rank 0 (the library: jsmpeg_hip_dist_gather), pack, send every rank its piece (jsmpeg_hip_dist_scatter)
+        flat = np.concatenate([u for units in mine for u in units])
+        gathered = [None] * WORLD
+        dist.gather_object(flat, gathered if rank == 0 else None, dst=0)
+        piece = torch.empty(pieces[rank]["size"], dtype=torch.uint8)
         if rank == 0:
-            shards = []
-            for buf, _, _ in packs:
-                t = torch.full((max_len,), 0xFF, dtype=torch.uint8)
-                t[:len(buf)] = torch.from_numpy(buf)
-                shards.append(t)
-        mine = torch.empty(max_len, dtype=torch.uint8)
-        jd.scatter_shards(dist, mine, shards, src=0)
-        buf, begin, end = packs[rank]
-        assert np.array_equal(mine.numpy()[:len(buf)], buf), "scatter delivered the wrong shard"
-        local = []
-        for b, e in zip(begin, end):
-            frames, _, _ = cabi.decode_stream(oracle_path, mine.numpy()[int(b):int(e)], keep="planes")
-            local += [hashing.frame_hash(*f) for f in frames]
-        h = torch.from_numpy(np.array(local, dtype=np.uint64).view(np.int64))
-        gathered = jd.gather_hashes(dist, torch, h)
-        q.put((rank, [g.numpy().view(np.uint64).tolist() for g in gathered]))
+            unit_bytes, k = {}, 0
+            for r in range(WORLD):
+                pos = 0
+                for units in sizes[r]:
+                    for n in units:
+                        unit_bytes[k] = gathered[r][pos:pos + n]
+                        pos += n
+                        k += 1
+            src = np.full(total, 0xFF, dtype=np.uint8)
+            jd.fill_source(src, pieces, offsets, unit_bytes)
+            for r in range(1, WORLD):
+                dist.send(torch.from_numpy(src[offsets[r]:offsets[r] + psizes[r]].copy()), dst=r)
+            piece.copy_(torch.from_numpy(src[offsets[0]:offsets[0] + psizes[0]]))
+        else:
+            dist.recv(piece, src=0)
+        # decode the piece: every unit an independent stream
+        local = {}
+        for u, b, e in zip(pieces[rank]["units"], pieces[rank]["begin"], pieces[rank]["end"]):
+            frames, _, _ = cabi.decode_stream(oracle_path, piece.numpy()[int(b):int(e)], keep="planes")
+            local[u] = [hashing.frame_hash(*f) for f in frames]
+        everything = [None] * WORLD
+        dist.all_gather_object(everything, local)
+        merged = {}
+        for d in everything:
+            merged.update(d)
+        # reassemble per stream, in GOP order
+        per_stream = {}
+        for u, (s, g, _) in enumerate(table):
+            per_stream.setdefault(s, []).extend(merged[u])
+        q.put((rank, per_stream, [len(p["units"]) for p in pieces]))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_scatter_decode_gather(libs):
+def test_two_rank_gop_shards_decode_like_whole_streams(libs, hip_lib):
     import torch.multiprocessing as mp
-    from jsmpeg_amd import cabi, hashing, synth
+    from jsmpeg_amd import cabi, hashing
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, port, libs["oracle"], q)) for r in range(WORLD)]
     [p.start() for p in procs]
-    results = dict(q.get(timeout=180) for _ in range(WORLD))
+    results = [q.get(timeout=180) for _ in range(WORLD)]
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    want = []
+    want = {}
     for r in range(WORLD):
-        per_rank = []
-        for k in range(STREAMS_PER_RANK):
-            es, _ = synth.generate_config("cfg1_720p", n_frames=FRAMES, stream=r * STREAMS_PER_RANK + k,
-                                          width=176, height=144)
+        for k, es in enumerate(_streams_of(r)):
             frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
-            per_rank += [hashing.frame_hash(*f) for f in frames]
-        want.append(per_rank)
-    assert results[0] == want and results[1] == want
+            want[r * STREAMS_PER_RANK + k] = [hashing.frame_hash(*f) for f in frames]
+    for rank, per_stream, counts in results:
+        assert per_stream == want, "rank %d" % rank
+        assert sum(counts) == WORLD * STREAMS_PER_RANK * (FRAMES // GOP) and min(counts) > 0
+
+
+def test_c_abi_cut_and_plan_equal_the_numpy_restatements(hip_lib):
+    from jsmpeg_amd import distributed as jd, synth
+    for kw in (dict(gop=6, custom_quant=1), dict(gop=1), dict(gop=12)):
+        es, _ = synth.generate_config("cfg1_720p", n_frames=24, width=176, height=144, **kw)
+        a, b = jd.split_gops(es), jd.split_gops_c(es)
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+        units, (ho, hb) = jd.gop_units(es)
+        assert sum(u[2] for u in units) == 24 and hb > 0 and units[0][3] == 0
+    # no sequence header / nothing at all: one unit
+    assert len(jd.split_gops_c(np.zeros(0, np.uint8))) == 1
+    assert len(jd.split_gops_c(np.frombuffer(b"\x00\x00\x01\x00abcd", np.uint8))) == 1
+    w = [100, 90, 80, 10, 10, 10, 5, 5, 77, 3]
+    owner = jd.plan_shards_c(w, 3)
+    assert [[i for i in range(len(w)) if owner[i] == r] for r in range(3)] == jd.plan_shards(w, 3)
 
 
 def test_plan_shards_balances():

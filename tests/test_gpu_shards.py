@@ -1,0 +1,66 @@
+"""(stream, GOP) shards on the GPU (include/jsmpeg_hip.h part 4): the units the C ABI cuts decode,
+as independent streams of one batch, to the pictures of the whole streams; the RCCL exchange steps run with the ranks
+present (one: the 1-GPU box) -- the same calls bench.py makes with N ranks.  Needs an MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from jsmpeg_amd import batch as jb
+from jsmpeg_amd import cabi, distributed as jd, hashing, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gop_units_as_batch_streams_decode_like_the_whole_streams(hip_lib, libs):
+    """The GPU version of test_split_gops_units_decode_like_the_whole_stream: three streams (one with custom matrices in
+    later sequence headers, which every decoder must ignore) cut into closed-GOP units, all units in ONE batch as
+    independent streams, every picture against the oracle's decode of the whole stream."""
+    streams = [synth.generate_config("cfg1_720p", n_frames=30, width=352, height=288, stream=s, gop=6, custom_quant=s == 1)[0]
+               for s in range(3)]
+    units, owner_stream = [], []
+    for s, es in enumerate(streams):
+        for u in jd.split_gops_c(es):
+            units.append(u)
+            owner_stream.append(s)
+    assert len(units) == 15
+    want = []
+    for es in streams:
+        frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+        want.append([hashing.frame_hash(*f) for f in frames])
+    with jb.Batch(352, 288, len(units), 3 * 30 + 8, sum(len(u) for u in units) + 4096) as b:
+        b.upload(units)
+        assert b.decode() == 90
+        dev = b.frame_hashes()
+        got = {}
+        for p, info in enumerate(b.pictures()):
+            got.setdefault(owner_stream[info.stream], []).append(int(dev[p]))     # batch streams = units, in stream / GOP order
+        for s in range(3):
+            assert got[s] == want[s], "stream %d" % s
+        c = b.counters()
+        assert c["levels"] == 6 and c["uncovered_pictures"] == 0
+
+
+def test_rccl_exchange_steps_with_the_ranks_present(hip_lib):
+    """jsmpeg_hip_dist_*: communicator, scatter of the source rank's pieces, gather, all-gather -- world size 1 here (the
+    source's own piece is a device copy, the collectives run over one rank), so that every call and argument path of
+    the N-rank job is exercised on the hardware there is."""
+    import torch
+    dev = torch.device("cuda", 0)
+    uid = jd.unique_id()
+    assert len(uid) == jd.DIST_ID_BYTES
+    st = torch.cuda.current_stream()
+    sptr = ctypes.c_void_p(st.cuda_stream)
+    with jd.Dist(0, 1, uid, device=0) as d:
+        src = torch.arange(0, 1 << 20, dtype=torch.int32, device=dev).view(torch.uint8)
+        dst = torch.zeros(300000, dtype=torch.uint8, device=dev)
+        d.scatter(0, ctypes.c_void_p(src.data_ptr()), [4096], [300000], ctypes.c_void_p(dst.data_ptr()), sptr)
+        back = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        d.gather(0, ctypes.c_void_p(dst.data_ptr()), [8192], [300000], ctypes.c_void_p(back.data_ptr()), sptr)
+        h = torch.arange(100, dtype=torch.int64, device=dev)
+        allh = torch.zeros(100, dtype=torch.int64, device=dev)
+        d.allgather(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(allh.data_ptr()), 800, sptr)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src[4096:4096 + 300000])
+        assert torch.equal(back[8192:8192 + 300000], dst) and int(back[:8192].sum()) == 0
+        assert torch.equal(allh, h)
