@@ -7,11 +7,17 @@ the host cores in the same run.
 
 Workload at N=1: 64 concurrent 1920x1080 I+P
 streams (GOP 12, distinct seeds, ~15 Mbit/s) x 120 pictures, batched on one
-GPU.  At N>1 every rank decodes its own 64 streams (weak scaling: cfg3 = 512
-streams on 8 GPUs); the compressed streams live on rank 0 and are scattered to
-their ranks over RCCL/xGMI inside every timed step (the path's one data
-exchange); the per-frame 64-bit plane hashes are
-all-gathered once at the end of the job for the parity report.
+GPU.  At N>1 the job has 64 streams per GPU (weak scaling: cfg3 = 512 streams
+on 8 GPUs), cut into closed-GOP units (C ABI part 4) that a balanced plan
+spreads over the ranks; the compressed units live packed in rank 0's HBM and
+travel to their owners inside every timed step by the decode library's own
+RCCL communicator (grouped send / recv over xGMI -- the path's one data
+exchange), double-buffered so that the scatter of step
+k+1 runs beside the kernels of step k; every rank decodes its piece as that
+many independent streams; the per-picture 64-bit plane hashes are all-gathered
+once at the end of the job for the parity report.  torch.distributed (gloo)
+carries only control traffic: the communicator id, the unit table, barriers
+and the max of the timings.
 
 A step = one pass of the whole hot path over the resident batch: start-code
 index -> tables -> slice parse -> reconstruct of all 7680 pictures, planes left
@@ -124,7 +130,7 @@ def cpu_baseline(sample_streams, width, height):
                 res["value"] = round(r["fps"], 2)
                 res["wasm_note"] = "reference wasm build (jsmpeg.min.js) under Node %s, 1 core, median of 3" % r.get("node", "?")
                 nproc = os.cpu_count() or 1
-                par = min(nproc, 32)
+                par = nproc              # all cores = what nproc says on this box
                 t0 = time.perf_counter()
                 procs = [subprocess.Popen(["node", host, wasm, "--once", paths[i % len(paths)]],
                                           stdout=subprocess.PIPE) for i in range(par)]
@@ -151,8 +157,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true", help="skip the MP2 audio stage figure attached as audio_stage")
     ap.add_argument("--force-dist", action="store_true",
-                    help="testing: run the multi-rank code path (RCCL scatter / all-gather) with the ranks present, even one")
+                    help="testing: run the multi-rank code path (GOP units, RCCL scatter / all-gather) with the ranks present, even one")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the extra run that starts every step from host memory (value_incl_h2d)")
     args = ap.parse_args()
+    args.h2d = False
 
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner, ...) is sent to
     # stderr instead -- file descriptor 1 becomes stderr, the JSON goes to a duplicate of the original stdout
@@ -175,10 +183,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
+    D = None
     if multi:
+        # control plane (communicator id, sizes, barriers, the max of the timings): torch.distributed over gloo;
+        # data plane: the decode library's own RCCL communicator (include/jsmpeg_hip.h part 4)
+        from jsmpeg_amd import distributed as jd
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [jd.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        D = jd.Dist(rank, world, box[0], device=local_rank)
 
     cfg = synth.CONFIGS[CONFIG]
     width, height = cfg["width"], cfg["height"]
@@ -190,37 +205,75 @@ def main():
     streams = [g[0] for g in gen]
     stats = {k: sum(g[2][k] for g in gen) for k in gen[0][2]}
     es_bytes = sum(len(s) for s in streams)
-    packed, begin, end = pack(streams)
     log("rank %d: generated %d streams, %.1f MB ES, %.1f Mbit/s per stream @30, in %.1fs"
         % (rank, n_streams, es_bytes / 1e6, es_bytes * 8 / n_streams / frames * 30 / 1e6, time.perf_counter() - t0))
 
-    n_pictures = n_streams * frames
-    b = jb.Batch(width, height, n_streams, n_pictures + 8, len(packed) + 4096, device=local_rank)
     stream = torch.cuda.current_stream()
     sptr = ctypes.c_void_p(stream.cuda_stream)
-
-    # ---- residency: rank 0 holds every rank's packed streams in HBM; each step scatters them ----
-    shard_len = int(len(packed))
-    if multi:
-        lens = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(lens, torch.tensor([shard_len], dtype=torch.int64, device=dev))
-        max_len = int(max(int(x.item()) for x in lens))
-        mine = torch.full((max_len,), 0xFF, dtype=torch.uint8, device=dev)
-        mine[:shard_len] = torch.from_numpy(packed).to(dev)
-        if rank == 0:
-            all_shards = [torch.empty(max_len, dtype=torch.uint8, device=dev) for _ in range(world)]
-            dist.gather(mine, all_shards, dst=0)
-        else:
-            all_shards = None
-            dist.gather(mine, None, dst=0)
-        d_es = [torch.empty(max_len, dtype=torch.uint8, device=dev) for _ in range(2)]   # double-buffered receive
-    else:
+    exchange = None
+    if not multi:
+        packed, begin, end = pack(streams)
+        n_pictures = n_streams * frames
+        b = jb.Batch(width, height, n_streams, n_pictures + 8, len(packed) + 4096, device=local_rank)
         d_es = torch.from_numpy(packed).to(dev)
-    hashes_dev = torch.zeros(n_pictures, dtype=torch.int64, device=dev)
+        shard_len = int(len(packed))
+        if args.h2d:
+            h_es = torch.from_numpy(packed).pin_memory()
+    else:
+        # ---- the job's (stream, GOP) units: every rank cuts its streams (C ABI), all agree on the table, the plan
+        # gives every unit an owner, rank 0 collects the compressed units and packs one piece per rank ----
+        my_units = [jd.split_gops_c(es) for es in streams]
+        my_pics = [[u[2] for u in jd.gop_units(es)[0]] for es in streams]
+        info_all = [None] * world
+        dist.all_gather_object(info_all, ([[len(u) for u in units] for units in my_units], my_pics))
+        table = jd.unit_table([units for r in info_all for units in r[0]])
+        unit_pics = [n for r in info_all for pics in r[1] for n in pics]
+        owner = jd.plan_shards_c([n for _, _, n in table], world)
+        pieces = jd.layout_pieces(table, owner, world)
+        offsets, psizes, src_total = jd.piece_offsets(pieces)
+        flat_len = [sum(n for units in r[0] for n in units) for r in info_all]
+        flat_off, acc = [], 0
+        for n in flat_len:
+            flat_off.append(acc)
+            acc += (n + 255) & ~255
+        d_flat = torch.from_numpy(np.concatenate([u for units in my_units for u in units])).to(dev)
+        d_collect = torch.empty(max(acc, 1), dtype=torch.uint8, device=dev) if rank == 0 else None
+        D.gather(0, ctypes.c_void_p(d_flat.data_ptr()), flat_off, flat_len,
+                 ctypes.c_void_p(d_collect.data_ptr()) if rank == 0 else None, sptr)
+        torch.cuda.synchronize()
+        d_src = None
+        if rank == 0:
+            host = d_collect.cpu().numpy()
+            unit_bytes, u = {}, 0
+            for r in range(world):
+                pos = flat_off[r]
+                for units in info_all[r][0]:
+                    for n in units:
+                        unit_bytes[u] = host[pos:pos + n]
+                        pos += n
+                        u += 1
+            src = np.full(src_total, 0xFF, dtype=np.uint8)
+            jd.fill_source(src, pieces, offsets, unit_bytes)
+            d_src = torch.from_numpy(src).to(dev)          # resident in the source rank's HBM before the timed region
+            del host, src, unit_bytes
+        del d_flat, d_collect
+        mine = pieces[rank]
+        begin, end = mine["begin"], mine["end"]
+        n_units = len(mine["units"])
+        n_pictures = sum(unit_pics[u] for u in mine["units"])
+        shard_len = int(mine["size"])
+        b = jb.Batch(width, height, max(1, n_units), n_pictures + 8, shard_len + 4096, device=local_rank)
+        d_piece = [torch.empty(shard_len, dtype=torch.uint8, device=dev) for _ in range(2)]   # double-buffered receive
+        xfer = torch.cuda.Stream(device=dev)               # the exchange runs beside the decode kernels
+        xptr = ctypes.c_void_p(xfer.cuda_stream)
+        exchange = {"units": len(table), "units_this_rank": n_units, "bytes_leaving_rank0_per_step": int(sum(psizes[1:])),
+                    "scatter_ms": []}
+        log("rank %d: %d of %d units, %d pictures, piece %.1f MB" % (rank, n_units, len(table), n_pictures, shard_len / 1e6))
     torch.cuda.synchronize()
 
     phase = {"index_ms": 0.0, "host_ms": 0.0, "parse_ms": 0.0, "recon_ms": 0.0, "total_ms": 0.0}
     levels = 0
+    h2d_ms = []
 
     if not multi:
         # inputs resident in HBM before the timed region: the batch's own ES buffer
@@ -230,23 +283,41 @@ def main():
     state = {"cur": 0, "pending": None}
 
     def start_scatter(i):
-        # the path's one exchange step: compressed stream shards, rank 0 -> owners, RCCL over xGMI
-        return dist.scatter(d_es[i], all_shards if rank == 0 else None, src=0, async_op=True)
+        # the path's one exchange step: the compressed units, rank 0 -> owners, grouped RCCL send / recv over xGMI
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        xfer.wait_stream(stream)
+        e0.record(xfer)
+        D.scatter(0, ctypes.c_void_p(d_src.data_ptr()) if rank == 0 else None, offsets, psizes,
+                  ctypes.c_void_p(d_piece[i].data_ptr()), xptr)
+        e1.record(xfer)
+        return e0, e1
 
     def step(collect, more):
-        """One pass of the hot path.  Multi-rank: this step's shard arrives by RCCL scatter; the NEXT step's scatter
-        (`more`: there is one inside the same timed region) is started as soon as this step's shard has been handed to
-        the decoder, so it travels over xGMI while the kernels of this step run."""
+        """One pass of the hot path.  Multi-rank: this step's piece arrives by the library's RCCL scatter; the NEXT step's
+        scatter (`more`: there is one inside the same timed region) is started as soon as this step's piece has been
+        handed to the decoder, so it travels over xGMI while the kernels of this step run."""
         nonlocal levels
         if multi:
             if state["pending"] is None:
                 state["pending"] = start_scatter(state["cur"])
-            state["pending"].wait()
-            b.upload_device(ctypes.c_void_p(d_es[state["cur"]].data_ptr()), shard_len, begin, end, sptr)
+            e0, e1 = state["pending"]
+            stream.wait_event(e1)
+            b.upload_device(ctypes.c_void_p(d_piece[state["cur"]].data_ptr()), shard_len, begin, end, sptr)   # returns when the piece has been copied
+            if collect:
+                exchange["scatter_ms"].append(e0.elapsed_time(e1))
             state["pending"] = None
             if more and overlap:
                 state["cur"] ^= 1
                 state["pending"] = start_scatter(state["cur"])
+        elif args.h2d:
+            # the variant that starts from HOST memory: one pinned copy of the packed streams per step (PCIe), then the same path
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            d_es.copy_(h_es, non_blocking=True)
+            b.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sptr)
+            e1.record()
+            if collect:
+                h2d_ms.append((e0, e1))
         n = b.decode(stream=sptr, sync=False)
         if n != n_pictures:
             raise SystemExit("rank %d: decoded %d pictures, expected %d" % (rank, n, n_pictures))
@@ -256,51 +327,93 @@ def main():
                 phase[k] += t[k]
             levels = b.counters()["levels"]
 
-    for i in range(args.warmup):
-        step(False, i + 1 < args.warmup)     # nothing is prefetched across the warm-up / timed boundary
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(True, i + 1 < args.steps)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_run(steps, warmup):
+        for i in range(warmup):
+            step(False, i + 1 < warmup)      # nothing is prefetched across the warm-up / timed boundary
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(True, i + 1 < steps)
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if multi:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    # ---- parity gate: frames of this rank's stream 0 against the oracle (checker only) ----
+    elapsed = timed_run(args.steps, args.warmup)
+    uncovered = b.counters()["uncovered_pictures"]
+
+    # ---- parity gate against the oracle (checker only) ----
     dev_hashes = b.frame_hashes()
-    if multi:
-        # exchange step 2 (reporting, once per job, outside the timed steps): 8 bytes per picture to every rank
-        h = torch.from_numpy(dev_hashes.view(np.int64).copy()).to(dev)
-        gathered = [torch.empty_like(h) for _ in range(world)]
-        dist.all_gather(gathered, h)
     infos = b.pictures()
     lib_oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
-    # every stream of the rank: the oracle decodes them on the host cores in parallel threads (the library releases the GIL)
     per_stream = {}
     for p, i in enumerate(infos):
         per_stream.setdefault(i.stream, []).append(int(dev_hashes[p]))
+    deviating = 0
+    if multi:
+        # exchange step 2 (reporting, once per job, outside the timed steps): 8 bytes per picture to every rank, through
+        # the library; every rank then checks the units of ITS OWN streams, wherever they were decoded
+        pics_of = [sum(unit_pics[u] for u in p["units"]) for p in pieces]
+        pad = max(pics_of)
+        hsrc = torch.zeros(pad, dtype=torch.int64, device=dev)
+        hsrc[:n_pictures] = torch.from_numpy(dev_hashes.view(np.int64).copy()).to(dev)
+        hall = torch.zeros(pad * world, dtype=torch.int64, device=dev)
+        D.allgather(ctypes.c_void_p(hsrc.data_ptr()), ctypes.c_void_p(hall.data_ptr()), pad * 8, sptr)
+        torch.cuda.synchronize()
+        hall = hall.cpu().numpy().view(np.uint64).reshape(world, pad)
+        where = {}
+        for r, p in enumerate(pieces):
+            pos = 0
+            for u in p["units"]:
+                where[u] = (r, pos)
+                pos += unit_pics[u]
+        first_unit = sum(len(x[0][k]) for x in info_all[:rank] for k in range(len(x[0])))
+
+        def got_of(s):          # stream s of this rank: the device hashes of its units, GOP by GOP
+            u = first_unit + sum(len(units) for units in my_units[:s])
+            return [[int(h) for h in hall[where[u + g][0], where[u + g][1]:where[u + g][1] + unit_pics[u + g]]]
+                    for g in range(len(my_units[s]))]
     check = list(range(n_streams)) if not os.environ.get("JSMPEG_BENCH_PARITY_STREAMS") else \
         [int(x) for x in os.environ["JSMPEG_BENCH_PARITY_STREAMS"].split(",")]
     failed = []
+    dev_lock = threading.Lock()
+
+    def oracle_hashes(es):
+        # picture by picture: decode, hash, drop (a stream's 120 decoded pictures are 376 MB)
+        out = []
+        with cabi.Mpeg1Decoder(lib_oracle, len(es) + 1024, cabi.MODE_EXPAND) as dec:
+            dec.write(es)
+            while dec.decode():
+                out.append(hashing.frame_hash(*dec.planes()))
+        return out
 
     def verify(s):
-        # picture by picture: decode, hash, drop (a stream's 120 decoded pictures are 376 MB)
-        want = []
-        with cabi.Mpeg1Decoder(lib_oracle, len(streams[s]) + 1024, cabi.MODE_EXPAND) as dec:
-            dec.write(streams[s])
-            while dec.decode():
-                want.append(hashing.frame_hash(*dec.planes()))
-        if per_stream.get(s, []) != want:
-            failed.append(s)
+        nonlocal deviating
+        whole = oracle_hashes(streams[s])
+        if not multi:
+            if per_stream.get(s, []) != whole:
+                failed.append(s)
+            return
+        # sharded by GOP: every unit is what its decoder was given -- the oracle decodes exactly that; and the whole
+        # stream beside it, to COUNT the pictures where a unit decoded alone differs from the unsplit stream (a
+        # macroblock never written in a unit's first two pictures shows the GOP before in the unsplit stream: header, part 4)
+        got, pos = got_of(s), 0
+        for g, unit in enumerate(my_units[s]):
+            want = oracle_hashes(unit)
+            if got[g] != want:
+                failed.append((s, g))
+            with dev_lock:
+                deviating += sum(1 for a, bb in zip(want, whole[pos:pos + len(want)]) if a != bb)
+            pos += len(want)
 
     t_par = time.perf_counter()
     idx = iter(check)
@@ -321,8 +434,27 @@ def main():
     if failed:
         raise SystemExit("rank %d: PARITY FAILURE against the oracle on streams %r -- no number reported" % (rank, sorted(failed)))
 
+    # ---- the variant that starts from host memory (both stated) -- N = 1 only, after the headline run ----
+    value_incl_h2d = None
+    if not multi and not args.no_h2d:
+        args.h2d = True
+        h_es = torch.from_numpy(packed).pin_memory()
+        saved = dict(phase)
+        dt = timed_run(max(2, args.steps // 2), 1)
+        value_incl_h2d = {"value": round(n_pictures * max(2, args.steps // 2) / dt, 1), "unit": "frames/s",
+                          "ms_per_step": round(dt / max(2, args.steps // 2) * 1e3, 3),
+                          "h2d_ms": round(sum(a.elapsed_time(bb) for a, bb in h2d_ms) / max(1, len(h2d_ms)), 3),
+                          "h2d_bytes": shard_len,
+                          "note": "every step starts with the packed compressed streams in pinned HOST memory: one PCIe copy + the device-side placement, then the same path; never `value`"}
+        args.h2d = False
+        phase.update(saved)
+
+    if multi:
+        totals = [None] * world
+        dist.all_gather_object(totals, (es_bytes, stats["macroblocks"], stats["predicted"], deviating, uncovered))
     if rank != 0:
         if multi:
+            D.close()
             dist.destroy_process_group()
         return
 
@@ -346,9 +478,19 @@ def main():
         log("copy probe failed: %r" % (e,))
 
     # ---- accounting: ES read once + planes written once + predicted MBs read once ----
-    g_streams, g_pictures = n_streams * world, n_pictures * world
-    mb_per_pic = ((width + 15) // 16) * ((height + 15) // 16)
-    alg_bytes_rank = es_bytes + 384 * stats["macroblocks"] + 384 * stats["predicted"]
+    g_streams = n_streams * world
+    if multi:
+        g_pictures = sum(unit_pics)
+        job_alg_bytes = sum(t[0] + 384 * t[1] + 384 * t[2] for t in totals)
+        deviating, uncovered = sum(t[3] for t in totals), sum(t[4] for t in totals)
+        # this rank's share: the plan balances the compressed bytes, the pictures follow
+        alg_bytes_rank = job_alg_bytes * n_pictures / max(1, g_pictures)
+        pred_rank = sum(t[2] for t in totals) * n_pictures / max(1, g_pictures)
+    else:
+        g_pictures = n_pictures
+        alg_bytes_rank = es_bytes + 384 * stats["macroblocks"] + 384 * stats["predicted"]
+        job_alg_bytes = alg_bytes_rank
+        pred_rank = stats["predicted"]
     ms_per_step = elapsed / args.steps * 1e3
     fps = g_pictures * args.steps / elapsed
     k = args.steps
@@ -359,25 +501,29 @@ def main():
         dom = dict(kernel="k_recon", launches_per_step=levels, avg_launch_ms=recon_ms / max(1, levels),
                    bytes_per_launch=alg_bytes_rank / max(1, levels))
     achieved = dom["bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic of the dominant kernel from the PMC counters: NOT measured in this run (counter passes need rocprofv3
+    # around the process) -- the figure of the last committed profile, with its source, or null
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
-            traffic = json.load(open(prof)).get(dom["kernel"])
+            pj = json.load(open(prof))
+            traffic = pj.get(dom["kernel"])
+            traffic_source = "static: profiles/pmc_traffic.json (%s), not measured in this run" % pj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         except Exception:
             traffic = None
     # the read-only share of the algorithmic bytes (north_star words the target as an "HBM-read roofline"): predicted
     # macroblocks (k_recon) or the compressed bytes (k_parse); and the measured HBM traffic as a rate
-    read_bytes = (384 * stats["predicted"] / max(1, levels)) if dom["kernel"] == "k_recon" else es_bytes
+    read_bytes = (384 * pred_rank / max(1, levels)) if dom["kernel"] == "k_recon" else es_bytes
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_rate": round(traffic / (dom["avg_launch_ms"] * 1e-3) / 1e9, 1) if traffic else None,
                 "read_share": {"bytes_per_launch": int(read_bytes),
                                "achieved": round(read_bytes / (dom["avg_launch_ms"] * 1e-3) / 1e9, 1), "unit": "GB/s"},
                 "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"],
                 "avg_launch_ms": round(dom["avg_launch_ms"], 4), "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"]),
-                "whole_step": {"achieved": round(alg_bytes_rank * world / (ms_per_step * 1e-3) / 1e9, 1),
-                               "frac": round(alg_bytes_rank * world / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                "whole_step": {"achieved": round(job_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                               "frac": round(job_alg_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                                "note": "all kernels + host turn-around of a step, per-GPU peak x n_gpus"},
                 "phases_ms": {kk: round(v / k, 4) for kk, v in phase.items()},
                 "peak_measured_achievable": 6290.0,
@@ -393,11 +539,26 @@ def main():
                                % (CONFIG, n_streams, frames),
                    "streams": g_streams, "pictures_per_step": g_pictures, "es_bytes_per_gpu": es_bytes,
                    "mbit_per_s_per_stream_at_30fps": round(es_bytes * 8 / n_streams / frames * 30 / 1e6, 2),
-                   "parallelism": "gop/stream shards, %d rank(s)" % world},
+                   "content": "uniform-random synthetic syntax elements (SURVEY.md 8d): every macroblock its own random motion "
+                              "vector (+-8 / 16 / 32 pixels by f_code), random levels -- no spatial or temporal coherence, the worst "
+                              "case for the prediction reads' cache lines; says nothing about coherent-motion content",
+                   "parallelism": ("(stream, GOP) units sharded over %d rank(s): grouped RCCL send / recv from rank 0 every step, "
+                                   "overlapped with the previous step's kernels" % world) if multi else "one rank, whole streams"},
         "mpixel_per_s": round(fps * width * height / 1e6, 1),
-        "parity_checked": "every stream of every rank (%d x %d pictures per rank), device hash == oracle" % (len(check), frames),
+        "parity_checked": ("every unit of every stream of every rank against the oracle fed the same unit (%d streams x %d pictures per rank)"
+                           if multi else "every stream of every rank (%d x %d pictures per rank), device hash == oracle") % (len(check), frames),
         "roofline": roofline,
     }
+    if value_incl_h2d:
+        line["value_incl_h2d"] = value_incl_h2d
+    if multi:
+        sm = exchange.pop("scatter_ms")
+        exchange["scatter_ms_avg_rank0"] = round(sum(sm) / max(1, len(sm)), 3)
+        exchange["note"] = ("scatter of step k+1 runs on its own HIP stream beside the kernels of step k; its time is inside "
+                            "ms_per_step only where it is not hidden")
+        exchange["pictures_differing_from_unsplit_streams"] = int(deviating)
+        exchange["pictures_with_unwritten_macroblocks"] = int(uncovered)
+        line["exchange"] = exchange
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(streams[:2], width, height)
     else:
@@ -415,6 +576,7 @@ def main():
     json_out.write(json.dumps(line) + "\n")
     json_out.flush()
     if multi:
+        D.close()
         dist.destroy_process_group()
 
 

@@ -371,10 +371,21 @@ extern "C" int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void 
 	}
 	if (batch_layout(b, n_streams, lens.data()) != 0) return -1;
 	HIP_TRY(hipMemsetAsync(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD, st));
-	for (uint32_t i = 0; i < n_streams; i++)
-		HIP_TRY(hipMemcpyAsync(b->d_es + b->h_streams[i].es_begin, (const uint8_t *)dev_es + begin[i], lens[i],
-		                       hipMemcpyDeviceToDevice, st));
-	HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
+	/* one placement launch for all streams (a rank's piece after the RCCL scatter is hundreds of GOP units): the three
+	 * tables ride in the start-code owner table, which the decode that follows rewrites anyway */
+	if (n_streams) {
+		if (3ull * n_streams > b->sc_cap || n_streams > 65535) return fail("too many streams for one placement launch");
+		std::vector<uint32_t> tab(3 * (size_t)n_streams);
+		uint32_t max_len = 0;
+		for (uint32_t i = 0; i < n_streams; i++) {
+			tab[i] = begin[i]; tab[n_streams + i] = b->h_streams[i].es_begin; tab[2 * (size_t)n_streams + i] = (uint32_t)lens[i];
+			max_len = std::max(max_len, (uint32_t)lens[i]);
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_sc_owner, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice, st));
+		HIP_TRY(jm_launch_place((const uint8_t *)dev_es, b->d_es, b->d_sc_owner, b->d_sc_owner + n_streams, b->d_sc_owner + 2 * (size_t)n_streams,
+		                        n_streams, max_len, st));
+		HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
+	}
 	HIP_TRY(hipStreamSynchronize(st));
 	return 0;
 }

@@ -23,6 +23,10 @@ struct JmScanBufs {
 };
 hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st);
 
+/* n byte ranges of a device buffer -> their places in the batch ES buffer (tables in device memory) */
+hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src_begin, const uint32_t *dst_begin, const uint32_t *len,
+                           uint32_t n_streams, uint32_t max_len, hipStream_t st);
+
 struct JmIndexBufs {
 	const uint8_t *es;
 	const uint32_t *sc_pos;

@@ -145,6 +145,46 @@ hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st) {
 }
 
 /* ------------------------------------------------------------------------
+ * Placement of a batch's streams: n byte ranges of one DEVICE buffer (what a
+ * rank holds after the RCCL scatter of its units) -> their 16-byte aligned
+ * places in the batch's ES buffer.  One launch instead of one copy call per
+ * stream (640 GOP units per rank: 2 ms of copy calls).  Workgroup (x, s)
+ * copies 64 KiB chunk x of stream s, 16 bytes per lane per turn where source
+ * and destination agree modulo 16, bytes otherwise.
+ * ---------------------------------------------------------------------- */
+#define JM_PLACE_CHUNK 65536u
+__global__ __launch_bounds__(JM_WG) void k_place(const uint8_t *src, uint8_t *dst, const uint32_t *src_begin, const uint32_t *dst_begin,
+                                                const uint32_t *len) {
+	const uint32_t s = blockIdx.y, n = len[s], c0 = blockIdx.x * JM_PLACE_CHUNK;
+	if (c0 >= n) return;
+	const uint32_t c1 = min(n, c0 + JM_PLACE_CHUNK);
+	const uint8_t *ps = src + src_begin[s];
+	uint8_t *pd = dst + dst_begin[s];
+	if ((((uintptr_t)ps ^ (uintptr_t)pd) & 15u) == 0) {
+		/* head up to the destination's next 16-byte boundary, 16-byte body, tail */
+		uint32_t a = c0;
+		const uint32_t mis = (uint32_t)((16u - ((uintptr_t)(pd + c0) & 15u)) & 15u);
+		const uint32_t head = min(mis, c1 - c0);
+		if (threadIdx.x < head) pd[c0 + threadIdx.x] = ps[c0 + threadIdx.x];
+		a += head;
+		const uint32_t n16 = (c1 - a) >> 4;
+		for (uint32_t i = threadIdx.x; i < n16; i += JM_WG)
+			reinterpret_cast<uint4 *>(pd + a)[i] = reinterpret_cast<const uint4 *>(ps + a)[i];
+		a += n16 << 4;
+		if (a + threadIdx.x < c1) pd[a + threadIdx.x] = ps[a + threadIdx.x];
+	} else {
+		for (uint32_t i = c0 + threadIdx.x; i < c1; i += JM_WG) pd[i] = ps[i];
+	}
+}
+
+hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src_begin, const uint32_t *dst_begin, const uint32_t *len,
+                           uint32_t n_streams, uint32_t max_len, hipStream_t st) {
+	if (n_streams == 0 || max_len == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_place, dim3((max_len + JM_PLACE_CHUNK - 1) / JM_PLACE_CHUNK, n_streams), dim3(JM_WG), 0, st, src, dst, src_begin, dst_begin, len);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
  * Tables: one workgroup per stream.
  * ---------------------------------------------------------------------- */
 __global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {

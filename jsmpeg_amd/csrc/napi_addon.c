@@ -24,7 +24,7 @@
  *
  * Batch interface (include/jsmpeg_hip.h part 2; no reference counterpart -- the reference decodes one picture per
  * call on one thread): many streams in, every picture's planes in HBM, read back on demand.
- *   batchCreate(width, height, maxStreams, maxPictures, maxEsBytes) -> handle | throws
+ *   batchCreate(width, height, maxStreams, maxPictures, maxEsBytes[, device]) -> handle | throws   (device: HIP ordinal, one batch per GPU)
  *   batchDestroy(handle)
  *   batchUpload(handle, [Uint8Array ES, ...])                       jsmpeg_hip_batch_upload
  *   batchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xE0)    jsmpeg_hip_batch_upload_ts (device demux, ts.js semantics)
@@ -47,7 +47,7 @@
  *                                                    views of mp2-wasm.js:91-99
  *
  * MP2 batch (include/jsmpeg_hip.h part 3, additive), used by JSMpeg.HIPBatch for the audio of its streams:
- *   mp2BatchCreate(maxStreams, maxBytes) -> handle | throws
+ *   mp2BatchCreate(maxStreams, maxBytes[, device]) -> handle | throws
  *   mp2BatchDestroy(handle)
  *   mp2BatchUpload(handle, [Uint8Array MP2, ...])                     jsmpeg_hip_mp2_batch_upload
  *   mp2BatchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xC0)   jsmpeg_hip_mp2_batch_upload_ts
@@ -329,10 +329,10 @@ static napi_value set_u32(napi_env env, napi_value obj, const char *name, double
 }
 
 static napi_value fn_batch_create(napi_env env, napi_callback_info info) {
-	size_t argc = 5;
-	napi_value argv[5], out;
+	size_t argc = 6;
+	napi_value argv[6], out;
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	if (argc < 5) { napi_throw_type_error(env, NULL, "jsmpeg_hip: batchCreate(width, height, maxStreams, maxPictures, maxEsBytes)"); return NULL; }
+	if (argc < 5) { napi_throw_type_error(env, NULL, "jsmpeg_hip: batchCreate(width, height, maxStreams, maxPictures, maxEsBytes[, device])"); return NULL; }
 	jsmpeg_hip_batch_config_t c;
 	double es = 0;
 	uint32_t w = 0, h = 0;
@@ -342,6 +342,12 @@ static napi_value fn_batch_create(napi_env env, napi_callback_info info) {
 	NAPI_OK(napi_get_value_uint32(env, argv[3], &c.max_pictures));
 	NAPI_OK(napi_get_value_double(env, argv[4], &es));
 	c.width = (int32_t)w; c.height = (int32_t)h; c.max_es_bytes = (uint64_t)es; c.device = -1;
+	if (argc > 5) {              /* HIP device ordinal: one batch per GPU of a node; absent / -1: the current device */
+		napi_valuetype vt;
+		int32_t dev = -1;
+		if (napi_typeof(env, argv[5], &vt) == napi_ok && vt == napi_number) NAPI_OK(napi_get_value_int32(env, argv[5], &dev));
+		c.device = dev;
+	}
 	jsmpeg_hip_batch_t *b = jsmpeg_hip_batch_create(&c);
 	if (!b) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }   /* no GPU: loud, never a CPU decode */
 	NAPI_OK(napi_create_external(env, b, NULL, NULL, &out));
@@ -712,15 +718,17 @@ static jsmpeg_hip_mp2_batch_t *mp2_batch_arg(napi_env env, napi_value v) {
 }
 
 static napi_value fn_mp2_batch_create(napi_env env, napi_callback_info info) {
-	size_t argc = 2;
-	napi_value argv[2], out;
+	size_t argc = 3;
+	napi_value argv[3], out;
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-	if (argc < 2) { napi_throw_type_error(env, NULL, "jsmpeg_hip: mp2BatchCreate(maxStreams, maxBytes)"); return NULL; }
+	if (argc < 2) { napi_throw_type_error(env, NULL, "jsmpeg_hip: mp2BatchCreate(maxStreams, maxBytes[, device])"); return NULL; }
 	uint32_t streams = 0;
 	double bytes = 0;
+	int32_t dev = -1;
 	NAPI_OK(napi_get_value_uint32(env, argv[0], &streams));
 	NAPI_OK(napi_get_value_double(env, argv[1], &bytes));
-	jsmpeg_hip_mp2_batch_t *b = jsmpeg_hip_mp2_batch_create(streams, (uint64_t)bytes, -1);
+	if (argc > 2) { napi_valuetype vt; if (napi_typeof(env, argv[2], &vt) == napi_ok && vt == napi_number) NAPI_OK(napi_get_value_int32(env, argv[2], &dev)); }
+	jsmpeg_hip_mp2_batch_t *b = jsmpeg_hip_mp2_batch_create(streams, (uint64_t)bytes, dev);
 	if (!b) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }   /* no GPU: loud, never a CPU decode */
 	NAPI_OK(napi_create_external(env, b, NULL, NULL, &out));
 	return out;

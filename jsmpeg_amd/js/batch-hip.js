@@ -36,8 +36,9 @@ function install(JSMpeg, options) {
     this.maxStreams = opts.maxStreams || 64;
     this.maxPictures = opts.maxPictures || this.maxStreams * 64;
     this.maxBytes = opts.maxBytes || 256 * 1024 * 1024;
+    this.device = opts.device === undefined || opts.device === null ? -1 : (opts.device | 0);   // HIP ordinal: one HIPBatch per GPU of a node; -1 = the current device
     this.native = binding();
-    this.handle = this.native.batchCreate(this.width, this.height, this.maxStreams, this.maxPictures, this.maxBytes);   // throws without a GPU
+    this.handle = this.native.batchCreate(this.width, this.height, this.maxStreams, this.maxPictures, this.maxBytes, this.device);   // throws without a GPU / on a bad ordinal
     const g = this.native.batchGeometry(this.handle);
     this.codedWidth = g.codedWidth; this.codedHeight = g.codedHeight;
     this.lumaBytes = g.lumaBytes; this.chromaBytes = g.chromaBytes;
@@ -45,7 +46,7 @@ function install(JSMpeg, options) {
     this.writes = null;
     this.audio = null;
     if (opts.audio) {
-      this.audio = { handle: this.native.mp2BatchCreate(this.maxStreams, opts.maxAudioBytes || Math.min(this.maxBytes, 256 * 1024 * 1024)),
+      this.audio = { handle: this.native.mp2BatchCreate(this.maxStreams, opts.maxAudioBytes || Math.min(this.maxBytes, 256 * 1024 * 1024), this.device),
                      frames: 0, streams: 0, writes: null };
     }
   }

@@ -8,7 +8,7 @@ const { HIPBatch } = require('../../jsmpeg_amd/js/batch-hip.js').install();
 const w = parseInt(process.argv[2], 10), h = parseInt(process.argv[3], 10);
 const files = process.argv.slice(4).map((f) => new Uint8Array(fs.readFileSync(f)));
 const total = files.reduce((a, b) => a + b.length, 0);
-const batch = new HIPBatch({ width: w, height: h, maxStreams: files.length, maxPictures: 4096, maxBytes: total + 65536 });
+const batch = new HIPBatch({ width: w, height: h, maxStreams: files.length, maxPictures: 4096, maxBytes: total + 65536, device: 0 });   // device: the HIP ordinal (one HIPBatch per GPU of a node)
 const md5 = (...parts) => { const x = crypto.createHash('md5'); for (const p of parts) x.update(Buffer.from(p.buffer, p.byteOffset, p.length)); return x.digest('hex'); };
 const streams = files.map(() => ({ planes: [], pts: [], rgba: [] }));
 batch.decodeTS(files, { onFrame(f) { streams[f.stream].planes.push(md5(f.y, f.cr, f.cb)); streams[f.stream].pts.push(f.pts); } });
