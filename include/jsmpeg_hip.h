@@ -126,11 +126,27 @@ int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, ui
  * the batch's HBM buffer.  Per stream the result equals feeding the buffer to one
  * JSMpeg.Demuxer.TS with that stream id connected, in one write(): the same
  * bytes, the same destination.write(pts, buffers) boundaries (completion by
- * PES_packet_length and by the stuffing guess, ts.js:127-147).  Input must be
- * packet aligned (every 188th byte a sync byte): the call fails on anything
- * else instead of resyncing.  Returns 0 or < 0. */
+ * PES_packet_length and by the stuffing guess, ts.js:127-147).  Input need not
+ * be packet aligned: where ts.js resyncs (a byte that is not 0x47 is dropped,
+ * the next sync byte with four more at 188-byte distances is taken, ts.js:43-50,
+ * 150-187) so does this, and a trailing partial packet stays unread like
+ * ts.js's leftover bytes.  Returns 0 or < 0. */
 int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
                                const uint64_t *ts_bytes, uint32_t stream_id);
+/* The same with every buffer handed over in SEVERAL write() calls (ts.js:25-41: what a write cannot parse waits, as
+ * leftover bytes, for the next): stream i is written in n_writes[i] calls whose sizes follow one another in
+ * write_bytes (all streams' sizes back to back); bytes of a buffer beyond the sum of its sizes are never written.
+ * Differs from one write only where a resync runs out of data at the end of a write. */
+int jsmpeg_hip_batch_upload_ts_writes(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                                      const uint64_t *ts_bytes, const uint32_t *n_writes, const uint64_t *write_bytes,
+                                      uint32_t stream_id);
+/* The packet framing of that alone (host code, no device): where the 188-byte packets lie that ts.js parses when
+ * the buffer is handed to it in write() calls of write_bytes[0 .. n_writes) bytes (n_writes == 0: one write).  Fills
+ * at most `cap` runs of consecutive packets (run_offset / run_packets, either may be NULL); returns the number of
+ * runs or < 0; *n_packets: packets in all; *leftover_at: first byte ts.js still holds as leftover. */
+int jsmpeg_hip_ts_packet_runs(const uint8_t *ts, uint64_t ts_bytes, const uint64_t *write_bytes, uint32_t n_writes,
+                              uint64_t *run_offset, uint32_t *run_packets, uint32_t cap, uint64_t *n_packets,
+                              uint64_t *leftover_at);
 /* The destination.write calls of stream `stream` of the last upload_ts: pts in
  * seconds, byte range inside that stream's elementary stream.  Returns their
  * number (fills at most `cap` entries; any array may be NULL) or < 0. */
@@ -228,7 +244,7 @@ int jsmpeg_hip_mp2_batch_upload_device(jsmpeg_hip_mp2_batch_t *b, const void *de
  * jsmpeg_hip_batch_upload_ts: n_streams MPEG-TS buffers (host) -> the payload of `stream_id` (0xC0 = the first
  * audio stream, ts.js:212-222), demultiplexed by the same GPU kernels straight into the batch's HBM buffer; per
  * stream the same bytes and the same destination.write(pts, buffers) boundaries as one JSMpeg.Demuxer.TS fed the
- * buffer in one write().  Packet-aligned input only.  The same TS buffers can be handed to both batches
+ * buffer in one write() (resync and leftover bytes like ts.js).  The same TS buffers can be handed to both batches
  * (video with 0xE0, audio with 0xC0).  Returns 0 or < 0. */
 int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
                                    const uint64_t *ts_bytes, uint32_t stream_id);

@@ -25,7 +25,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
-                 "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_ts_writes",
+                 "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
                  "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
@@ -71,6 +71,12 @@ def lib():
         L.jsmpeg_hip_batch_render_rgba.argtypes = [vp, u32, u32, vp, vp]
         L.jsmpeg_hip_batch_upload_ts.restype = ctypes.c_int
         L.jsmpeg_hip_batch_upload_ts.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), u32]
+        L.jsmpeg_hip_batch_upload_ts_writes.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_upload_ts_writes.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u32),
+                                                       ctypes.POINTER(u64), u32]
+        L.jsmpeg_hip_ts_packet_runs.restype = ctypes.c_int
+        L.jsmpeg_hip_ts_packet_runs.argtypes = [vp, u64, ctypes.POINTER(u64), u32, ctypes.POINTER(u64), ctypes.POINTER(u32), u32,
+                                               ctypes.POINTER(u64), ctypes.POINTER(u64)]
         L.jsmpeg_hip_batch_ts_writes.restype = ctypes.c_int
         L.jsmpeg_hip_batch_ts_writes.argtypes = [vp, u32, vp, vp, vp, u32]
         L.jsmpeg_hip_batch_read_es.restype = ctypes.c_int64
@@ -130,13 +136,20 @@ class Batch:
         lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
         self._ok(self.L.jsmpeg_hip_batch_upload(self.h, n, ptrs, lens))
 
-    def upload_ts(self, ts_buffers, stream_id=0xE0):
-        """MPEG-TS in, demultiplexed on the device (reference src/ts.js semantics, one write() per buffer)."""
+    def upload_ts(self, ts_buffers, stream_id=0xE0, write_sizes=None):
+        """MPEG-TS in, demultiplexed on the device (reference src/ts.js semantics: resync, leftover bytes).  One write()
+        per buffer, or -- write_sizes: per buffer a list of byte counts -- that buffer in several write() calls."""
         arrs = [np.ascontiguousarray(s, dtype=np.uint8) for s in ts_buffers]
         n = len(arrs)
         ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
         lens = (ctypes.c_uint64 * n)(*[a.size for a in arrs])
-        self._ok(self.L.jsmpeg_hip_batch_upload_ts(self.h, n, ptrs, lens, stream_id))
+        if write_sizes is None:
+            self._ok(self.L.jsmpeg_hip_batch_upload_ts(self.h, n, ptrs, lens, stream_id))
+            return
+        counts = (ctypes.c_uint32 * n)(*[len(w) for w in write_sizes])
+        flat = [int(x) for w in write_sizes for x in w]
+        sizes = (ctypes.c_uint64 * max(1, len(flat)))(*flat)
+        self._ok(self.L.jsmpeg_hip_batch_upload_ts_writes(self.h, n, ptrs, lens, counts, sizes, stream_id))
 
     def ts_writes(self, stream):
         """[(pts seconds, offset, length)]: the destination.write calls ts.js would have made for `stream`."""

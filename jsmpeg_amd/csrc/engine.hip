@@ -17,6 +17,7 @@
 #include "index_tables.h"
 #include "jsmpeg_hip.h"
 #include "kernels.h"
+#include "ts_sync.h"
 
 /* ------------------------------------------------------------------ errors */
 
@@ -243,23 +244,63 @@ extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams
 
 /* Ingest side on the device (reference src/ts.js): n_streams MPEG-TS buffers -> the video elementary streams,
  * demultiplexed by k_ts_* straight into the batch's ES buffer.  Equivalent to feeding each buffer to one
- * JSMpeg.Demuxer.TS with `stream_id` connected in ONE write() and concatenating what the destination receives. */
+ * JSMpeg.Demuxer.TS with `stream_id` connected in the given write() calls and concatenating what the destination
+ * receives.  Where the packets lie -- sync bytes, resync after garbage, what a write() leaves over for the next
+ * (ts.js:25-50, 150-187) -- is found by a host pre-pass (ts_sync.h); the packets' content is parsed on the device. */
+static int upload_ts_impl(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts, const uint64_t *ts_bytes,
+                          const uint32_t *n_writes, const uint64_t *write_bytes, uint32_t stream_id);
+
 extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
                                           const uint64_t *ts_bytes, uint32_t stream_id) {
+	return upload_ts_impl(b, n_streams, ts, ts_bytes, nullptr, nullptr, stream_id);
+}
+
+extern "C" int jsmpeg_hip_batch_upload_ts_writes(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts,
+                                                 const uint64_t *ts_bytes, const uint32_t *n_writes, const uint64_t *write_bytes,
+                                                 uint32_t stream_id) {
+	if (n_streams && (!n_writes || !write_bytes)) { fail("null write table"); return -1; }
+	return upload_ts_impl(b, n_streams, ts, ts_bytes, n_writes, write_bytes, stream_id);
+}
+
+/* The packet framing alone (host code, no device needed): where the 188-byte packets lie that ts.js parses when the
+ * buffer is handed to it in the given write() calls (n_writes == 0: one write).  Fills at most `cap` (offset, packets)
+ * runs; returns the number of runs or < 0; *n_packets, *leftover_at: totals (may be NULL). */
+extern "C" int jsmpeg_hip_ts_packet_runs(const uint8_t *ts, uint64_t ts_bytes, const uint64_t *write_bytes, uint32_t n_writes,
+                                         uint64_t *run_offset, uint32_t *run_packets, uint32_t cap, uint64_t *n_packets,
+                                         uint64_t *leftover_at) {
+	g_err[0] = 0;
+	if (!ts && ts_bytes) return fail("null buffer");
+	std::vector<JmTsRun> runs;
+	const uint64_t pk = jm_ts_sync_runs(ts, ts_bytes, n_writes ? write_bytes : nullptr, n_writes, runs, leftover_at);
+	if (n_packets) *n_packets = pk;
+	for (size_t i = 0; i < runs.size() && i < cap; i++) {
+		if (run_offset) run_offset[i] = runs[i].src;
+		if (run_packets) run_packets[i] = runs[i].packets;
+	}
+	return (int)runs.size();
+}
+
+static int upload_ts_impl(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *ts, const uint64_t *ts_bytes,
+                          const uint32_t *n_writes, const uint64_t *write_bytes, uint32_t stream_id) {
 	g_err[0] = 0;
 	if (!b || (n_streams && (!ts || !ts_bytes))) return fail("null argument");
 	if (n_streams > b->cfg.max_streams) return fail("%u streams > max_streams %u", n_streams, b->cfg.max_streams);
 	if (stream_id == 0 || stream_id > 255) return fail("stream id %u out of range", stream_id);
 	HIP_TRY(hipSetDevice(b->device));
-	/* layout of the TS scratch: 16-byte aligned stream regions, 16 readable bytes behind each */
+	/* the packets of every stream (host pre-pass), then the layout of the TS scratch: the packets of a stream back to
+	 * back from a 16-byte aligned start, 16 readable bytes behind each stream */
+	std::vector<std::vector<JmTsRun>> runs(n_streams);
 	std::vector<uint64_t> begin(n_streams), len(n_streams);
 	b->ts_pkt_first.assign(n_streams + 1, 0);
 	uint64_t off = 0;
 	uint32_t max_packets = 0;
+	const uint64_t *wb = write_bytes;
 	for (uint32_t i = 0; i < n_streams; i++) {
-		begin[i] = off; len[i] = ts_bytes[i];
-		off += (ts_bytes[i] + 16 + 15) & ~15ull;
-		const uint64_t pk = ts_bytes[i] / 188;
+		const uint32_t nw = n_writes ? n_writes[i] : 0;
+		const uint64_t pk = jm_ts_sync_runs(ts[i], ts_bytes[i], nw ? wb : nullptr, nw, runs[i], nullptr);
+		if (n_writes) wb += nw;
+		begin[i] = off; len[i] = pk * 188;
+		off += (len[i] + 16 + 15) & ~15ull;
 		if (b->ts_pkt_first[i] + pk > 0x3fffffffull) return fail("too many TS packets in one batch");
 		b->ts_pkt_first[i + 1] = b->ts_pkt_first[i] + (uint32_t)pk;
 		max_packets = std::max(max_packets, (uint32_t)pk);
@@ -289,8 +330,13 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 	         *d_es_given = d_es_total + ms, *d_status = d_es_given + ms, *d_es_begin = d_status + ms;
 	if (n_streams == 0) { b->ts_n_writes.clear(); return batch_layout(b, 0, nullptr); }
 	hipStream_t st = nullptr;
-	for (uint32_t i = 0; i < n_streams; i++)
-		if (ts_bytes[i]) HIP_TRY(hipMemcpy(b->d_ts + begin[i], ts[i], ts_bytes[i], hipMemcpyHostToDevice));
+	for (uint32_t i = 0; i < n_streams; i++) {
+		uint64_t at = begin[i];
+		for (const JmTsRun &r : runs[i]) {                      /* in sync from the first byte: one run, one copy */
+			HIP_TRY(hipMemcpy(b->d_ts + at, ts[i] + r.src, 188ull * r.packets, hipMemcpyHostToDevice));
+			at += 188ull * r.packets;
+		}
+	}
 	HIP_TRY(hipMemcpy(b->d_ts_begin, begin.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(b->d_ts_len, len.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(d_pkt_first, b->ts_pkt_first.data(), sizeof(uint32_t) * (n_streams + 1), hipMemcpyHostToDevice));
@@ -307,8 +353,7 @@ extern "C" int jsmpeg_hip_batch_upload_ts(jsmpeg_hip_batch_t *b, uint32_t n_stre
 	const uint32_t *h_n_writes = small.data(), *h_es_given = small.data() + 2 * ms, *h_status = small.data() + 3 * ms;
 	std::vector<uint64_t> es_len(n_streams);
 	for (uint32_t i = 0; i < n_streams; i++) {
-		if (h_status[i] == 1) return fail("stream %u: a TS packet does not start with the sync byte: the device demux needs "
-		                                  "packet-aligned input (feed unaligned input through the reference's ts.js, which resyncs)", i);
+		if (h_status[i] == 1) return fail("internal: stream %u: a framed TS packet does not start with the sync byte", i);
 		if (h_status[i] == 3) return fail("stream %u: a PES / adaptation-field header runs past the end of its TS packet", i);
 		if (h_status[i]) return fail("stream %u: more than 16 PIDs carry PES headers", i);
 		es_len[i] = h_es_given[i];     /* what the destination received; a PES still open at the end of the input stays pending, like in ts.js */

@@ -15,6 +15,7 @@
 
 #include "jsmpeg_hip.h"
 #include "kernels.h"
+#include "ts_sync.h"
 #include "mp2_dev.h"
 #include "mp2_window.h"
 
@@ -255,13 +256,14 @@ extern "C" int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_
 	if (stream_id == 0 || stream_id > 255) return mp2_fail("stream id %s%ld out of range", "", stream_id);
 	MP2_TRY(hipSetDevice(b->device));
 	std::vector<uint64_t> begin(n_streams), len(n_streams);
+	std::vector<std::vector<JmTsRun>> runs(n_streams);       /* where ts.js's packets lie (sync, resync: ts_sync.h) */
 	b->ts_pkt_first.assign(n_streams + 1, 0);
 	uint64_t off = 0;
 	uint32_t max_packets = 0;
 	for (uint32_t i = 0; i < n_streams; i++) {
-		begin[i] = off; len[i] = ts_bytes[i];
-		off += (ts_bytes[i] + 16 + 15) & ~15ull;              /* 16-byte aligned regions, 16 readable bytes behind each */
-		const uint64_t pk = ts_bytes[i] / 188;
+		const uint64_t pk = jm_ts_sync_runs(ts[i], ts_bytes[i], nullptr, 0, runs[i], nullptr);
+		begin[i] = off; len[i] = pk * 188;
+		off += (len[i] + 16 + 15) & ~15ull;                    /* 16-byte aligned regions, 16 readable bytes behind each */
 		if (b->ts_pkt_first[i] + pk > 0x3fffffffull) return mp2_fail("too many TS packets in one batch");
 		b->ts_pkt_first[i + 1] = b->ts_pkt_first[i] + (uint32_t)pk;
 		if ((uint32_t)pk > max_packets) max_packets = (uint32_t)pk;
@@ -290,7 +292,13 @@ extern "C" int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_
 	uint32_t *d_pkt_first = b->d_ts_small, *d_n_writes = d_pkt_first + ms + 1, *d_es_total = d_n_writes + ms,
 	         *d_es_given = d_es_total + ms, *d_status = d_es_given + ms, *d_es_begin = d_status + ms;
 	for (uint32_t i = 0; i < n_streams; i++)
-		if (ts_bytes[i]) MP2_TRY(hipMemcpy(b->d_ts + begin[i], ts[i], ts_bytes[i], hipMemcpyHostToDevice));
+		{
+			uint64_t at = begin[i];
+			for (const JmTsRun &r : runs[i]) {
+				MP2_TRY(hipMemcpy(b->d_ts + at, ts[i] + r.src, 188ull * r.packets, hipMemcpyHostToDevice));
+				at += 188ull * r.packets;
+			}
+		}
 	MP2_TRY(hipMemcpy(b->d_ts_begin, begin.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
 	MP2_TRY(hipMemcpy(b->d_ts_len, len.data(), sizeof(uint64_t) * n_streams, hipMemcpyHostToDevice));
 	MP2_TRY(hipMemcpy(d_pkt_first, b->ts_pkt_first.data(), sizeof(uint32_t) * (n_streams + 1), hipMemcpyHostToDevice));
@@ -307,8 +315,7 @@ extern "C" int jsmpeg_hip_mp2_batch_upload_ts(jsmpeg_hip_mp2_batch_t *b, uint32_
 	const uint32_t *h_n_writes = small.data(), *h_es_given = small.data() + 2 * ms, *h_status = small.data() + 3 * ms;
 	std::vector<uint64_t> es_len(n_streams);
 	for (uint32_t i = 0; i < n_streams; i++) {
-		if (h_status[i] == 1) return mp2_fail("stream %s%ld: a TS packet does not start with the sync byte: the device demux needs "
-		                                      "packet-aligned input (feed unaligned input through the reference's ts.js, which resyncs)", "", i);
+		if (h_status[i] == 1) return mp2_fail("internal: stream %s%ld: a framed TS packet does not start with the sync byte", "", i);
 		if (h_status[i] == 3) return mp2_fail("stream %s%ld: a PES / adaptation-field header runs past the end of its TS packet", "", i);
 		if (h_status[i]) return mp2_fail("stream %s%ld: more than 16 PIDs carry PES headers", "", i);
 		es_len[i] = h_es_given[i];     /* what the destination received; a PES still open at the end stays pending, like in ts.js */

@@ -103,7 +103,7 @@ function install(JSMpeg, options) {
     return n;
   };
 
-  // MPEG-TS buffers (packet aligned) -> device demux with ts.js semantics -> decode.  Returns the picture count.
+  // MPEG-TS buffers -> device demux with ts.js semantics (resync after garbage, partial last packet left unread) -> decode.  Returns the picture count.
   HIPBatch.prototype.uploadTS = function (buffers, streamId) {
     this.native.batchUploadTS(this.handle, buffers, streamId || 0xE0);
     this.writes = buffers.map((_, s) => this.native.batchTsWrites(this.handle, s));

@@ -24,20 +24,29 @@ class _TsWrite(ctypes.Structure):
     _fields_ = [("pts", ctypes.c_double), ("offset", ctypes.c_uint32), ("length", ctypes.c_uint32)]
 
 
-def oracle_ts_demux(oracle_path, ts, stream_id=0xE0):
-    """CHECKER ONLY: the reference's TS demuxer restated on the CPU (oracle/ts_oracle.c), one write() of the whole
-    buffer.  Returns (es bytes, [(pts, offset, length)] per destination.write call)."""
+def oracle_ts_demux(oracle_path, ts, stream_id=0xE0, write_sizes=None):
+    """CHECKER ONLY: the reference's TS demuxer restated on the CPU (oracle/ts_oracle.c): one write() of the whole
+    buffer, or the buffer in write() calls of `write_sizes` bytes.  Returns (es bytes, [(pts, offset, length)] per
+    destination.write call)."""
     lib = ctypes.CDLL(oracle_path)
-    fn = lib.ts_oracle_demux
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
-                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_int]
     ts = np.ascontiguousarray(ts, dtype=np.uint8)
     es = np.zeros(len(ts) + 16, dtype=np.uint8)
     cap = len(ts) // 94 + 16
     writes = (_TsWrite * cap)()
     n_es = ctypes.c_size_t()
-    n = fn(ts.ctypes.data, len(ts), stream_id, es.ctypes.data, len(es), ctypes.byref(n_es), writes, cap)
+    if write_sizes is None:
+        fn = lib.ts_oracle_demux
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_int]
+        n = fn(ts.ctypes.data, len(ts), stream_id, es.ctypes.data, len(es), ctypes.byref(n_es), writes, cap)
+    else:
+        fn = lib.ts_oracle_demux_writes
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                       ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_int]
+        ws = (ctypes.c_uint64 * len(write_sizes))(*[int(x) for x in write_sizes])
+        n = fn(ts.ctypes.data, len(ts), ws, len(write_sizes), stream_id, es.ctypes.data, len(es), ctypes.byref(n_es), writes, cap)
     if n < 0 or n > cap:
         raise RuntimeError("ts_oracle_demux failed (%d)" % n)
     return es[:n_es.value].copy(), [(writes[i].pts, writes[i].offset, writes[i].length) for i in range(n)]

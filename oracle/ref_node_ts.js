@@ -1,7 +1,7 @@
 // Test infrastructure (oracle side, container only): runs the UNMODIFIED reference demuxer (src/ts.js) under Node on a
-// .ts file with ONE write() of the whole file and the given stream id connected; prints the destination.write calls
-// as JSON: [{pts, length, md5}], plus the md5 of all written bytes.
-//   node ref_node_ts.js <file.ts> [streamId=224]
+// .ts file with ONE write() of the whole file -- or write() calls of the given sizes -- and the given stream id
+// connected; prints the destination.write calls as JSON: [{pts, length, md5}], plus the md5 of all written bytes.
+//   node ref_node_ts.js <file.ts> [streamId=224] [size1,size2,...]
 'use strict';
 const fs = require('fs');
 const crypto = require('crypto');
@@ -21,6 +21,13 @@ demux.connect(sid, { write(pts, buffers) {
   for (const b of buffers) { const buf = Buffer.from(b.buffer, b.byteOffset, b.length); h.update(buf); all.update(buf); n += b.length; }
   writes.push({ pts, length: n, md5: h.digest('hex') });
 } });
-demux.write(data.buffer.slice(data.byteOffset, data.byteOffset + data.length));
+if (process.argv[4]) {
+  let at = 0;
+  for (const n of process.argv[4].split(',').map(Number)) {
+    const e = Math.min(data.length, at + n);
+    demux.write(data.buffer.slice(data.byteOffset + at, data.byteOffset + e));
+    at = e;
+  }
+} else demux.write(data.buffer.slice(data.byteOffset, data.byteOffset + data.length));
 console.warn = warn;
 process.stdout.write(JSON.stringify({ writes, total_md5: all.digest('hex') }) + '\n');

@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE ONLY (checker): CPU restatement of the reference's MPEG-TS demuxer,
- * JSMpeg.Demuxer.TS (reference src/ts.js:25-210), for one connected stream id and ONE write() of the
- * whole buffer -- the ingest-side parity tests of the device demux (k_ts_*).  Never linked into or
+ * JSMpeg.Demuxer.TS (reference src/ts.js:25-210), for one connected stream id and one or several
+ * write() calls -- the ingest-side parity tests of the device demux (k_ts_*).  Never linked into or
  * called by the product.  Pinned against the reference itself: oracle/ref_node_ts.js runs the
  * unmodified ts.js under Node, tests/golden/ts_*.json hold the agreed write sequences.
  *
@@ -71,9 +71,13 @@ static int resync(bits_t *s) {                                                  
 	return 0;
 }
 
+/* test hook: where parse_packet found packets (byte offset of the sync byte in the whole input) */
+static uint64_t *g_packet_at; static size_t g_packet_cap, g_packet_n; static const uint8_t *g_packet_base;
+
 static int parse_packet(demux_t *d, bits_t *s) {                                                        /* ts.js:43-148 */
 	if (bits_read(s, 8) != 0x47 && !resync(s)) return 0;
 	const size_t end = (s->index >> 3) + 187;
+	if (g_packet_at) { if (g_packet_n < g_packet_cap) g_packet_at[g_packet_n] = (uint64_t)((s->b - g_packet_base) + (s->index >> 3) - 1); g_packet_n++; }
 	bits_read(s, 1);                                   /* transportError */
 	const unsigned payload_start = bits_read(s, 1);
 	bits_read(s, 1);                                   /* transportPriority */
@@ -148,4 +152,51 @@ int ts_oracle_demux(const uint8_t *ts, size_t n, int stream_id, uint8_t *es_out,
 	while (bits_has(&s, 188 << 3) && parse_packet(&d, &s)) {}
 	if (es_bytes) *es_bytes = d.es_len;      /* includes bytes still pending in pi.buffers (never written out) */
 	return d.overflow && d.es_len > es_cap ? -1 : d.n_writes;
+}
+
+/* The same over several TS.write() calls: the buffer is written in pieces of write_bytes[0 .. n_writes) bytes
+ * (ts.js:25-41: every write parses leftover + buffer, what it cannot parse is the next write's leftover). */
+int ts_oracle_demux_writes(const uint8_t *ts, size_t n, const uint64_t *write_bytes, int n_writes, int stream_id, uint8_t *es_out,
+                           size_t es_cap, size_t *es_bytes, ts_oracle_write_t *writes, int writes_cap) {
+	static demux_t d;
+	memset(&d, 0, sizeof(d));
+	d.connected_id = stream_id; d.es = es_out; d.es_cap = es_cap; d.writes = writes; d.writes_cap = writes_cap;
+	size_t leftover = 0, end = 0;
+	for (int w = 0; w < n_writes; w++) {
+		end += (size_t)write_bytes[w];
+		if (end > n) end = n;
+		bits_t s = { ts + leftover, end - leftover, 0 };     /* new BitBuffer over leftover + buffer */
+		while (bits_has(&s, 188 << 3) && parse_packet(&d, &s)) {}
+		leftover += s.index >> 3;
+		if (leftover > end) leftover = end;
+	}
+	if (es_bytes) *es_bytes = d.es_len;
+	return d.overflow && d.es_len > es_cap ? -1 : d.n_writes;
+}
+
+/* The packets ts.js parses (byte offsets of their sync bytes) and the leftover position, for the framing tests of the
+ * ingest stage's host pre-pass.  Returns the number of packets. */
+long ts_oracle_packets(const uint8_t *ts, size_t n, const uint64_t *write_bytes, int n_writes, uint64_t *packet_at, size_t cap,
+                       uint64_t *leftover_at) {
+	static demux_t d;
+	static uint8_t sink[1 << 16];
+	memset(&d, 0, sizeof(d));
+	d.connected_id = 0xE0; d.es = sink; d.es_cap = 0; d.writes = NULL; d.writes_cap = 0;
+	g_packet_at = packet_at; g_packet_cap = cap; g_packet_n = 0; g_packet_base = ts;
+	static uint64_t one_dummy;
+	if (!packet_at) g_packet_at = &one_dummy, g_packet_cap = 0;
+	const uint64_t all = n;
+	if (n_writes == 0) { write_bytes = &all; n_writes = 1; }
+	size_t leftover = 0, end = 0;
+	for (int w = 0; w < n_writes; w++) {
+		end += (size_t)write_bytes[w];
+		if (end > n) end = n;
+		bits_t s = { ts + leftover, end - leftover, 0 };
+		while (bits_has(&s, 188 << 3) && parse_packet(&d, &s)) {}
+		leftover += s.index >> 3;
+		if (leftover > end) leftover = end;
+	}
+	if (leftover_at) *leftover_at = leftover;
+	g_packet_at = NULL;
+	return (long)g_packet_n;
 }

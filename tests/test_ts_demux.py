@@ -17,8 +17,6 @@ from oracle import checkers
 
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ts_*.json")))
 IDS = [os.path.basename(p)[3:-5] for p in FIXTURES]
-ALIGNED = [p for p in FIXTURES if "resync" not in p]
-ALIGNED_IDS = [os.path.basename(p)[3:-5] for p in ALIGNED]
 
 
 def load_case(path):
@@ -35,7 +33,7 @@ def as_fixture_writes(es, writes):
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
 def test_oracle_matches_reference_fixture(path, libs):
     fx, ts = load_case(path)
-    es, writes = checkers.oracle_ts_demux(libs["oracle"], ts, fx["stream_id"])
+    es, writes = checkers.oracle_ts_demux(libs["oracle"], ts, fx["stream_id"], fx.get("write_sizes"))
     assert as_fixture_writes(es, writes) == fx["writes"]
 
 
@@ -50,24 +48,65 @@ def test_oracle_feeds_the_decoder_like_ts_js(libs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", ALIGNED, ids=ALIGNED_IDS)
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
 def test_device_demux_matches_reference_fixture(path, hip_lib):
+    """Every fixture -- aligned input, garbage in front of and between packets (resync), a partial last packet, and the
+    buffers handed over in several write() calls (leftover bytes) -- through the ingest stage of the batch."""
     from jsmpeg_amd import batch as jb
     fx, ts = load_case(path)
+    ws = fx.get("write_sizes")
     with jb.Batch(176, 144, 2, 64, 1 << 20) as b:
-        b.upload_ts([ts, ts[:188 * 7]], fx["stream_id"])          # a second, shorter stream beside it
+        # a second, shorter stream beside it (written in one piece)
+        b.upload_ts([ts, ts[:188 * 7]], fx["stream_id"], None if ws is None else [ws, [188 * 7]])
         es = b.read_es(0)
         assert as_fixture_writes(es, b.ts_writes(0)) == fx["writes"]
         assert hashlib.md5(es.tobytes()).hexdigest() == fx["total_md5"]
 
 
-@pytest.mark.gpu
-def test_device_demux_rejects_unaligned_input(hip_lib):
+def test_packet_framing_matches_the_restatement_on_random_damage(libs, hip_lib):
+    """The host pre-pass of the ingest stage (csrc/ts_sync.h, jsmpeg_hip_ts_packet_runs) frames packets exactly where
+    ts.js does -- by its CPU restatement, which the fixtures pin to ts.js itself: random junk (with and without sync
+    bytes in it) spliced into a TS, truncated ends, random write() sizes: same packets, same leftover position."""
+    import ctypes
     from jsmpeg_amd import batch as jb
-    ts = ts_craft.case_garbage_prefix_resync()
-    with jb.Batch(176, 144, 1, 16, 1 << 20) as b:
-        with pytest.raises(RuntimeError, match="sync byte"):
-            b.upload_ts([ts])
+    L = jb.lib()
+    ora = ctypes.CDLL(libs["oracle"])
+    ora.ts_oracle_packets.restype = ctypes.c_long
+    rng = np.random.RandomState(5)
+    base = ts_craft.case_video_audio_null()
+    u64 = ctypes.c_uint64
+    for trial in range(300):
+        parts, at = [], 0
+        for cut in sorted(rng.choice(np.arange(1, len(base) // 188), size=rng.randint(0, 4), replace=False)):
+            parts.append(base[at:cut * 188])
+            junk = rng.randint(0, 256, size=rng.randint(1, 1300)).astype(np.uint8)
+            if trial % 3 == 0:
+                junk[junk == 0x47] = 0x48
+            parts.append(junk)
+            at = cut * 188
+        parts.append(base[at:len(base) - rng.randint(0, 400)])
+        ts = np.ascontiguousarray(np.concatenate(parts))
+        sizes, left = [], len(ts)
+        if trial % 4:
+            while left > 0:
+                n = int(min(left, rng.randint(1, 4000)))
+                sizes.append(n)
+                left -= n
+        ws = (u64 * max(1, len(sizes)))(*sizes)
+        cap = len(ts) // 188 + 8
+        want_at = (u64 * cap)()
+        want_left = u64()
+        n_want = ora.ts_oracle_packets(ctypes.c_void_p(ts.ctypes.data), ctypes.c_size_t(len(ts)), ws, ctypes.c_int(len(sizes)),
+                                       want_at, ctypes.c_size_t(cap), ctypes.byref(want_left))
+        ro, rp = (u64 * cap)(), (ctypes.c_uint32 * cap)()
+        n_pk, left_at = u64(), u64()
+        n_runs = L.jsmpeg_hip_ts_packet_runs(ctypes.c_void_p(ts.ctypes.data), u64(len(ts)), ws, ctypes.c_uint32(len(sizes)), ro, rp,
+                                             ctypes.c_uint32(cap), ctypes.byref(n_pk), ctypes.byref(left_at))
+        assert n_runs >= 0
+        got = [ro[i] + 188 * k for i in range(n_runs) for k in range(rp[i])]
+        assert n_pk.value == n_want == len(got), trial
+        assert got == list(want_at[:n_want]), trial
+        assert left_at.value == want_left.value, trial
 
 
 @pytest.mark.gpu

@@ -143,6 +143,17 @@ def case_partial_last_packet():
     return ts[:len(ts) - 100].copy()
 
 
+def case_garbage_in_the_middle():
+    """Junk between packets: 30 bytes without a sync byte after the tenth packet, later 200 bytes that contain lone 0x47
+    bytes (false syncs: no four more behind them) -- ts.js drops the bad byte and resyncs each time (ts.js:43-50, 150-187)."""
+    ts = case_video_audio_null()
+    junk1 = np.frombuffer(bytes((b % 0x40) + 1 for b in _rng_bytes(11, 30)), dtype=np.uint8)
+    j2 = bytearray((b % 0x40) + 0x80 for b in _rng_bytes(12, 200))
+    j2[3] = 0x47; j2[60] = 0x47; j2[191] = 0x47
+    junk2 = np.frombuffer(bytes(j2), dtype=np.uint8)
+    return np.concatenate([ts[:188 * 10], junk1, ts[188 * 10:188 * 25], junk2, ts[188 * 25:]])
+
+
 CASES = {
     "video_only": case_video_only,
     "video_audio_null": case_video_audio_null,
@@ -151,4 +162,13 @@ CASES = {
     "pid_changes_stream_id": case_pid_changes_stream_id,
     "garbage_prefix_resync": case_garbage_prefix_resync,
     "partial_last_packet": case_partial_last_packet,
+    "garbage_in_the_middle": case_garbage_in_the_middle,
+}
+
+# the same buffers handed to the demuxer in SEVERAL write() calls (ts.js:25-41: leftover bytes); the last size takes the rest
+WRITES = {
+    "video_only": [1000, 333, 188 * 5 + 7, 1, 187, 1 << 30],
+    "garbage_prefix_resync": [40, 100, 1200, 188, 1 << 30],          # the first resync attempts run out of data
+    "garbage_in_the_middle": [188 * 10 + 5, 600, 188 * 14, 150, 300, 2000, 1 << 30],
+    "partial_last_packet": [5000, 5000, 1 << 30],
 }
