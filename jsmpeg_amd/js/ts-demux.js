@@ -74,4 +74,5 @@ TSDemux.prototype.write = function (data) {
 };
 
 TSDemux.VIDEO_1 = 0xE0;
+TSDemux.AUDIO_1 = 0xC0;   // ts.js:212-222
 module.exports = TSDemux;
