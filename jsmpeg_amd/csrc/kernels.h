@@ -56,7 +56,9 @@ struct JmParseBufs {
 	int mb_size;
 	uint32_t *covered;           /* [n_pics] += records written, per picture (zeroed by the caller), or null */
 	uint8_t epoch;
-	int debug_flags;             /* diagnostics only: 1 = LUTs from global memory, 2 = 64-lane workgroups */
+	uint32_t lanes_per_wave;     /* set by jm_launch_parse: slices a wavefront takes (64, fewer for small batches) */
+	int cold_threshold;          /* ... and the lanes that must queue for the header step before it runs */
+	int debug_flags;             /* diagnostics only: 4 = per-slice abort records, 8 = always 64 slices per wavefront */
 	uint32_t *dbg;               /* diagnostics only: 4 words per start-code entry, or null */
 };
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);

@@ -229,6 +229,7 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
 #define JM_PARSE_WG 512   /* 8 wavefronts share one copy of the tables: 2 workgroups = 16 wavefronts per CU */
 #endif
 #define JM_PARSE_WAVES (JM_PARSE_WG / 64)
+#define JM_PARSE_FILL_WAVES 4096u   /* wavefronts that fill the GPU for this kernel: 256 CUs x 16 */
 
 __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
@@ -240,8 +241,11 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		for (uint32_t i = threadIdx.x; i < sizeof(JmVlcLuts) / 16; i += blockDim.x) dst[i] = src[i];
 	}
 	__syncthreads();   /* the only workgroup barrier: from here on the wavefronts run on their own */
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	/* lanes_per_wave < 64 (small batches, jm_launch_parse): a wavefront takes only that many slices -- fewer lanes are at
+	 * fewer different syntax elements, a turn issues fewer of the step kinds, and the one wavefront whose walk is the
+	 * whole pass gets through it sooner; the idle lanes cost nothing while SIMDs would stand idle anyway */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t i = (uint32_t)lane < b.lanes_per_wave ? (blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave) * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
 	JmLane L;
 	L.es_ring = &es_ring[wave][0][lane];
 	L.tk_ring = &tk_ring[wave][0][lane];
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
 		if (n_cold == 0 && !others) break;
 		if (blocked) { if (live) jm_lane_service(L); }
-		if (jm_run_cold(n_cold, others ? 1 : 0, JM_T_COLD)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
 		if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
 		if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
 		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
@@ -296,9 +300,26 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 }
 
-hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st) {
-	if (b.n_sc == 0) return hipSuccess;
-	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + JM_PARSE_WG - 1) / JM_PARSE_WG), dim3(JM_PARSE_WG), 0, st, b);
+hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
+	if (b_in.n_sc == 0) return hipSuccess;
+	JmParseBufs b = b_in;
+	/* slices per wavefront: 64, except for small batches (fewer than 512 full wavefronts: half the SIMDs would stand
+	 * idle while a few wavefronts walk 64 slices each) -- there the smallest power of two that still keeps the pass
+	 * within 4096 wavefronts, down to ONE slice per wavefront for a single picture (measured, MI355X: one 1080p
+	 * picture 1.31 -> 0.69 ms per decode(), one 720p stream of 360 pictures 1.48 -> 1.30 ms of parse; batches of 512+
+	 * wavefronts are fastest at 64) */
+	uint32_t lanes = 64;
+	if (b.n_sc <= 512u * 64u) {
+		lanes = 1;
+		while (lanes < 64 && (uint64_t)lanes * JM_PARSE_FILL_WAVES < b.n_sc) lanes <<= 1;
+	}
+	if (b.debug_flags & 8) lanes = 64;
+	{ static const int forced = getenv("JSMPEG_HIP_PARSE_LANES") ? atoi(getenv("JSMPEG_HIP_PARSE_LANES")) : 0;   /* tuning only */
+	  if (forced >= 1 && forced <= 64) lanes = (uint32_t)forced; }
+	b.lanes_per_wave = lanes;
+	b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+	const uint32_t per_wg = lanes * JM_PARSE_WAVES;
+	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + per_wg - 1) / per_wg), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }
 
