@@ -324,8 +324,8 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 }
 
 /* ------------------------------------------------------------------------
- * Reconstruct: one lane per 8x8 block, one workgroup per tile of TW x 4 blocks
- * of one plane (recon_block.h, JmTiles), one wavefront per block row of it.
+ * Reconstruct: one lane per 8x8 block, one workgroup per tile of TW x 8 blocks
+ * of one plane (recon_block.h, JmTiles), two block rows of it per wavefront.
  * All tiles of a picture are dispatched to the same XCD (workgroup b runs on
  * XCD b % 8) so the forward frame's prediction reads hit one L2.
  *
@@ -339,7 +339,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
  * loads and stores), which a workgroup that simply ends never waits for.
  * ---------------------------------------------------------------------- */
 #ifndef JM_RECON_WG
-#define JM_RECON_WG 256   /* 4 wavefronts = 4 block rows of a tile; LDS: 144 bytes per lane */
+#define JM_RECON_WG 256   /* 4 wavefronts = 8 block rows of a tile; LDS: 144 bytes per lane */
 #endif
 #define JM_SLOT_HALVES 72 /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
 
@@ -377,21 +377,22 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
-	Q.rw = *reinterpret_cast<const uint4_like_t *>(D.mb + Q.mbaddr);
+	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>((JM_GLOBAL const JmMbRec *)D.mb + Q.mbaddr);
 	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
 	uint4 tq = make_uint4(0, 0, 0, 0);
-	if (threadIdx.x < 8) tq = reinterpret_cast<const uint4 *>(D.qm)[threadIdx.x];
+	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];
 	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
 	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
 	own.zero();
 	JmReconCtx c;
 	c.g = b.g;
-	c.mb = D.mb;
-	c.tok = D.tok;
+	/* the descriptor's addresses are device memory: say so (JM_GLOBAL), or every access through them is a flat one */
+	c.mb = (JM_GLOBAL const JmMbRec *)D.mb;
+	c.tok = (JM_GLOBAL const uint16_t *)D.tok;
 	c.has_fwd = D.fwd != nullptr;
-	c.dst = D.dst;
-	c.fwd = c.has_fwd ? D.fwd : D.dst;
-	c.stale = D.stale;
+	c.dst = (JM_GLOBAL uint8_t *)D.dst;
+	c.fwd = (JM_GLOBAL const uint8_t *)(c.has_fwd ? D.fwd : D.dst);
+	c.stale = (JM_GLOBAL const uint8_t *)D.stale;
 	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
 	c.zero_uncovered = b.zero_uncovered;

@@ -31,6 +31,16 @@
 #define JM_D inline
 #endif
 
+/* Pointers into device memory that did not come straight from a kernel argument (picture descriptors hold addresses)
+ * carry their address space in the type: without it the compiler emits flat_load / flat_store for them -- which
+ * count in BOTH wait counters, so every wait for LDS (before each barrier) also waits for the prediction rows that
+ * are meant to stay in flight across it. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JM_GLOBAL __attribute__((address_space(1)))
+#else
+#define JM_GLOBAL
+#endif
+
 /* start codes (reference mpeg1.c:686-691) */
 enum {
 	JM_CODE_PICTURE = 0x00,

@@ -33,12 +33,12 @@
 
 struct JmReconCtx {
 	JmGeom g;
-	const JmMbRec *mb;       /* this picture's macroblock records        */
-	const uint16_t *tok;     /* this picture's token base                */
-	uint8_t *dst;            /* this picture's frame: Y | Cr | Cb        */
-	const uint8_t *fwd;      /* forward reference frame (any valid address when has_fwd == 0) */
+	JM_GLOBAL const JmMbRec *mb;       /* this picture's macroblock records        */
+	JM_GLOBAL const uint16_t *tok;     /* this picture's token base                */
+	JM_GLOBAL uint8_t *dst;            /* this picture's frame: Y | Cr | Cb        */
+	JM_GLOBAL const uint8_t *fwd;      /* forward reference frame (any valid address when has_fwd == 0) */
 	int has_fwd;
-	const uint8_t *stale;    /* batch mode: the frame whose content unwritten macroblocks keep (null: zeros) */
+	JM_GLOBAL const uint8_t *stale;    /* batch mode: the frame whose content unwritten macroblocks keep (null: zeros) */
 	const uint8_t *qm;       /* raster quantiser matrices: intra at [0, 64), non-intra at [64, 128) */
 	const uint8_t *zz;       /* zig-zag scan index -> raster position (mpeg1.c ZIG_ZAG) */
 	uint8_t epoch;
@@ -151,7 +151,7 @@ JM_HD int jm_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
 /* What a lane carries from the front phase to the back phase of its block. */
 struct JmBlk {
-	uint8_t *out;            /* top-left pixel of the block in the destination plane */
+	JM_GLOBAL uint8_t *out;            /* top-left pixel of the block in the destination plane */
 	int stride;
 	int cnt;                 /* tokens of the block */
 	bool live;               /* the macroblock was written this batch */
@@ -162,7 +162,7 @@ struct JmBlk {
 	int konst;               /* no tokens: 0; intra DC only: dc; only the (0,0) coefficient: (level * 32 + 128) >> 8
 	                            -- what the full transform gives for those (mpeg1.c:1578-1581) */
 	int qscale;
-	const uint32_t *tkw;     /* the block's token run, dword aligned */
+	JM_GLOBAL const uint32_t *tkw;     /* the block's token run, dword aligned */
 	uint32_t tw[4];          /* its first eight tokens */
 	uint32_t R[27];          /* raw prediction rows (front -> predict) */
 	uint32_t m, oh, ov;
@@ -219,45 +219,48 @@ JM_HD void jm_recon_where(const JmGeom &G, int g, JmLoc &Q) {
 		Q.plane_off = G.luma_bytes + (pl ? 0u : G.chroma_bytes);
 	}
 }
-JM_HD void jm_recon_locate(const JmGeom &G, const JmMbRec *mb, int g, JmLoc &Q) {
+JM_HD void jm_recon_locate(const JmGeom &G, JM_GLOBAL const JmMbRec *mb, int g, JmLoc &Q) {
 	jm_recon_where(G, g, Q);
-	Q.rw = *reinterpret_cast<const uint4_like_t *>(mb + Q.mbaddr);
+	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>(mb + Q.mbaddr);
 }
 
-/* TILES.  A workgroup reconstructs a tile of TW x 4 blocks of ONE plane -- wavefront w takes block row 4 ty + w,
- * lane l the block tx TW + l of it -- rather than 256 consecutive blocks of the block raster (one block row):
- * the forward windows of four block rows overlap (vectors reach +-8 .. +-64 pixels, a block row is 8), so the
- * cache lines one wavefront pulls into the CU's L1 serve the other three; with random vectors the kernel is bound
- * by L1 misses in flight, not by HBM (tools/ubench_pred.hip: the 256 x 1 shape 0.73 ms, 60 x 4 0.62 ms for the
- * luma of 640 pictures at +-32).  A wavefront still stores whole row pieces: TW x 8 contiguous bytes.
- * TW = the plane's width in blocks split into the fewest pieces of at most 64. */
-#define JM_TILE_ROWS 4         /* block rows per tile: 4 (a wavefront per row; measured 1.09 ms per level) or 2 (two wavefronts side by side per row: 1.11) */
+/* TILES.  A workgroup reconstructs a tile of TW x 8 blocks of ONE plane; wavefront w takes the block rows 2w and
+ * 2w + 1 of it, lanes 0..31 the upper, lanes 32..63 the lower -- in the luma plane the four blocks of a macroblock sit
+ * in ONE wavefront (lanes l, l + 1, l + 32, l + 33: one record line, one token run, two overlapping prediction
+ * windows with the same vector) and the four wavefronts cover four macroblock rows whose forward windows overlap
+ * (vectors reach +-8 .. +-64 pixels): the cache lines one lane pulls into the CU's L1 serve its neighbours.  With
+ * random vectors the kernel is bound by L1 misses in flight, not by HBM (tools/ubench_pred.hip, luma of 640 pictures
+ * at +-16: 256 consecutive blocks per workgroup 0.69 ms, 60 x 4 tiles 0.60, 32 x 8 tiles in this lane order 0.50).
+ * A wavefront still stores whole row pieces: TW x 8 contiguous bytes for each of its two block rows.
+ * TW = 32 (the plane's last tile column takes what is left). */
+#define JM_TILE_ROWS 8
 struct JmTiles {
-	int tw_y, cols_y, rows_y;      /* luma: a wavefront's width in blocks, tile columns, tile rows */
+	int tw_y, cols_y, rows_y;      /* luma: tile width in blocks (<= 32), tile columns, tile rows */
 	int tw_c, cols_c, rows_c;      /* each chroma plane */
 	int per_picture;               /* cols_y * rows_y + 2 * cols_c * rows_c */
 };
 JM_HD void jm_tiles_init(JmTiles &T, const JmGeom &G) {
 	const int bw = 2 * G.mb_width, bh = 2 * G.mb_height, bwc = G.mb_width, bhc = G.mb_height;
-	const int wpr = 4 / JM_TILE_ROWS;                                  /* wavefronts side by side in a tile */
-	T.cols_y = (bw + 64 * wpr - 1) / (64 * wpr); T.tw_y = (bw + T.cols_y * wpr - 1) / (T.cols_y * wpr); T.rows_y = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
-	T.cols_c = (bwc + 64 * wpr - 1) / (64 * wpr); T.tw_c = (bwc + T.cols_c * wpr - 1) / (T.cols_c * wpr); T.rows_c = (bhc + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
+	/* 32 blocks wide, the last column takes what is left: tile edges at multiples of 256 bytes, so that a wavefront's
+	 * row pieces are whole 32-byte sectors (30-block tiles, edges at multiples of 240 bytes, measured 4 % slower than
+	 * the 60 x 4 tiles they were to replace: partial sectors at every tile edge) */
+	T.cols_y = (bw + 31) / 32; T.tw_y = bw < 32 ? bw : 32; T.rows_y = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
+	T.cols_c = (bwc + 31) / 32; T.tw_c = bwc < 32 ? bwc : 32; T.rows_c = (bhc + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
 	T.per_picture = T.cols_y * T.rows_y + 2 * T.cols_c * T.rows_c;
 }
 /* lane `lane` of wavefront `wave` of tile `tile` of a picture: where its block is; false: no block (past the
- * plane's edge or the wavefront's width) -- Q then describes a neighbouring block, so that every lane has loads to issue */
+ * plane's edge or the tile's width) -- Q then describes a neighbouring block, so that every lane has loads to issue */
 JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int wave, int lane, JmLoc &Q) {
 	const int ny = T.cols_y * T.rows_y, nc = T.cols_c * T.rows_c;
-	const int wpr = 4 / JM_TILE_ROWS;
 	int pl = 0, t = tile, cols = T.cols_y, tw = T.tw_y;       /* pl: 0 luma, 1 / 2 the chroma planes in block-number order (block 4, block 5) */
 	if (tile >= ny) { pl = tile >= ny + nc ? 2 : 1; t = tile - ny - (pl - 1) * nc; cols = T.cols_c; tw = T.tw_c; }
 	const int ty = t / cols, tx = t - ty * cols;
-	int bx = (tx * wpr + wave % wpr) * tw + lane, by = ty * JM_TILE_ROWS + wave / wpr;
+	const int lx = lane & 31;
+	int bx = tx * tw + lx, by = ty * JM_TILE_ROWS + 2 * wave + (lane >> 5);
 	const int bw = pl ? G.mb_width : 2 * G.mb_width, bh = pl ? G.mb_height : 2 * G.mb_height;
-	const bool ok = lane < tw && bx < bw && by < bh;
-	/* a lane without a block looks at the nearest block that exists (its loads then coalesce with that lane's; all of
-	 * them looking at block 0 of the picture made one hot spot of it: 1.5 instead of 1.1 ms per level) */
-	if (lane >= tw) bx -= lane - (tw - 1);
+	const bool ok = lx < tw && bx < bw && by < bh;
+	/* a lane without a block looks at the nearest block that exists (its loads then coalesce with that lane's) */
+	if (lx >= tw) bx -= lx - (tw - 1);
 	if (bx >= bw) bx = bw - 1;
 	if (by >= bh) by = bh - 1;
 	if (pl == 0) {
@@ -300,7 +303,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	uint32_t t0 = rec_tok;
 #pragma unroll
 	for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)(((rec_cnt >> (8 * j)) & 0xff) + 1) & ~1u;
-	B.tkw = reinterpret_cast<const uint32_t *>(c.tok + t0);
+	B.tkw = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + t0);
 	B.tw[0] = B.tw[1] = B.tw[2] = B.tw[3] = 0;
 	/* every lane loads -- blocks without tokens read the picture's first slots, blocks without prediction
 	 * the first bytes of the frame (one address for all of them) -- so that there is no branch around
@@ -308,7 +311,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	 * rows stay in flight across the set-up barrier and are only awaited where they are used
 	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
-		const uint32_t *tk = B.cnt > 0 ? B.tkw : reinterpret_cast<const uint32_t *>(c.tok);
+		JM_GLOBAL const uint32_t *tk = B.cnt > 0 ? B.tkw : reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok);
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
 	}
 
@@ -327,14 +330,14 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		if (sx + 8 + (int)B.oh > stride) sx = stride - 8 - (int)B.oh;
 		if (sy + 8 + (int)B.ov > ph) sy = ph - 8 - (int)B.ov;
 		const uint32_t off = (uint32_t)(sy * stride + sx);
-		const uint32_t *w = reinterpret_cast<const uint32_t *>(B.pred ? c.fwd + plane_off + (off & ~3u) : c.fwd);
+		JM_GLOBAL const uint32_t *w = reinterpret_cast<JM_GLOBAL const uint32_t *>(B.pred ? c.fwd + plane_off + (off & ~3u) : c.fwd);
 		B.m = B.pred ? off & 3u : 0u;
 		const int wstride = B.pred ? stride >> 2 : 0;
 		if (!B.pred) { B.oh = B.ov = 0; }
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
-			const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
+			JM_GLOBAL const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
 		}
 	}
@@ -520,10 +523,10 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	X.store = B.live || c.zero_uncovered != 0;
 	if (!B.live && c.zero_uncovered && c.stale) {
 		/* a macroblock this picture never wrote: the reference's plane set still holds the picture before last there */
-		const uint8_t *src = c.stale + (B.out - c.dst);
+		JM_GLOBAL const uint8_t *src = c.stale + (B.out - c.dst);
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
-			const uint32_t *w = reinterpret_cast<const uint32_t *>(src + r * B.stride);
+			JM_GLOBAL const uint32_t *w = reinterpret_cast<JM_GLOBAL const uint32_t *>(src + r * B.stride);
 			X.p[2 * r] = w[0]; X.p[2 * r + 1] = w[1];
 		}
 	}
@@ -553,7 +556,7 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
-		uint32_t *o = (uint32_t *)(B.out + r * B.stride);
+		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(B.out + r * B.stride);
 #if defined(__HIP_DEVICE_COMPILE__)
 		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
 		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);

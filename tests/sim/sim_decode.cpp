@@ -199,7 +199,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			uint8_t qm[128];
 			memcpy(qm, st.intra_q, 64); memcpy(qm + 64, st.nonintra_q, 64);
 			c.qm = qm; c.zz = luts.zigzag; c.epoch = epoch; c.zero_uncovered = 1;
-			// k_recon, one emulated 256-lane workgroup (a tile of TW x 4 blocks of one plane) at a time: front, rank the
+			// k_recon, one emulated 256-lane workgroup (a tile of TW x 8 blocks of one plane) at a time: front, rank the
 			// blocks that need the transform, scatter into the packed slots, transform slots [0, total), back
 			static HostSlot slots[256];
 			static JmBlk B[256];

@@ -58,6 +58,54 @@ __global__ __launch_bounds__(256) void k_pred(const uint8_t *src, uint8_t *dst, 
 	} else if (a0 == 0x12345678u && a1 == 0x9abcdef0u) *(uint32_t *)o = 1;
 }
 
+/* wave = WB x HB blocks (WB * HB = 64), workgroup = GX x GY waves */
+template <int MODE, bool STORE, int WB, int HB, int GX, int GY>
+__global__ __launch_bounds__(256) void k_pred2(const uint8_t *src, uint8_t *dst, uint32_t frame_bytes, uint32_t n_frames, uint32_t range) {
+	const int W = 1920, H = 1088, BW = W / 8, BH = H / 8;
+	const int tcols = (BW + WB * GX - 1) / (WB * GX), trows = (BH + HB * GY - 1) / (HB * GY);
+	const uint32_t bpf = (uint32_t)(tcols * trows);
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t blk = q % bpf, f = (q / bpf) * 8 + xcd;
+	if (f >= n_frames) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int ty = blk / tcols, tx = blk - ty * tcols;
+	const int bx = (tx * GX + wave % GX) * WB + lane % WB, by = (ty * GY + wave / GX) * HB + lane / WB;
+	if (bx >= BW || by >= BH) return;
+	const uint32_t h = hash32((uint32_t)(f * 8160 + (by >> 1) * 120 + (bx >> 1)));
+	int mvx = MODE == 2 ? 0 : (int)(h % (2 * range + 1)) - (int)range, mvy = MODE == 2 ? 0 : (int)((h >> 12) % (2 * range + 1)) - (int)range;
+	int sx = bx * 8 + mvx, sy = by * 8 + mvy;
+	sx = sx < 0 ? 0 : (sx > W - 12 ? W - 12 : sx);
+	sy = sy < 0 ? 0 : (sy > H - 9 ? H - 9 : sy);
+	const uint8_t *fs = src + (size_t)f * frame_bytes;
+	const uint32_t off = (uint32_t)(sy * W + sx);
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(fs + (off & ~3u));
+	uint32_t a0 = 0, a1 = 0;
+	uint32_t R[27];
+#pragma unroll
+	for (int j = 0; j < 9; j++) { const uint32_t *wr = w + j * (W / 4); R[3 * j] = wr[0]; R[3 * j + 1] = wr[1]; R[3 * j + 2] = wr[2]; }
+#pragma unroll
+	for (int j = 0; j < 9; j++) { a0 ^= R[3 * j] + R[3 * j + 2]; a1 += R[3 * j + 1]; }
+	uint8_t *o = dst + (size_t)f * frame_bytes + (size_t)(by * 8) * W + bx * 8;
+	if (STORE) {
+#pragma unroll
+		for (int r = 0; r < 8; r++) { uint2 v = make_uint2(a0 + r, a1 ^ r); __builtin_nontemporal_store(v.x, (uint32_t *)(o + r * W)); __builtin_nontemporal_store(v.y, (uint32_t *)(o + r * W) + 1); }
+	} else if (a0 == 0x12345678u && a1 == 0x9abcdef0u) *(uint32_t *)o = 1;
+}
+template <int MODE, bool STORE, int WB, int HB, int GX, int GY>
+static void run2(const char *name, const uint8_t *src, uint8_t *dst, uint32_t fb, uint32_t n, uint32_t range) {
+	const int tcols = (240 + WB * GX - 1) / (WB * GX), trows = (136 + HB * GY - 1) / (HB * GY);
+	const uint32_t grid = ((n + 7) / 8) * 8 * (uint32_t)(tcols * trows);
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	float best = 1e9f;
+	for (int rep = 0; rep < 3; rep++) {
+		CK(hipEventRecord(e0));
+		hipLaunchKernelGGL((k_pred2<MODE, STORE, WB, HB, GX, GY>), dim3(grid), dim3(256), 0, 0, src, dst, fb, n, range);
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+	}
+	printf("%-40s range %2u: %.3f ms\n", name, range, best);
+}
+
 template <int MODE, bool STORE, int TW>
 static void run(const char *name, const uint8_t *src, uint8_t *dst, uint32_t fb, uint32_t n, uint32_t range) {
 	const uint32_t bpf = TW ? (240 / TW) * (136 / 4) : (240 * 136 + 255) / 256, grid = ((n + 7) / 8) * 8 * bpf;
@@ -86,6 +134,17 @@ int main() {
 		run<1, false, 0>("256x1 rotated, no stores", src, dst, fb, n, range);
 		run<0, false, 60>("60x4 row order, no stores", src, dst, fb, n, range);
 		run<1, false, 60>("60x4 rotated, no stores", src, dst, fb, n, range);
+	}
+	for (uint32_t range : { 8u, 16u, 32u }) {
+		run2<0, true, 16, 4, 1, 4>("wave 16x4, wg 1x4 (16x16 blocks), stores", src, dst, fb, n, range);
+		run2<0, true, 16, 4, 4, 1>("wave 16x4, wg 4x1 (64x4 blocks), stores", src, dst, fb, n, range);
+		run2<0, true, 16, 4, 2, 2>("wave 16x4, wg 2x2 (32x8 blocks), stores", src, dst, fb, n, range);
+		run2<0, true, 32, 2, 1, 4>("wave 32x2, wg 1x4 (32x8 blocks), stores", src, dst, fb, n, range);
+		run2<0, true, 32, 2, 2, 2>("wave 32x2, wg 2x2 (64x4 blocks), stores", src, dst, fb, n, range);
+		run2<0, true, 8, 8, 2, 2>("wave 8x8, wg 2x2 (16x16 blocks), stores", src, dst, fb, n, range);
+		run2<0, false, 16, 4, 1, 4>("wave 16x4, wg 1x4, no stores", src, dst, fb, n, range);
+		run2<0, false, 32, 2, 1, 4>("wave 32x2, wg 1x4, no stores", src, dst, fb, n, range);
+		run2<0, false, 8, 8, 2, 2>("wave 8x8, wg 2x2, no stores", src, dst, fb, n, range);
 	}
 	run<2, true, 0>("256x1 zero vectors, stores", src, dst, fb, n, 0);
 	run<2, true, 60>("60x4 zero vectors, stores", src, dst, fb, n, 0);
