@@ -437,7 +437,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	JmPix X;
 	X.store = false;
 	if (valid) X = jm_recon_pixels(c, B, mine);
-	if (X.store) jm_recon_store(B, X);
+	if (X.store) jm_recon_store(c, B, X);
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

@@ -151,7 +151,8 @@ JM_HD int jm_clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
 /* What a lane carries from the front phase to the back phase of its block. */
 struct JmBlk {
-	JM_GLOBAL uint8_t *out;            /* top-left pixel of the block in the destination plane */
+	uint32_t out;            /* byte offset of the block's top-left pixel in the frame (Y | Cr | Cb): 32-bit offsets from the
+	                            wave-uniform frame address keep the address arithmetic of loads and stores in one register */
 	int stride;
 	int cnt;                 /* tokens of the block */
 	bool live;               /* the macroblock was written this batch */
@@ -162,7 +163,7 @@ struct JmBlk {
 	int konst;               /* no tokens: 0; intra DC only: dc; only the (0,0) coefficient: (level * 32 + 128) >> 8
 	                            -- what the full transform gives for those (mpeg1.c:1578-1581) */
 	int qscale;
-	JM_GLOBAL const uint32_t *tkw;     /* the block's token run, dword aligned */
+	uint32_t tkw;            /* the block's token run, dword aligned: token number from the picture's token base */
 	uint32_t tw[4];          /* its first eight tokens */
 	uint32_t R[27];          /* raw prediction rows (front -> predict) */
 	uint32_t m, oh, ov;
@@ -283,7 +284,7 @@ JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int 
 JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	const int bnum = Q.bnum, x0 = Q.x0, y0 = Q.y0, stride = Q.stride, ph = Q.ph;
 	const uint32_t plane_off = Q.plane_off;
-	B.out = c.dst + plane_off + (uint32_t)(y0 * stride + x0);
+	B.out = plane_off + (uint32_t)(y0 * stride + x0);
 	B.stride = stride;
 
 	/* the 16-byte record as four dwords; fields by shifts (no indexed local) */
@@ -303,7 +304,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	uint32_t t0 = rec_tok;
 #pragma unroll
 	for (int j = 0; j < 5; j++) if (j < bnum) t0 += (uint32_t)(((rec_cnt >> (8 * j)) & 0xff) + 1) & ~1u;
-	B.tkw = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + t0);
+	B.tkw = t0;
 	B.tw[0] = B.tw[1] = B.tw[2] = B.tw[3] = 0;
 	/* every lane loads -- blocks without tokens read the picture's first slots, blocks without prediction
 	 * the first bytes of the frame (one address for all of them) -- so that there is no branch around
@@ -311,7 +312,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	 * rows stay in flight across the set-up barrier and are only awaited where they are used
 	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
-		JM_GLOBAL const uint32_t *tk = B.cnt > 0 ? B.tkw : reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok);
+		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? B.tkw : 0u));
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
 	}
 
@@ -330,14 +331,14 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		if (sx + 8 + (int)B.oh > stride) sx = stride - 8 - (int)B.oh;
 		if (sy + 8 + (int)B.ov > ph) sy = ph - 8 - (int)B.ov;
 		const uint32_t off = (uint32_t)(sy * stride + sx);
-		JM_GLOBAL const uint32_t *w = reinterpret_cast<JM_GLOBAL const uint32_t *>(B.pred ? c.fwd + plane_off + (off & ~3u) : c.fwd);
+		const uint32_t woff = B.pred ? plane_off + (off & ~3u) : 0u;
 		B.m = B.pred ? off & 3u : 0u;
-		const int wstride = B.pred ? stride >> 2 : 0;
+		const uint32_t wstride = B.pred ? (uint32_t)stride : 0u;
 		if (!B.pred) { B.oh = B.ov = 0; }
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
-			JM_GLOBAL const uint32_t *wr = w + (r < 8 ? r : last) * wstride;
+			JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
 		}
 	}
@@ -393,7 +394,7 @@ JM_HD void jm_recon_scatter(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 		}
 		base += 8;
 		if (base >= B.cnt) break;
-		tw[0] = B.tkw[base / 2]; tw[1] = B.tkw[base / 2 + 1]; tw[2] = B.tkw[base / 2 + 2]; tw[3] = B.tkw[base / 2 + 3];
+		{ JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.tkw + (uint32_t)base)); tw[0] = tk[0]; tw[1] = tk[1]; tw[2] = tk[2]; tw[3] = tk[3]; }
 	}
 }
 
@@ -519,11 +520,11 @@ template <class Slot>
 JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	JmPix X;
 #pragma unroll
-	for (int i = 0; i < 16; i++) X.p[i] = B.live ? B.P[i] : 0u;
+	for (int i = 0; i < 16; i++) X.p[i] = B.P[i];          /* zero unless predicted (jm_recon_predict), and only live blocks are */
 	X.store = B.live || c.zero_uncovered != 0;
 	if (!B.live && c.zero_uncovered && c.stale) {
 		/* a macroblock this picture never wrote: the reference's plane set still holds the picture before last there */
-		JM_GLOBAL const uint8_t *src = c.stale + (B.out - c.dst);
+		JM_GLOBAL const uint8_t *src = c.stale + B.out;
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
 			JM_GLOBAL const uint32_t *w = reinterpret_cast<JM_GLOBAL const uint32_t *>(src + r * B.stride);
@@ -553,10 +554,10 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 }
 
 /* coalesced row stores: 8 bytes per lane per row */
-JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
+JM_HD void jm_recon_store(const JmReconCtx &c, const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
-		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(B.out + r * B.stride);
+		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(c.dst + (B.out + (uint32_t)(r * B.stride)));
 #if defined(__HIP_DEVICE_COMPILE__)
 		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
 		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);
@@ -570,7 +571,7 @@ JM_HD void jm_recon_store(const JmBlk &B, const JmPix &X) {
 template <class Slot>
 JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	const JmPix X = jm_recon_pixels(c, B, s);
-	if (X.store) jm_recon_store(B, X);
+	if (X.store) jm_recon_store(c, B, X);
 }
 
 #endif
