@@ -78,7 +78,8 @@ JM_D uint32_t jm_lerp(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amd
 JM_D uint32_t jm_perm(uint32_t b, uint32_t a, uint32_t sel) { return __builtin_amdgcn_perm(b, a, sel); }
 /* two int16 lanes: saturating add; saturate each to 0..255 and pack into the low 16 bits */
 JM_D uint32_t jm_pk_add_sat(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
-JM_D uint32_t jm_sat_pk_u8(uint32_t a) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(a)); return d & 0xffffu; }
+JM_D uint32_t jm_sat_pk_u8(uint32_t a) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(a)); return d; }   /* the instruction writes {16'b0, sat8(hi), sat8(lo)}: no mask needed */
+
 /* 4 bytes starting `shift` (0..3) bytes into lo:hi */
 JM_D uint32_t jm_alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
 #else
