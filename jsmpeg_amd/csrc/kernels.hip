@@ -339,9 +339,19 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
  * loads and stores), which a workgroup that simply ends never waits for.
  * ---------------------------------------------------------------------- */
 #ifndef JM_RECON_WG
-#define JM_RECON_WG 256   /* 4 wavefronts = 8 block rows of a tile; LDS: 144 bytes per lane */
+#define JM_RECON_WG 256   /* 4 wavefronts = 8 block rows of a tile */
 #endif
-#define JM_SLOT_HALVES 72 /* 144 bytes per lane: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
+#define JM_SLOT_HALVES 72 /* 144 bytes per slot: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
+/* Transform slots per workgroup.  220 x 144 bytes + the matrices = 31.9 KB: FIVE workgroups per CU (a slot per lane,
+ * 36.9 KB, allows four; LDS is handed out in 1280-byte granules, 25 of them per workgroup is the most that fits five
+ * times; with the smaller footprint the compiler also aims for 5 wavefronts per SIMD and gets the kernel into 96
+ * registers without scratch).  A tile with more than 220 blocks that need the transform (dense intra content) takes
+ * them in further passes of up to 128 at the end of the kernel. */
+#ifndef JM_RECON_SLOTS
+#define JM_RECON_SLOTS 220
+#endif
+#define JM_RECON_PASS (JM_RECON_SLOTS < JM_RECON_WG / 2 ? JM_RECON_SLOTS : JM_RECON_WG / 2)
+static_assert(JM_RECON_SLOTS >= 32 && JM_RECON_SLOTS <= JM_RECON_WG, "a wavefront round takes 32 slots");
 
 struct LdsSlot {
 	int16_t *base;
@@ -366,7 +376,7 @@ struct LdsSlot {
 };
 
 __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
-	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_WG];
+	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -382,8 +392,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	uint4 tq = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];
 	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
-	LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES };
-	own.zero();
+	if (threadIdx.x < JM_RECON_SLOTS) { LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES }; own.zero(); }
 	JmReconCtx c;
 	c.g = b.g;
 	/* the descriptor's addresses are device memory: say so (JM_GLOBAL), or every access through them is a flat one */
@@ -398,13 +407,12 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	c.zero_uncovered = b.zero_uncovered;
 
 	/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the loads;
-	 * no branch around them, see recon_block.h -- lanes without a block look at block 0 and are masked after) */
+	 * no branch around them, see recon_block.h -- lanes without a block look at a neighbour's and are masked after) */
 	JmBlk B;
 	jm_recon_front(c, Q, B);
 	if (!valid) { B.idct = false; B.lowf = false; B.k00 = false; B.live = false; B.pred = false; B.cnt = 0; B.konst = 0; }
-	/* the blocks that need the transform, packed to the front of the workgroup's slots: first the ones
-	 * whose coefficients all lie in the top-left 4x4 (wavefronts that hold only those run the cheap
-	 * transform), then the rest */
+	/* the blocks that need the transform, packed into the workgroup's slots: first the ones whose coefficients all
+	 * lie in the top-left 4x4 (wavefronts that hold only those run the cheap transform), then the rest */
 	const uint64_t needA = __ballot(B.idct && B.lowf), needB = __ballot(B.idct && !B.lowf);
 	const uint32_t beforeA = __builtin_amdgcn_mbcnt_hi((uint32_t)(needA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needA, 0));
 	const uint32_t beforeB = __builtin_amdgcn_mbcnt_hi((uint32_t)(needB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needB, 0));
@@ -414,21 +422,32 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	uint32_t prior = 0, sum = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
-	const uint32_t totalA = sum & 0xffffu, total = totalA + (sum >> 16);
-	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : totalA + (prior >> 16) + beforeB;
-	LdsSlot mine = { coef + rank * JM_SLOT_HALVES };
+	const uint32_t totalA = sum & 0xffffu, totalB = sum >> 16;
+	/* where the second class starts: right behind the first -- or at the next multiple of 32, when that leaves one
+	 * wavefront fewer with the full transform to run (the wavefront that straddles the boundary runs it for all its 32
+	 * slots; the gap's slots are all zero and cost the cheap transform nothing extra) */
+	uint32_t firstB = totalA;
+	{
+		const uint32_t up = (totalA + 31u) & ~31u;
+		if ((totalB + 31u) / 32u < (totalA + totalB + 31u) / 32u - totalA / 32u && up + totalB <= JM_RECON_SLOTS) firstB = up;
+	}
+	const uint32_t total = firstB + totalB;
+	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : firstB + (prior >> 16) + beforeB;
+	const bool later = B.idct && rank >= JM_RECON_SLOTS;      /* no slot in the first pass: see the end of the kernel */
+	LdsSlot mine = { coef + (later ? 0u : rank) * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
-	if (B.idct) jm_recon_scatter(c, B, mine);
+	if (B.idct && !later) jm_recon_scatter(c, B, mine);
 	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
 	__syncthreads();
 	/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the workgroup
 	 * 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past the last
 	 * packed block skip it altogether */
-	for (uint32_t r0 = 0; r0 < total; r0 += JM_RECON_WG / 2) {
+	const uint32_t held = total < JM_RECON_SLOTS ? total : JM_RECON_SLOTS;
+	for (uint32_t r0 = 0; r0 < held; r0 += JM_RECON_WG / 2) {
 		const uint32_t s0 = r0 + wave * 32;
-		if (s0 < total) {
+		if (s0 + (lane & 31) < held) {                                                  /* both lanes of a pair, or neither */
 			LdsSlot sl = { coef + (s0 + (lane & 31)) * JM_SLOT_HALVES };
-			if (s0 + 32 <= totalA) jm_recon_idct_pair<true>(sl, (int)(lane >> 5));      /* wave-uniform */
+			if (s0 + 32 <= firstB) jm_recon_idct_pair<true>(sl, (int)(lane >> 5));      /* wave-uniform */
 			else jm_recon_idct_pair<false>(sl, (int)(lane >> 5));
 		}
 	}
@@ -436,8 +455,41 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* phase 3 */
 	JmPix X;
 	X.store = false;
+	if (later) B.idct = false;           /* for now the prediction alone (an idct block's konst is 0) */
 	if (valid) X = jm_recon_pixels(c, B, mine);
-	if (X.store) jm_recon_store(c, B, X);
+	if (X.store && !later) jm_recon_store(c, B, X);
+
+	/* further passes (workgroup-uniform, rare: more than JM_RECON_SLOTS blocks of the tile need the transform): the
+	 * blocks left over take the slots again, JM_RECON_PASS at a time; their lanes look at the record and the tokens
+	 * a second time (nothing of the first look is kept alive for this but the predicted pixels) */
+	for (uint32_t base = JM_RECON_SLOTS; base < total; base += JM_RECON_PASS) {
+		__syncthreads();                                   /* everybody has read their residuals */
+		const bool now = later && rank >= base && rank < base + JM_RECON_PASS;
+		LdsSlot t = { coef + (now ? rank - base : 0u) * JM_SLOT_HALVES };
+		JmBlk B2;
+		if (now) {
+			JmLoc Q2;
+			jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q2);
+			Q2.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>(c.mb + Q2.mbaddr);
+			jm_recon_front<false>(c, Q2, B2);
+			t.zero();
+			jm_recon_scatter(c, B2, t);
+		}
+		__syncthreads();
+		const uint32_t n = total - base < JM_RECON_PASS ? total - base : JM_RECON_PASS, s0 = wave * 32;
+		if (s0 + (lane & 31) < n) {
+			LdsSlot sl = { coef + (s0 + (lane & 31)) * JM_SLOT_HALVES };
+			jm_recon_idct_pair<false>(sl, (int)(lane >> 5));
+		}
+		__syncthreads();
+		if (now) {
+#pragma unroll
+			for (int i = 0; i < 16; i++) B2.P[i] = X.p[i];
+			B2.pred = B.pred;
+			X = jm_recon_pixels(c, B2, t);
+			if (X.store) jm_recon_store(c, B2, X);
+		}
+	}
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

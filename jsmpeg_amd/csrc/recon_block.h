@@ -281,7 +281,9 @@ JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int 
 	return ok;
 }
 
-/* PHASE 1 (every lane, its own block): what the block holds, the token and prediction loads. */
+/* PHASE 1 (every lane, its own block): what the block holds, the token and prediction loads.  PRED == false: without
+ * the prediction loads (the kernel's second look at blocks whose transform had to wait for a free slot). */
+template <bool PRED = true>
 JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	const int bnum = Q.bnum, x0 = Q.x0, y0 = Q.y0, stride = Q.stride, ph = Q.ph;
 	const uint32_t plane_off = Q.plane_off;
@@ -319,7 +321,7 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
 	B.m = B.oh = B.ov = 0;
-	{
+	if (PRED) {
 		int mh = B.pred ? rec_mvh : 0, mv = B.pred ? rec_mvv : 0;
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
 		const int H = mh >> 1, V = mv >> 1;
