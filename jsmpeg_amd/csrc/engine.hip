@@ -94,8 +94,8 @@ struct jsmpeg_hip_batch_t {
 	std::vector<JmStream> h_streams;
 	JmStream *d_streams;
 
-	uint32_t sc_cap, scan_blocks_cap;
-	uint64_t *d_block_counts;
+	uint32_t sc_cap;
+	uint64_t *d_scan_state;
 	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
 	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
@@ -121,7 +121,7 @@ struct jsmpeg_hip_batch_t {
 
 static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
-	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_block_counts); hipFree(b->d_sc_pos);
+	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_scan_state); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
@@ -139,16 +139,15 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 		return fail("max_es_bytes too large: batch ES positions are 32-bit");
 	b->es_cap = c.max_es_bytes + (uint64_t)JM_STREAM_GAP * (c.max_streams + 1) + JM_ES_PAD + 64;
 	b->sc_cap = (uint32_t)(b->es_cap / 16 + 4096);
-	b->scan_blocks_cap = (uint32_t)(b->es_cap / JM_SCAN_BLOCK_BYTES + 2);
 	HIP_TRY(jm_malloc(&b->d_es, b->es_cap));
 	HIP_TRY(hipMemset(b->d_es, 0xff, b->es_cap));
 	HIP_TRY(jm_malloc(&b->d_streams, sizeof(JmStream) * std::max(1u, c.max_streams)));
-	HIP_TRY(jm_malloc(&b->d_block_counts, sizeof(uint64_t) * (b->scan_blocks_cap + 1)));
+	HIP_TRY(jm_malloc(&b->d_scan_state, jm_scan_state_bytes(b->es_cap)));
 	HIP_TRY(jm_malloc(&b->d_sc_pos, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_sc_code, b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
-	HIP_TRY(jm_malloc(&b->d_counters, 4 * sizeof(uint32_t)));
+	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
 	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, and room for a second pass (step 4b) */
 	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
@@ -164,7 +163,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_pool_alloc, pool_bytes));
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
-	HIP_TRY(hipHostMalloc(&b->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc(&b->h_counters, JM_N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
 	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
 	return 0;
 }
@@ -182,7 +181,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	}
 	jsmpeg_hip_batch_t *b = new jsmpeg_hip_batch_t();
 	b->cfg = *config;
-	b->d_es = nullptr; b->d_streams = nullptr; b->d_block_counts = nullptr; b->d_sc_pos = nullptr;
+	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
@@ -458,9 +457,9 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 1. start-code index + tables (device) ---- */
 	HIP_TRY(hipEventRecord(b->ev[0], st));
-	HIP_TRY(hipMemsetAsync(b->d_counters, 0, 4 * sizeof(uint32_t), st));
+	HIP_TRY(hipMemsetAsync(b->d_counters, 0, JM_N_COUNTERS * sizeof(uint32_t), st));
 	JmScanBufs sb;
-	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.block_counts = b->d_block_counts;
+	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.state = b->d_scan_state; sb.slice_sc = nullptr;
 	sb.sc_pos = b->d_sc_pos; sb.sc_code = b->d_sc_code; sb.pic_sc = b->d_pic_sc; sb.counters = b->d_counters;
 	sb.sc_cap = b->sc_cap; sb.pic_cap = b->cfg.max_pictures; sb.pos_bias = 0;
 	HIP_TRY(jm_launch_scan(sb, st));
@@ -473,7 +472,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	HIP_TRY(hipEventRecord(b->ev[1], st));
 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
-	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if (b->h_counters[2]) return fail("start-code / picture table overflow: %u start codes, %u pictures (max_pictures %u)",
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
@@ -732,7 +731,7 @@ struct mpeg1_decoder_t {
 
 	/* device mirror of the store + scan scratch */
 	uint8_t *d_es; unsigned d_es_cap; unsigned mirrored; /* bytes [0, mirrored) are in d_es */
-	uint64_t *d_block_counts; uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner, *d_pic_sc, *d_counters;
+	uint64_t *d_scan_state; uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner, *d_pic_sc, *d_counters;
 	unsigned scan_cap;
 	uint32_t *h_scan_pos; uint8_t *h_scan_code; uint32_t *h_counters; /* pinned */
 
@@ -764,7 +763,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 		return nullptr;
 	}
 	mpeg1_decoder_t *d = new mpeg1_decoder_t();
-	d->bytes = nullptr; d->d_es = nullptr; d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr;
+	d->bytes = nullptr; d->d_es = nullptr; d->d_scan_state = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr;
 	d->d_sc_owner = nullptr; d->d_pic_sc = nullptr; d->d_counters = nullptr; d->h_scan_pos = nullptr;
 	d->h_scan_code = nullptr; d->h_counters = nullptr; d->d_stream = nullptr; d->d_pic = nullptr; d->d_desc = nullptr;
 	d->d_mb = nullptr; d->d_tokens = nullptr; d->d_pool_alloc = nullptr; d->d_pool = nullptr;
@@ -776,8 +775,8 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	bool ok = hipGetDevice(&d->device) == hipSuccess && luts_for_device(d->device, &d->d_luts) == 0 &&
 	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipHostMalloc(&d->bytes, d->capacity + JM_ES_PAD, hipHostMallocDefault) == hipSuccess &&
-	          hipHostMalloc(&d->h_counters, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
-	          jm_malloc(&d->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
+	          hipHostMalloc(&d->h_counters, JM_N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+	          jm_malloc(&d->d_counters, JM_N_COUNTERS * sizeof(uint32_t)) == hipSuccess &&
 	          jm_malloc(&d->d_stream, sizeof(JmStream)) == hipSuccess && jm_malloc(&d->d_pic, sizeof(JmPic)) == hipSuccess &&
 	          jm_malloc(&d->d_desc, sizeof(JmReconDesc)) == hipSuccess;
 	if (!ok) {
@@ -791,7 +790,7 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 static int dec_fail_cleanup(mpeg1_decoder_t *d) {
 	if (!d) return -1;
 	if (d->stream) hipStreamSynchronize(d->stream);
-	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
+	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_scan_state); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
 	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
 	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_desc);
 	hipFree(d->d_mb); hipFree(d->d_tokens); hipFree(d->d_pool_alloc); hipFree(d->d_rgba); hipHostFree(d->h_frame);
@@ -860,12 +859,12 @@ static int dec_ensure_scan(mpeg1_decoder_t *d, unsigned bytes) {
 	}
 	unsigned need = bytes / 4 + 64; /* at most one start code per 4 bytes */
 	if (d->scan_cap < need) {
-		hipFree(d->d_block_counts); hipFree(d->d_sc_pos); hipFree(d->d_sc_code); hipFree(d->d_sc_owner); hipFree(d->d_pic_sc);
+		hipFree(d->d_scan_state); hipFree(d->d_sc_pos); hipFree(d->d_sc_code); hipFree(d->d_sc_owner); hipFree(d->d_pic_sc);
 		hipHostFree(d->h_scan_pos); hipHostFree(d->h_scan_code);
-		d->d_block_counts = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr; d->d_sc_owner = nullptr;
+		d->d_scan_state = nullptr; d->d_sc_pos = nullptr; d->d_sc_code = nullptr; d->d_sc_owner = nullptr;
 		d->d_pic_sc = nullptr; d->h_scan_pos = nullptr; d->h_scan_code = nullptr; d->scan_cap = 0;
 		need = std::max(need * 2, 4096u);
-		HIP_TRY(jm_malloc(&d->d_block_counts, sizeof(uint64_t) * ((size_t)need * 4 / JM_SCAN_BLOCK_BYTES + 4)));
+		HIP_TRY(jm_malloc(&d->d_scan_state, jm_scan_state_bytes((uint64_t)need * 4)));
 		HIP_TRY(jm_malloc(&d->d_sc_pos, sizeof(uint32_t) * need));
 		HIP_TRY(jm_malloc(&d->d_sc_code, need));
 		HIP_TRY(jm_malloc(&d->d_sc_owner, sizeof(uint32_t) * need));
@@ -897,13 +896,13 @@ static int dec_scan_new_bytes(mpeg1_decoder_t *d, unsigned old_length) {
 	HIP_TRY(hipMemcpyAsync(d->d_es + from_copy, d->bytes + from_copy, d->length - from_copy, hipMemcpyHostToDevice, d->stream));
 	HIP_TRY(hipMemsetAsync(d->d_es + d->length, 0xff, JM_ES_PAD, d->stream));
 	d->mirrored = d->length;
-	HIP_TRY(hipMemsetAsync(d->d_counters, 0, 4 * sizeof(uint32_t), d->stream));
+	HIP_TRY(hipMemsetAsync(d->d_counters, 0, JM_N_COUNTERS * sizeof(uint32_t), d->stream));
 	JmScanBufs sb;
-	sb.es = d->d_es + scan_from; sb.n_bytes = n; sb.block_counts = d->d_block_counts; sb.sc_pos = d->d_sc_pos;
+	sb.es = d->d_es + scan_from; sb.n_bytes = n; sb.state = d->d_scan_state; sb.slice_sc = nullptr; sb.sc_pos = d->d_sc_pos;
 	sb.sc_code = d->d_sc_code; sb.pic_sc = d->d_pic_sc; sb.counters = d->d_counters; sb.sc_cap = d->scan_cap;
 	sb.pic_cap = d->scan_cap; sb.pos_bias = scan_from;
 	HIP_TRY(jm_launch_scan(sb, d->stream));
-	HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->h_counters, d->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	unsigned found = std::min(d->h_counters[0], d->scan_cap);
 	if (found) {

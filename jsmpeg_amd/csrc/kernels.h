@@ -7,20 +7,27 @@
 #include "mpeg1_dev.h"
 #include "vlc_lut.h"
 
-/* bytes per workgroup of the start-code scan */
-#define JM_SCAN_BLOCK_BYTES 4096
+/* the start-code scan takes the ES in pieces of 256 lanes x 64 bytes, 1 .. 8 pieces per workgroup (chunk) */
+#define JM_SCAN_PIECE_BYTES 16384u
+#define JM_SCAN_MAX_SUBS 7u        /* per-chunk counts are kept in 16-bit halves (at most 4096 start codes per piece); 7 pieces = 28 KiB of LDS: five workgroups per CU */
+/* the scan's state array for an ES of n bytes: ticket counter + two words per chunk (zeroed by the launch) */
+static inline size_t jm_scan_state_bytes(uint64_t n_bytes) {
+	return sizeof(uint64_t) * (size_t)(2 + 2 * ((n_bytes + JM_SCAN_PIECE_BYTES - 1) / JM_SCAN_PIECE_BYTES + 1));
+}
 
 struct JmScanBufs {
-	const uint8_t *es;       /* batch ES buffer (readable JM_ES_PAD bytes past n_bytes) */
+	const uint8_t *es;       /* batch ES buffer, 16-byte aligned (readable JM_ES_PAD bytes past n_bytes) */
 	uint32_t n_bytes;
-	uint64_t *block_counts;  /* [n_blocks + 1]: low 32 = start codes, high 32 = picture codes */
+	uint64_t *state;         /* [jm_scan_state_bytes(n_bytes)]: the chained scan's tickets and per-chunk sums */
 	uint32_t *sc_pos;        /* out [sc_cap] */
 	uint8_t *sc_code;        /* out [sc_cap] */
 	uint32_t *pic_sc;        /* out [pic_cap]: start-code index of every picture code */
-	uint32_t *counters;      /* [0] n_sc, [1] n_pics, [2] overflow flag, [3] deepest level + 1 */
+	uint32_t *slice_sc;      /* out [sc_cap]: start-code index of every slice code (01 .. AF), or null */
+	uint32_t *counters;      /* [0] n_sc, [1] n_pics, [2] overflow flag, [3] deepest level + 1, [4] slice codes; JM_N_COUNTERS words */
 	uint32_t sc_cap, pic_cap;
 	uint32_t pos_bias;       /* added to every position (sequential mode scans a sub-range) */
 };
+#define JM_N_COUNTERS 8
 hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st);
 
 /* n byte ranges of a device buffer -> their places in the batch ES buffer (tables in device memory) */

@@ -19,128 +19,202 @@
 #define JM_WG 256
 
 /* ------------------------------------------------------------------------
- * Start-code scan (reference buffer.c:73-110 is a serial byte loop).
- * Each lane tests the 16 byte positions of one 16-byte chunk for 00 00 01 xx.
- * Pass 1 counts per workgroup, pass 2 is a single-workgroup exclusive scan of
- * the counts, pass 3 recomputes the matches and writes them in stream order.
+ * Start-code scan (reference buffer.c:73-110 is a serial byte loop): ONE pass
+ * over the bytes.  A workgroup takes a chunk of 1 .. 7 pieces of 16 KiB, a
+ * lane 64 contiguous bytes of each piece:
+ *   - candidates "two zero bytes in a row" for all 64 positions with byte-
+ *     parallel arithmetic on the 17 dwords (6 instructions per dword); the few
+ *     dwords that hold one are looked at byte by byte (01 next?  which code?);
+ *   - the lane's matches as 64-bit masks (all codes / picture codes / slice
+ *     codes), counted and scanned over the workgroup;
+ *   - the workgroup's place in the batch-wide order by a chained scan with
+ *     look-back: it publishes its totals, sums its predecessors' (their
+ *     totals, or their running sums once they know them), publishes its own
+ *     running sum.  Chunks are handed out by a ticket counter, so every
+ *     predecessor a workgroup waits for is already running;
+ *   - the matches are written in stream order: sc_pos / sc_code for every
+ *     start code, pic_sc for picture codes, slice_sc for slice codes (the
+ *     list the slice parse assigns its lanes from).
+ * Against the three-pass form of round 1 (count, single-workgroup prefix,
+ * find again and write: 160 + 97 + 250 us for cfg2's 495 MB) the bytes are
+ * read once and compared with an eighth of the instructions: 0.19 ms.  What
+ * is left is latency: the look-back walks over the chunks still in flight.
  * ---------------------------------------------------------------------- */
+#define JM_SCAN_AGG 1ull        /* state word holds the chunk's own totals */
+#define JM_SCAN_INC 2ull        /* ... the running sums up to and including the chunk */
 
-struct ChunkMatch { uint32_t mask; uint32_t picmask; uint8_t code[16]; };
-
-static __device__ __forceinline__ ChunkMatch scan_chunk(const uint8_t *es, uint32_t off, uint32_t n_bytes) {
-	ChunkMatch m;
-	m.mask = 0; m.picmask = 0;
-	if (off >= n_bytes) return m;
-	const uint4 v = *reinterpret_cast<const uint4 *>(es + off);
-	const uint32_t nx = *reinterpret_cast<const uint32_t *>(es + off + 16);
-	uint32_t w[5] = { v.x, v.y, v.z, v.w, nx };
+/* state[0]: ticket counter; chunk c: state[2 + 2c] = flag:2 | start codes:31 | picture codes:31, state[3 + 2c] = flag:2 | slice codes */
+static __device__ __forceinline__ uint64_t scan_state_load(const uint64_t *p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void scan_state_store(uint64_t *p, uint64_t v) {
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {
 #pragma unroll
-	for (int j = 0; j < 16; j++) {
-		/* bytes j .. j+3 as one little-endian word: 00 00 01 cc == 0xcc010000 */
-		uint32_t lo = w[j >> 2], hi = w[(j >> 2) + 1];
-		uint32_t q = (j & 3) ? (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (j & 3))) : lo;
-		bool hit = ((q & 0x00ffffffu) == 0x00010000u) && (off + j + 3 < n_bytes);
-		uint8_t code = (uint8_t)(q >> 24);
-		m.code[j] = code;
-		if (hit) { m.mask |= 1u << j; if (code == JM_CODE_PICTURE) m.picmask |= 1u << j; }
+	for (int d = 32; d >= 1; d >>= 1) {
+		const uint32_t lo = __shfl_xor((uint32_t)x, d, 64), hi = __shfl_xor((uint32_t)(x >> 32), d, 64);
+		x += ((uint64_t)hi << 32) | lo;
 	}
-	return m;
+	return x;
 }
-
-/* inclusive scan over the 256 lanes of a workgroup (4 waves) */
-static __device__ __forceinline__ uint32_t wg_inclusive_scan(uint32_t v, uint32_t *wave_tot /* LDS [4] */) {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		uint32_t t = __shfl_up(v, d, 64);
-		if (lane >= d) v += t;
+/* sums of the two packed counts of chunks 0 .. chunk-1 (one wavefront) */
+static __device__ void scan_look_back(const uint64_t *state, uint32_t chunk, int lane, uint64_t &sum0, uint64_t &sum1) {
+	sum0 = sum1 = 0;
+	bool open0 = true, open1 = true;                     /* no running sum met yet */
+	for (int64_t first = (int64_t)chunk - 1; first >= 0 && (open0 || open1); first -= 64) {
+		const int64_t p = first - lane;                  /* lane l looks at the l-th predecessor of this window */
+		uint64_t v0, v1;
+		for (;;) {
+			v0 = p >= 0 ? scan_state_load(state + 2 + 2 * p) : (JM_SCAN_INC << 62);
+			v1 = p >= 0 ? scan_state_load(state + 3 + 2 * p) : (JM_SCAN_INC << 62);
+			if (!__any((v0 >> 62) == 0 || (v1 >> 62) == 0)) break;
+			__builtin_amdgcn_s_sleep(2);
+		}
+		if (open0) {
+			const uint64_t inc = __ballot((v0 >> 62) == JM_SCAN_INC), val = v0 & ((1ull << 62) - 1);
+			const int nearest = inc ? __ffsll((unsigned long long)inc) - 1 : 63;
+			sum0 += wave_sum64(lane <= nearest ? val : 0);
+			open0 = inc == 0;
+		}
+		if (open1) {
+			const uint64_t inc = __ballot((v1 >> 62) == JM_SCAN_INC), val = v1 & ((1ull << 62) - 1);
+			const int nearest = inc ? __ffsll((unsigned long long)inc) - 1 : 63;
+			sum1 += wave_sum64(lane <= nearest ? val : 0);
+			open1 = inc == 0;
+		}
 	}
-	if (lane == 63) wave_tot[wave] = v;
-	__syncthreads();
-	uint32_t add = 0;
-#pragma unroll
-	for (int i = 0; i < 4; i++) if (i < wave) add += wave_tot[i];
-	return v + add;
 }
 
-__global__ __launch_bounds__(JM_WG) void k_scan_count(JmScanBufs b) {
-	__shared__ uint32_t wave_tot[4];
-	uint32_t off = blockIdx.x * JM_SCAN_BLOCK_BYTES + threadIdx.x * 16;
-	ChunkMatch m = scan_chunk(b.es, off, b.n_bytes);
-	uint32_t packed = (uint32_t)__popc(m.mask) | ((uint32_t)__popc(m.picmask) << 16);
-	uint32_t incl = wg_inclusive_scan(packed, wave_tot);
-	if (threadIdx.x == JM_WG - 1)
-		b.block_counts[blockIdx.x] = (uint64_t)(incl & 0xffffu) | ((uint64_t)(incl >> 16) << 32);
-}
-
-__global__ __launch_bounds__(1024) void k_scan_prefix(uint64_t *counts, uint32_t n_blocks, uint32_t *counters) {
-	/* one workgroup, eight consecutive entries per lane and round (8192 per round): a serial add over a lane's eight,
-	 * a wave scan of the lane sums, wave totals through LDS */
-	__shared__ uint64_t wave_tot[16];
-	__shared__ uint64_t carry_s;
+__global__ __launch_bounds__(JM_WG) void k_scan(JmScanBufs b, uint32_t n_chunks, uint32_t subs) {
+	__shared__ uint32_t s_chunk;
+	__shared__ uint32_t wave_tot[2][JM_WG / 64][2];
+	__shared__ uint32_t s_base[3];
+	__shared__ uint32_t kept[JM_SCAN_MAX_SUBS][4][JM_WG];      /* per 16 KiB piece and lane: match mask (2 words), places in the chunk */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) carry_s = 0;
+	/* a ticket is an atomic on ONE address, ~13 ns each whoever asks (16 KiB chunks: 30 000 tickets = 0.39 ms for cfg2):
+	 * large inputs take seven pieces per ticket */
+	if (threadIdx.x == 0) s_chunk = atomicAdd(reinterpret_cast<uint32_t *>(b.state), 1u);
 	__syncthreads();
-	for (uint32_t base = 0; base < n_blocks; base += 8192) {
-		const uint32_t i0 = base + threadIdx.x * 8;
-		uint64_t v[8], sum = 0;
+	const uint32_t chunk = s_chunk;
+	if (chunk >= n_chunks) return;
+	const uint32_t off0 = chunk * subs * JM_SCAN_PIECE_BYTES + threadIdx.x * 64u;
+
+	uint32_t run0 = 0, run1 = 0;                           /* matches in the pieces before: start | picture << 16, slice codes */
+	for (uint32_t sub = 0; sub < subs; sub++) {
+		const uint32_t off = off0 + sub * JM_SCAN_PIECE_BYTES;
+		/* the lane's 64 bytes + the four behind them (0xff past the end: no candidates there) */
+		uint32_t w[17];
 #pragma unroll
-		for (int k = 0; k < 8; k++) { v[k] = i0 + k < n_blocks ? counts[i0 + k] : 0; sum += v[k]; }
-		uint64_t x = sum;
+		for (int k = 0; k < 4; k++) {
+			uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+			if (off + 16u * k < b.n_bytes) v = *reinterpret_cast<const uint4 *>(b.es + off + 16u * k);
+			w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+		}
+		w[16] = off + 64u < b.n_bytes ? *reinterpret_cast<const uint32_t *>(b.es + off + 64u) : ~0u;
+		/* bit 7 of every byte: the byte is not zero (no carries between bytes: 0x7f + 0x7f < 0x100) */
+		uint32_t nz[17];
+#pragma unroll
+		for (int k = 0; k < 17; k++) nz[k] = ((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[k];
+		uint32_t hit[2] = { 0, 0 }, pic[2] = { 0, 0 }, slc[2] = { 0, 0 };
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			/* bit 7 of byte j of dword k: bytes 4k + j and 4k + j + 1 are both zero */
+			uint32_t cand = ~(nz[k] | __builtin_amdgcn_alignbit(nz[k + 1], nz[k], 8)) & 0x80808080u;
+			while (cand) {
+				const uint32_t j = (uint32_t)(__ffs(cand) - 1) >> 3;
+				cand &= cand - 1;
+				const uint32_t q = jm_alignbyte(w[k + 1], w[k], j);          /* bytes 4k + j .. + 3: 00 00 ?? cc */
+				if ((q & 0x00ff0000u) == 0x00010000u && off + 4u * k + j + 3u < b.n_bytes) {
+					const uint32_t code = q >> 24, bit = 1u << ((4 * k + j) & 31);
+					hit[k >> 3] |= bit;
+					if (code == JM_CODE_PICTURE) pic[k >> 3] |= bit;
+					if (code - 1u < 0xAFu) slc[k >> 3] |= bit;               /* slice codes 01 .. AF */
+				}
+			}
+		}
+		/* the lane's place among the piece's matches, the piece's among the chunk's */
+		const uint32_t mine0 = (uint32_t)(__popc(hit[0]) + __popc(hit[1])) | ((uint32_t)(__popc(pic[0]) + __popc(pic[1])) << 16);
+		const uint32_t mine1 = (uint32_t)(__popc(slc[0]) + __popc(slc[1]));
+		uint32_t v0 = mine0, v1 = mine1;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
-			uint32_t lo = __shfl_up((uint32_t)x, d, 64), hi = __shfl_up((uint32_t)(x >> 32), d, 64);
-			if (lane >= d) x += ((uint64_t)hi << 32) | lo;   /* the two 32-bit halves never carry into each other */
+			const uint32_t t0 = __shfl_up(v0, d, 64), t1 = __shfl_up(v1, d, 64);
+			if (lane >= d) { v0 += t0; v1 += t1; }
 		}
-		if (lane == 63) wave_tot[wave] = x;
-		__syncthreads();
-		uint64_t add = carry_s;
-		for (int k = 0; k < wave; k++) add += wave_tot[k];
-		uint64_t run = add + x - sum;                        /* exclusive prefix of this lane's first entry */
+		if (lane == 63) { wave_tot[sub & 1][wave][0] = v0; wave_tot[sub & 1][wave][1] = v1; }
+		__syncthreads();                                   /* (the other half of wave_tot is free again a barrier later) */
+		uint32_t tot0 = 0, tot1 = 0;
 #pragma unroll
-		for (int k = 0; k < 8; k++) { if (i0 + k < n_blocks) counts[i0 + k] = run; run += v[k]; }
-		__syncthreads();
-		if (threadIdx.x == 1023) carry_s = add + x;
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		counts[n_blocks] = carry_s;
-		counters[0] = (uint32_t)carry_s;
-		counters[1] = (uint32_t)(carry_s >> 32);
-	}
-}
-
-__global__ __launch_bounds__(JM_WG) void k_scan_write(JmScanBufs b) {
-	__shared__ uint32_t wave_tot[4];
-	uint32_t off = blockIdx.x * JM_SCAN_BLOCK_BYTES + threadIdx.x * 16;
-	ChunkMatch m = scan_chunk(b.es, off, b.n_bytes);
-	uint32_t packed = (uint32_t)__popc(m.mask) | ((uint32_t)__popc(m.picmask) << 16);
-	uint32_t incl = wg_inclusive_scan(packed, wave_tot);
-	uint32_t excl = incl - packed;
-	uint64_t base = b.block_counts[blockIdx.x];
-	uint32_t sc_i = (uint32_t)base + (excl & 0xffffu), pic_i = (uint32_t)(base >> 32) + (excl >> 16);
-	uint32_t mask = m.mask;
-	while (mask) {
-		int j = __ffs(mask) - 1;
-		mask &= mask - 1;
-		if (sc_i < b.sc_cap) {
-			b.sc_pos[sc_i] = off + j + b.pos_bias;
-			b.sc_code[sc_i] = m.code[j];
-		} else b.counters[2] = 1;
-		if (m.picmask & (1u << j)) {
-			if (pic_i < b.pic_cap) b.pic_sc[pic_i] = sc_i; else b.counters[2] = 1;
-			pic_i++;
+		for (int i = 0; i < JM_WG / 64; i++) {
+			const uint32_t t0 = wave_tot[sub & 1][i][0], t1 = wave_tot[sub & 1][i][1];
+			if (i < wave) { v0 += t0; v1 += t1; }
+			tot0 += t0; tot1 += t1;
 		}
-		sc_i++;
+		kept[sub][0][threadIdx.x] = hit[0]; kept[sub][1][threadIdx.x] = hit[1];
+		kept[sub][2][threadIdx.x] = run0 + v0 - mine0; kept[sub][3][threadIdx.x] = run1 + v1 - mine1;
+		run0 += tot0; run1 += tot1;                        /* at most 4096 of each per piece: 8 pieces fit the 16-bit halves */
+	}
+	/* the chunk's place among the batch's: wavefront 0 publishes and looks back */
+	if (wave == 0) {
+		const uint64_t own0 = ((uint64_t)(run0 & 0xffffu) << 31) | (run0 >> 16), own1 = run1;
+		if (lane == 0 && chunk > 0) {
+			scan_state_store(b.state + 2 + 2 * (uint64_t)chunk, (JM_SCAN_AGG << 62) | own0);
+			scan_state_store(b.state + 3 + 2 * (uint64_t)chunk, (JM_SCAN_AGG << 62) | own1);
+		}
+		uint64_t before0, before1;
+		scan_look_back(b.state, chunk, lane, before0, before1);
+		if (lane == 0) {
+			scan_state_store(b.state + 2 + 2 * (uint64_t)chunk, (JM_SCAN_INC << 62) | (before0 + own0));
+			scan_state_store(b.state + 3 + 2 * (uint64_t)chunk, (JM_SCAN_INC << 62) | (before1 + own1));
+			s_base[0] = (uint32_t)(before0 >> 31); s_base[1] = (uint32_t)(before0 & 0x7fffffffu); s_base[2] = (uint32_t)before1;
+			if (chunk == n_chunks - 1) {
+				b.counters[0] = (uint32_t)((before0 + own0) >> 31);
+				b.counters[1] = (uint32_t)((before0 + own0) & 0x7fffffffu);
+				b.counters[4] = (uint32_t)(before1 + own1);
+			}
+		}
+	}
+	__syncthreads();
+	/* write the matches in stream order */
+	for (uint32_t sub = 0; sub < subs; sub++) {
+		const uint32_t h0 = kept[sub][0][threadIdx.x], h1 = kept[sub][1][threadIdx.x];
+		if ((h0 | h1) == 0) continue;
+		const uint32_t e0 = kept[sub][2][threadIdx.x], e1 = kept[sub][3][threadIdx.x];
+		uint32_t sc_i = s_base[0] + (e0 & 0xffffu), pic_i = s_base[1] + (e0 >> 16), slc_i = s_base[2] + e1;
+		const uint32_t off = off0 + sub * JM_SCAN_PIECE_BYTES;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			uint32_t m = h ? h1 : h0;
+			while (m) {
+				const uint32_t pos = off + 32u * h + (uint32_t)(__ffs(m) - 1);
+				m &= m - 1;
+				const uint32_t code = b.es[pos + 3];
+				if (sc_i < b.sc_cap) {
+					b.sc_pos[sc_i] = pos + b.pos_bias;
+					b.sc_code[sc_i] = (uint8_t)code;
+					if (code - 1u < 0xAFu) { if (b.slice_sc) b.slice_sc[slc_i] = sc_i; slc_i++; }
+				} else b.counters[2] = 1;
+				if (code == JM_CODE_PICTURE) {
+					if (pic_i < b.pic_cap) b.pic_sc[pic_i] = sc_i; else b.counters[2] = 1;
+					pic_i++;
+				}
+				sc_i++;
+			}
+		}
 	}
 }
 
 hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st) {
-	uint32_t n_blocks = (b.n_bytes + JM_SCAN_BLOCK_BYTES - 1) / JM_SCAN_BLOCK_BYTES;
-	if (n_blocks == 0) n_blocks = 1;
-	hipLaunchKernelGGL(k_scan_count, dim3(n_blocks), dim3(JM_WG), 0, st, b);
-	hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(1024), 0, st, b.block_counts, n_blocks, b.counters);
-	hipLaunchKernelGGL(k_scan_write, dim3(n_blocks), dim3(JM_WG), 0, st, b);
+	/* pieces per chunk: as many as leave ~2048 chunks (the workgroups the GPU holds at a time), at most JM_SCAN_MAX_SUBS */
+	uint32_t subs = b.n_bytes / (JM_SCAN_PIECE_BYTES * 2048u);
+	subs = subs < 1 ? 1 : (subs > JM_SCAN_MAX_SUBS ? JM_SCAN_MAX_SUBS : subs);
+	const uint32_t chunk_bytes = subs * JM_SCAN_PIECE_BYTES;
+	uint32_t n_chunks = (b.n_bytes + chunk_bytes - 1) / chunk_bytes;
+	if (n_chunks == 0) n_chunks = 1;
+	hipError_t e = hipMemsetAsync(b.state, 0, sizeof(uint64_t) * (2 + 2 * (size_t)n_chunks), st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(k_scan, dim3(n_chunks), dim3(JM_WG), 0, st, b, n_chunks, subs);
 	return hipGetLastError();
 }
 
