@@ -96,7 +96,7 @@ struct jsmpeg_hip_batch_t {
 
 	uint32_t sc_cap;
 	uint64_t *d_scan_state;
-	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_counters;
+	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_slice_sc; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
 	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
@@ -122,7 +122,7 @@ struct jsmpeg_hip_batch_t {
 static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_scan_state); hipFree(b->d_sc_pos);
-	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_counters);
+	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_slice_sc); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
@@ -147,6 +147,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_sc_code, b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_slice_sc, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
 	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, and room for a second pass (step 4b) */
@@ -182,7 +183,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	jsmpeg_hip_batch_t *b = new jsmpeg_hip_batch_t();
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
-	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_counters = nullptr;
+	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
@@ -459,7 +460,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	HIP_TRY(hipEventRecord(b->ev[0], st));
 	HIP_TRY(hipMemsetAsync(b->d_counters, 0, JM_N_COUNTERS * sizeof(uint32_t), st));
 	JmScanBufs sb;
-	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.state = b->d_scan_state; sb.slice_sc = nullptr;
+	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.state = b->d_scan_state; sb.slice_sc = b->d_slice_sc; sb.sc_owner = b->d_sc_owner;
 	sb.sc_pos = b->d_sc_pos; sb.sc_code = b->d_sc_code; sb.pic_sc = b->d_pic_sc; sb.counters = b->d_counters;
 	sb.sc_cap = b->sc_cap; sb.pic_cap = b->cfg.max_pictures; sb.pos_bias = 0;
 	HIP_TRY(jm_launch_scan(sb, st));
@@ -522,6 +523,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	pb.es = b->d_es; pb.sc_pos = b->d_sc_pos; pb.sc_code = b->d_sc_code; pb.sc_owner = b->d_sc_owner;
 	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
 	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
+	pb.slice_sc = b->d_slice_sc; pb.n_lanes = std::min(b->h_counters[4], b->sc_cap);   /* a lane per slice code (not per start code) */
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
 	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */
@@ -898,7 +900,7 @@ static int dec_scan_new_bytes(mpeg1_decoder_t *d, unsigned old_length) {
 	d->mirrored = d->length;
 	HIP_TRY(hipMemsetAsync(d->d_counters, 0, JM_N_COUNTERS * sizeof(uint32_t), d->stream));
 	JmScanBufs sb;
-	sb.es = d->d_es + scan_from; sb.n_bytes = n; sb.state = d->d_scan_state; sb.slice_sc = nullptr; sb.sc_pos = d->d_sc_pos;
+	sb.es = d->d_es + scan_from; sb.n_bytes = n; sb.state = d->d_scan_state; sb.slice_sc = nullptr; sb.sc_owner = nullptr; sb.sc_pos = d->d_sc_pos;
 	sb.sc_code = d->d_sc_code; sb.pic_sc = d->d_pic_sc; sb.counters = d->d_counters; sb.sc_cap = d->scan_cap;
 	sb.pic_cap = d->scan_cap; sb.pos_bias = scan_from;
 	HIP_TRY(jm_launch_scan(sb, d->stream));
@@ -1069,7 +1071,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	JmParseBufs pb;
 	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
 	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
-	pb.n_sc = (uint32_t)n_entries; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
+	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;

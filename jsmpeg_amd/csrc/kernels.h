@@ -23,6 +23,7 @@ struct JmScanBufs {
 	uint8_t *sc_code;        /* out [sc_cap] */
 	uint32_t *pic_sc;        /* out [pic_cap]: start-code index of every picture code */
 	uint32_t *slice_sc;      /* out [sc_cap]: start-code index of every slice code (01 .. AF), or null */
+	uint32_t *sc_owner;      /* out [sc_cap]: JM_NONE for every start code found (k_index then names the pictures), or null */
 	uint32_t *counters;      /* [0] n_sc, [1] n_pics, [2] overflow flag, [3] deepest level + 1, [4] slice codes; JM_N_COUNTERS words */
 	uint32_t sc_cap, pic_cap;
 	uint32_t pos_bias;       /* added to every position (sequential mode scans a sub-range) */
@@ -38,7 +39,7 @@ struct JmIndexBufs {
 	const uint8_t *es;
 	const uint32_t *sc_pos;
 	const uint8_t *sc_code;
-	uint32_t *sc_owner;          /* [sc_cap], preset to JM_NONE by the launch */
+	uint32_t *sc_owner;          /* [sc_cap], preset to JM_NONE by the scan */
 	const uint32_t *pic_sc;
 	const uint32_t *counters;
 	JmStream *streams;
@@ -60,6 +61,8 @@ struct JmParseBufs {
 	JmMbRec *mb;                 /* [n_pics * mb_size] */
 	uint16_t *tokens;
 	uint32_t n_sc;
+	const uint32_t *slice_sc;    /* the start-code entries that take a lane (the scan's list of slice codes), or null: all n_sc */
+	uint32_t n_lanes;            /* entries of slice_sc */
 	int mb_size;
 	uint32_t *covered;           /* [n_pics] += records written, per picture (zeroed by the caller), or null */
 	uint8_t epoch;

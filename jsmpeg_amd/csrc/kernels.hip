@@ -193,6 +193,7 @@ __global__ __launch_bounds__(JM_WG) void k_scan(JmScanBufs b, uint32_t n_chunks,
 				if (sc_i < b.sc_cap) {
 					b.sc_pos[sc_i] = pos + b.pos_bias;
 					b.sc_code[sc_i] = (uint8_t)code;
+					if (b.sc_owner) b.sc_owner[sc_i] = JM_NONE;
 					if (code - 1u < 0xAFu) { if (b.slice_sc) b.slice_sc[slc_i] = sc_i; slc_i++; }
 				} else b.counters[2] = 1;
 				if (code == JM_CODE_PICTURE) {
@@ -286,8 +287,6 @@ __global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {
 }
 
 hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
-	hipError_t e = hipMemsetAsync(b.sc_owner, 0xff, (size_t)b.sc_cap * sizeof(uint32_t), st);
-	if (e != hipSuccess) return e;
 	if (b.n_streams) hipLaunchKernelGGL(k_index, dim3(b.n_streams), dim3(JM_WG), 0, st, b);
 	return hipGetLastError();
 }
@@ -319,7 +318,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * fewer different syntax elements, a turn issues fewer of the step kinds, and the one wavefront whose walk is the
 	 * whole pass gets through it sooner; the idle lanes cost nothing while SIMDs would stand idle anyway */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t i = (uint32_t)lane < b.lanes_per_wave ? (blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave) * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
+	const uint32_t j = (uint32_t)lane < b.lanes_per_wave ? (blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave) * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
+	/* the lane's start-code entry: the j-th slice code of the batch (picture, sequence and group codes take no lane:
+	 * cfg2's 8304 wavefronts become 8160, which is what two full rounds of 512 workgroups hold) */
+	uint32_t i = 0xffffffffu;
+	if (b.slice_sc) { if (j < b.n_lanes) i = b.slice_sc[j]; }
+	else i = j;
 	JmLane L;
 	L.es_ring = &es_ring[wave][0][lane];
 	L.tk_ring = &tk_ring[wave][0][lane];
@@ -375,17 +379,18 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 }
 
 hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
-	if (b_in.n_sc == 0) return hipSuccess;
 	JmParseBufs b = b_in;
+	if (!b.slice_sc) b.n_lanes = b.n_sc;
+	if (b.n_lanes == 0) return hipSuccess;
 	/* slices per wavefront: 64, except for small batches (fewer than 512 full wavefronts: half the SIMDs would stand
 	 * idle while a few wavefronts walk 64 slices each) -- there the smallest power of two that still keeps the pass
 	 * within 4096 wavefronts, down to ONE slice per wavefront for a single picture (measured, MI355X: one 1080p
 	 * picture 1.31 -> 0.69 ms per decode(), one 720p stream of 360 pictures 1.48 -> 1.30 ms of parse; batches of 512+
 	 * wavefronts are fastest at 64) */
 	uint32_t lanes = 64;
-	if (b.n_sc <= 512u * 64u) {
+	if (b.n_lanes <= 512u * 64u) {
 		lanes = 1;
-		while (lanes < 64 && (uint64_t)lanes * JM_PARSE_FILL_WAVES < b.n_sc) lanes <<= 1;
+		while (lanes < 64 && (uint64_t)lanes * JM_PARSE_FILL_WAVES < b.n_lanes) lanes <<= 1;
 	}
 	if (b.debug_flags & 8) lanes = 64;
 	{ static const int forced = getenv("JSMPEG_HIP_PARSE_LANES") ? atoi(getenv("JSMPEG_HIP_PARSE_LANES")) : 0;   /* tuning only */
@@ -393,7 +398,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	b.lanes_per_wave = lanes;
 	b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
 	const uint32_t per_wg = lanes * JM_PARSE_WAVES;
-	hipLaunchKernelGGL(k_parse, dim3((b.n_sc + per_wg - 1) / per_wg), dim3(JM_PARSE_WG), 0, st, b);
+	hipLaunchKernelGGL(k_parse, dim3((b.n_lanes + per_wg - 1) / per_wg), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }
 
