@@ -96,7 +96,7 @@ struct jsmpeg_hip_batch_t {
 
 	uint32_t sc_cap;
 	uint64_t *d_scan_state;
-	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_slice_sc; uint32_t *d_counters;
+	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_slice_sc; uint32_t *d_slice_order; uint32_t *d_order_hist; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
 	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
@@ -122,7 +122,7 @@ struct jsmpeg_hip_batch_t {
 static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_scan_state); hipFree(b->d_sc_pos);
-	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_slice_sc); hipFree(b->d_counters);
+	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_slice_sc); hipFree(b->d_slice_order); hipFree(b->d_order_hist); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
@@ -148,6 +148,8 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_sc_owner, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(jm_malloc(&b->d_slice_sc, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(jm_malloc(&b->d_slice_order, sizeof(uint32_t) * b->sc_cap));
+	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * 2 * JM_ORDER_BINS));
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
 	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, and room for a second pass (step 4b) */
@@ -183,7 +185,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	jsmpeg_hip_batch_t *b = new jsmpeg_hip_batch_t();
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
-	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_counters = nullptr;
+	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
@@ -524,6 +526,17 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
 	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
 	pb.slice_sc = b->d_slice_sc; pb.n_lanes = std::min(b->h_counters[4], b->sc_cap);   /* a lane per slice code (not per start code) */
+	if (!getenv("JSMPEG_HIP_STREAM_ORDER")) {   /* (the variable: slices in stream order, for measurements) */
+		JmOrderBufs ob;
+		ob.slice_sc = b->d_slice_sc; ob.sc_pos = b->d_sc_pos; ob.sc_owner = b->d_sc_owner;
+		ob.n_slices = pb.n_lanes; ob.n_sc = b->n_sc; ob.es_bytes = b->es_bytes;
+		const uint32_t mean = b->es_bytes / std::max(1u, pb.n_lanes);
+		ob.shift = 0;
+		while ((mean >> ob.shift) >= 512u) ob.shift++;          /* the mean length lands in bins 256 .. 511 of 1024 */
+		ob.hist = b->d_order_hist; ob.order = b->d_slice_order;
+		HIP_TRY(jm_launch_order(ob, st));
+		pb.slice_sc = b->d_slice_order;
+	}
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
 	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */

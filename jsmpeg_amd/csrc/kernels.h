@@ -50,6 +50,20 @@ struct JmIndexBufs {
 };
 hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st);
 
+/* The order in which the slice parse takes the slices: longest first (by bytes up to the next start code), so that
+ * the 64 slices of a wavefront and the 8 wavefronts of a workgroup have about the same way to go. */
+#define JM_ORDER_BINS 1024u
+struct JmOrderBufs {
+	const uint32_t *slice_sc;    /* [n_slices] the scan's list, stream order */
+	const uint32_t *sc_pos;
+	const uint32_t *sc_owner;
+	uint32_t n_slices, n_sc, es_bytes;
+	uint32_t shift;              /* bin = 1 + (bytes >> shift), capped; 0: slices no picture owns (last) */
+	uint32_t *hist;              /* [2 * JM_ORDER_BINS]: counts, cursors -- zeroed by the launch */
+	uint32_t *order;             /* out [n_slices] */
+};
+hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st);
+
 struct JmParseBufs {
 	const uint8_t *es;
 	const uint32_t *sc_pos;

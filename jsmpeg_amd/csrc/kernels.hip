@@ -292,6 +292,76 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
 }
 
 /* ------------------------------------------------------------------------
+ * Slice order: a counting sort of the slices by length, longest first.  The
+ * slice parse is one lane per slice and a lane's way is as long as its slice:
+ * in stream order every 12th picture of cfg2 is an intra picture whose slices
+ * take twice the turns, most workgroups hold a wavefront or two of them, and a
+ * workgroup keeps its 80 KB of LDS until its last wavefront is through -- half
+ * the CU stands idle behind them.  Sorted (1024 bins of mean / 256 bytes), the
+ * long slices share wavefronts and start first: 5.3 -> 4.1 ms for cfg2.
+ * ---------------------------------------------------------------------- */
+static __device__ __forceinline__ uint32_t order_bin(const JmOrderBufs &b, uint32_t j, uint32_t &i) {
+	i = b.slice_sc[j];
+	if (b.sc_owner[i] == JM_NONE) return 0;
+	const uint32_t len = (i + 1 < b.n_sc ? b.sc_pos[i + 1] : b.es_bytes) - b.sc_pos[i];
+	const uint32_t bin = 1u + (len >> b.shift);
+	return bin < JM_ORDER_BINS ? bin : JM_ORDER_BINS - 1;
+}
+
+__global__ __launch_bounds__(JM_WG) void k_order_count(JmOrderBufs b) {
+	__shared__ uint32_t lh[JM_ORDER_BINS];
+	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) lh[k] = 0;
+	__syncthreads();
+	const uint32_t j = blockIdx.x * JM_WG + threadIdx.x;
+	uint32_t i;
+	if (j < b.n_slices) atomicAdd(&lh[order_bin(b, j, i)], 1u);
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) if (lh[k]) atomicAdd(&b.hist[k], lh[k]);
+}
+
+__global__ __launch_bounds__(JM_WG) void k_order_place(JmOrderBufs b) {
+	/* first[k] = slices in longer bins than k: every workgroup works it out for itself from the 1024 counts */
+	__shared__ uint32_t first[JM_ORDER_BINS];
+	__shared__ uint32_t lh[JM_ORDER_BINS];       /* this workgroup's slices per bin, then where its run of the bin starts */
+	__shared__ uint32_t wave_tot[JM_WG / 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	constexpr uint32_t PER = JM_ORDER_BINS / JM_WG;
+	uint32_t v[PER], sum = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < PER; k++) { v[k] = b.hist[JM_ORDER_BINS - 1 - (threadIdx.x * PER + k)]; sum += v[k]; }   /* longest bin first */
+	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) lh[k] = 0;
+	uint32_t x = sum;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(x, d, 64); if (lane >= d) x += t; }
+	if (lane == 63) wave_tot[wave] = x;
+	__syncthreads();
+	uint32_t run = x - sum;
+	for (int w = 0; w < wave; w++) run += wave_tot[w];
+#pragma unroll
+	for (uint32_t k = 0; k < PER; k++) { first[JM_ORDER_BINS - 1 - (threadIdx.x * PER + k)] = run; run += v[k]; }
+	/* a place in the bin: rank among the workgroup's slices of the bin (LDS), the workgroup's run of the bin by ONE
+	 * global atomic per bin it holds -- the lengths crowd into a few dozen bins, and an atomic per slice on those few
+	 * addresses takes 0.45 ms for cfg2's 522 k slices */
+	const uint32_t j = blockIdx.x * JM_WG + threadIdx.x;
+	uint32_t i = 0, bin = 0, rank = 0;
+	if (j < b.n_slices) { bin = order_bin(b, j, i); rank = atomicAdd(&lh[bin], 1u); }
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) { const uint32_t n = lh[k]; if (n) lh[k] = atomicAdd(&b.hist[JM_ORDER_BINS + k], n); }
+	__syncthreads();
+	if (j < b.n_slices) b.order[first[bin] + lh[bin] + rank] = i;
+}
+
+hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
+	if (b.n_slices == 0) return hipSuccess;
+	hipError_t e = hipMemsetAsync(b.hist, 0, 2 * JM_ORDER_BINS * sizeof(uint32_t), st);
+	if (e != hipSuccess) return e;
+	const uint32_t groups = (b.n_slices + JM_WG - 1) / JM_WG;
+	hipLaunchKernelGGL(k_order_count, dim3(groups), dim3(JM_WG), 0, st, b);
+	hipLaunchKernelGGL(k_order_place, dim3(groups), dim3(JM_WG), 0, st, b);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------
  * Slice parse: one lane per start-code entry that a picture owns.  A
  * workgroup is four independent wavefronts sharing the VLC tables; each
  * wavefront owns a [32][64]-dword compressed-data ring tile and a
@@ -319,8 +389,8 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * whole pass gets through it sooner; the idle lanes cost nothing while SIMDs would stand idle anyway */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t j = (uint32_t)lane < b.lanes_per_wave ? (blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave) * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
-	/* the lane's start-code entry: the j-th slice code of the batch (picture, sequence and group codes take no lane:
-	 * cfg2's 8304 wavefronts become 8160, which is what two full rounds of 512 workgroups hold) */
+	/* the lane's start-code entry: the j-th slice of the batch's slice list (picture, sequence and group codes take no
+	 * lane) -- in the order jm_launch_order gave it: longest first */
 	uint32_t i = 0xffffffffu;
 	if (b.slice_sc) { if (j < b.n_lanes) i = b.slice_sc[j]; }
 	else i = j;
@@ -357,6 +427,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
+#ifdef JM_PARSE_STATS   /* diagnostics build (tools/parse_stats.py): turn statistics per wavefront into b.dbg */
+	uint32_t st_turns = 0, st_cold = 0, st_coef1 = 0, st_coef2 = 0, st_blocked = 0, st_dc = 0, st_slow = 0, st_live = 0;
+#define JM_STAT(x) x
+#else
+#define JM_STAT(x)
+#endif
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
 		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, its token slots) */
 		const bool live = L.state != JM_ST_DONE;
@@ -365,13 +441,23 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
 		if (n_cold == 0 && !others) break;
 		if (blocked) { if (live) jm_lane_service(L); }
-		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
+		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { JM_STAT(st_cold++;) if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
 		if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
+		JM_STAT(st_coef1 += __popcll(__ballot(ready && L.state == JM_ST_COEF));)
 		if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+		JM_STAT(st_slow += __popcll(__ballot(ready && L.state == JM_ST_SLOW));)
 		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
 #pragma unroll
-		for (int k = 1; k < JM_COEF_REPEAT; k++) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+		for (int k = 1; k < JM_COEF_REPEAT; k++) { JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c); }
 	}
+#ifdef JM_PARSE_STATS
+	if (b.dbg && lane == 0) {
+		uint32_t *o = b.dbg + (size_t)(blockIdx.x * JM_PARSE_WAVES + wave) * 8;
+		o[0] = st_turns; o[1] = st_cold; o[2] = st_coef1; o[3] = st_coef2; o[4] = st_blocked; o[5] = st_dc; o[6] = st_slow; o[7] = st_live;
+	}
+#endif
 	if (mine) {
 		jm_lane_finish(L);
 		if (b.covered && L.stored) atomicAdd(&b.covered[b.sc_owner[i]], L.stored);

@@ -1,0 +1,34 @@
+"""Turn statistics of k_parse (needs a -DJM_PARSE_STATS build and JSMPEG_HIP_DEBUG=4): per wavefront the turns, the
+header steps run, and how many lanes each step kind found ready.   python tools/parse_stats.py [streams] [frames]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["JSMPEG_HIP_DEBUG"] = "4"
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+from jsmpeg_amd import batch as jb, synth  # noqa: E402
+
+n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+cfg = synth.CONFIGS[bench.CONFIG]
+streams = [g[0] for g in bench.generate_streams(0, n_streams, frames)]
+total = sum(len(s) for s in streams)
+L = jb.lib()
+L.jsmpeg_hip_batch_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, total + 64 * n_streams + 4096) as b:
+    b.upload(streams)
+    b.decode()
+    n_slices = b.counters()["slices"] if "slices" in b.counters() else n_streams * frames * 68
+    n_waves = (n_slices + 63) // 64
+    a = np.zeros((n_waves, 8), np.uint32)
+    assert L.jsmpeg_hip_batch_debug_read(b.h, 8, a.ctypes.data, 0, a.nbytes) == 0, jb.last_error()
+    a = a[a[:, 0] != 0xeeeeeeee].astype(np.float64)
+    t = a[:, 0]
+    print("wavefronts %d  turns per wavefront: mean %.0f  min %.0f  max %.0f" % (len(a), t.mean(), t.min(), t.max()))
+    print("header steps per turn %.3f" % (a[:, 1].sum() / t.sum()))
+    for name, col in (("live", 7), ("blocked", 4), ("DC ready", 5), ("COEF ready (1st)", 2), ("SLOW ready", 6), ("COEF ready (2nd)", 3)):
+        print("%-18s lanes per turn %.1f" % (name, a[:, col].sum() / t.sum()))
+    print(b.timings())
