@@ -77,6 +77,8 @@ struct JmParseBufs {
 	uint32_t n_sc;
 	const uint32_t *slice_sc;    /* the start-code entries that take a lane (the scan's list of slice codes), or null: all n_sc */
 	uint32_t n_lanes;            /* entries of slice_sc */
+	uint32_t *ticket;            /* one word of device memory for large passes (zeroed by the launch), or null */
+	uint32_t n_batches;          /* set by jm_launch_parse: wavefront-sized batches of slices */
 	int mb_size;
 	uint32_t *covered;           /* [n_pics] += records written, per picture (zeroed by the caller), or null */
 	uint8_t epoch;

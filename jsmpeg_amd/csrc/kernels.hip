@@ -373,6 +373,7 @@ hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
 #endif
 #define JM_PARSE_WAVES (JM_PARSE_WG / 64)
 #define JM_PARSE_FILL_WAVES 4096u   /* wavefronts that fill the GPU for this kernel: 256 CUs x 16 */
+#define JM_PARSE_RESIDENT_WGS (JM_PARSE_FILL_WAVES / JM_PARSE_WAVES)
 
 __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
@@ -388,9 +389,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * fewer different syntax elements, a turn issues fewer of the step kinds, and the one wavefront whose walk is the
 	 * whole pass gets through it sooner; the idle lanes cost nothing while SIMDs would stand idle anyway */
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t j = (uint32_t)lane < b.lanes_per_wave ? (blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave) * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
-	/* the lane's start-code entry: the j-th slice of the batch's slice list (picture, sequence and group codes take no
-	 * lane) -- in the order jm_launch_order gave it: longest first */
+	/* A wavefront takes batch after batch of lanes_per_wave slices: its first by its place in the grid, the next ones
+	 * from a ticket counter (large passes are launched with as many workgroups as the GPU holds, jm_launch_parse) --
+	 * a wavefront that is through starts on the next slices at once instead of waiting for the seven others of its
+	 * workgroup, and the pass has no rounds of workgroups to fall between. */
+	for (uint32_t batch = blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave; batch < b.n_batches;) {
+	const uint32_t j = (uint32_t)lane < b.lanes_per_wave ? batch * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
 	uint32_t i = 0xffffffffu;
 	if (b.slice_sc) { if (j < b.n_lanes) i = b.slice_sc[j]; }
 	else i = j;
@@ -454,13 +458,18 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {
-		uint32_t *o = b.dbg + (size_t)(blockIdx.x * JM_PARSE_WAVES + wave) * 8;
+		uint32_t *o = b.dbg + (size_t)batch * 8;
 		o[0] = st_turns; o[1] = st_cold; o[2] = st_coef1; o[3] = st_coef2; o[4] = st_blocked; o[5] = st_dc; o[6] = st_slow; o[7] = st_live;
 	}
 #endif
 	if (mine) {
 		jm_lane_finish(L);
 		if (b.covered && L.stored) atomicAdd(&b.covered[b.sc_owner[i]], L.stored);
+	}
+	if (!b.ticket) break;
+	uint32_t t = 0;
+	if (lane == 0) t = atomicAdd(b.ticket, 1u);
+	batch = gridDim.x * JM_PARSE_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 	}
 }
 
@@ -483,8 +492,16 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	  if (forced >= 1 && forced <= 64) lanes = (uint32_t)forced; }
 	b.lanes_per_wave = lanes;
 	b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
-	const uint32_t per_wg = lanes * JM_PARSE_WAVES;
-	hipLaunchKernelGGL(k_parse, dim3((b.n_lanes + per_wg - 1) / per_wg), dim3(JM_PARSE_WG), 0, st, b);
+	b.n_batches = (b.n_lanes + lanes - 1) / lanes;
+	/* as many workgroups as there are batches -- or, for large passes, as the GPU holds at a time (2 per CU: 80 KB of
+	 * LDS each), their wavefronts drawing further batches by ticket */
+	uint32_t groups = (b.n_batches + JM_PARSE_WAVES - 1) / JM_PARSE_WAVES;
+	if (groups > JM_PARSE_RESIDENT_WGS && b.ticket) {
+		groups = JM_PARSE_RESIDENT_WGS;
+		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
+		if (e != hipSuccess) return e;
+	} else b.ticket = nullptr;
+	hipLaunchKernelGGL(k_parse, dim3(groups), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }
 

@@ -466,7 +466,7 @@ JM_HD int jm_lane_wants(const JmLane &L) {
  * bits).  Only the long header step is worth queueing for (measured, profiles/r01_parse_notes.md):
  * it runs when JM_T_COLD lanes wait for it, or when nothing else in the wave can move. */
 #ifndef JM_T_COLD
-#define JM_T_COLD 20
+#define JM_T_COLD 24
 #endif
 JM_HD bool jm_run_cold(int n_cold, int n_other, int threshold) { return n_cold >= threshold || (n_cold > 0 && n_other == 0); }
 

@@ -25,10 +25,13 @@ with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, to
     n_waves = (n_slices + 63) // 64
     a = np.zeros((n_waves, 8), np.uint32)
     assert L.jsmpeg_hip_batch_debug_read(b.h, 8, a.ctypes.data, 0, a.nbytes) == 0, jb.last_error()
-    a = a[a[:, 0] != 0xeeeeeeee].astype(np.float64)
+    a = a[a[:, 0] != 0xeeeeeeee]
+    service = (a[:, 7] >> 20).astype(np.float64)
+    a[:, 7] &= (1 << 20) - 1
+    a = a.astype(np.float64)
     t = a[:, 0]
     print("wavefronts %d  turns per wavefront: mean %.0f  min %.0f  max %.0f" % (len(a), t.mean(), t.min(), t.max()))
-    print("header steps per turn %.3f" % (a[:, 1].sum() / t.sum()))
+    print("header steps per turn %.3f, ring services per turn %.3f" % (a[:, 1].sum() / t.sum(), service.sum() / t.sum()))
     for name, col in (("live", 7), ("blocked", 4), ("DC ready", 5), ("COEF ready (1st)", 2), ("SLOW ready", 6), ("COEF ready (2nd)", 3)):
         print("%-18s lanes per turn %.1f" % (name, a[:, col].sum() / t.sum()))
     print(b.timings())

@@ -20,6 +20,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_valu(uint32_t *out, int iters, uint64_t *cyc) {
 	int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 	const int k = (int)blockIdx.x | 3;
+	uint64_t d0 = a0, d1 = a1, d2 = a2, d3 = a3;
 	const uint64_t t0 = __builtin_readcyclecounter();
 	for (int i = 0; i < iters; i++) {
 #pragma unroll
@@ -60,6 +61,51 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t *out, int iters, uint64_t
 				asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a5) : "v"(a6));
 				asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a6) : "v"(a7));
 				asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a7) : "v"(a0));
+			} else if (KIND == 5) {   /* v_lshlrev_b64 */
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d0) : "v"(a4));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d1) : "v"(a5));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d2) : "v"(a6));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d3) : "v"(a7));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d0) : "v"(a4));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d1) : "v"(a5));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d2) : "v"(a6));
+				asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d3) : "v"(a7));
+			} else if (KIND == 6) {   /* v_alignbit_b32 */
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a1) : "v"(a2), "v"(a3));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a2) : "v"(a3), "v"(a4));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a3) : "v"(a4), "v"(a5));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a4) : "v"(a5), "v"(a6));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a5) : "v"(a6), "v"(a7));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a6) : "v"(a7), "v"(a0));
+				asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a7) : "v"(a0), "v"(a1));
+			} else if (KIND == 7) {   /* two-operand logic / shifts / moves / selects */
+				asm volatile("v_mov_b32 %0, %1" : "+v"(a0) : "v"(a1));
+				asm volatile("v_and_b32 %0, %0, %1" : "+v"(a1) : "v"(a2));
+				asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a2));
+				asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a3) : "v"(a4));
+				asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a4) : "v"(a5));
+				asm volatile("v_or_b32 %0, %0, %1" : "+v"(a5) : "v"(a6));
+				asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a6) : "v"(a7));
+				asm volatile("v_mov_b32 %0, %1" : "+v"(a7) : "v"(a0));
+			} else if (KIND == 8) {   /* three-operand adds / shifts-and-adds */
+				asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2));
+				asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a1) : "v"(a2));
+				asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a2) : "v"(a3), "v"(a4));
+				asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a3) : "v"(a4), "v"(a5));
+				asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a4) : "v"(a5), "v"(a6));
+				asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a5) : "v"(a6));
+				asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(a6));
+				asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a7) : "v"(a0));
+			} else if (KIND == 9) {   /* compares into vcc / sgpr pairs */
+				asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a0), "v"(a1) : "vcc");
+				asm volatile("v_cmp_eq_u32 vcc, %0, %1" :: "v"(a1), "v"(a2) : "vcc");
+				asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a2), "v"(a3) : "vcc");
+				asm volatile("v_cmp_eq_u32 vcc, %0, %1" :: "v"(a3), "v"(a4) : "vcc");
+				asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a4), "v"(a5) : "vcc");
+				asm volatile("v_cmp_eq_u32 vcc, %0, %1" :: "v"(a5), "v"(a6) : "vcc");
+				asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a6), "v"(a7) : "vcc");
+				asm volatile("v_cmp_eq_u32 vcc, %0, %1" :: "v"(a7), "v"(a0) : "vcc");
 			} else {                  /* a dependent chain: one wave's own latency */
 				asm volatile("v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(a1));
 				asm volatile("v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(a1));
@@ -73,7 +119,7 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t *out, int iters, uint64_t
 		}
 	}
 	const uint64_t t1 = __builtin_readcyclecounter();
-	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (uint32_t)(d0 + d1 + d2 + d3);
 	if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -154,6 +200,11 @@ int main(int argc, char **argv) {
 	run_valu<2>("bytemix", out, cyc);
 	run_valu<3>("mul_lo", out, cyc);
 	run_valu<4>("dep-chain", out, cyc);
+	run_valu<5>("lshl_b64", out, cyc);
+	run_valu<6>("alignbit", out, cyc);
+	run_valu<7>("2op-logic", out, cyc);
+	run_valu<8>("3op-add", out, cyc);
+	run_valu<9>("cmp", out, cyc);
 
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	const size_t GB = 1ull << 30;
