@@ -191,7 +191,7 @@ int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
 /* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
  * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture,
  * [6] pictures with macroblocks the stream never writes (they keep the decoded
- * picture before last, see part 4), [7] reserved. */
+ * picture before last, see part 4), [7] slice start codes found (01 .. AF; [4] counts the ones a picture owns). */
 int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]);
 
 /* ------------------------------------------------------------------ part 3

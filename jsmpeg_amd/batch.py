@@ -225,7 +225,7 @@ class Batch:
         c = (ctypes.c_uint64 * 8)()
         self._ok(self.L.jsmpeg_hip_batch_counters(self.h, c))
         return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5],
-                    uncovered_pictures=c[6])
+                    uncovered_pictures=c[6], slice_codes=c[7])
 
     @property
     def frame_pool_ptr(self):

@@ -113,7 +113,7 @@ struct jsmpeg_hip_batch_t {
 	uint32_t *d_dbg;
 	uint8_t epoch;
 
-	uint32_t n_sc, n_pics, n_levels, n_decoded, n_slices;
+	uint32_t n_sc, n_pics, n_levels, n_decoded, n_slices, n_slice_codes;
 	hipEvent_t ev[5];
 	bool timed;
 	uint32_t *h_counters; /* pinned */
@@ -191,7 +191,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (auto &e : b->ev) e = nullptr;
-	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
+	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = b->n_slice_codes = 0;
 	b->timed = false; b->stream = nullptr;
 	if (config->device >= 0) {
 		if (hipSetDevice(config->device) != hipSuccess) { fail("hipSetDevice(%d) failed", config->device); delete b; return nullptr; }
@@ -455,7 +455,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	hipStream_t st = (hipStream_t)hip_stream;
 	b->stream = st;
 	b->timed = false;
-	b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = 0;
+	b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = b->n_slice_codes = 0;
 	if (b->n_streams == 0) return 0;
 
 	/* ---- 1. start-code index + tables (device) ---- */
@@ -480,6 +480,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	if (b->h_counters[2]) return fail("start-code / picture table overflow: %u start codes, %u pictures (max_pictures %u)",
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
 	b->n_sc = b->h_counters[0]; b->n_pics = b->h_counters[1]; b->n_levels = b->h_counters[3];
+	b->n_slice_codes = std::min(b->h_counters[4], b->sc_cap);
 	b->h_pics.resize(b->n_pics);
 	if (b->n_pics) HIP_TRY(hipMemcpy(b->h_pics.data(), b->d_pics, sizeof(JmPic) * b->n_pics, hipMemcpyDeviceToHost));
 	b->level_off.assign(b->n_levels + 1, 0);
@@ -700,7 +701,7 @@ extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8])
 	if (!b) return fail("null batch");
 	out[0] = b->n_sc; out[1] = b->n_pics; out[2] = b->n_decoded; out[3] = b->n_levels; out[4] = b->n_slices;
 	out[5] = (uint64_t)b->g.mb_size;
-	out[6] = b->n_uncovered; out[7] = 0;
+	out[6] = b->n_uncovered; out[7] = b->n_slice_codes;
 	return 0;
 }
 
@@ -722,6 +723,9 @@ extern "C" int jsmpeg_hip_batch_debug_read(jsmpeg_hip_batch_t *b, int what, void
 	case 6: src = (const uint8_t *)b->d_streams; break;
 	case 7: src = (const uint8_t *)b->d_es; break;
 	case 8: src = (const uint8_t *)b->d_dbg; break;
+	case 9: src = (const uint8_t *)b->d_slice_sc; break;      /* the scan's list of slice codes, stream order */
+	case 10: src = (const uint8_t *)b->d_slice_order; break;  /* ... in the order the slice parse takes them */
+	case 11: src = (const uint8_t *)b->d_pic_sc; break;
 	default: return fail("bad debug selector");
 	}
 	HIP_TRY(hipMemcpy(dst, src + offset, bytes, hipMemcpyDeviceToHost));
