@@ -91,6 +91,66 @@ __global__ __launch_bounds__(256) void k_pred2(const uint8_t *src, uint8_t *dst,
 		for (int r = 0; r < 8; r++) { uint2 v = make_uint2(a0 + r, a1 ^ r); __builtin_nontemporal_store(v.x, (uint32_t *)(o + r * W)); __builtin_nontemporal_store(v.y, (uint32_t *)(o + r * W) + 1); }
 	} else if (a0 == 0x12345678u && a1 == 0x9abcdef0u) *(uint32_t *)o = 1;
 }
+/* the same 32 x 8 tile (wave 32 x 2 blocks, 4 waves), but the forward window of the tile goes through LDS: the workgroup
+ * loads (256 + 2R + 16) x (64 + 2R + 1) bytes with 16-byte loads, whole row pieces (every sector used in full), and the
+ * lanes gather their 9 x 12 bytes from there */
+template <bool STORE, int R>
+__global__ __launch_bounds__(256) void k_pred3(const uint8_t *src, uint8_t *dst, uint32_t frame_bytes, uint32_t n_frames, uint32_t range) {
+	const int W = 1920, H = 1088, BW = W / 8, BH = H / 8;
+	constexpr int WW = 256 + 2 * R + 16, WH = 64 + 2 * R + 1;     /* window: bytes per row (multiple of 16), rows */
+	__shared__ __attribute__((aligned(16))) uint8_t win[WW * WH];
+	const int tcols = (BW + 31) / 32, trows = (BH + 7) / 8;
+	const uint32_t bpf = (uint32_t)(tcols * trows);
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t blk = q % bpf, f = (q / bpf) * 8 + xcd;
+	if (f >= n_frames) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int ty = blk / tcols, tx = blk - ty * tcols;
+	const uint8_t *fs = src + (size_t)f * frame_bytes;
+	/* window origin: 16-byte aligned in x, clamped into the plane */
+	int wx0 = tx * 256 - R; wx0 = wx0 < 0 ? 0 : wx0; wx0 &= ~15; if (wx0 + WW > W) wx0 = W - WW;
+	int wy0 = ty * 64 - R; wy0 = wy0 < 0 ? 0 : wy0; if (wy0 + WH > H) wy0 = H - WH;
+	for (int i = threadIdx.x; i < WH * (WW / 16); i += 256) {
+		const int r = i / (WW / 16), c = i - r * (WW / 16);
+		*reinterpret_cast<uint4 *>(win + r * WW + c * 16) = *reinterpret_cast<const uint4 *>(fs + (size_t)(wy0 + r) * W + wx0 + c * 16);
+	}
+	__syncthreads();
+	const int bx = tx * 32 + (lane & 31), by = ty * 8 + wave * 2 + (lane >> 5);
+	if (bx >= BW || by >= BH) return;
+	const uint32_t h = hash32((uint32_t)(f * 8160 + (by >> 1) * 120 + (bx >> 1)));
+	int mvx = (int)(h % (2 * range + 1)) - (int)range, mvy = (int)((h >> 12) % (2 * range + 1)) - (int)range;
+	int sx = bx * 8 + mvx, sy = by * 8 + mvy;
+	sx = sx < wx0 ? wx0 : (sx > wx0 + WW - 12 ? wx0 + WW - 12 : sx);
+	sy = sy < wy0 ? wy0 : (sy > wy0 + WH - 9 ? wy0 + WH - 9 : sy);
+	const uint32_t off = (uint32_t)((sy - wy0) * WW + (sx - wx0));
+	const uint32_t *w = reinterpret_cast<const uint32_t *>(win + (off & ~3u));
+	uint32_t a0 = 0, a1 = 0;
+	uint32_t Rr[27];
+#pragma unroll
+	for (int j = 0; j < 9; j++) { const uint32_t *wr = w + j * (WW / 4); Rr[3 * j] = wr[0]; Rr[3 * j + 1] = wr[1]; Rr[3 * j + 2] = wr[2]; }
+#pragma unroll
+	for (int j = 0; j < 9; j++) { a0 ^= Rr[3 * j] + Rr[3 * j + 2]; a1 += Rr[3 * j + 1]; }
+	uint8_t *o = dst + (size_t)f * frame_bytes + (size_t)(by * 8) * W + bx * 8;
+	if (STORE) {
+#pragma unroll
+		for (int r = 0; r < 8; r++) { uint2 v = make_uint2(a0 + r, a1 ^ r); __builtin_nontemporal_store(v.x, (uint32_t *)(o + r * W)); __builtin_nontemporal_store(v.y, (uint32_t *)(o + r * W) + 1); }
+	} else if (a0 == 0x12345678u && a1 == 0x9abcdef0u) *(uint32_t *)o = 1;
+}
+template <bool STORE, int R>
+static void run3(const char *name, const uint8_t *src, uint8_t *dst, uint32_t fb, uint32_t n, uint32_t range) {
+	const int tcols = (240 + 31) / 32, trows = (136 + 7) / 8;
+	const uint32_t grid = ((n + 7) / 8) * 8 * (uint32_t)(tcols * trows);
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	float best = 1e9f;
+	for (int rep = 0; rep < 3; rep++) {
+		CK(hipEventRecord(e0));
+		hipLaunchKernelGGL((k_pred3<STORE, R>), dim3(grid), dim3(256), 0, 0, src, dst, fb, n, range);
+		CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+	}
+	printf("%-40s range %2u: %.3f ms\n", name, range, best);
+}
+
 template <int MODE, bool STORE, int WB, int HB, int GX, int GY>
 static void run2(const char *name, const uint8_t *src, uint8_t *dst, uint32_t fb, uint32_t n, uint32_t range) {
 	const int tcols = (240 + WB * GX - 1) / (WB * GX), trows = (136 + HB * GY - 1) / (HB * GY);
@@ -146,6 +206,12 @@ int main() {
 		run2<0, false, 32, 2, 1, 4>("wave 32x2, wg 1x4, no stores", src, dst, fb, n, range);
 		run2<0, false, 8, 8, 2, 2>("wave 8x8, wg 2x2, no stores", src, dst, fb, n, range);
 	}
+	run3<true, 8>("32x8 tile, window R=8 via LDS, stores", src, dst, fb, n, 8);
+	run3<true, 16>("32x8 tile, window R=16 via LDS, stores", src, dst, fb, n, 16);
+	run3<false, 16>("32x8 tile, window R=16 via LDS, no stores", src, dst, fb, n, 16);
+	run3<true, 16>("32x8 tile, window R=16 via LDS, vectors +-8", src, dst, fb, n, 8);
+	run2<0, true, 32, 2, 1, 4>("wave 32x2, wg 1x4 direct (again)", src, dst, fb, n, 8);
+	run2<0, true, 32, 2, 1, 4>("wave 32x2, wg 1x4 direct (again)", src, dst, fb, n, 16);
 	run<2, true, 0>("256x1 zero vectors, stores", src, dst, fb, n, 0);
 	run<2, true, 60>("60x4 zero vectors, stores", src, dst, fb, n, 0);
 	run<2, false, 0>("256x1 zero vectors, no stores", src, dst, fb, n, 0);
