@@ -432,7 +432,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	/* every turn either consumes bits of some lane, changes a lane's state, or unblocks lanes: the
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
 #ifdef JM_PARSE_STATS   /* diagnostics build (tools/parse_stats.py): turn statistics per wavefront into b.dbg */
-	uint32_t st_turns = 0, st_cold = 0, st_coef1 = 0, st_coef2 = 0, st_blocked = 0, st_dc = 0, st_slow = 0, st_live = 0;
+	uint32_t st_turns = 0, st_cold = 0, st_coef1 = 0, st_coef2 = 0, st_blocked = 0, st_dc = 0, st_slow = 0, st_live = 0, st_service = 0;
 #define JM_STAT(x) x
 #else
 #define JM_STAT(x)
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		const uint64_t blocked = __ballot(live && !ready);
 		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
 		if (n_cold == 0 && !others) break;
-		if (blocked) { if (live) jm_lane_service(L); }
+		if (blocked) { JM_STAT(st_service++;) if (live) jm_lane_service(L); }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
 		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { JM_STAT(st_cold++;) if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
 		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {
 		uint32_t *o = b.dbg + (size_t)batch * 8;
-		o[0] = st_turns; o[1] = st_cold; o[2] = st_coef1; o[3] = st_coef2; o[4] = st_blocked; o[5] = st_dc; o[6] = st_slow; o[7] = st_live;
+		o[0] = st_turns; o[1] = st_cold; o[2] = st_coef1; o[3] = st_coef2; o[4] = st_blocked; o[5] = st_dc; o[6] = st_slow; o[7] = st_live | (st_service << 20);
 	}
 #endif
 	if (mine) {

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 os.environ["JSMPEG_HIP_DEBUG"] = "4"
 import numpy as np  # noqa: E402
 import bench  # noqa: E402
+bench.CONFIG = os.environ.get("JSMPEG_KBENCH_CONFIG", bench.CONFIG)
 from jsmpeg_amd import batch as jb, synth  # noqa: E402
 
 n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -21,8 +22,8 @@ L.jsmpeg_hip_batch_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.
 with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, total + 64 * n_streams + 4096) as b:
     b.upload(streams)
     b.decode()
-    n_slices = b.counters()["slices"] if "slices" in b.counters() else n_streams * frames * 68
-    n_waves = (n_slices + 63) // 64
+    n_slices = b.counters()["slices"]
+    n_waves = n_slices        # at most one entry per slice (small passes take fewer than 64 slices per wavefront)
     a = np.zeros((n_waves, 8), np.uint32)
     assert L.jsmpeg_hip_batch_debug_read(b.h, 8, a.ctypes.data, 0, a.nbytes) == 0, jb.last_error()
     a = a[a[:, 0] != 0xeeeeeeee]
