@@ -469,7 +469,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmIndexBufs ib;
 	ib.es = b->d_es; ib.sc_pos = b->d_sc_pos; ib.sc_code = b->d_sc_code; ib.sc_owner = b->d_sc_owner;
 	ib.pic_sc = b->d_pic_sc; ib.counters = b->d_counters; ib.streams = b->d_streams; ib.pics = b->d_pics;
-	ib.counters_rw = b->d_counters; ib.n_streams = b->n_streams; ib.sc_cap = b->sc_cap;
+	ib.counters_rw = b->d_counters; ib.n_streams = b->n_streams; ib.sc_cap = b->sc_cap; ib.pic_cap = b->cfg.max_pictures;
 	ib.width = b->cfg.width; ib.height = b->cfg.height;
 	HIP_TRY(jm_launch_index(ib, st));
 	HIP_TRY(hipEventRecord(b->ev[1], st));

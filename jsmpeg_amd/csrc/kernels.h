@@ -45,7 +45,7 @@ struct JmIndexBufs {
 	JmStream *streams;
 	JmPic *pics;
 	uint32_t *counters_rw;
-	uint32_t n_streams, sc_cap;
+	uint32_t n_streams, sc_cap, pic_cap;
 	int width, height;
 };
 hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st);

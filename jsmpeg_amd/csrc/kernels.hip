@@ -265,8 +265,10 @@ hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src
 __global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {
 	__shared__ JmStream st;
 	const uint32_t s = blockIdx.x;
+	if (b.counters[2]) return;       /* more start codes / picture codes than the tables hold: the host fails the pass */
 	uint32_t n_sc = b.counters[0], n_pics = b.counters[1];
 	if (n_sc > b.sc_cap) n_sc = b.sc_cap;
+	if (n_pics > b.pic_cap) n_pics = b.pic_cap;
 	if (threadIdx.x == 0) {
 		st = b.streams[s];
 		jm_index_stream(st, b.es, b.sc_pos, b.sc_code, n_sc, b.pic_sc, n_pics, b.width, b.height);

@@ -97,3 +97,19 @@ def test_slice_order_is_longest_first():
     bins = np.minimum(1 + (length >> shift), 1023)
     assert (np.diff(bins) <= 0).all()
     assert length[:40].mean() > length[-40:].mean()
+
+
+@pytest.mark.parametrize("code", [0xB5, 0x01, 0x00])
+def test_more_start_codes_than_the_tables_hold(code):
+    """a start code every four bytes (more than one per 16 bytes of capacity): the pass ends with an error, not a fault,
+    and the batch decodes the next input"""
+    from jsmpeg_amd import synth
+    n = 1 << 20
+    es = np.tile(np.array([0, 0, 1, code], np.uint8), n // 4)
+    good, _ = synth.generate_config("cfg1_720p", n_frames=3)
+    with jb.Batch(1280, 720, 1, 64, n + 4096) as b:
+        b.upload([es])
+        with pytest.raises(RuntimeError, match="overflow"):
+            b.decode()
+        b.upload([good])
+        assert b.decode() == 3 and b.counters()["decoded"] == 3
