@@ -1,9 +1,10 @@
 /*
  * gfx950 kernels of the MPEG-1 decode path.  The per-lane bodies live in
  * slice_parse.h / recon_block.h / index_tables.h; this file holds what is
- * GPU-shaped: the byte-parallel start-code scan (ballot-free two-pass
- * compaction with wave prefix sums), LDS staging of the VLC tables and of the
- * coefficient tiles, and the XCD-aware workgroup -> picture mapping.
+ * GPU-shaped: the byte-parallel start-code scan (one pass, a chained scan with
+ * look-back over ticketed chunks), the slice order (a counting sort by length),
+ * LDS staging of the VLC tables and of the coefficient tiles, wavefronts that
+ * draw their slices by ticket, and the XCD-aware workgroup -> picture mapping.
  *
  * No MFMA anywhere: the path is integer byte work bounded by HBM traffic
  * (DESIGN.md section 4).
