@@ -365,97 +365,109 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
  * complete, the skipped macroblocks and the macroblock header
  * (mpeg1.c:1026-1136).  The blocks follow in BLOCK / COEF steps. */
 JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
+	/* Written as a flat chain of guarded sections (`go`: the walk continues) with ONE exit, and the motion-vector
+	 * registers updated by selects: the nested early returns of the first form made the compiler copy the lane's
+	 * registers at every join of its divergent branches (98 of the step's 265 VALU instructions were moves). */
 	const JmVlcLuts *T = c.lut;
 	const bool is_p = c.pic_type == JM_PIC_PREDICTIVE;
+	int st = JM_ST_COLD;
+	bool go = true;
 	/* ---- the macroblock whose last block just ended: its record, and the end of the slice
 	 * (mpeg1.c:1018-1020) ---- */
 	if (L.cur >= 0) {
 		jm_store_mbrec(L.mb + L.addr, L.tok_first, L.rec_mvh, L.rec_mvv, L.cnts, L.qf, c.epoch);
 		L.stored++;
 		L.cur = -1;
-		if (jm_slice_ended(L)) { L.state = JM_ST_DONE; return; }
+		if (jm_slice_ended(L)) { st = JM_ST_DONE; go = false; }
 	}
 	/* ---- macroblock_address_increment (mpeg1.c:1028-1043) ---- */
-	{
+	if (go) {
 		const uint32_t e = T->mba[jm_bits32(L, L.bp) >> 21];
-		if (!(e >> 8) || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
-		L.bp += e >> 8;
-		const int t = (int)(e & 0xff);
-		/* 34 = macroblock_stuffing (adds nothing), 35 = macroblock_escape (adds 33): both want another code */
-		L.inc += t == 35 ? 33 : (t == 34 ? 0 : t);
-		if (t >= 34) return;
+		if (!(e >> 8) || L.bp >= L.bp_end) { st = JM_ST_DONE; go = false; }
+		else {
+			L.bp += e >> 8;
+			const int t = (int)(e & 0xff);
+			/* 34 = macroblock_stuffing (adds nothing), 35 = macroblock_escape (adds 33): both want another code */
+			L.inc += t == 35 ? 33 : (t == 34 ? 0 : t);
+			if (t >= 34) go = false;
+		}
 	}
-	int inc = L.inc;
-	L.inc = 0;
-	if (L.slice_begin) {
-		/* first increment of a slice is relative to the row start and
-		 * skips nothing (mpeg1.c:1046-1051) */
-		L.slice_begin = 0;
-		L.addr += inc;
-	} else {
-		if (L.addr + inc >= c.mb_size) {                 /* illegal increment: mpeg1.c:1053-1057 */
-			if (jm_slice_ended(L)) L.state = JM_ST_DONE;
-			return;
-		}
-		if (inc > 1) {
-			L.dc = JM_DC_RESET;
-			if (is_p) L.mvh = L.mvv = L.pmh = L.pmv = 0;
-		}
-		while (inc > 1) {
-			/* skipped macroblock: prediction only (mpeg1.c:1072-1082) */
+	if (go) {
+		int inc = L.inc;
+		L.inc = 0;
+		if (L.slice_begin) {
+			/* first increment of a slice is relative to the row start and
+			 * skips nothing (mpeg1.c:1046-1051) */
+			L.slice_begin = 0;
+			L.addr += inc;
+		} else if (L.addr + inc >= c.mb_size) {              /* illegal increment: mpeg1.c:1053-1057 */
+			if (jm_slice_ended(L)) st = JM_ST_DONE;
+			go = false;
+		} else {
+			if (inc > 1) {
+				L.dc = JM_DC_RESET;
+				if (is_p) L.mvh = L.mvv = L.pmh = L.pmv = 0;
+			}
+			while (inc > 1) {
+				/* skipped macroblock: prediction only (mpeg1.c:1072-1082) */
+				L.addr++;
+				if (L.addr >= 0)
+					{ jm_store_mbrec(L.mb + L.addr, L.tw - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch); L.stored++; }
+				inc--;
+			}
 			L.addr++;
-			if (L.addr >= 0)
-				{ jm_store_mbrec(L.mb + L.addr, L.tw - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch); L.stored++; }
-			inc--;
 		}
-		L.addr++;
+		if (go && (L.addr < 0 || L.addr >= c.mb_size)) { st = JM_ST_DONE; go = false; }   /* reference would write out of bounds */
 	}
-	if (L.addr < 0 || L.addr >= c.mb_size) { L.state = JM_ST_DONE; return; }   /* reference would write out of bounds */
-
 	/* ---- macroblock_type, quantizer_scale (mpeg1.c:1092-1108): at most 6 + 5 bits, one look ---- */
-	int type;
-	{
+	int type = 0;
+	if (go) {
 		const uint32_t w = jm_bits32(L, L.bp);
 		const uint32_t e = is_p ? T->type_p[w >> 26] : T->type_i[w >> 30];
 		const int len = (int)(e >> 8);
-		if (!len) { L.state = JM_ST_DONE; return; }
 		type = (int)(e & 31);
-		int used = len;
-		if (type & 0x10) { L.qscale = (int)((w << len) >> 27); used += 5; }
-		L.bp += (uint32_t)used;
+		const bool q = (type & 0x10) != 0;
+		L.qscale = q ? (int)((w << len) >> 27) : L.qscale;
+		L.bp += (uint32_t)(q ? len + 5 : len);
+		if (!len) { st = JM_ST_DONE; go = false; }
 	}
-	L.intra = type & 0x01;
-	if (L.intra) {
-		L.mvh = L.mvv = L.pmh = L.pmv = 0;              /* mpeg1.c:1110-1114 */
-		L.qf = (uint32_t)(L.qscale | JM_MB_INTRA);
-	} else {
-		L.dc = JM_DC_RESET;                             /* mpeg1.c:1116-1119 */
-		if (type & 0x08) {
-			bool bad = false;
-			const int ph = jm_motion_component(L, c, L.pmh, bad);
-			const int pv = jm_motion_component(L, c, L.pmv, bad);
-			if (bad) { L.state = JM_ST_DONE; return; }
-			L.pmh = ph; L.pmv = pv;
-			L.mvh = c.full_pel ? ph << 1 : ph;
-			L.mvv = c.full_pel ? pv << 1 : pv;
-		} else if (is_p) L.mvh = L.mvv = L.pmh = L.pmv = 0;   /* mpeg1.c:1200-1204 */
-		L.qf = (uint32_t)(L.qscale | JM_MB_PRED);
+	/* ---- motion vectors (mpeg1.c:1110-1119, 1149-1204) ---- */
+	if (go) {
+		const bool intra = (type & 0x01) != 0, has_mv = !intra && (type & 0x08) != 0;
+		int ph = L.pmh, pv = L.pmv;
+		bool bad = false;
+		if (has_mv) {
+			ph = jm_motion_component(L, c, ph, bad);
+			pv = jm_motion_component(L, c, pv, bad);
+		}
+		const bool zero = intra || (!has_mv && is_p);      /* intra: mpeg1.c:1110-1114; no vector in a P picture: 1200-1204 */
+		L.pmh = zero ? 0 : ph; L.pmv = zero ? 0 : pv;
+		const int fh = c.full_pel ? ph << 1 : ph, fv = c.full_pel ? pv << 1 : pv;
+		L.mvh = zero ? 0 : (has_mv ? fh : L.mvh); L.mvv = zero ? 0 : (has_mv ? fv : L.mvv);
+		L.dc = intra ? L.dc : JM_DC_RESET;                 /* mpeg1.c:1116-1119 */
+		L.intra = intra ? 1 : 0;
+		L.qf = (uint32_t)(L.qscale | (intra ? JM_MB_INTRA : JM_MB_PRED));
+		L.tok_first = L.tw - L.tok_rel;
+		L.rec_mvh = L.mvh; L.rec_mvv = L.mvv;
+		if (bad) { st = JM_ST_DONE; go = false; }
 	}
-	L.tok_first = L.tw - L.tok_rel;
-	L.rec_mvh = L.mvh; L.rec_mvv = L.mvv;
-
 	/* ---- coded_block_pattern (mpeg1.c:1130-1136) ---- */
-	int cbp = L.intra ? 0x3f : 0;
-	if (type & 0x02) {
-		const uint32_t e = T->cbp[jm_bits32(L, L.bp) >> 23];
-		L.bp += e >> 8;
-		cbp = (e >> 8) ? (int)(e & 0xff) : -1;
+	if (go) {
+		int cbp = L.intra ? 0x3f : 0;
+		if (type & 0x02) {
+			const uint32_t e = T->cbp[jm_bits32(L, L.bp) >> 23];
+			L.bp += e >> 8;
+			cbp = (e >> 8) ? (int)(e & 0xff) : -1;
+		}
+		if (cbp < 0) st = JM_ST_DONE;
+		else {
+			L.cbp = cbp;
+			L.cnts = 0;
+			if (cbp) st = jm_open_block(L, cbp);
+			else L.cur = 6;                                /* no coded block: the next COLD step stores the record */
+		}
 	}
-	if (cbp < 0) { L.state = JM_ST_DONE; return; }
-	L.cbp = cbp;
-	L.cnts = 0;
-	if (cbp) L.state = jm_open_block(L, cbp);
-	else L.cur = 6;                                    /* no coded block: the next COLD step stores the record */
+	L.state = st;
 }
 
 /* What the lane is waiting for. */
