@@ -45,6 +45,9 @@ typedef struct synth_params_t {
 	                            bit 0 (value 1): valid but unusual syntax -- slices that start / end mid-row or span rows,
 	                            extra_information_slice / _picture, macroblock_stuffing, extension and
 	                            user_data start codes after the picture header (0: one plain slice per row) */
+	int32_t mv_jitter;       /* 0: every macroblock its own uniform-random vector (no coherence at all: the worst case for
+	                            the prediction reads); k > 0: one random vector per picture + per-macroblock jitter of
+	                            +-k coded units (coherent motion: a pan with noise) */
 } synth_params_t;
 
 /* ------------------------------------------------------------------ rng */
@@ -275,6 +278,7 @@ typedef struct {
 	rng_t r;
 	bitw_t w;
 	synth_stats_t st;
+	int gmh, gmv;                /* mv_jitter > 0: the picture's vector, coded units */
 } gen_t;
 
 static void put_sequence_header(gen_t *G, int custom) {
@@ -421,7 +425,12 @@ static void put_slice(gen_t *G, int a0, int a1, int type, int full_pel, int f_co
 					 * shrink toward 0 until every read is in-picture */
 					int lo = -16 * f, hi = 16 * f - 1, mh = 0, mv = 0;
 					for (int t = 0; t < 12; t++) {
-						int th = rng_range(&G->r, lo, hi), tv = rng_range(&G->r, lo, hi);
+						int th, tv;
+						if (G->p->mv_jitter > 0) {
+							const int j = G->p->mv_jitter;
+							th = G->gmh + rng_range(&G->r, -j, j); tv = G->gmv + rng_range(&G->r, -j, j);
+							th = th < lo ? lo : (th > hi ? hi : th); tv = tv < lo ? lo : (tv > hi ? hi : tv);
+						} else { th = rng_range(&G->r, lo, hi); tv = rng_range(&G->r, lo, hi); }
 						if (t >= 6) { th /= (1 << (t - 5)); tv /= (1 << (t - 5)); }
 						int hh = full_pel ? th * 2 : th, vv = full_pel ? tv * 2 : tv;
 						if (mv_in_picture(&G->g, col, row, hh, vv)) { mh = th; mv = tv; break; }
@@ -494,6 +503,10 @@ size_t synth_es_generate(const synth_params_t *p, uint8_t *out, size_t cap, uint
 			n_p++;
 			full_pel = (n_p % 11) == 0;
 			f_code = rng_range(&G.r, 1, p->f_code_max < 1 ? 1 : p->f_code_max);
+			if (p->mv_jitter > 0) {
+				const int f = 1 << (f_code - 1);
+				G.gmh = rng_range(&G.r, -16 * f, 16 * f - 1); G.gmv = rng_range(&G.r, -16 * f, 16 * f - 1);
+			}
 		}
 		put_picture_header(&G, in_gop, type, full_pel, f_code);
 		if (!(p->syntax_quirks & 1))

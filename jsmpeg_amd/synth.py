@@ -13,7 +13,7 @@ class SynthParams(ctypes.Structure):
                [("seed", ctypes.c_uint32)] + \
                [(n, ctypes.c_int32) for n in ("ac_max", "qscale_lo", "qscale_hi", "escape_permille",
                                                "custom_quant", "quirk_levels", "dc_size_max",
-                                               "coded_permille", "f_code_max", "syntax_quirks")]
+                                               "coded_permille", "f_code_max", "syntax_quirks", "mv_jitter")]
 
 
 class SynthStats(ctypes.Structure):
@@ -65,10 +65,10 @@ CONFIGS = {
 
 def generate_es(width, height, n_frames, gop=12, seed=BASE_SEED, ac_max=4, qscale_lo=4, qscale_hi=11,
                 escape_permille=20, custom_quant=0, quirk_levels=0, dc_size_max=3, coded_permille=400,
-                f_code_max=3, syntax_quirks=0, with_stats=False):
+                f_code_max=3, syntax_quirks=0, mv_jitter=0, with_stats=False):
     """Returns (es_bytes: np.uint8[n], pic_offsets: np.uint32[n_frames+1]) [+ stats dict]."""
     p = SynthParams(width, height, n_frames, gop, seed & 0xFFFFFFFF, ac_max, qscale_lo, qscale_hi,
-                    escape_permille, custom_quant, quirk_levels, dc_size_max, coded_permille, f_code_max, syntax_quirks)
+                    escape_permille, custom_quant, quirk_levels, dc_size_max, coded_permille, f_code_max, syntax_quirks, mv_jitter)
     mbs = ((width + 15) // 16) * ((height + 15) // 16)
     cap = 4096 + n_frames * (mbs * (64 + 40 * max(ac_max, 1)) + 4096)
     buf = np.empty(cap, dtype=np.uint8)
