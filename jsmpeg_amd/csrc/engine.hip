@@ -98,7 +98,7 @@ struct jsmpeg_hip_batch_t {
 	uint64_t *d_scan_state;
 	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_slice_sc; uint32_t *d_slice_order; uint32_t *d_order_hist; uint32_t *d_counters;
 	JmPic *d_pics; std::vector<JmPic> h_pics;
-	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc; std::vector<uint32_t> level_off;
+	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc;
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
 	uint32_t desc_cap, n_uncovered;
 	hipEvent_t ev_cov;
@@ -152,7 +152,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * (2 * JM_ORDER_BINS + 16)));   /* + the parse pass's ticket counter */
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
-	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, and room for a second pass (step 4b) */
+	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, the ones without a forward reference twice (steps 4a, 4b) */
 	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
 	HIP_TRY(jm_malloc(&b->d_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures), hipHostMallocDefault));
@@ -483,37 +483,31 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	b->n_slice_codes = std::min(b->h_counters[4], b->sc_cap);
 	b->h_pics.resize(b->n_pics);
 	if (b->n_pics) HIP_TRY(hipMemcpy(b->h_pics.data(), b->d_pics, sizeof(JmPic) * b->n_pics, hipMemcpyDeviceToHost));
-	b->level_off.assign(b->n_levels + 1, 0);
-	for (const JmPic &p : b->h_pics) if (p.decoded) { b->level_off[p.level + 1]++; b->n_decoded++; b->n_slices += p.n_slices; }
-	for (uint32_t l = 0; l < b->n_levels; l++) b->level_off[l + 1] += b->level_off[l];
+	for (const JmPic &p : b->h_pics) if (p.decoded) { b->n_decoded++; b->n_slices += p.n_slices; }
 	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
-	/* The reconstruct plan: dependency levels (a picture after its forward reference), and per picture the frame its
-	 * UNWRITTEN macroblocks keep showing.  The reference keeps two plane sets and rotates them after every picture
-	 * (mpeg1.c:986-994): a macroblock a picture never writes -- e.g. a last macroblock of 6 bits that hides in the
-	 * slack of the slice's last byte, so that next_bytes_are_start_code ends the slice before it (mpeg1.c:1018-1020)
-	 * -- keeps the decoded picture before last.  Here every picture has its own frame, so such a block is copied
-	 * from that picture's frame (`stale`).  Inside a chain that frame is two levels down; for the first two pictures
-	 * of a chain it belongs to the chain before: whether such a picture really has unwritten macroblocks is only
-	 * known after the parse (step 4b). */
-	std::vector<int32_t> level(b->n_pics, 0), stale(b->n_pics, -1);
+	/* The reconstruct plan.  A picture comes after its forward reference -- and, if it leaves macroblocks UNWRITTEN,
+	 * after the frame those keep showing: the reference keeps two plane sets and rotates them after every picture
+	 * (mpeg1.c:986-994), so a macroblock a picture never writes -- e.g. a last macroblock of 6 bits (forward vector
+	 * repeated, nothing coded: common in a pan) that hides in the slack of the slice's last byte, so that
+	 * next_bytes_are_start_code ends the slice before it (mpeg1.c:1018-1020) -- keeps the decoded picture before
+	 * last.  Here every picture has its own frame, so such a block is copied from that picture's frame (`stale`).
+	 * Whether a picture has unwritten macroblocks is only known after the parse: the pictures without a forward
+	 * reference are reconstructed right behind it (step 4a: intra pictures hardly ever have such macroblocks), the
+	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs. */
+	std::vector<int32_t> stale(b->n_pics, -1);
+	uint32_t n_roots = 0;
 	{
 		std::vector<int64_t> last1(b->n_streams, -1), last2(b->n_streams, -1);   /* the stream's last two decoded pictures */
-		uint32_t n_levels = 0;
 		for (uint32_t p = 0; p < b->n_pics; p++) {
 			const JmPic &pic = b->h_pics[p];
 			if (!pic.decoded) continue;
-			level[p] = pic.fwd >= 0 ? level[pic.fwd] + 1 : 0;
-			n_levels = std::max(n_levels, (uint32_t)level[p] + 1);
+			if (pic.fwd < 0) n_roots++;
 			if (pic.stream < b->n_streams) { stale[p] = (int32_t)last2[pic.stream]; last2[pic.stream] = last1[pic.stream]; last1[pic.stream] = p; }
 		}
-		b->n_levels = n_levels;
-		b->level_off.assign(n_levels + 1, 0);
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) b->level_off[level[p] + 1]++;
-		for (uint32_t l = 0; l < n_levels; l++) b->level_off[l + 1] += b->level_off[l];
-		b->h_desc.resize(std::max<size_t>(1, b->n_decoded));
-		std::vector<uint32_t> cur(b->level_off.begin(), b->level_off.end());
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) fill_desc(b, b->h_desc[cur[level[p]]++], p, stale[p]);
-		if (b->n_decoded) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * b->n_decoded, hipMemcpyHostToDevice, st));
+		b->h_desc.resize(std::max<size_t>(1, (size_t)b->n_decoded + n_roots));
+		uint32_t k = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
+		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
 	}
 	if (++b->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
@@ -551,46 +545,46 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	if (b->n_pics) HIP_TRY(hipMemcpyAsync(b->h_covered, b->d_covered, sizeof(uint32_t) * b->n_pics, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(b->ev_cov, st));
 
-	/* ---- 4. reconstruct, one launch per dependency level ---- */
+	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
-	for (uint32_t l = 0; l < b->n_levels; l++) {
-		rb.desc = b->d_desc + b->level_off[l];
-		rb.n_level_pics = b->level_off[l + 1] - b->level_off[l];
-		HIP_TRY(jm_launch_recon(rb, st));
-	}
+	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
+	HIP_TRY(jm_launch_recon(rb, st));
 
-	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4 meanwhile).
-	 * A picture with unwritten macroblocks whose `stale` frame was not finished before its own level ran (only the
-	 * first two pictures of a chain can be that) has copied unfinished data: it, and what hangs on it, is
-	 * reconstructed again in stream order. ---- */
+	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4a meanwhile):
+	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
+	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
 	HIP_TRY(hipEventSynchronize(b->ev_cov));
 	{
-		std::vector<uint8_t> redo(b->n_pics, 0);
-		std::vector<uint32_t> again;
+		std::vector<int32_t> level(b->n_pics, 0);
+		uint32_t n_levels = b->n_decoded ? 1 : 0;
 		b->n_uncovered = 0;
 		for (uint32_t p = 0; p < b->n_pics; p++) {
 			const JmPic &pic = b->h_pics[p];
 			if (!pic.decoded) continue;
 			const bool uncovered = b->h_covered[p] < (uint32_t)b->g.mb_size;
 			b->n_uncovered += uncovered;
-			if ((uncovered && stale[p] >= 0 && (level[stale[p]] >= level[p] || redo[stale[p]])) || (pic.fwd >= 0 && redo[pic.fwd])) {
-				redo[p] = 1;
-				again.push_back(p);
-			}
+			int32_t l = pic.fwd >= 0 ? level[pic.fwd] + 1 : 0;          /* fwd, stale < p: their levels are known */
+			if (uncovered && stale[p] >= 0) l = std::max(l, level[stale[p]] + 1);
+			level[p] = l;
+			n_levels = std::max(n_levels, (uint32_t)l + 1);
 		}
+		b->n_levels = n_levels;
+		std::vector<uint32_t> off(n_levels + 1, 0);
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;
+		for (uint32_t l = 0; l < n_levels; l++) off[l + 1] += off[l];
+		const uint32_t n_later = off[n_levels];
+		if ((size_t)n_roots + n_later > b->desc_cap) return fail("internal: descriptor table too small");
 		if (getenv("JSMPEG_HIP_DEBUG_COVER"))
-			fprintf(stderr, "cover: %u of %u pictures with unwritten macroblocks, %zu reconstructed again\n", b->n_uncovered, b->n_pics, again.size());
-		if (!again.empty()) {
-			if (b->n_decoded + again.size() > b->desc_cap) return fail("internal: descriptor table too small for the second pass");
-			std::vector<JmReconDesc> d2(again.size());
-			for (size_t i = 0; i < again.size(); i++) fill_desc(b, d2[i], again[i], stale[again[i]]);
-			HIP_TRY(hipMemcpyAsync(b->d_desc + b->n_decoded, d2.data(), sizeof(JmReconDesc) * d2.size(), hipMemcpyHostToDevice, st));
-			HIP_TRY(hipStreamSynchronize(st));   /* d2 is pageable and goes out of scope */
-			for (size_t i = 0; i < again.size(); i++) {
-				rb.desc = b->d_desc + b->n_decoded + i;
-				rb.n_level_pics = 1;
+			fprintf(stderr, "cover: %u of %u pictures with unwritten macroblocks, %u levels, %u pictures behind the first\n", b->n_uncovered, b->n_pics, n_levels, n_later);
+		if (n_later) {
+			std::vector<uint32_t> cur(off.begin(), off.end());
+			for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) fill_desc(b, b->h_desc[n_roots + cur[level[p]]++], p, stale[p]);
+			HIP_TRY(hipMemcpyAsync(b->d_desc + n_roots, b->h_desc.data() + n_roots, sizeof(JmReconDesc) * n_later, hipMemcpyHostToDevice, st));
+			for (uint32_t l = 1; l < n_levels; l++) {
+				rb.desc = b->d_desc + n_roots + off[l];
+				rb.n_level_pics = off[l + 1] - off[l];
 				HIP_TRY(jm_launch_recon(rb, st));
 			}
 		}
