@@ -47,7 +47,7 @@ typedef struct synth_params_t {
 	                            user_data start codes after the picture header (0: one plain slice per row) */
 	int32_t mv_jitter;       /* 0: every macroblock its own uniform-random vector (no coherence at all: the worst case for
 	                            the prediction reads); k > 0: one random vector per picture + per-macroblock jitter of
-	                            +-k coded units (coherent motion: a pan with noise) */
+	                            +-(k - 1) coded units (coherent motion: 1 = a pure pan, 2 = a pan with +-1 of noise, ...) */
 } synth_params_t;
 
 /* ------------------------------------------------------------------ rng */
@@ -427,7 +427,7 @@ static void put_slice(gen_t *G, int a0, int a1, int type, int full_pel, int f_co
 					for (int t = 0; t < 12; t++) {
 						int th, tv;
 						if (G->p->mv_jitter > 0) {
-							const int j = G->p->mv_jitter;
+							const int j = G->p->mv_jitter - 1;
 							th = G->gmh + rng_range(&G->r, -j, j); tv = G->gmv + rng_range(&G->r, -j, j);
 							th = th < lo ? lo : (th > hi ? hi : th); tv = tv < lo ? lo : (tv > hi ? hi : tv);
 						} else { th = rng_range(&G->r, lo, hi); tv = rng_range(&G->r, lo, hi); }

@@ -63,6 +63,11 @@ CASES = {
     "skipped_pictures_352x288": ("cfg1_720p", 20, dict(width=352, height=288, syntax_quirks=2)),
     "long_slices_352x288": ("cfg1_720p", 16, dict(width=352, height=288, syntax_quirks=5)),
     "skipped_pictures_quirks_176x144": ("cfg1_720p", 20, dict(width=176, height=144, syntax_quirks=3, gop=5)),
+    # coherent motion (one vector per picture + jitter): last macroblocks that only repeat the vector are 6 bits and get
+    # lost in the slack of their slice's last byte in pictures 9, 11, 13, 17, 23 of I P I P ..., each the first P of its chain -- the
+    # batch engine then lays its levels out across the GOPs (a picture after the frame its unwritten macroblocks show)
+    "coherent_pan_352x288": ("cfg1_720p", 24, dict(width=352, height=288, gop=2, mv_jitter=1, f_code_max=1, coded_permille=60,
+                                                   ac_max=1, stream=6045)),
 }
 
 

@@ -20,7 +20,7 @@ for c in range(cases):
               qscale_lo=int(rng.integers(1, 8)), qscale_hi=int(rng.integers(8, 32)), escape_permille=int(rng.choice([0, 20, 300, 1000])),
               custom_quant=int(rng.integers(0, 2)), quirk_levels=int(rng.integers(0, 2)), dc_size_max=int(rng.integers(0, 9)),
               coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 8)), syntax_quirks=int(rng.choice([0, 1, 2, 3, 5, 7])),
-              mv_jitter=int(rng.choice([0, 0, 1, 5])))
+              mv_jitter=int(rng.choice([0, 0, 1, 2, 6])))
     if ov["syntax_quirks"] & 2:      # the sweep tells consumed-not-decoded pictures by the repeat they cause: real pictures must differ
         ov["ac_max"], ov["dc_size_max"] = max(ov["ac_max"], 1), max(ov["dc_size_max"], 2)
     n = int(rng.integers(2, 20))

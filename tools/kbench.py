@@ -15,7 +15,7 @@ n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 cfg = synth.CONFIGS[bench.CONFIG]
-if os.environ.get("JSMPEG_SYNTH_MV_JITTER"):       # coherent motion: one vector per picture + this much jitter per macroblock
+if os.environ.get("JSMPEG_SYNTH_MV_JITTER"):       # coherent motion: one vector per picture, +-(k - 1) of jitter per macroblock
     cfg["mv_jitter"] = int(os.environ["JSMPEG_SYNTH_MV_JITTER"])
 gen = bench.generate_streams(0, n_streams, frames)
 streams = [g[0] for g in gen]

@@ -54,6 +54,6 @@ def run(name, specs, reps=3):
 run("all intra (GOP 1)", [(60, dict(gop=1))] * 64)
 run("all intra (GOP 1), 5 reps", [(60, dict(gop=1))] * 64, reps=5)
 run("GOP 60", [(120, dict(gop=60))] * 64)
-run("GOP 12, coherent motion", [(120, dict(mv_jitter=1))] * 64)
+run("GOP 12, coherent motion (pan +- 1)", [(120, dict(mv_jitter=2))] * 64)
 run("ragged: 1 x 1200 + 63 x 12", [(1200, {})] + [(12, {})] * 63)
 run("8 streams x 120", [(120, {})] * 8)
