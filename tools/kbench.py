@@ -15,6 +15,8 @@ n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 cfg = synth.CONFIGS[bench.CONFIG]
+for kv in filter(None, os.environ.get("JSMPEG_SYNTH_OVERRIDES", "").split(",")):     # e.g. gop=6,ac_max=8
+    cfg[kv.split("=")[0]] = int(kv.split("=")[1])
 if os.environ.get("JSMPEG_SYNTH_MV_JITTER"):       # coherent motion: one vector per picture, +-(k - 1) of jitter per macroblock
     cfg["mv_jitter"] = int(os.environ["JSMPEG_SYNTH_MV_JITTER"])
 gen = bench.generate_streams(0, n_streams, frames)
