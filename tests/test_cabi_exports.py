@@ -53,3 +53,35 @@ def test_hot_kernels_use_no_scratch():
     usage = build.check_kernel_resources()
     assert any("k_parse" in k for k in usage) and any("k_recon" in k for k in usage)
     assert any("k_mp2_matrix" in k for k in usage) and any("k_mp2_window" in k for k in usage)
+
+
+def test_graft_entry_functions_have_no_undefined_names():
+    """smoke() only runs on the GPU box: a name it uses without importing it (it happened once) must fail HERE"""
+    import ast
+    import builtins
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    tree = ast.parse(src)
+    module_names = set(dir(builtins))
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            module_names |= {(a.asname or a.name).split(".")[0] for a in node.names}
+        elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            module_names.add(node.name)
+        elif isinstance(node, ast.Assign):
+            for t in node.targets:
+                module_names |= {n.id for n in ast.walk(t) if isinstance(n, ast.Name)}
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        local = {a.arg for a in fn.args.args}
+        for node in ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                local |= {(a.asname or a.name).split(".")[0] for a in node.names}
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                local.add(node.id)
+            elif isinstance(node, (ast.FunctionDef, ast.Lambda)) and node is not fn:
+                local |= {a.arg for a in node.args.args}
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                local.add(node.name)
+            elif isinstance(node, ast.comprehension):
+                local |= {n.id for n in ast.walk(node.target) if isinstance(n, ast.Name)}
+        used = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+        assert not (used - local - module_names), "%s(): undefined %r" % (fn.name, sorted(used - local - module_names))
