@@ -499,8 +499,10 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	/* as many workgroups as there are batches -- or, for large passes, as the GPU holds at a time (2 per CU: 80 KB of
 	 * LDS each), their wavefronts drawing further batches by ticket */
 	uint32_t groups = (b.n_batches + JM_PARSE_WAVES - 1) / JM_PARSE_WAVES;
-	if (groups > JM_PARSE_RESIDENT_WGS && b.ticket) {
-		groups = JM_PARSE_RESIDENT_WGS;
+	static const uint32_t resident = getenv("JSMPEG_HIP_PARSE_RESIDENT") ? (uint32_t)atoi(getenv("JSMPEG_HIP_PARSE_RESIDENT"))
+	                                                                      : JM_PARSE_RESIDENT_WGS;   /* tests: the ticket path on small inputs */
+	if (groups > resident && resident >= 1 && b.ticket) {
+		groups = resident;
 		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
 		if (e != hipSuccess) return e;
 	} else b.ticket = nullptr;

@@ -155,3 +155,39 @@ def test_damaged_input_neither_faults_nor_hangs(hip_lib):
                          timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "40 damaged streams decoded without fault or hang" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(JSMPEG_HIP_PARSE_RESIDENT="1", JSMPEG_HIP_PARSE_LANES="64"),
+                                 dict(JSMPEG_HIP_PARSE_RESIDENT="2", JSMPEG_HIP_PARSE_LANES="4")])
+def test_parse_wavefronts_draw_batches_by_ticket(env):
+    """Large passes launch as many parse workgroups as the GPU holds and their wavefronts draw further batches of slices
+    from a ticket counter; small inputs never get there -- here they do (the environment limits the workgroups: the
+    library reads it once per process, hence the subprocess), golden fixtures through the batch interface."""
+    import subprocess
+    import sys
+    code = r'''
+import glob, hashlib, json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from jsmpeg_amd import batch as jb, synth
+bad = []
+for path in sorted(glob.glob(os.path.join(%r, "tests", "golden", "frames_*.json"))):
+    fx = json.load(open(path))
+    if fx["n_frames"] * fx["info"]["coded_size"] > 40e6 or "abi_frame_md5" in fx:
+        continue
+    es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    with jb.Batch(fx["info"]["width"], fx["info"]["height"], 2, 2 * fx["n_frames"] + 4, 2 * len(es) + 8192) as b:
+        b.upload([es, es])
+        assert b.decode() == 2 * fx["n_frames"]
+        for p in range(2 * fx["n_frames"]):
+            h = hashlib.md5()
+            for plane in b.read_frame(p):
+                h.update(plane.tobytes())
+            if h.hexdigest() != fx["frame_md5"][p %% fx["n_frames"]]:
+                bad.append((os.path.basename(path), p))
+print("BAD", bad)
+assert not bad
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
