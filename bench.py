@@ -292,6 +292,20 @@ def main():
         e1.record(xfer)
         return e0, e1
 
+    h2d_stage, h2d_stream = [], []
+
+    def start_h2d(i):
+        if not h2d_stream:
+            h2d_stream.append(torch.cuda.Stream(device=dev))
+            h2d_stage.extend([d_es, torch.empty_like(d_es)])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h2d_stream[0].wait_stream(stream)          # the buffer's last reader (the placement two steps ago) is through
+        with torch.cuda.stream(h2d_stream[0]):
+            e0.record()
+            h2d_stage[i].copy_(h_es, non_blocking=True)
+            e1.record()
+        return e0, e1
+
     def step(collect, more):
         """One pass of the hot path.  Multi-rank: this step's piece arrives by the library's RCCL scatter; the NEXT step's
         scatter (`more`: there is one inside the same timed region) is started as soon as this step's piece has been
@@ -310,14 +324,20 @@ def main():
                 state["cur"] ^= 1
                 state["pending"] = start_scatter(state["cur"])
         elif args.h2d:
-            # the variant that starts from HOST memory: one pinned copy of the packed streams per step (PCIe), then the same path
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            d_es.copy_(h_es, non_blocking=True)
-            b.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sptr)
-            e1.record()
+            # the variant that starts from HOST memory: one pinned copy of the packed streams per step (PCIe) into one of two
+            # device buffers, on its own HIP stream -- the copy for step k+1 travels while the kernels of step k run (like
+            # the exchange at N > 1; nothing is prefetched across the warm-up / timed boundary) -- then the same path
+            if state["pending"] is None:
+                state["pending"] = start_h2d(state["cur"])
+            e0, e1 = state["pending"]
+            stream.wait_event(e1)
+            b.upload_device(ctypes.c_void_p(h2d_stage[state["cur"]].data_ptr()), shard_len, begin, end, sptr)
             if collect:
                 h2d_ms.append((e0, e1))
+            state["pending"] = None
+            if more:
+                state["cur"] ^= 1
+                state["pending"] = start_h2d(state["cur"])
         n = b.decode(stream=sptr, sync=False)
         if n != n_pictures:
             raise SystemExit("rank %d: decoded %d pictures, expected %d" % (rank, n, n_pictures))
@@ -440,12 +460,12 @@ def main():
         args.h2d = True
         h_es = torch.from_numpy(packed).pin_memory()
         saved = dict(phase)
-        dt = timed_run(max(2, args.steps // 2), 1)
-        value_incl_h2d = {"value": round(n_pictures * max(2, args.steps // 2) / dt, 1), "unit": "frames/s",
-                          "ms_per_step": round(dt / max(2, args.steps // 2) * 1e3, 3),
+        dt = timed_run(max(2, args.steps), 1)
+        value_incl_h2d = {"value": round(n_pictures * max(2, args.steps) / dt, 1), "unit": "frames/s",
+                          "ms_per_step": round(dt / max(2, args.steps) * 1e3, 3),
                           "h2d_ms": round(sum(a.elapsed_time(bb) for a, bb in h2d_ms) / max(1, len(h2d_ms)), 3),
                           "h2d_bytes": shard_len,
-                          "note": "every step starts with the packed compressed streams in pinned HOST memory: one PCIe copy + the device-side placement, then the same path; never `value`"}
+                          "note": "every step starts with the packed compressed streams in pinned HOST memory: one PCIe copy (double-buffered, on its own stream: the copy of step k+1 runs beside the kernels of step k) + the device-side placement, then the same path; never `value`"}
         args.h2d = False
         phase.update(saved)
 
