@@ -101,7 +101,8 @@ typedef struct jsmpeg_hip_picture_info_t {
 	uint32_t es_offset;         /* byte offset of the picture start code in that stream */
 	int32_t type;               /* picture_coding_type: 1 = I, 2 = P          */
 	int32_t decoded;            /* 0: skipped exactly where the reference skips (B/D, f_code 0, before the header) */
-	int32_t level;              /* dependency depth inside its chain           */
+	int32_t level;              /* dependency depth inside its chain (the reconstruct order may put a picture
+	                               with unwritten macroblocks deeper: counters[3]) */
 	int32_t forward;            /* picture index of its forward reference, -1  */
 	uint32_t n_slices;
 } jsmpeg_hip_picture_info_t;
@@ -158,9 +159,11 @@ int64_t jsmpeg_hip_batch_read_es(jsmpeg_hip_batch_t *b, uint32_t stream, void *o
 
 /* The hot path over the resident batch: start-code index -> tables -> slice
  * parse -> reconstruct, level by level.  Work is enqueued on `hip_stream`; the
- * call returns once everything is enqueued (it synchronises once internally,
- * after the index, to size the launches).  Returns the number of pictures
- * found or < 0. */
+ * call returns once everything is enqueued.  It waits for the device twice on
+ * the way: after the index, to size the launches, and for the end of the slice
+ * parse (the pictures without a forward reference are being reconstructed
+ * meanwhile), whose report of unwritten macroblocks decides the order of the
+ * remaining reconstruct launches.  Returns the number of pictures found or < 0. */
 int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream);
 /* Waits for the last decode; returns 0 or < 0. */
 int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b);
