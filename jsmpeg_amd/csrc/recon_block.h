@@ -234,36 +234,54 @@ JM_HD void jm_recon_locate(const JmGeom &G, JM_GLOBAL const JmMbRec *mb, int g, 
  * random vectors the kernel is bound by L1 misses in flight, not by HBM (tools/ubench_pred.hip, luma of 640 pictures
  * at +-16: 256 consecutive blocks per workgroup 0.69 ms, 60 x 4 tiles 0.60, 32 x 8 tiles in this lane order 0.50).
  * A wavefront still stores whole row pieces: TW x 8 contiguous bytes for each of its two block rows.
- * TW = 32 (the plane's last tile column takes what is left). */
+ * TW = 32; what is left of the plane's width is one more column (JmPlaneTiles below). */
 #define JM_TILE_ROWS 8
+/* A plane's tiles: `full` columns of 32 blocks x `rows` tile rows of 8 block rows, numbered row by row; then the
+ * column of what is left (`rem` blocks wide) -- as tiles of 16 x 16 blocks (a wavefront: 4 block rows of 16) when at
+ * most 16 blocks are left, `rows16` of them: 1080p luma is 7 columns + 16 blocks, 128 tiles instead of 136 with the
+ * last column's lanes half idle. */
+struct JmPlaneTiles { int full, rows, rem, rem16, rows16, count; };
 struct JmTiles {
-	int tw_y, cols_y, rows_y;      /* luma: tile width in blocks (<= 32), tile columns, tile rows */
-	int tw_c, cols_c, rows_c;      /* each chroma plane */
-	int per_picture;               /* cols_y * rows_y + 2 * cols_c * rows_c */
+	JmPlaneTiles y, c;             /* luma, each chroma plane */
+	int per_picture;               /* y.count + 2 * c.count */
 };
+JM_HD void jm_plane_tiles_init(JmPlaneTiles &P, int bw, int bh) {
+	/* tile edges at multiples of 256 bytes, so that a wavefront's row pieces are whole 32-byte sectors (30-block tiles,
+	 * edges at multiples of 240 bytes, measured 4 % slower than the 60 x 4 tiles they were to replace) */
+	P.full = bw / 32; P.rem = bw - 32 * P.full;
+	P.rows = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
+	P.rem16 = P.rem > 0 && P.rem <= 16;
+	P.rows16 = (bh + 15) / 16;
+	P.count = P.full * P.rows + (P.rem ? (P.rem16 ? P.rows16 : P.rows) : 0);
+}
 JM_HD void jm_tiles_init(JmTiles &T, const JmGeom &G) {
-	const int bw = 2 * G.mb_width, bh = 2 * G.mb_height, bwc = G.mb_width, bhc = G.mb_height;
-	/* 32 blocks wide, the last column takes what is left: tile edges at multiples of 256 bytes, so that a wavefront's
-	 * row pieces are whole 32-byte sectors (30-block tiles, edges at multiples of 240 bytes, measured 4 % slower than
-	 * the 60 x 4 tiles they were to replace: partial sectors at every tile edge) */
-	T.cols_y = (bw + 31) / 32; T.tw_y = bw < 32 ? bw : 32; T.rows_y = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
-	T.cols_c = (bwc + 31) / 32; T.tw_c = bwc < 32 ? bwc : 32; T.rows_c = (bhc + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
-	T.per_picture = T.cols_y * T.rows_y + 2 * T.cols_c * T.rows_c;
+	jm_plane_tiles_init(T.y, 2 * G.mb_width, 2 * G.mb_height);
+	jm_plane_tiles_init(T.c, G.mb_width, G.mb_height);
+	T.per_picture = T.y.count + 2 * T.c.count;
 }
 /* lane `lane` of wavefront `wave` of tile `tile` of a picture: where its block is; false: no block (past the
  * plane's edge or the tile's width) -- Q then describes a neighbouring block, so that every lane has loads to issue */
 JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int wave, int lane, JmLoc &Q) {
-	const int ny = T.cols_y * T.rows_y, nc = T.cols_c * T.rows_c;
-	int pl = 0, t = tile, cols = T.cols_y, tw = T.tw_y;       /* pl: 0 luma, 1 / 2 the chroma planes in block-number order (block 4, block 5) */
-	if (tile >= ny) { pl = tile >= ny + nc ? 2 : 1; t = tile - ny - (pl - 1) * nc; cols = T.cols_c; tw = T.tw_c; }
-	const int ty = t / cols, tx = t - ty * cols;
-	const int lx = lane & 31;
-	int bx = tx * tw + lx, by = ty * JM_TILE_ROWS + 2 * wave + (lane >> 5);
-	const int bw = pl ? G.mb_width : 2 * G.mb_width, bh = pl ? G.mb_height : 2 * G.mb_height;
-	const bool ok = lx < tw && bx < bw && by < bh;
+	int pl = 0, t = tile;                                      /* pl: 0 luma, 1 / 2 the chroma planes in block-number order (block 4, block 5) */
+	if (tile >= T.y.count) { pl = tile >= T.y.count + T.c.count ? 2 : 1; t = tile - T.y.count - (pl - 1) * T.c.count; }
+	const JmPlaneTiles &P = pl ? T.c : T.y;
+	const int bh = pl ? G.mb_height : 2 * G.mb_height;
+	const int n_full = P.full * P.rows;
+	int bx, by, lx, tw;
+	if (t < n_full) {
+		const int ty = t / P.full, tx = t - ty * P.full;
+		lx = lane & 31; tw = 32;
+		bx = tx * 32 + lx; by = ty * JM_TILE_ROWS + 2 * wave + (lane >> 5);
+	} else if (P.rem16) {
+		lx = lane & 15; tw = P.rem;
+		bx = P.full * 32 + lx; by = (t - n_full) * 16 + 4 * wave + (lane >> 4);
+	} else {
+		lx = lane & 31; tw = P.rem;
+		bx = P.full * 32 + lx; by = (t - n_full) * JM_TILE_ROWS + 2 * wave + (lane >> 5);
+	}
+	const bool ok = lx < tw && by < bh;
 	/* a lane without a block looks at the nearest block that exists (its loads then coalesce with that lane's) */
 	if (lx >= tw) bx -= lx - (tw - 1);
-	if (bx >= bw) bx = bw - 1;
 	if (by >= bh) by = bh - 1;
 	if (pl == 0) {
 		Q.mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
