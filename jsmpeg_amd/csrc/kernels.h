@@ -7,9 +7,11 @@
 #include "mpeg1_dev.h"
 #include "vlc_lut.h"
 
-/* the start-code scan takes the ES in pieces of 256 lanes x 64 bytes, 1 .. 8 pieces per workgroup (chunk) */
+/* the start-code scan takes the ES in pieces of 256 lanes x 64 bytes, 1 .. JM_SCAN_MAX_SUBS pieces per workgroup (chunk) */
 #define JM_SCAN_PIECE_BYTES 16384u
+#ifndef JM_SCAN_MAX_SUBS
 #define JM_SCAN_MAX_SUBS 7u        /* per-chunk counts are kept in 16-bit halves (at most 4096 start codes per piece); 7 pieces = 28 KiB of LDS: five workgroups per CU */
+#endif
 /* the scan's state array for an ES of n bytes: ticket counter + two words per chunk (zeroed by the launch) */
 static inline size_t jm_scan_state_bytes(uint64_t n_bytes) {
 	return sizeof(uint64_t) * (size_t)(2 + 2 * ((n_bytes + JM_SCAN_PIECE_BYTES - 1) / JM_SCAN_PIECE_BYTES + 1));
