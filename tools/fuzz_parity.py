@@ -36,22 +36,27 @@ for c in range(cases):
     for es in streams:
         frames, _, info = cabi.decode_stream(build.LIB_ORACLE, es, keep="planes")
         want_abi.append(frames)       # one entry per decode() == true: a consumed-not-decoded picture (B / D / f_code 0) repeats the one before
-        want.append([f for i, f in enumerate(frames) if i == 0 or not (ov["syntax_quirks"] & 2) or not all(np.array_equal(a, bb) for a, bb in zip(f, frames[i - 1]))])
+        want.append(frames)           # ... and the batch interface is compared picture by picture where IT says "decoded" (a decoded
+                                      # picture may equal the one before too: a P picture without slices shows the picture before last)
     ok = True
     why = []
     with jb.Batch(ov["width"], ov["height"], n_streams, 2 * n_streams * n + 4, sum(len(s) for s in streams) + 4096) as b:
         b.upload(streams)
         got_n = b.decode()
         dev = b.frame_hashes()
-        per = {}
+        per, seen = {}, {}
         for p, inf in enumerate(b.pictures()):
+            k = seen.get(inf.stream, 0)                  # the k-th picture header of its stream = the oracle's k-th decode()
+            seen[inf.stream] = k + 1
             if inf.decoded:
-                per.setdefault(inf.stream, []).append(p)
+                per.setdefault(inf.stream, []).append((p, k))
         for s in range(n_streams):
-            if [int(dev[p]) for p in per.get(s, [])] != [hashing.frame_hash(*f) for f in want[s]]:
+            distinct = sum(1 for i, f in enumerate(want[s]) if i == 0 or not all(np.array_equal(a, bb) for a, bb in zip(f, want[s][i - 1])))
+            if seen.get(s, 0) != len(want[s]) or len(per.get(s, [])) < distinct or \
+               any(int(dev[p]) != hashing.frame_hash(*want[s][k]) for p, k in per.get(s, [])):
                 ok = False; why.append("batch stream %d" % s)
-        p_last = per[0][-1]
-        if not np.array_equal(b.read_rgba(p_last), checkers.oracle_rgba(build.LIB_ORACLE, *want[0][-1], ov["width"], ov["height"])):
+        p_last, k_last = per[0][-1]
+        if not np.array_equal(b.read_rgba(p_last), checkers.oracle_rgba(build.LIB_ORACLE, *want[0][k_last], ov["width"], ov["height"])):
             ok = False; why.append("rgba")
     got, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], keep="planes")
     if len(got) != len(want_abi[0]) or any(not all(np.array_equal(a, bb) for a, bb in zip(x, y)) for x, y in zip(got, want_abi[0])):
@@ -70,18 +75,20 @@ for c in range(cases):
         demuxed, writes = checkers.oracle_ts_demux(build.LIB_ORACLE, ts, 0xE0)
         given = demuxed[:sum(w[2] for w in writes)]
         fr = cabi.decode_stream(build.LIB_ORACLE, given, keep="planes")[0] if len(given) else []
-        want_ts.append([hashing.frame_hash(*f) for i, f in enumerate(fr) if i == 0 or not (ov["syntax_quirks"] & 2) or not all(np.array_equal(a, bb) for a, bb in zip(f, fr[i - 1]))])
+        want_ts.append([hashing.frame_hash(*f) for f in fr])
     with jb.Batch(ov["width"], ov["height"], n_streams, 2 * n_streams * n + 4, sum(len(s) for s in streams) + 4096) as b:
         b.upload_ts(tss)
         b.decode()
         dev_ts = b.frame_hashes()
-        per_ts = {}
+        per_ts, seen_ts = {}, {}
         for p, inf in enumerate(b.pictures()):
+            k = seen_ts.get(inf.stream, 0)
+            seen_ts[inf.stream] = k + 1
             if inf.decoded:
-                per_ts.setdefault(inf.stream, []).append(int(dev_ts[p]))
+                per_ts.setdefault(inf.stream, []).append((int(dev_ts[p]), k))
         for s in range(n_streams):
-            if per_ts.get(s, []) != want_ts[s]:
-                ok = False; why.append("ts path stream %d: %d vs %d pictures" % (s, len(per_ts.get(s, [])), len(want_ts[s])))
+            if seen_ts.get(s, 0) != len(want_ts[s]) or any(h != want_ts[s][k] for h, k in per_ts.get(s, [])):
+                ok = False; why.append("ts path stream %d: %d vs %d pictures" % (s, seen_ts.get(s, 0), len(want_ts[s])))
     if not ok:
         bad += 1
         print("case %d MISMATCH (%s): frames=%d streams=%d params=%r" % (c, "; ".join(why), n, n_streams, ov))
