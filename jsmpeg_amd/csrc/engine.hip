@@ -17,6 +17,7 @@
 #include "index_tables.h"
 #include "jsmpeg_hip.h"
 #include "kernels.h"
+#include "recon_plan.h"
 #include "ts_sync.h"
 
 /* ------------------------------------------------------------------ errors */
@@ -494,16 +495,9 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * Whether a picture has unwritten macroblocks is only known after the parse: the pictures without a forward
 	 * reference are reconstructed right behind it (step 4a: intra pictures hardly ever have such macroblocks), the
 	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs. */
-	std::vector<int32_t> stale(b->n_pics, -1);
-	uint32_t n_roots = 0;
+	std::vector<int32_t> stale;
+	const uint32_t n_roots = jm_plan_stale(b->h_pics.data(), b->n_pics, b->n_streams, stale);
 	{
-		std::vector<int64_t> last1(b->n_streams, -1), last2(b->n_streams, -1);   /* the stream's last two decoded pictures */
-		for (uint32_t p = 0; p < b->n_pics; p++) {
-			const JmPic &pic = b->h_pics[p];
-			if (!pic.decoded) continue;
-			if (pic.fwd < 0) n_roots++;
-			if (pic.stream < b->n_streams) { stale[p] = (int32_t)last2[pic.stream]; last2[pic.stream] = last1[pic.stream]; last1[pic.stream] = p; }
-		}
 		b->h_desc.resize(std::max<size_t>(1, (size_t)b->n_decoded + n_roots));
 		uint32_t k = 0;
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
@@ -557,19 +551,8 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
 	HIP_TRY(hipEventSynchronize(b->ev_cov));
 	{
-		std::vector<int32_t> level(b->n_pics, 0);
-		uint32_t n_levels = b->n_decoded ? 1 : 0;
-		b->n_uncovered = 0;
-		for (uint32_t p = 0; p < b->n_pics; p++) {
-			const JmPic &pic = b->h_pics[p];
-			if (!pic.decoded) continue;
-			const bool uncovered = b->h_covered[p] < (uint32_t)b->g.mb_size;
-			b->n_uncovered += uncovered;
-			int32_t l = pic.fwd >= 0 ? level[pic.fwd] + 1 : 0;          /* fwd, stale < p: their levels are known */
-			if (uncovered && stale[p] >= 0) l = std::max(l, level[stale[p]] + 1);
-			level[p] = l;
-			n_levels = std::max(n_levels, (uint32_t)l + 1);
-		}
+		std::vector<int32_t> level;
+		const uint32_t n_levels = jm_plan_levels(b->h_pics.data(), b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
 		b->n_levels = n_levels;
 		std::vector<uint32_t> off(n_levels + 1, 0);
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;

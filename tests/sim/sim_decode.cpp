@@ -13,6 +13,7 @@
 
 #include "index_tables.h"
 #include "recon_block.h"
+#include "recon_plan.h"
 #include "slice_parse.h"
 
 struct HostSlot {
@@ -253,5 +254,17 @@ uint64_t sim_cost(void) { return g_cost; }
 void sim_kcost(const int *t) { for (int k = 0; k <= JM_ST_KINDS; k++) g_kcost[k] = t[k]; }
 const uint64_t *sim_served(void) { return g_served; }
 void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; g_cost = 0; }
+
+// The engine's reconstruct plan (recon_plan.h) on plain arrays: stale[] and level[] out, returns the number of levels.
+int sim_plan(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded, const int32_t *fwd, const uint32_t *stream,
+             const uint32_t *covered, uint32_t mb_size, int32_t *out_stale, int32_t *out_level, uint32_t *out_uncovered) {
+	std::vector<JmPic> pics(n_pics);
+	for (uint32_t p = 0; p < n_pics; p++) { pics[p] = JmPic(); pics[p].decoded = decoded[p]; pics[p].fwd = fwd[p]; pics[p].stream = stream[p]; }
+	std::vector<int32_t> stale, level;
+	jm_plan_stale(pics.data(), n_pics, n_streams, stale);
+	const uint32_t n = jm_plan_levels(pics.data(), n_pics, stale, covered, mb_size, level, out_uncovered);
+	for (uint32_t p = 0; p < n_pics; p++) { out_stale[p] = stale[p]; out_level[p] = level[p]; }
+	return (int)n;
+}
 
 }  // extern "C"

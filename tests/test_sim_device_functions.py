@@ -46,3 +46,80 @@ def test_device_functions_match_golden(path, sim):
     assert n == fx["n_frames"]
     got = [hashlib.md5(out[i * fb:(i + 1) * fb].tobytes()).hexdigest() for i in range(n)]
     assert got == fx["frame_md5"]
+
+
+def plan_reference(decoded, fwd, stream, covered, mb_size):
+    """the rule in plain Python: a picture after its forward reference and, with unwritten macroblocks, after the decoded
+    picture before last of its stream (what those macroblocks show, mpeg1.c:986-994)"""
+    n = len(decoded)
+    stale, level, last = [-1] * n, [0] * n, {}
+    for p in range(n):
+        if not decoded[p]:
+            continue
+        l1, l2 = last.get(stream[p], (-1, -1))
+        stale[p] = l2
+        last[stream[p]] = (p, l1)
+        lv = level[fwd[p]] + 1 if fwd[p] >= 0 else 0
+        if covered[p] < mb_size and stale[p] >= 0:
+            lv = max(lv, level[stale[p]] + 1)
+        level[p] = lv
+    return stale, level
+
+
+def run_plan(sim, decoded, fwd, stream, covered, mb_size, n_streams):
+    n = len(decoded)
+    arr = lambda v, t: np.asarray(v, dtype=t)
+    d, f, s, c = arr(decoded, np.uint8), arr(fwd, np.int32), arr(stream, np.uint32), arr(covered, np.uint32)
+    st, lv, unc = np.zeros(n, np.int32), np.zeros(n, np.int32), ctypes.c_uint32(0)
+    sim.sim_plan.restype = ctypes.c_int
+    sim.sim_plan.argtypes = [ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 4 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                                                                        ctypes.c_void_p]
+    nl = sim.sim_plan(n, n_streams, d.ctypes.data, f.ctypes.data, s.ctypes.data, c.ctypes.data, mb_size, st.ctypes.data, lv.ctypes.data,
+                      ctypes.byref(unc))
+    return nl, list(st), list(lv), unc.value
+
+
+def test_reconstruct_plan_hand_cases(sim):
+    """I P P | I P P of one stream, 10 macroblocks per picture"""
+    decoded, fwd, stream = [1] * 6, [-1, 0, 1, -1, 3, 4], [0] * 6
+    full = [10] * 6
+    # everything written: plain chains, two levels deep
+    nl, st, lv, unc = run_plan(sim, decoded, fwd, stream, full, 10, 1)
+    assert (nl, lv, unc) == (3, [0, 1, 2, 0, 1, 2], 0) and st == [-1, -1, 0, 1, 2, 3]
+    # the first P of the second GOP leaves a macroblock unwritten: it shows picture 2 (level 2) -> level 3, its P after it
+    cov = list(full); cov[4] = 9
+    nl, st, lv, unc = run_plan(sim, decoded, fwd, stream, cov, 10, 1)
+    assert (nl, lv, unc) == (5, [0, 1, 2, 0, 3, 4], 1)
+    # the I picture of the second GOP does: after picture 1 (level 1) -> level 2, and its chain behind it
+    cov = list(full); cov[3] = 0
+    nl, st, lv, unc = run_plan(sim, decoded, fwd, stream, cov, 10, 1)
+    assert (nl, lv, unc) == (5, [0, 1, 2, 2, 3, 4], 1)
+    # unwritten macroblocks in the first two pictures of a stream show zeros: no dependency
+    cov = list(full); cov[0] = 3; cov[1] = 3
+    nl, st, lv, unc = run_plan(sim, decoded, fwd, stream, cov, 10, 1)
+    assert (nl, lv, unc) == (3, [0, 1, 2, 0, 1, 2], 2)
+    # a picture that is not decoded (B) neither counts nor rotates
+    decoded2, fwd2 = [1, 0, 1, 1], [-1, -1, 0, 2]
+    nl, st, lv, unc = run_plan(sim, decoded2, fwd2, [0] * 4, [10, 0, 10, 9], 10, 1)
+    assert (nl, lv, st, unc) == (3, [0, 0, 1, 2], [-1, -1, -1, 0], 1)
+
+
+def test_reconstruct_plan_random(sim):
+    rng = np.random.default_rng(5)
+    for case in range(200):
+        n_streams = int(rng.integers(1, 5))
+        n = int(rng.integers(1, 120))
+        stream = sorted(int(x) for x in rng.integers(0, n_streams, size=n))          # pictures come stream after stream
+        decoded = [int(rng.random() < 0.85) for _ in range(n)]
+        fwd, last = [], {}
+        for p in range(n):
+            is_p = decoded[p] and stream[p] in last and rng.random() < 0.8
+            fwd.append(last[stream[p]] if is_p else -1)
+            if decoded[p]:
+                last[stream[p]] = p
+        covered = [int(10 if rng.random() < 0.7 else rng.integers(0, 10)) for _ in range(n)]
+        st_ref, lv_ref = plan_reference(decoded, fwd, stream, covered, 10)
+        nl, st, lv, unc = run_plan(sim, decoded, fwd, stream, covered, 10, n_streams)
+        assert st == st_ref and lv == lv_ref
+        assert nl == (max(lv_ref[p] for p in range(n) if decoded[p]) + 1 if any(decoded) else 0)
+        assert unc == sum(1 for p in range(n) if decoded[p] and covered[p] < 10)
