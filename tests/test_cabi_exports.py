@@ -85,3 +85,17 @@ def test_graft_entry_functions_have_no_undefined_names():
                 local |= {n.id for n in ast.walk(node.target) if isinstance(n, ast.Name)}
         used = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
         assert not (used - local - module_names), "%s(): undefined %r" % (fn.name, sorted(used - local - module_names))
+
+
+def test_hot_kernels_keep_their_occupancy():
+    """registers / LDS of the hot kernels as the design counts on them: k_recon five workgroups per
+    CU (96 registers, 25 LDS granules of 1280 bytes), k_parse two workgroups of eight wavefronts per CU (80 KB, four
+    wavefronts per SIMD), k_scan five workgroups per CU; no scratch anywhere (build.check_kernel_resources raises)"""
+    use = build.check_kernel_resources()
+    recon = next(v for n, v in use.items() if "k_recon" in n)
+    parse = next(v for n, v in use.items() if "7k_parse" in n)
+    scan = next(v for n, v in use.items() if "k_scan" in n)
+    assert recon["VGPRs"] <= 96 and recon["LDS Size"] <= 25 * 1280 and recon["Occupancy"] >= 5
+    assert parse["VGPRs"] <= 128 and parse["LDS Size"] <= 81920 and parse["Occupancy"] >= 4
+    assert scan["LDS Size"] <= 23 * 1280 and scan["VGPRs"] <= 96
+    assert all(v.get("ScratchSize", 0) == 0 for v in use.values())
