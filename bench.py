@@ -162,6 +162,16 @@ def main():
     args = ap.parse_args()
     args.h2d = False
 
+    # ---- one process per GPU: this process is one of the ranks (WORLD_SIZE set, or --gpus 1), or only their launcher
+    # (--gpus N > 1 without WORLD_SIZE: the same command line again under torch.distributed.run, N local ranks) ----
+    from jsmpeg_amd import batch as jb, launch
+    visible = int(jb.lib().jsmpeg_hip_device_count())
+    how = launch.plan(args.gpus, os.environ, visible, os.path.abspath(__file__), sys.argv[1:])
+    if how["mode"] == "spawn":
+        log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(how["cmd"])))
+        raise SystemExit(subprocess.call(how["cmd"], env=how["env"]))
+    rank, local_rank, world = how["rank"], how["local_rank"], how["world"]
+
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner, ...) is sent to
     # stderr instead -- file descriptor 1 becomes stderr, the JSON goes to a duplicate of the original stdout
     sys.stdout.flush()
@@ -170,14 +180,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from jsmpeg_amd import batch as jb
     from jsmpeg_amd import build, cabi, hashing, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)

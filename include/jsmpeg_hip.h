@@ -66,7 +66,13 @@ void *mpeg1_decoder_get_y_ptr(mpeg1_decoder_t *self);
 void *mpeg1_decoder_get_cr_ptr(mpeg1_decoder_t *self);
 void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *self);
 /* mpeg1.h:27 -- decode exactly one picture; false = no complete picture
- * start code buffered (mpeg1.c:853-864).  Never reports errors. */
+ * start code buffered (mpeg1.c:853-864).  The reference's signature has no
+ * error channel; a HIP failure (allocation, device lost) is reported as
+ * false + a non-empty jsmpeg_hip_last_error() -- the call clears the message
+ * on entry, so "false and a message" always means THIS call failed; the cursor
+ * is put back onto the picture's start code.  Callers must tell the two apart
+ * (the N-API addon throws, jsmpeg_amd.cabi.Mpeg1Decoder.decode raises): a
+ * failure must never read as "no more pictures". */
 bool mpeg1_decoder_decode(mpeg1_decoder_t *self);
 
 /* Additive: DEVICE pointer to the most recently decoded frame (Y | Cr | Cb

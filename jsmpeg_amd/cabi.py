@@ -51,9 +51,15 @@ class Mpeg1Decoder:
 
     def __init__(self, path, buffer_size=512 * 1024, mode=MODE_EXPAND):
         self.lib = load(path)
+        # the product library has an error channel beside the reference's 15 functions; the checker libraries do not
+        self._last_error = getattr(self.lib, "jsmpeg_hip_last_error", None)
+        if self._last_error is not None:
+            self._last_error.restype = ctypes.c_char_p
+            self._last_error.argtypes = []
         self.h = self.lib.mpeg1_decoder_create(buffer_size, mode)
         if not self.h:
-            raise RuntimeError("mpeg1_decoder_create failed (%s)" % path)
+            why = self._last_error() if self._last_error is not None else b""
+            raise RuntimeError("mpeg1_decoder_create failed (%s)%s" % (path, ": " + why.decode("utf-8", "replace") if why else ""))
 
     def close(self):
         if self.h:
@@ -74,7 +80,14 @@ class Mpeg1Decoder:
         self.lib.mpeg1_decoder_did_write(self.h, n)
 
     def decode(self):
-        return bool(self.lib.mpeg1_decoder_decode(self.h))
+        """One picture.  False = no complete picture buffered.  On the product library a device failure comes back as
+        false + a message in jsmpeg_hip_last_error() (include/jsmpeg_hip.h): raised here, never read as end of data."""
+        got = bool(self.lib.mpeg1_decoder_decode(self.h))
+        if not got and self._last_error is not None:
+            msg = self._last_error()
+            if msg:
+                raise RuntimeError("mpeg1_decoder_decode failed: " + msg.decode("utf-8", "replace"))
+        return got
 
     @property
     def index(self):

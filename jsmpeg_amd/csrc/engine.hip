@@ -300,7 +300,9 @@ static int upload_ts_impl(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8
 	const uint64_t *wb = write_bytes;
 	for (uint32_t i = 0; i < n_streams; i++) {
 		const uint32_t nw = n_writes ? n_writes[i] : 0;
-		const uint64_t pk = jm_ts_sync_runs(ts[i], ts_bytes[i], nw ? wb : nullptr, nw, runs[i], nullptr);
+		/* with a write table, zero writes deliver nothing (bytes beyond the writes are never written); without one the
+		 * whole buffer is one write */
+		const uint64_t pk = n_writes && nw == 0 ? 0 : jm_ts_sync_runs(ts[i], ts_bytes[i], nw ? wb : nullptr, nw, runs[i], nullptr);
 		if (n_writes) wb += nw;
 		begin[i] = off; len[i] = pk * 188;
 		off += (len[i] + 16 + 15) & ~15ull;
@@ -1082,9 +1084,9 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 
 /* mpeg1.c:853-864 + decode_picture's control flow, mpeg1.c:947-995 */
 extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
+	g_err[0] = 0;               /* first: "false + a message" is this call's failure, never one an earlier call left behind */
 	if (!d || !d->has_sequence_header) return false;
-	g_err[0] = 0;
-	if (hipSetDevice(d->device) != hipSuccess) return false;
+	if (hipSetDevice(d->device) != hipSuccess) { fail("hipSetDevice(%d) failed", d->device); return false; }
 	size_t k = first_code_from(d, (d->index + 7) >> 3);
 	while (k < d->codes.size() && d->codes[k].code != JM_CODE_PICTURE) k++;
 	if (k == d->codes.size()) { d->index = d->length << 3; return false; }

@@ -10,8 +10,13 @@
 /* the start-code scan takes the ES in pieces of 256 lanes x 64 bytes, 1 .. JM_SCAN_MAX_SUBS pieces per workgroup (chunk) */
 #define JM_SCAN_PIECE_BYTES 16384u
 #ifndef JM_SCAN_MAX_SUBS
-#define JM_SCAN_MAX_SUBS 7u        /* per-chunk counts are kept in 16-bit halves (at most 4096 start codes per piece); 7 pieces = 28 KiB of LDS: five workgroups per CU */
+#define JM_SCAN_MAX_SUBS 7u        /* 7 pieces = 28 KiB of LDS: five workgroups per CU */
 #endif
+/* per-chunk counts are kept in 16-bit halves.  The scan tests every byte position, so "00 00 01" repeated gives a start
+ * code every 3 bytes -- ceil(16384 / 3) = 5462 per piece, all of them picture codes when the fourth byte is 00 -- and a
+ * chunk of 12 or more pieces would carry into the neighbouring half; the match table is 4 KiB of LDS per piece */
+static_assert(JM_SCAN_MAX_SUBS >= 1 && JM_SCAN_MAX_SUBS * 5462u < 65536u, "k_scan: a chunk's start-code count must fit 16 bits");
+static_assert(JM_SCAN_MAX_SUBS * 4u * 256u * 4u <= 60u * 1024u, "k_scan: the match table must fit the LDS of one workgroup");
 /* the scan's state array for an ES of n bytes: ticket counter + two words per chunk (zeroed by the launch) */
 static inline size_t jm_scan_state_bytes(uint64_t n_bytes) {
 	return sizeof(uint64_t) * (size_t)(2 + 2 * ((n_bytes + JM_SCAN_PIECE_BYTES - 1) / JM_SCAN_PIECE_BYTES + 1));

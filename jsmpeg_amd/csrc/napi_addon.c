@@ -99,9 +99,14 @@ static mpeg1_decoder_t *handle_arg(napi_env env, napi_value v) {
 	return w ? w->d : NULL;
 }
 static void wrap_finalize(napi_env env, void *data, void *hint) {
-	(void)env; (void)hint;
+	(void)hint;
 	dec_wrap_t *w = (dec_wrap_t *)data;
-	if (w->d) mpeg1_decoder_destroy(w->d);   /* a handle dropped without destroy() */
+	/* a handle dropped without destroy().  Views that look at the decoder's pinned planes may outlive the handle (the
+	 * renderer keeps them), and a finalizer may not detach ArrayBuffers: the decoder then keeps its memory (a leak
+	 * bounded by one decoder, chosen over views into freed memory); destroy() is the way to give it back. */
+	const int views_alive = w->views && !w->copied;
+	if (w->views) napi_delete_reference(env, w->views);
+	if (w->d && !views_alive) mpeg1_decoder_destroy(w->d);
 	free(w);
 }
 /* forget the cached views; detach their buffers when they look at decoder memory */
@@ -563,9 +568,11 @@ static mp2_decoder_t *mp2_handle_arg(napi_env env, napi_value v) {
 	return w ? w->d : NULL;
 }
 static void mp2_wrap_finalize(napi_env env, void *data, void *hint) {
-	(void)env; (void)hint;
+	(void)hint;
 	mp2_wrap_t *w = (mp2_wrap_t *)data;
-	if (w->d) mp2_decoder_destroy(w->d);
+	const int views_alive = w->views && !w->copied;      /* same rule as wrap_finalize */
+	if (w->views) napi_delete_reference(env, w->views);
+	if (w->d && !views_alive) mp2_decoder_destroy(w->d);
 	free(w);
 }
 static void mp2_wrap_drop_views(napi_env env, mp2_wrap_t *w) {
