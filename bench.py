@@ -129,6 +129,16 @@ def cpu_baseline(sample_streams, width, height):
                 r = json.loads(out)
                 res["value"] = round(r["fps"], 2)
                 res["wasm_note"] = "reference wasm build (jsmpeg.min.js) under Node %s, 1 core, median of 3" % r.get("node", "?")
+                # (ii) of SURVEY.md 8d: the reference's pure-JS decoder (src/mpeg1.js:44-64), from the shipped bundle
+                js_host, js_bundle = os.path.join(ROOT, "oracle", "js_baseline.js"), build.JS_REF
+                if os.path.exists(js_bundle) and os.path.exists(js_host):
+                    try:
+                        rj = json.loads(subprocess.check_output(["node", js_host, js_bundle] + paths, timeout=900))
+                        res["js_fps"] = round(rj["fps"], 2)
+                        res["js_note"] = ("reference JSMpeg.Decoder.MPEG1Video (src/mpeg1.js, from jsmpeg.min.js) under Node %s, "
+                                          "1 core, median of 3" % rj.get("node", "?"))
+                    except Exception as e:
+                        res["js_error"] = repr(e)[:200]
                 nproc = os.cpu_count() or 1
                 par = nproc              # all cores = what nproc says on this box
                 t0 = time.perf_counter()
@@ -351,21 +361,47 @@ def main():
                 phase[k] += t[k]
             levels = b.counters()["levels"]
 
+    # ---- what the parity gate certifies (it hashes the frame pool once, after the last timed step): the whole pool is
+    # overwritten with a pattern between the warm-up and the timed region (untimed), so every plane the gate sees was
+    # written INSIDE the timed region; and every SCRUB_EVERY-th picture's frame is overwritten again right before the
+    # LAST timed step (inside the timed region: a fill of 1/16 of the pool, its time reported), so a last step that
+    # wrote nothing cannot hash green from an earlier step's planes ----
+    SCRUB_EVERY = 16
+
+    class _DevMem:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+    frame_stride = int(b.frame_stride)
+    pool_pictures = n_pictures
+    pool = torch.as_tensor(_DevMem(b.frame_pool_ptr, pool_pictures * frame_stride), device=dev).view(pool_pictures, frame_stride)
+    scrub = {"ms": None, "frames": 0}
+
     def timed_run(steps, warmup):
         for i in range(warmup):
             step(False, i + 1 < warmup)      # nothing is prefetched across the warm-up / timed boundary
+        torch.cuda.synchronize()
+        pool.fill_(0xA5)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
+            if i + 1 == steps:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                pool[(steps % SCRUB_EVERY)::SCRUB_EVERY].fill_(0x5A)
+                e1.record(stream)
+                scrub["events"] = (e0, e1)
+                scrub["frames"] = len(range(steps % SCRUB_EVERY, pool_pictures, SCRUB_EVERY))
             step(True, i + 1 < steps)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        scrub["ms"] = scrub["events"][0].elapsed_time(scrub["events"][1])
         if multi:
             tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -373,6 +409,8 @@ def main():
         return dt
 
     elapsed = timed_run(args.steps, args.warmup)
+    gate_scrub = dict(scrub)
+    gate_scrub.pop("events", None)
     uncovered = b.counters()["uncovered_pictures"]
 
     # ---- parity gate against the oracle (checker only) ----
@@ -571,6 +609,10 @@ def main():
         "mpixel_per_s": round(fps * width * height / 1e6, 1),
         "parity_checked": ("every unit of every stream of every rank against the oracle fed the same unit (%d streams x %d pictures per rank)"
                            if multi else "every stream of every rank (%d x %d pictures per rank), device hash == oracle") % (len(check), frames),
+        "parity_gate": {"pool_overwritten_before_timed_region": True, "frames_overwritten_before_last_timed_step": gate_scrub["frames"],
+                        "of_frames": n_pictures, "fill_ms_inside_timed_region": round(gate_scrub["ms"], 3),
+                        "note": "the gate hashes the pool once, after the last timed step: every plane it sees was written inside the "
+                                "timed region, and every %dth picture's frame by the last step itself" % SCRUB_EVERY},
         "roofline": roofline,
     }
     if value_incl_h2d:

@@ -20,6 +20,7 @@ LIB_ORACLE = os.path.join(ORACLE, "libmpeg1_oracle.so")
 REF_DIR = os.path.join(ORACLE, "_ref")
 LIB_REF = os.path.join(REF_DIR, "libjsmpeg_ref.so")
 WASM_REF = os.path.join(REF_DIR, "jsmpeg_ref.wasm")
+JS_REF = os.path.join(REF_DIR, "jsmpeg_ref.min.js")
 
 
 def _newer(target, sources):

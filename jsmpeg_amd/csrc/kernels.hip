@@ -574,7 +574,13 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
+#ifdef JM_EXP_NO_RECORD   /* timing experiment (wrong output): a made-up record instead of the load the block's other loads hang on */
+	{ const uint32_t h = (uint32_t)Q.mbaddr * 2654435761u;
+	  Q.rw.x = (uint32_t)Q.mbaddr * 12u; Q.rw.y = ((h >> 8) & 0x1fu) | (((h >> 16) & 0x1fu) << 16); Q.rw.z = 0x00020200u | (h & 3u);
+	  Q.rw.w = 0x0002u | ((8u | ((h >> 24) & 7u ? JM_MB_PRED : JM_MB_INTRA)) << 16) | ((uint32_t)b.epoch << 24); }
+#else
 	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>((JM_GLOBAL const JmMbRec *)D.mb + Q.mbaddr);
+#endif
 	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
 	uint4 tq = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];

@@ -333,14 +333,21 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	 * rows stay in flight across the set-up barrier and are only awaited where they are used
 	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
+#ifdef JM_EXP_NO_TOKEN_LOAD   /* timing experiment (wrong output): tokens made up from the record */
+		B.tw[0] = 0x04010001u + (B.tkw & 0xfu); B.tw[1] = 0x0c021003u; B.tw[2] = 0x14051404u; B.tw[3] = 0x1c071806u;
+#else
 		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? B.tkw : 0u));
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
+#endif
 	}
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
 	B.m = B.oh = B.ov = 0;
 	if (PRED) {
 		int mh = B.pred ? rec_mvh : 0, mv = B.pred ? rec_mvv : 0;
+#ifdef JM_EXP_ZERO_MV   /* timing experiment (wrong output): perfectly coalesced prediction reads */
+		mh = mv = 0;
+#endif
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
 		const int H = mh >> 1, V = mv >> 1;
 		B.oh = (uint32_t)(mh & 1); B.ov = (uint32_t)(mv & 1);
@@ -359,8 +366,12 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
+#ifdef JM_EXP_NO_PRED_LOAD   /* timing experiment (wrong output): no prediction reads at all */
+			B.R[3 * r] = woff + r; B.R[3 * r + 1] = wstride; B.R[3 * r + 2] = (uint32_t)last;
+#else
 			JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
+#endif
 		}
 	}
 
@@ -576,6 +587,9 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 
 /* coalesced row stores: 8 bytes per lane per row */
 JM_HD void jm_recon_store(const JmReconCtx &c, const JmBlk &B, const JmPix &X) {
+#ifdef JM_EXP_NO_STORE   /* timing experiment (wrong output): the pixels are computed, (almost) never stored */
+	if (X.p[0] != 0x12345678u || X.p[15] != 0x9abcdef1u) return;
+#endif
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(c.dst + (B.out + (uint32_t)(r * B.stride)));

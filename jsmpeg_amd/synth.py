@@ -82,13 +82,51 @@ def generate_es(width, height, n_frames, gop=12, seed=BASE_SEED, ac_max=4, qscal
     return buf[:n].copy(), offs
 
 
-def generate_config(name, n_frames=None, stream=0, **overrides):
+def stuff_zero_bytes(es, pic_offsets, before_pictures=0, before_slices=0):
+    """zero_byte stuffing in front of start codes (valid MPEG-1: next_start_code() skips any number of zero bytes; what
+    a CBR encoder pads pictures with): `before_pictures` zero bytes in front of every picture start code but the
+    stream's first, `before_slices` in front of every slice start code but a picture's first.  The counts cycle 1..n
+    from code to code, so a stream holds every amount up to n.  Returns (es, pic_offsets) with the offsets moved so
+    that a picture's range still begins with its start code (the stuffing belongs to the range before it)."""
+    es = np.ascontiguousarray(es, dtype=np.uint8)
+    z = (es[:-3] == 0) & (es[1:-2] == 0) & (es[2:-1] == 1)
+    pos = np.flatnonzero(z)
+    code = es[pos + 3]
+    ins = np.zeros(len(pos), dtype=np.int64)
+    k_pic = k_sl = 0
+    seen_picture = False
+    prev_code = -1
+    for i, (p, c) in enumerate(zip(pos, code)):
+        if c == 0x00:
+            if seen_picture and before_pictures:
+                ins[i] = 1 + k_pic % before_pictures
+                k_pic += 1
+            seen_picture = True
+        elif 0x01 <= c <= 0xAF and before_slices and 0x01 <= prev_code <= 0xAF:
+            ins[i] = 1 + k_sl % before_slices
+            k_sl += 1
+        prev_code = int(c)
+    out = np.zeros(len(es) + int(ins.sum()), dtype=np.uint8)
+    shift = np.zeros(len(es) + 1, dtype=np.int64)
+    np.add.at(shift, pos, ins)
+    shift = np.cumsum(shift)
+    out[np.arange(len(es)) + shift[:len(es)]] = es
+    offs = np.asarray(pic_offsets, dtype=np.int64)
+    new_offs = offs + shift[np.minimum(offs, len(es))]
+    return out, new_offs.astype(np.uint32)
+
+
+def generate_config(name, n_frames=None, stream=0, stuff_pictures=0, stuff_slices=0, **overrides):
     c = dict(CONFIGS[name])
     cfg = c.pop("cfg")
     frames = c.pop("frames")
     c.update(overrides)
     seed = (BASE_SEED + cfg + 7919 * stream) & 0xFFFFFFFF
-    return generate_es(n_frames=n_frames or frames, seed=seed, **c)
+    out = generate_es(n_frames=n_frames or frames, seed=seed, **c)
+    if stuff_pictures or stuff_slices:
+        es, offs = stuff_zero_bytes(out[0], out[1], stuff_pictures, stuff_slices)
+        out = (es, offs) + tuple(out[2:])
+    return out
 
 
 def mux_ts(es, pic_offsets, fps=30.0):

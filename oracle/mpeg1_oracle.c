@@ -109,11 +109,28 @@ static uint32_t peek_bits(const mpeg1_decoder_t *d, int n) {
 }
 static uint32_t read_bits(mpeg1_decoder_t *d, int n) { uint32_t v = peek_bits(d, n); d->index += (unsigned)n; return v; }
 
-/* readHuffman: mpeg1.js:66-72 / mpeg1.c:1742-1748, table-driven here */
+/* readHuffman: mpeg1.js:66-72 / mpeg1.c:1742-1748, table-driven here.
+ * A bit string that is no code: the reference walks its tree one bit at a time, `state = T[state + bit]`, and a
+ * missing branch is -1 -- the loop ends on `state >= 0` and the function returns T[state + 2] = T[1], which is 6 in
+ * every one of its tables (they all begin 1*3, 2*3, 0).  So an invalid string consumes its bits up to and including
+ * the first one no code continues with, and yields 6 -- in JS, wasm and C alike.  Valid MPEG-1 runs into this: with
+ * zero_byte stuffing between a picture's last slice and the next start code decode_slice keeps calling
+ * decode_macroblock (mpeg1.c:1018-1020), each call reads eight zero bits as an "increment of 6", finds it illegal at
+ * the end of the picture (mpeg1.c:1053-1057) and returns -- a byte per call until the start code is aligned. */
 static int32_t read_vlc(mpeg1_decoder_t *d, const vlc_t *t) {
 	uint32_t idx = peek_bits(d, t->maxlen);
 	int len = t->len[idx];
-	if (len == 0) { d->index += (unsigned)t->maxlen; return 0; }  /* invalid code: outside the contract */
+	if (len == 0) {
+		/* shortest prefix of the next bits that no code begins with */
+		for (int n = 1; n <= t->maxlen; n++) {
+			const uint32_t lo = (idx >> (t->maxlen - n)) << (t->maxlen - n), hi = lo + (1u << (t->maxlen - n));
+			int any = 0;
+			for (uint32_t k = lo; k < hi && !any; k++) any = t->len[k] != 0;
+			if (!any) { d->index += (unsigned)n; return 6; }
+		}
+		d->index += (unsigned)t->maxlen;
+		return 6;
+	}
 	d->index += (unsigned)len;
 	return t->val[idx];
 }

@@ -71,6 +71,42 @@ CASES = {
 }
 
 
+# Valid syntax the generator never writes, added as byte stuffing on top of a generated stream (synth.stuff_zero_bytes):
+# zero_byte stuffing in front of start codes.  A case is tried like every other; when the four runs agree it becomes a
+# fixture (frames_*.json), when they do not the DISAGREEMENT is the record (excluded_*.json: which runs differ, on
+# which pictures) -- the evidence behind "outside the contract" in DESIGN.md section 2.
+PROBES = {
+    # what a CBR encoder pads a picture with: 1..3 zero bytes between the last slice and the next picture start code
+    "picture_end_stuffing_352x288": ("cfg1_720p", 14, dict(width=352, height=288, stuff_pictures=3)),
+    # the same in front of slice start codes (next_start_code() inside a picture)
+    "slice_stuffing_352x288": ("cfg1_720p", 14, dict(width=352, height=288, stuff_slices=3)),
+}
+CASES.update(PROBES)
+
+
+def disagreement_record(name, cfg, n, ov, es, runs, why):
+    """excluded_<name>.json: the four runs' hash lists compared picture by picture."""
+    keys = sorted(runs)
+    longest = max(len(v) for v in runs.values())
+    rows = []
+    for i in range(longest):
+        hs = {k: (runs[k][i] if i < len(runs[k]) else None) for k in keys}
+        if len(set(hs.values())) > 1:
+            groups = {}
+            for k, h in hs.items():
+                groups.setdefault(h, []).append(k)
+            rows.append({"picture": i, "groups": sorted(groups.values())})
+    rec = dict(case=name, config=cfg, n_frames=n, overrides=ov, es_bytes=int(len(es)),
+               es_md5=hashlib.md5(es.tobytes()).hexdigest(), verdict=why,
+               decoded_frames={k: len(v) for k, v in runs.items()},
+               pairs_equal={"%s==%s" % (a, b): runs[a] == runs[b] for i, a in enumerate(keys) for b in keys[i + 1:]},
+               differing_pictures=len(rows), first_differences=rows[:16],
+               frame_md5_by_run={k: v for k, v in runs.items()})
+    with open(os.path.join(HERE, "excluded_%s.json" % name), "w") as fo:
+        json.dump(rec, fo, indent=1)
+    print("%-22s EXCLUDED: %s (%d pictures differ between runs)" % (name, why, len(rows)))
+
+
 def node_hashes(ts_path, impl):
     out = subprocess.check_output(["node", os.path.join(ROOT, "oracle", "ref_node_decode.js"), ts_path, impl])
     return json.loads(out)["hashes"]
@@ -96,8 +132,18 @@ def main():
         finally:
             os.unlink(f.name)
         abi_list = runs["ref_native"]
-        if runs["oracle"] != abi_list:
+        if runs["oracle"] != abi_list and name not in PROBES:
             raise SystemExit("%s: the restatement disagrees with the reference's C on the full decode() sequence" % name)
+        if name in PROBES:
+            wr = {k: [h for i, h in enumerate(v) if i == 0 or h != v[i - 1]] for k, v in runs.items()}
+            if any(v != wr["ref_js"] for v in wr.values()) or len(wr["ref_js"]) != n:
+                why = ("the reference's own JS and wasm / C decoders disagree" if wr["ref_js"] != wr["ref_wasm"] or wr["ref_js"] != wr["ref_native"]
+                       else "the reference decodes %d of %d pictures" % (len(wr["ref_js"]), n))
+                disagreement_record(name, cfg, n, ov, es, runs, why)
+                continue
+            stale = os.path.join(HERE, "excluded_%s.json" % name)
+            if os.path.exists(stale):
+                os.unlink(stale)
 
         def without_repeats(v):
             return [h for i, h in enumerate(v) if i == 0 or h != v[i - 1]]
