@@ -457,7 +457,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		JM_STAT(st_slow += __popcll(__ballot(ready && L.state == JM_ST_SLOW));)
 		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
 #pragma unroll
-		for (int k = 1; k < JM_COEF_REPEAT; k++) { JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c); }
+		for (int k = 1; k < JM_COEF_REPEAT; k++) {
+#ifdef JM_TURN_DC2   /* experiment: an intra block per COEF step of the turn, not one per turn */
+			if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
+#endif
+			JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+		}
 	}
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {

@@ -62,7 +62,17 @@
 #ifndef JM_COEF_REPEAT
 #define JM_COEF_REPEAT 2   /* COEF steps per turn                                                         */
 #endif
-#define JM_STEP_BITS (116 + 9 * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 9 each */
+#ifdef JM_TURN_DC2
+#define JM_STEP_BITS (116 + (JM_PAIR_BITS + 16) * JM_COEF_REPEAT)
+#else
+#define JM_STEP_BITS (116 + JM_PAIR_BITS * JM_COEF_REPEAT)
+#endif
+#define JM_STEP_BITS_NOTE /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
+#ifdef JM_TURN_DC2
+#define JM_COEF_SLOTS 4    /* ... + the DC token of the experiment's second DC step */
+#else
+#define JM_COEF_SLOTS 3    /* token slots a COEF step may use: two tokens and the alignment slot of an odd run */
+#endif
 #define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
 
 enum { JM_ST_COLD = 0, JM_ST_DC = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
@@ -108,7 +118,7 @@ struct JmLane {
 	uint64_t cnts;
 	/* current block */
 	int n, cnt;
-	uint32_t tsel;          /* 512 while the next coefficient is the first of its block, else 0 (coeff9 variant) */
+	uint32_t tsel;          /* 512 while the next coefficient is the first of a non-intra block, else 0 (the pair table's context) */
 };
 
 /* ---- bits: MSB-first like bit_buffer_peek/read (buffer.c:113-135) ---- */
@@ -179,13 +189,16 @@ JM_HD void jm_lane_service(JmLane &L) {
 	jm_lane_refill(L);
 	jm_lane_drain(L);
 }
-/* a turn needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for its tokens (DC; per COEF step a coefficient, or the alignment slot) */
+/* a turn needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for its tokens (DC 1, SLOW 1, per COEF step JM_COEF_SLOTS) */
 JM_HD bool jm_lane_blocked(const JmLane &L) {
-	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 2 - 2 * JM_COEF_REPEAT;
+	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 2 - JM_COEF_SLOTS * JM_COEF_REPEAT;
+}
+JM_HD void jm_emit_at(JmLane &L, uint32_t tw, uint16_t t) {
+	const uint32_t slot = tw & (JM_TK_RING - 1);
+	reinterpret_cast<uint16_t *>(L.tk_ring + (slot >> 1) * JM_RING_STRIDE)[slot & 1] = t;
 }
 JM_HD void jm_emit(JmLane &L, uint16_t t) {
-	const uint32_t slot = L.tw & (JM_TK_RING - 1);
-	reinterpret_cast<uint16_t *>(L.tk_ring + (slot >> 1) * JM_RING_STRIDE)[slot & 1] = t;
+	jm_emit_at(L, L.tw, t);
 	L.tw++;
 }
 /* end of the slice: the tokens still in the ring, dword by dword (never past the last token's dword) */
@@ -246,7 +259,7 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
  * (a reference into the lane state would make the state addressable: scratch memory) */
 JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &bad) {
 	const uint32_t w = jm_bits32(L, L.bp);
-	const uint32_t e = c.lut->motion[w >> 21];
+	const uint32_t e = jm_lut2(c.lut->mot1, c.lut->mot2, w);
 	const int len = (int)(e >> 8);
 	if (!len) bad = true;
 	const int code = (int)(e & 0xff) - 16, r_size = c.f_code - 1, f = 1 << r_size;
@@ -295,36 +308,44 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
 	L.state = len ? JM_ST_COEF : JM_ST_DONE;
 }
 
-/* COEF step: one run/level symbol of at most 8 bits + sign (mpeg1.c:1491-1552; a token instead of
- * block_data), or end_of_block -- which closes the block and opens the next coded one of the
- * macroblock, or leaves the macroblock to the COLD step (that stores its record).  Anything else
- * hands the lane to the SLOW step without consuming a bit. */
+/* COEF step: UP TO TWO DCT symbols from one look at the next 10 bits (vlc_lut.h, pair tables; mpeg1.c:1491-1552
+ * symbol by symbol; tokens instead of block_data): run/level codes of at most 8 bits + sign and end_of_block -- which
+ * closes the block and opens the next coded one of the macroblock, or leaves the macroblock to the COLD step (that
+ * stores its record).  In cfg2 a coded block is 2.7 symbols, 1.5 looks.  Anything else at the head (escape, a code
+ * of 10+ bits) hands the lane to the SLOW step without consuming a bit. */
 JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 	const uint32_t w = jm_bits32(L, L.bp);
-	const uint32_t e = (&c.lut->coeff9[0][0])[L.tsel + (w >> 23)];
-	const int len = (int)(e >> 12);
-	const int level = (int)((int32_t)(e << 25) >> 25);
-	const int n = L.n + (int)((e >> 7) & 31);
+	/* the first coefficient of a non-intra block reads "1s" as (0, +-1): its own entries, 512 further on */
+	const uint32_t idx = (w >> (32 - JM_PAIR_BITS)) + (L.tsel & (uint32_t)((int32_t)w >> 31));
+	const uint32_t s = c.lut->pair_s[idx], d = c.lut->pair_d[idx];
+	const int len = (int)(s & 15u);
 	if (len == 0) { L.state = JM_ST_SLOW; return; }
-	if (level == 0) {
+	const int n_new = L.n + (int)(s >> 8);
+	/* a position past 63: the reference indexes ZIG_ZAG out of range there.  The lane stops; the macroblock is never
+	 * recorded, so it does not matter that a first symbol that still fitted is not emitted */
+	if (n_new > 64 || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
+	const uint32_t nc = (s >> 4) & 3u;
+	const uint32_t base = (uint32_t)L.n << 10;
+	/* both slots are written whatever nc says: a slot at or past tw is not part of the stream until tw passes it
+	 * (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free) */
+	jm_emit_at(L, L.tw, (uint16_t)(base + (d & 0xffffu)));
+	jm_emit_at(L, L.tw + 1, (uint16_t)(base + (d >> 16)));
+	L.tw += nc;
+	L.cnt += (int)nc;
+	L.n = n_new;
+	L.tsel = 0;
+	L.bp += (uint32_t)len;
+	if (s & 64u) {
 		/* end_of_block.  Runs are dword aligned for the reconstruct loads: an odd run leaves one slot
 		 * unused (never read: the record carries the count). */
-		L.bp += (uint32_t)len;
 		L.tw += (uint32_t)(L.cnt & 1);
 		L.cnts |= (uint64_t)(uint32_t)L.cnt << (8 * L.cur);
 		const int rem = L.cbp & (0x1f >> L.cur);         /* pattern bits of the blocks after this one */
 		L.state = rem ? jm_open_block(L, rem) : JM_ST_COLD;
-		return;
 	}
-	if (n > 63 || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }   /* reference indexes ZIG_ZAG out of range here */
-	jm_emit(L, jm_token(n, level));
-	L.n = n + 1;
-	L.cnt++;
-	L.tsel = 0;
-	L.bp += (uint32_t)len;
 }
 
-/* SLOW step: one symbol the 9-bit table does not resolve -- the escape
+/* SLOW step: one symbol the pair table does not resolve -- the escape
  * (mpeg1.js:767-780) and the codes of 10 to 16 bits. */
 JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	/* both forms are worked out for every lane and selected at the end: the lanes of a wave that are here hold a mix of
@@ -382,7 +403,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	}
 	/* ---- macroblock_address_increment (mpeg1.c:1028-1043) ---- */
 	if (go) {
-		const uint32_t e = T->mba[jm_bits32(L, L.bp) >> 21];
+		const uint32_t e = jm_lut2(T->mba1, T->mba2, jm_bits32(L, L.bp));
 		if (!(e >> 8) || L.bp >= L.bp_end) { st = JM_ST_DONE; go = false; }
 		else {
 			L.bp += e >> 8;

@@ -245,6 +245,27 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 	return out;
 }
 
+// Table probes (tests/test_vlc_tables.py): what the parse kernel's LUTs say for the next 32 bits `w`.
+static const JmVlcLuts &sim_luts() { static JmVlcLuts L; static bool ready = false; if (!ready) { jm_build_luts(&L); ready = true; } return L; }
+void sim_lut_pair(uint32_t w, int first, uint32_t *s, uint32_t *d) {
+	const JmVlcLuts &L = sim_luts();
+	const uint32_t idx = (w >> (32 - JM_PAIR_BITS)) + ((first ? 512u : 0u) & (uint32_t)((int32_t)w >> 31));
+	*s = L.pair_s[idx]; *d = L.pair_d[idx];
+}
+uint32_t sim_lut_mba(uint32_t w) { const JmVlcLuts &L = sim_luts(); return jm_lut2(L.mba1, L.mba2, w); }
+uint32_t sim_lut_motion(uint32_t w) { const JmVlcLuts &L = sim_luts(); return jm_lut2(L.mot1, L.mot2, w); }
+uint32_t sim_lut_far(uint32_t i) { const JmVlcLuts &L = sim_luts(); return i < 96 ? L.far_[i] : 0; }
+uint32_t sim_lut_small(int which, uint32_t w) {
+	const JmVlcLuts &L = sim_luts();
+	switch (which) {
+	case 0: return L.cbp[w >> 23];
+	case 1: return L.dcl[w >> 25];
+	case 2: return L.dcc[w >> 24];
+	case 3: return L.type_p[w >> 26];
+	default: return L.type_i[w >> 30];
+	}
+}
+
 const uint64_t *sim_turns(void) { return g_turns; }
 const uint64_t *sim_states(void) { return g_states; }
 void sim_thresholds(const int *t) { for (int k = 0; k < JM_ST_DONE; k++) g_thr[k] = t[k]; }

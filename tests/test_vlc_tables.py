@@ -57,6 +57,154 @@ def test_premultiplier_formula():
     assert spec_tables.load()["PREMULTIPLIER"] == want
 
 
+# ---- the parse kernel's lookup tables (jsmpeg_amd/csrc/vlc_lut.h), entry by entry, against a bit-by-bit walk of the
+# golden code lists: what the device reads from LDS is what readHuffman would have walked to ----
+
+@pytest.fixture(scope="module")
+def lut():
+    import ctypes
+    import glob
+    so = os.path.join(ROOT, "tests", "sim", "libjsmpeg_sim.so")
+    src = os.path.join(ROOT, "tests", "sim", "sim_decode.cpp")
+    csrc = os.path.join(ROOT, "jsmpeg_amd", "csrc")
+    deps = [src] + glob.glob(os.path.join(csrc, "*.h"))
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", csrc, "-o", so, src])
+    lib = ctypes.CDLL(so)
+    for name in ("sim_lut_mba", "sim_lut_motion", "sim_lut_far", "sim_lut_small"):
+        getattr(lib, name).restype = ctypes.c_uint32
+    lib.sim_lut_mba.argtypes = lib.sim_lut_motion.argtypes = lib.sim_lut_far.argtypes = [ctypes.c_uint32]
+    lib.sim_lut_small.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    lib.sim_lut_pair.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    lib.sim_lut_pair.restype = None
+    return lib
+
+
+def _walk(codes, bits):
+    """the code that `bits` (a '0'/'1' string) begins with, like readHuffman one bit at a time; None if none does"""
+    for n in range(1, len(bits) + 1):
+        if bits[:n] in codes:
+            return bits[:n]
+    return None
+
+
+def _w(bits):
+    return int((bits + "0" * 32)[:32], 2)
+
+
+def test_two_level_tables_decode_every_code_with_every_suffix(lut):
+    """mba / motion: 5 bits, then the 7 bits after four zeros; every code followed by every possible tail of the 11-bit window"""
+    for key, fn, bias in (("MBA", lut.sim_lut_mba, 0), ("MOTION", lut.sim_lut_motion, 16)):
+        codes = GOLDEN[key]
+        seen = 0
+        for p in range(1 << 11):
+            bits = format(p, "011b")
+            hit = _walk(codes, bits)
+            e = fn(_w(bits))
+            if hit is None:
+                assert e >> 8 == 0, (key, bits)
+            else:
+                assert (e >> 8, (e & 0xff) - bias) == (len(hit), codes[hit]), (key, bits)
+                seen += 1
+        assert seen > 0
+    for which, key, width in ((0, "CBP", 9), (1, "DCSIZE_LUMA", 7), (2, "DCSIZE_CHROMA", 8), (3, "MBTYPE_P", 6), (4, "MBTYPE_I", 2)):
+        codes = GOLDEN[key]
+        for p in range(1 << width):
+            bits = format(p, "0%db" % width)
+            hit = _walk(codes, bits)
+            e = lut.sim_lut_small(which, _w(bits))
+            assert (e >> 8, e & 0xff) == ((len(hit), codes[hit]) if hit else (0, e & 0xff)), (key, bits)
+
+
+def _dct_symbol(bits, first):
+    """one DCT symbol at the head of `bits` the way decode_block reads it (mpeg1.js:757-790): ('eob', n) / ('coef', n, run, level)
+    with n = bits used including the sign; None if the bits end first or the escape / no code starts here"""
+    coeff = {b: v for b, v in GOLDEN["DCT_COEFF"].items() if v not in (0x0001, 0xFFFF)}
+    if bits[:1] == "1":
+        if first:
+            return ("coef", 2, 0, -1 if bits[1:2] == "1" else 1) if len(bits) >= 2 else None
+        if len(bits) < 2:
+            return None
+        if bits[1] == "0":
+            return ("eob", 2)
+        return ("coef", 3, 0, -1 if bits[2] == "1" else 1) if len(bits) >= 3 else None
+    hit = _walk(coeff, bits)
+    if hit is None or len(hit) + 1 > len(bits):
+        return None
+    v = coeff[hit]
+    return ("coef", len(hit) + 1, v >> 8, -(v & 0xff) if bits[len(hit)] == "1" else (v & 0xff))
+
+
+def test_pair_table_decodes_every_10_bit_window_like_a_symbol_by_symbol_walk(lut):
+    """every window of both contexts: the first symbol, and the second when it lies completely inside the 10 bits"""
+    import ctypes
+    pairs = singles = 0
+    for first in (0, 1):
+        for p in range(1 << 10):
+            bits = format(p, "010b")
+            s, d = ctypes.c_uint32(), ctypes.c_uint32()
+            lut.sim_lut_pair(_w(bits), first, ctypes.byref(s), ctypes.byref(d))
+            s, d = s.value, d.value
+            length, nc, eob, adv = s & 15, (s >> 4) & 3, (s >> 6) & 1, s >> 8
+            a = _dct_symbol(bits, bool(first))
+            if a is None:
+                assert s == 0, (first, bits)
+                continue
+            if a[0] == "eob":
+                assert (length, nc, eob, adv) == (2, 0, 1, 0), (first, bits)
+                continue
+            _, n1, r1, l1 = a
+            assert d & 0xffff == (r1 << 10) | (l1 & 1023), (first, bits)
+            b = _dct_symbol(bits[n1:], False)
+            if b is None:
+                assert (length, nc, eob, adv) == (n1, 1, 0, r1 + 1), (first, bits)
+                singles += 1
+            elif b[0] == "eob":
+                assert (length, nc, eob, adv) == (n1 + 2, 1, 1, r1 + 1), (first, bits)
+                pairs += 1
+            else:
+                _, n2, r2, l2 = b
+                assert (length, nc, eob, adv) == (n1 + n2, 2, 0, r1 + 1 + r2 + 1), (first, bits)
+                assert d >> 16 == ((r1 + 1 + r2) << 10) | (l2 & 1023), (first, bits)
+                pairs += 1
+    assert pairs > 500 and singles > 100
+
+
+def test_every_ordered_pair_of_dct_symbols_through_the_tables(lut):
+    """every run/level code with either sign, and end_of_block, followed by every such symbol: what the pair table and the
+    long-code table hand the parser is the pair, its first symbol alone, or "not here" (escape / 10+ bits: the SLOW step)"""
+    import ctypes
+    coeff = {b: v for b, v in GOLDEN["DCT_COEFF"].items() if v not in (0x0001, 0xFFFF)}
+    syms = [("10", "eob", 0, 0)] + [("11" + sg, "coef", 0, -1 if sg == "1" else 1) for sg in "01"]
+    for b, v in coeff.items():
+        for sg in "01":
+            syms.append((b + sg, "coef", v >> 8, -(v & 0xff) if sg == "1" else (v & 0xff)))
+    checked = 0
+    for bits_a, kind_a, ra, la in syms:
+        if kind_a == "eob":
+            continue
+        for bits_b, kind_b, rb, lb in syms:
+            bits = bits_a + bits_b
+            s, d = ctypes.c_uint32(), ctypes.c_uint32()
+            lut.sim_lut_pair(_w(bits), 0, ctypes.byref(s), ctypes.byref(d))
+            s, d = s.value, d.value
+            if len(bits_a) > 10:
+                assert s == 0
+                # the long-code table: leading zeros, a one, four more bits
+                lz = len(bits_a) - len(bits_a.lstrip("0"))
+                code = bits_a[:-1]
+                e = lut.sim_lut_far((lz - 6) * 16 + int((bits_a[lz + 1:lz + 5] + "0000")[:4], 2))
+                assert (e >> 11, (e >> 6) & 31, e & 63) == (len(code), ra, abs(la)), bits_a
+                continue
+            assert d & 0xffff == (ra << 10) | (la & 1023) and s & 15 >= len(bits_a)
+            if len(bits) <= 10:
+                assert s & 15 == len(bits) and ((s >> 6) & 1) == (kind_b == "eob")
+                if kind_b == "coef":
+                    assert (s >> 4) & 3 == 2 and d >> 16 == ((ra + 1 + rb) << 10) | (lb & 1023)
+            checked += 1
+    assert checked > 10000
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not have_reference(), reason="needs /root/reference")
 def test_golden_dump_is_current():
