@@ -197,6 +197,10 @@ int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *ho
  * tables, [1] host table turn-around, [2] slice parse, [3] reconstruct,
  * [4] total.  Valid after jsmpeg_hip_batch_sync. */
 int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
+/* hipEvent timings of the reconstruct launches of the last decode, one per dependency level in launch order ([0]: the
+ * pictures without a forward reference), milliseconds; at most `cap` (and at most 64) are written.  Returns the
+ * number written or < 0.  Valid after jsmpeg_hip_batch_sync. */
+int jsmpeg_hip_batch_level_timings(jsmpeg_hip_batch_t *b, float *out_ms, uint32_t cap);
 /* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
  * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture,
  * [6] pictures with macroblocks the stream never writes (they keep the decoded

@@ -24,7 +24,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
-                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
+                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
@@ -220,6 +220,15 @@ class Batch:
         ms = (ctypes.c_float * 5)()
         self._ok(self.L.jsmpeg_hip_batch_timings(self.h, ms))
         return dict(index_ms=ms[0], host_ms=ms[1], parse_ms=ms[2], recon_ms=ms[3], total_ms=ms[4])
+
+    def level_timings(self):
+        """ms of every reconstruct launch of the last decode, in launch order ([0] = the intra level)"""
+        ms = (ctypes.c_float * 64)()
+        fn = self.L.jsmpeg_hip_batch_level_timings
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_uint32]
+        n = self._ok(fn(self.h, ms, 64))
+        return [float(ms[i]) for i in range(n)]
 
     def counters(self):
         c = (ctypes.c_uint64 * 8)()

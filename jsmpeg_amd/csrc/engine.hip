@@ -116,6 +116,8 @@ struct jsmpeg_hip_batch_t {
 
 	uint32_t n_sc, n_pics, n_levels, n_decoded, n_slices, n_slice_codes;
 	hipEvent_t ev[5];
+	hipEvent_t ev_level[65];     /* before every reconstruct launch (the first 64) and after the last */
+	uint32_t n_level_ev;
 	bool timed;
 	uint32_t *h_counters; /* pinned */
 };
@@ -131,6 +133,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (b->h_covered) hipHostFree(b->h_covered);
 	if (b->ev_cov) hipEventDestroy(b->ev_cov);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
+	for (auto &e : b->ev_level) if (e) hipEventDestroy(e);
 	delete b;
 }
 
@@ -169,6 +172,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_counters, JM_N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
 	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+	for (auto &e : b->ev_level) HIP_TRY(hipEventCreate(&e));
 	return 0;
 }
 
@@ -192,6 +196,8 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
 	for (auto &e : b->ev) e = nullptr;
+	for (auto &e : b->ev_level) e = nullptr;
+	b->n_level_ev = 0;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = b->n_slice_codes = 0;
 	b->timed = false; b->stream = nullptr;
 	if (config->device >= 0) {
@@ -451,9 +457,24 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	D.pad_[0] = D.pad_[1] = 0;
 }
 
+/* JSMPEG_HIP_TRACE=1: where the HOST's time goes in one decode call (stderr, ms since the call began) */
+#include <chrono>
+struct HostTrace {
+	bool on; std::chrono::steady_clock::time_point t0; char line[1024]; size_t n;
+	HostTrace() : on(getenv("JSMPEG_HIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), n(0) { line[0] = 0; }
+	void mark(const char *what) {
+		if (!on) return;
+		const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		n += (size_t)snprintf(line + n, n < sizeof(line) ? sizeof(line) - n : 0, " %s %.3f", what, ms);
+		if (n >= sizeof(line)) n = sizeof(line) - 1;
+	}
+	~HostTrace() { if (on) fprintf(stderr, "decode host trace (ms):%s\n", line); }
+};
+
 extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) {
 	g_err[0] = 0;
 	if (!b) return fail("null batch");
+	HostTrace tr;
 	HIP_TRY(hipSetDevice(b->device));
 	hipStream_t st = (hipStream_t)hip_stream;
 	b->stream = st;
@@ -479,13 +500,16 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
 	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	tr.mark("index-enqueued");
 	HIP_TRY(hipStreamSynchronize(st));
+	tr.mark("index-done");
 	if (b->h_counters[2]) return fail("start-code / picture table overflow: %u start codes, %u pictures (max_pictures %u)",
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
 	b->n_sc = b->h_counters[0]; b->n_pics = b->h_counters[1]; b->n_levels = b->h_counters[3];
 	b->n_slice_codes = std::min(b->h_counters[4], b->sc_cap);
 	b->h_pics.resize(b->n_pics);
 	if (b->n_pics) HIP_TRY(hipMemcpy(b->h_pics.data(), b->d_pics, sizeof(JmPic) * b->n_pics, hipMemcpyDeviceToHost));
+	tr.mark("pics-copied");
 	for (const JmPic &p : b->h_pics) if (p.decoded) { b->n_decoded++; b->n_slices += p.n_slices; }
 	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
 	/* The reconstruct plan.  A picture comes after its forward reference -- and, if it leaves macroblocks UNWRITTEN,
@@ -536,7 +560,9 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		HIP_TRY(hipMemsetAsync(b->d_dbg, 0xee, (size_t)b->sc_cap * 16, st));
 		pb.dbg = b->d_dbg;
 	}
+	tr.mark("plan1");
 	HIP_TRY(jm_launch_parse(pb, st));
+	tr.mark("parse-enqueued");
 	HIP_TRY(hipEventRecord(b->ev[3], st));
 	if (b->n_pics) HIP_TRY(hipMemcpyAsync(b->h_covered, b->d_covered, sizeof(uint32_t) * b->n_pics, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(b->ev_cov, st));
@@ -546,12 +572,16 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
 	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
+	b->n_level_ev = 0;
+	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 	HIP_TRY(jm_launch_recon(rb, st));
 
 	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4a meanwhile):
 	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
 	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
+	tr.mark("roots-enqueued");
 	HIP_TRY(hipEventSynchronize(b->ev_cov));
+	tr.mark("parse-done");
 	{
 		std::vector<int32_t> level;
 		const uint32_t n_levels = jm_plan_levels(b->h_pics.data(), b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
@@ -570,11 +600,14 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 			for (uint32_t l = 1; l < n_levels; l++) {
 				rb.desc = b->d_desc + n_roots + off[l];
 				rb.n_level_pics = off[l + 1] - off[l];
+				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 				HIP_TRY(jm_launch_recon(rb, st));
 			}
 		}
 	}
+	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], st));
 	HIP_TRY(hipEventRecord(b->ev[4], st));
+	tr.mark("levels-enqueued");
 	b->timed = true;
 	return (int)b->n_pics;
 }
@@ -674,6 +707,17 @@ extern "C" int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]) 
 	for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], b->ev[i], b->ev[i + 1]));
 	HIP_TRY(hipEventElapsedTime(&out_ms[4], b->ev[0], b->ev[4]));
 	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_level_timings(jsmpeg_hip_batch_t *b, float *out_ms, uint32_t cap) {
+	g_err[0] = 0;
+	if (!b || !b->timed || !out_ms) return fail("no timed decode");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipEventSynchronize(b->ev[4]));
+	const uint32_t n = std::min(b->n_level_ev, cap);
+	/* the last interval of a capped list runs to the end of the reconstruct */
+	for (uint32_t i = 0; i < n; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], b->ev_level[i], b->ev_level[i + 1 < b->n_level_ev ? i + 1 : b->n_level_ev]));
+	return (int)n;
 }
 
 extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]) {

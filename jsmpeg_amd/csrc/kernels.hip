@@ -458,9 +458,6 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
 #pragma unroll
 		for (int k = 1; k < JM_COEF_REPEAT; k++) {
-#ifdef JM_TURN_DC2   /* experiment: an intra block per COEF step of the turn, not one per turn */
-			if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
-#endif
 			JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
 		}
 	}
@@ -530,9 +527,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
  * loops pays for its own store acknowledgements (one in-order counter for
  * loads and stores), which a workgroup that simply ends never waits for.
  * ---------------------------------------------------------------------- */
-#ifndef JM_RECON_WG
-#define JM_RECON_WG 256   /* 4 wavefronts = 8 block rows of a tile */
-#endif
+#define JM_RECON_WG (64 * JM_RECON_WAVES)   /* 4 wavefronts = 8 block rows of a tile */
 #define JM_SLOT_HALVES 72 /* 144 bytes per slot: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
 /* Transform slots per workgroup.  220 x 144 bytes + the matrices = 31.9 KB: FIVE workgroups per CU (a slot per lane,
  * 36.9 KB, allows four; LDS is handed out in 1280-byte granules, 25 of them per workgroup is the most that fits five
@@ -540,7 +535,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
  * registers without scratch).  A tile with more than 220 blocks that need the transform (dense intra content) takes
  * them in further passes of up to 128 at the end of the kernel. */
 #ifndef JM_RECON_SLOTS
-#define JM_RECON_SLOTS 220
+#define JM_RECON_SLOTS (55 * JM_RECON_WAVES)
 #endif
 #define JM_RECON_PASS (JM_RECON_SLOTS < JM_RECON_WG / 2 ? JM_RECON_SLOTS : JM_RECON_WG / 2)
 static_assert(JM_RECON_SLOTS >= 32 && JM_RECON_SLOTS <= JM_RECON_WG, "a wavefront round takes 32 slots");
@@ -579,13 +574,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
-#ifdef JM_EXP_NO_RECORD   /* timing experiment (wrong output): a made-up record instead of the load the block's other loads hang on */
-	{ const uint32_t h = (uint32_t)Q.mbaddr * 2654435761u;
-	  Q.rw.x = (uint32_t)Q.mbaddr * 12u; Q.rw.y = ((h >> 8) & 0x1fu) | (((h >> 16) & 0x1fu) << 16); Q.rw.z = 0x00020200u | (h & 3u);
-	  Q.rw.w = 0x0002u | ((8u | ((h >> 24) & 7u ? JM_MB_PRED : JM_MB_INTRA)) << 16) | ((uint32_t)b.epoch << 24); }
-#else
 	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>((JM_GLOBAL const JmMbRec *)D.mb + Q.mbaddr);
-#endif
 	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
 	uint4 tq = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];

@@ -235,7 +235,11 @@ JM_HD void jm_recon_locate(const JmGeom &G, JM_GLOBAL const JmMbRec *mb, int g, 
  * at +-16: 256 consecutive blocks per workgroup 0.69 ms, 60 x 4 tiles 0.60, 32 x 8 tiles in this lane order 0.50).
  * A wavefront still stores whole row pieces: TW x 8 contiguous bytes for each of its two block rows.
  * TW = 32; what is left of the plane's width is one more column (JmPlaneTiles below). */
-#define JM_TILE_ROWS 8
+#ifndef JM_RECON_WAVES
+#define JM_RECON_WAVES 4                        /* wavefronts of a reconstruct workgroup (kernels.hip: JM_RECON_WG = 64 x this) */
+#endif
+#define JM_TILE_ROWS (2 * JM_RECON_WAVES)
+#define JM_TILE16_ROWS (4 * JM_RECON_WAVES)    /* block rows of a 16-wide tile: four per wavefront */
 /* A plane's tiles: `full` columns of 32 blocks x `rows` tile rows of 8 block rows, numbered row by row; then the
  * column of what is left (`rem` blocks wide) -- as tiles of 16 x 16 blocks (a wavefront: 4 block rows of 16) when at
  * most 16 blocks are left, `rows16` of them: 1080p luma is 7 columns + 16 blocks, 128 tiles instead of 136 with the
@@ -251,7 +255,7 @@ JM_HD void jm_plane_tiles_init(JmPlaneTiles &P, int bw, int bh) {
 	P.full = bw / 32; P.rem = bw - 32 * P.full;
 	P.rows = (bh + JM_TILE_ROWS - 1) / JM_TILE_ROWS;
 	P.rem16 = P.rem > 0 && P.rem <= 16;
-	P.rows16 = (bh + 15) / 16;
+	P.rows16 = (bh + JM_TILE16_ROWS - 1) / JM_TILE16_ROWS;
 	P.count = P.full * P.rows + (P.rem ? (P.rem16 ? P.rows16 : P.rows) : 0);
 }
 JM_HD void jm_tiles_init(JmTiles &T, const JmGeom &G) {
@@ -274,7 +278,7 @@ JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int 
 		bx = tx * 32 + lx; by = ty * JM_TILE_ROWS + 2 * wave + (lane >> 5);
 	} else if (P.rem16) {
 		lx = lane & 15; tw = P.rem;
-		bx = P.full * 32 + lx; by = (t - n_full) * 16 + 4 * wave + (lane >> 4);
+		bx = P.full * 32 + lx; by = (t - n_full) * JM_TILE16_ROWS + 4 * wave + (lane >> 4);
 	} else {
 		lx = lane & 31; tw = P.rem;
 		bx = P.full * 32 + lx; by = (t - n_full) * JM_TILE_ROWS + 2 * wave + (lane >> 5);
@@ -333,21 +337,14 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	 * rows stay in flight across the set-up barrier and are only awaited where they are used
 	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
-#ifdef JM_EXP_NO_TOKEN_LOAD   /* timing experiment (wrong output): tokens made up from the record */
-		B.tw[0] = 0x04010001u + (B.tkw & 0xfu); B.tw[1] = 0x0c021003u; B.tw[2] = 0x14051404u; B.tw[3] = 0x1c071806u;
-#else
 		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? B.tkw : 0u));
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
-#endif
 	}
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
 	B.m = B.oh = B.ov = 0;
 	if (PRED) {
 		int mh = B.pred ? rec_mvh : 0, mv = B.pred ? rec_mvv : 0;
-#ifdef JM_EXP_ZERO_MV   /* timing experiment (wrong output): perfectly coalesced prediction reads */
-		mh = mv = 0;
-#endif
 		if (bnum >= 4) { mh = mh / 2; mv = mv / 2; }       /* chroma: truncate toward zero, mpeg1.c:1312-1315 */
 		const int H = mh >> 1, V = mv >> 1;
 		B.oh = (uint32_t)(mh & 1); B.ov = (uint32_t)(mv & 1);
@@ -366,12 +363,8 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
-#ifdef JM_EXP_NO_PRED_LOAD   /* timing experiment (wrong output): no prediction reads at all */
-			B.R[3 * r] = woff + r; B.R[3 * r + 1] = wstride; B.R[3 * r + 2] = (uint32_t)last;
-#else
 			JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
-#endif
 		}
 	}
 
@@ -587,9 +580,6 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 
 /* coalesced row stores: 8 bytes per lane per row */
 JM_HD void jm_recon_store(const JmReconCtx &c, const JmBlk &B, const JmPix &X) {
-#ifdef JM_EXP_NO_STORE   /* timing experiment (wrong output): the pixels are computed, (almost) never stored */
-	if (X.p[0] != 0x12345678u || X.p[15] != 0x9abcdef1u) return;
-#endif
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(c.dst + (B.out + (uint32_t)(r * B.stride)));

@@ -62,17 +62,8 @@
 #ifndef JM_COEF_REPEAT
 #define JM_COEF_REPEAT 2   /* COEF steps per turn                                                         */
 #endif
-#ifdef JM_TURN_DC2
-#define JM_STEP_BITS (116 + (JM_PAIR_BITS + 16) * JM_COEF_REPEAT)
-#else
-#define JM_STEP_BITS (116 + JM_PAIR_BITS * JM_COEF_REPEAT)
-#endif
-#define JM_STEP_BITS_NOTE /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
-#ifdef JM_TURN_DC2
-#define JM_COEF_SLOTS 4    /* ... + the DC token of the experiment's second DC step */
-#else
+#define JM_STEP_BITS (116 + JM_PAIR_BITS * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
 #define JM_COEF_SLOTS 3    /* token slots a COEF step may use: two tokens and the alignment slot of an odd run */
-#endif
 #define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
 
 enum { JM_ST_COLD = 0, JM_ST_DC = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };

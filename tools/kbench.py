@@ -31,6 +31,11 @@ with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, to
         if r:
             acc = t if acc is None else {k: acc[k] + t[k] for k in t}
     lv = b.counters()["levels"]
+    try:
+        lt = b.level_timings()
+        print("recon launches ms:", " ".join("%.3f" % x for x in lt))
+    except Exception as e:  # an older library under JSMPEG_HIP_LIB
+        print("no level timings:", e)
     ms = acc["total_ms"] / (reps - 1)
     print({k: round(v / (reps - 1), 3) for k, v in acc.items()}, "recon per level %.3f" % (acc["recon_ms"] / (reps - 1) / lv),
           "| %s %d x %d: %.0f frames/s, %.0f Mpixel/s" % (bench.CONFIG, n_streams, frames, n_streams * frames / ms * 1e3,

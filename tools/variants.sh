@@ -13,6 +13,6 @@ if [ "$1" = build ]; then
 else
   shift
   for so in variants/*.so; do
-    echo -n "$(basename $so .so): "; JSMPEG_HIP_LIB=$PWD/$so timeout 200 python tools/kbench.py "$@" 2>&1 | tail -1
+    echo -n "$(basename $so .so): "; JSMPEG_HIP_LIB=$PWD/$so timeout 200 python tools/kbench.py "$@" 2>&1 | tail -2 | tr '\n' ' '; echo
   done
 fi
