@@ -174,8 +174,9 @@ def main():
 
     # ---- one process per GPU: this process is one of the ranks (WORLD_SIZE set, or --gpus 1), or only their launcher
     # (--gpus N > 1 without WORLD_SIZE: the same command line again under torch.distributed.run, N local ranks) ----
+    import torch                     # FIRST: the decode library must bind to the HIP runtime torch loads, not bring its own
     from jsmpeg_amd import batch as jb, launch
-    visible = int(jb.lib().jsmpeg_hip_device_count())
+    visible = int(torch.cuda.device_count())
     how = launch.plan(args.gpus, os.environ, visible, os.path.abspath(__file__), sys.argv[1:])
     if how["mode"] == "spawn":
         log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(how["cmd"])))
@@ -287,6 +288,7 @@ def main():
 
     phase = {"index_ms": 0.0, "host_ms": 0.0, "parse_ms": 0.0, "recon_ms": 0.0, "total_ms": 0.0}
     levels = 0
+    level_ms = []        # reconstruct launches of the last timed step, HIP events on the launch stream
     h2d_ms = []
 
     if not multi:
@@ -360,6 +362,7 @@ def main():
             for k in phase:
                 phase[k] += t[k]
             levels = b.counters()["levels"]
+            level_ms[:] = b.level_timings()
 
     # ---- what the parity gate certifies (it hashes the frame pool once, after the last timed step): the whole pool is
     # overwritten with a pattern between the warm-up and the timed region (untimed), so every plane the gate sees was
@@ -577,6 +580,36 @@ def main():
     # the read-only share of the algorithmic bytes (north_star words the target as an "HBM-read roofline"): predicted
     # macroblocks (k_recon) or the compressed bytes (k_parse); and the measured HBM traffic as a rate
     read_bytes = (384 * pred_rank / max(1, levels)) if dom["kernel"] == "k_recon" else es_bytes
+    # per level: what a reconstruct launch takes by what it holds (the first launch = the pictures without a forward
+    # reference: planes written, nothing read back)
+    lv = None
+    if level_ms:
+        rest = level_ms[1:] or level_ms
+        intra_bytes = (alg_bytes_rank - 2 * 384 * pred_rank) / max(1, levels)       # its share of ES + planes, no prediction reads
+        lv = {"ms": [round(x, 4) for x in level_ms], "intra_ms": round(level_ms[0], 4), "predicted_min_ms": round(min(rest), 4),
+              "predicted_max_ms": round(max(rest), 4),
+              "intra_level": {"algorithmic_bytes": int(intra_bytes), "achieved": round(intra_bytes / (level_ms[0] * 1e-3) / 1e9, 1),
+                              "frac": round(intra_bytes / (level_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s",
+                              "note": "planes written + compressed bytes, no prediction reads: bound by the transform's VALU issue, not by HBM"},
+              "note": "reconstruct launches of the last timed step in launch order; the last predicted level holds the generator's full_pel pictures (vectors twice as long)"}
+    # k_parse against ITS ceiling: VALU issue.  Instructions per pass from the last committed counter profile (static, like
+    # `traffic`), issue rate measured on this GPU model by tools/ubench.hip (profiles/r02_ubench.txt)
+    parse_roof = None
+    try:
+        vj = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        n_inst = vj["k_parse"] * (n_streams * frames) / float(STREAMS_PER_GPU * FRAMES_PER_STREAM)
+        peak = 1024 / 1.15             # G wavefront-instructions/s: 1024 SIMDs, 1.15 ns per two-operand instruction at 8 wavefronts per SIMD
+        ach = n_inst / (parse_ms * 1e-3) / 1e9
+        parse_roof = {"kernel": "k_parse", "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
+                      "unit": "G wavefront-instructions/s", "frac": round(ach / peak, 4), "avg_launch_ms": round(parse_ms, 4),
+                      "instructions_per_pass": int(n_inst), "instructions_source": "static: profiles/pmc_valu.json (%s), SQ_INSTS_VALU, not measured in this run" % vj.get("source", "?"),
+                      "peak_note": "1024 SIMDs / 1.15 ns per two-operand VALU instruction (tools/ubench.hip, 8 wavefronts per SIMD: the chip holds "
+                                   "1.2-1.5 GHz under that load); three-operand forms, 24-bit multiplies and byte permutes issue at 1.8 ns",
+                      "hbm_fetch_over_es": round(tj.get("fetch_bytes", {}).get("k_parse", 0) / max(1, es_bytes), 2) or None,
+                      "hbm_traffic_over_es": round(tj.get("k_parse", 0) / max(1, es_bytes), 2) or None}
+    except Exception as e:
+        log("k_parse roofline not attached: %r" % (e,))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_rate": round(traffic / (dom["avg_launch_ms"] * 1e-3) / 1e9, 1) if traffic else None,
@@ -588,6 +621,7 @@ def main():
                                "frac": round(job_alg_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                                "note": "all kernels + host turn-around of a step, per-GPU peak x n_gpus"},
                 "phases_ms": {kk: round(v / k, 4) for kk, v in phase.items()},
+                "levels": lv,
                 "peak_measured_achievable": 6290.0,
                 "device_copy_measured": {"value": copy_gbs, "unit": "GB/s",
                                          "note": "read + write traffic of a 2 GiB torch device-to-device copy on this GPU, same run: "
@@ -614,6 +648,7 @@ def main():
                         "note": "the gate hashes the pool once, after the last timed step: every plane it sees was written inside the "
                                 "timed region, and every %dth picture's frame by the last step itself" % SCRUB_EVERY},
         "roofline": roofline,
+        "roofline_parse": parse_roof,
     }
     if value_incl_h2d:
         line["value_incl_h2d"] = value_incl_h2d

@@ -15,6 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, d_trace, d_fetch, d_write = sys.argv[1:5]
+d_valu = sys.argv[5] if len(sys.argv) > 5 else None      # optional fourth pass: --pmc SQ_INSTS_VALU SQ_WAVES
 
 
 def db(d):
@@ -52,7 +53,22 @@ with open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag), "w") as f:
         hbm = (2 * fa[1] + wa[1]) * 1024
         traffic[k] = int(hbm)
         f.write("%-16s %6d %14.1f %14.1f %14.1f %16.1f\n" % (k[:16], fa[0], fa[1], fa[3], wa[1], hbm / 1e6))
-json.dump({k: v for k, v in traffic.items() if k.startswith("k_")},
-          open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+tj = {k: v for k, v in traffic.items() if k.startswith("k_")}
+tj["source"] = "profiles/%s_pmc.txt" % tag
+tj["fetch_bytes"] = {k: int(2 * fetch[k][1] * 1024) for k in fetch if k.startswith("k_")}
+tj["write_bytes"] = {k: int(write[k][1] * 1024) for k in write if k.startswith("k_")}
+json.dump(tj, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+if d_valu and glob.glob(os.path.join(d_valu, "**", "*.db"), recursive=True):
+    valu = {short(r[0]): r[1:] for r in db(d_valu).execute(q, ("SQ_INSTS_VALU",))}
+    waves = {short(r[0]): r[1:] for r in db(d_valu).execute(q, ("SQ_WAVES",))}
+    with open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag), "a") as f:
+        f.write("\n# rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES (its own run): wavefront-instructions per dispatch\n")
+        f.write("%-16s %6s %16s %12s %12s\n" % ("kernel", "n", "valu_instr_avg", "waves_avg", "valu_per_wave"))
+        for k in sorted(valu):
+            w = waves.get(k, (0, 0, 0, 0))[1]
+            f.write("%-16s %6d %16.0f %12.0f %12.1f\n" % (k[:16], valu[k][0], valu[k][1], w, valu[k][1] / w if w else 0))
+    vj = {k: int(v[1]) for k, v in valu.items() if k.startswith("k_")}
+    vj["source"] = "profiles/%s_pmc.txt" % tag
+    json.dump(vj, open(os.path.join(ROOT, "profiles", "pmc_valu.json"), "w"), indent=1)
 print(open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag)).read())
 print(open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag)).read())
