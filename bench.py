@@ -273,17 +273,43 @@ def main():
             del host, src, unit_bytes
         del d_flat, d_collect
         mine = pieces[rank]
-        begin, end = mine["begin"], mine["end"]
         n_units = len(mine["units"])
-        n_pictures = sum(unit_pics[u] for u in mine["units"])
         shard_len = int(mine["size"])
-        b = jb.Batch(width, height, max(1, n_units), n_pictures + 8, shard_len + 4096, device=local_rank)
         d_piece = [torch.empty(shard_len, dtype=torch.uint8, device=dev) for _ in range(2)]   # double-buffered receive
         xfer = torch.cuda.Stream(device=dev)               # the exchange runs beside the decode kernels
         xptr = ctypes.c_void_p(xfer.cuda_stream)
-        exchange = {"units": len(table), "units_this_rank": n_units, "bytes_leaving_rank0_per_step": int(sum(psizes[1:])),
-                    "scatter_ms": []}
-        log("rank %d: %d of %d units, %d pictures, piece %.1f MB" % (rank, n_units, len(table), n_pictures, shard_len / 1e6))
+        # ---- the other ingest mode: every rank KEEPS the units of the streams that arrived on it, the plan moves only
+        # the imbalance, rank to rank (jsmpeg_hip_plan_rebalance / jsmpeg_hip_dist_exchange) ----
+        home = [r for r in range(world) for units in info_all[r][0] for _ in units]
+        owner_l = jd.plan_rebalance_c([n for _, _, n in table], home, world)
+        lays = jd.layout_local(table, home, owner_l, world)
+        lay = lays[rank]
+        first_unit = sum(len(units) for x in info_all[:rank] for units in x[0])
+        my_bytes = {first_unit + k: u for k, u in enumerate(u for units in my_units for u in units)}
+        h_send = np.full(lay["send_size"], 0xFF, dtype=np.uint8)
+        for u, pos in zip(lay["send_units"], lay["send_pos"]):
+            h_send[pos:pos + len(my_bytes[u])] = my_bytes[u]
+        h_work = np.full(lay["size"], 0xFF, dtype=np.uint8)
+        for u, bb, ee in zip(lay["units"], lay["begin"], lay["end"]):
+            if home[u] == rank:
+                h_work[int(bb):int(ee)] = my_bytes[u]            # the units this rank keeps: resident before the timed region
+        d_send = torch.from_numpy(h_send).to(dev)
+        d_work = [torch.from_numpy(h_work).to(dev) for _ in range(2)]   # what arrives lands behind the kept units, double-buffered
+        del h_send, h_work, my_bytes
+        sent_by_rank = [int(sum(ly["send_bytes"])) for ly in lays]
+        modes = {
+            "single_source": dict(begin=mine["begin"], end=mine["end"], shard_len=shard_len, bufs=d_piece, units_of_rank=[p["units"] for p in pieces],
+                                  n_pictures=sum(unit_pics[u] for u in mine["units"]), n_units=n_units, ms=[]),
+            "local_ingest": dict(begin=lay["begin"], end=lay["end"], shard_len=int(lay["size"]), bufs=d_work, units_of_rank=[ly["units"] for ly in lays],
+                                 n_pictures=sum(unit_pics[u] for u in lay["units"]), n_units=len(lay["units"]), ms=[]),
+        }
+        X = modes["single_source"]                     # the headline: what north_star words ("RCCL ... of stream slices")
+        n_pictures = X["n_pictures"]
+        b = jb.Batch(width, height, max(1, max(m["n_units"] for m in modes.values())), max(m["n_pictures"] for m in modes.values()) + 8,
+                     max(m["shard_len"] for m in modes.values()) + 4096, device=local_rank)
+        exchange = {"units": len(table), "units_this_rank": n_units, "bytes_leaving_rank0_per_step": int(sum(psizes[1:]))}
+        log("rank %d: %d of %d units, %d pictures, piece %.1f MB; keeping its own streams: %d units, %.1f MB leave this rank"
+            % (rank, n_units, len(table), n_pictures, shard_len / 1e6, len(lay["units"]), sent_by_rank[rank] / 1e6))
     torch.cuda.synchronize()
 
     phase = {"index_ms": 0.0, "host_ms": 0.0, "parse_ms": 0.0, "recon_ms": 0.0, "total_ms": 0.0}
@@ -299,12 +325,17 @@ def main():
     state = {"cur": 0, "pending": None}
 
     def start_scatter(i):
-        # the path's one exchange step: the compressed units, rank 0 -> owners, grouped RCCL send / recv over xGMI
+        # the path's one exchange step: the compressed units, grouped RCCL send / recv over xGMI -- rank 0 -> owners
+        # (single source), or rank -> rank for the units the rebalancing plan moved (every rank ingests its own streams)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         xfer.wait_stream(stream)
         e0.record(xfer)
-        D.scatter(0, ctypes.c_void_p(d_src.data_ptr()) if rank == 0 else None, offsets, psizes,
-                  ctypes.c_void_p(d_piece[i].data_ptr()), xptr)
+        if X is modes["single_source"]:
+            D.scatter(0, ctypes.c_void_p(d_src.data_ptr()) if rank == 0 else None, offsets, psizes,
+                      ctypes.c_void_p(d_piece[i].data_ptr()), xptr)
+        else:
+            D.exchange(ctypes.c_void_p(d_send.data_ptr()), lay["send_offset"], lay["send_bytes"],
+                       ctypes.c_void_p(d_work[i].data_ptr()), lay["recv_offset"], lay["recv_bytes"], xptr)
         e1.record(xfer)
         return e0, e1
 
@@ -332,9 +363,9 @@ def main():
                 state["pending"] = start_scatter(state["cur"])
             e0, e1 = state["pending"]
             stream.wait_event(e1)
-            b.upload_device(ctypes.c_void_p(d_piece[state["cur"]].data_ptr()), shard_len, begin, end, sptr)   # returns when the piece has been copied
+            b.upload_device(ctypes.c_void_p(X["bufs"][state["cur"]].data_ptr()), X["shard_len"], X["begin"], X["end"], sptr)   # returns when the piece has been copied
             if collect:
-                exchange["scatter_ms"].append(e0.elapsed_time(e1))
+                X["ms"].append(e0.elapsed_time(e1))
             state["pending"] = None
             if more and overlap:
                 state["cur"] ^= 1
@@ -376,11 +407,12 @@ def main():
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
 
     frame_stride = int(b.frame_stride)
-    pool_pictures = n_pictures
-    pool = torch.as_tensor(_DevMem(b.frame_pool_ptr, pool_pictures * frame_stride), device=dev).view(pool_pictures, frame_stride)
     scrub = {"ms": None, "frames": 0}
 
     def timed_run(steps, warmup):
+        pool_pictures = n_pictures
+        pool = torch.as_tensor(_DevMem(b.frame_pool_ptr, pool_pictures * frame_stride), device=dev).view(pool_pictures, frame_stride)
+        state["cur"], state["pending"] = 0, None
         for i in range(warmup):
             step(False, i + 1 < warmup)      # nothing is prefetched across the warm-up / timed boundary
         torch.cuda.synchronize()
@@ -417,17 +449,16 @@ def main():
     uncovered = b.counters()["uncovered_pictures"]
 
     # ---- parity gate against the oracle (checker only) ----
-    dev_hashes = b.frame_hashes()
-    infos = b.pictures()
     lib_oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
-    per_stream = {}
-    for p, i in enumerate(infos):
-        per_stream.setdefault(i.stream, []).append(int(dev_hashes[p]))
-    deviating = 0
-    if multi:
-        # exchange step 2 (reporting, once per job, outside the timed steps): 8 bytes per picture to every rank, through
-        # the library; every rank then checks the units of ITS OWN streams, wherever they were decoded
-        pics_of = [sum(unit_pics[u] for u in p["units"]) for p in pieces]
+    check = list(range(n_streams)) if not os.environ.get("JSMPEG_BENCH_PARITY_STREAMS") else \
+        [int(x) for x in os.environ["JSMPEG_BENCH_PARITY_STREAMS"].split(",")]
+    oracle_cache = {}            # what the oracle says is decoded once per stream / unit, whatever the mode that is checked
+
+    def device_hashes_by_unit(units_of_rank):
+        """exchange step 2 (reporting, once per run, outside the timed steps): 8 bytes per picture to every rank, through
+        the library; returns got_of(s): the device hashes of the units of THIS rank's stream s, wherever they were decoded"""
+        dev_hashes = b.frame_hashes()
+        pics_of = [sum(unit_pics[u] for u in units) for units in units_of_rank]
         pad = max(pics_of)
         hsrc = torch.zeros(pad, dtype=torch.int64, device=dev)
         hsrc[:n_pictures] = torch.from_numpy(dev_hashes.view(np.int64).copy()).to(dev)
@@ -436,68 +467,107 @@ def main():
         torch.cuda.synchronize()
         hall = hall.cpu().numpy().view(np.uint64).reshape(world, pad)
         where = {}
-        for r, p in enumerate(pieces):
+        for r, units in enumerate(units_of_rank):
             pos = 0
-            for u in p["units"]:
+            for u in units:
                 where[u] = (r, pos)
                 pos += unit_pics[u]
-        first_unit = sum(len(x[0][k]) for x in info_all[:rank] for k in range(len(x[0])))
+        first = sum(len(x[0][k]) for x in info_all[:rank] for k in range(len(x[0])))
 
         def got_of(s):          # stream s of this rank: the device hashes of its units, GOP by GOP
-            u = first_unit + sum(len(units) for units in my_units[:s])
+            u = first + sum(len(units) for units in my_units[:s])
             return [[int(h) for h in hall[where[u + g][0], where[u + g][1]:where[u + g][1] + unit_pics[u + g]]]
                     for g in range(len(my_units[s]))]
-    check = list(range(n_streams)) if not os.environ.get("JSMPEG_BENCH_PARITY_STREAMS") else \
-        [int(x) for x in os.environ["JSMPEG_BENCH_PARITY_STREAMS"].split(",")]
-    failed = []
-    dev_lock = threading.Lock()
+        return got_of
 
-    def oracle_hashes(es):
-        # picture by picture: decode, hash, drop (a stream's 120 decoded pictures are 376 MB)
-        out = []
-        with cabi.Mpeg1Decoder(lib_oracle, len(es) + 1024, cabi.MODE_EXPAND) as dec:
-            dec.write(es)
-            while dec.decode():
-                out.append(hashing.frame_hash(*dec.planes()))
-        return out
+    def oracle_hashes(key, es):
+        # picture by picture: decode, hash, drop (a stream's 120 decoded pictures are 376 MB); cached per stream / unit
+        if key not in oracle_cache:
+            out = []
+            with cabi.Mpeg1Decoder(lib_oracle, len(es) + 1024, cabi.MODE_EXPAND) as dec:
+                dec.write(es)
+                while dec.decode():
+                    out.append(hashing.frame_hash(*dec.planes()))
+            oracle_cache[key] = out
+        return oracle_cache[key]
 
-    def verify(s):
-        nonlocal deviating
-        whole = oracle_hashes(streams[s])
-        if not multi:
-            if per_stream.get(s, []) != whole:
-                failed.append(s)
-            return
-        # sharded by GOP: every unit is what its decoder was given -- the oracle decodes exactly that; and the whole
-        # stream beside it, to COUNT the pictures where a unit decoded alone differs from the unsplit stream (a
-        # macroblock never written in a unit's first two pictures shows the GOP before in the unsplit stream: header, part 4)
-        got, pos = got_of(s), 0
-        for g, unit in enumerate(my_units[s]):
-            want = oracle_hashes(unit)
-            if got[g] != want:
-                failed.append((s, g))
-            with dev_lock:
-                deviating += sum(1 for a, bb in zip(want, whole[pos:pos + len(want)]) if a != bb)
-            pos += len(want)
+    def parity_gate(units_of_rank, what):
+        """Every stream of this rank against the oracle; no number is reported unless all of them match.  Returns the
+        pictures where a unit decoded alone differs from the unsplit stream (multi-rank only)."""
+        per_stream, got_of = {}, None
+        if multi:
+            got_of = device_hashes_by_unit(units_of_rank)
+        else:
+            dev_hashes = b.frame_hashes()
+            for p, i in enumerate(b.pictures()):
+                per_stream.setdefault(i.stream, []).append(int(dev_hashes[p]))
+        failed, deviating = [], [0]
+        dev_lock = threading.Lock()
 
-    t_par = time.perf_counter()
-    idx = iter(check)
-    lock = threading.Lock()
-
-    def runner():
-        while True:
-            with lock:
-                s = next(idx, None)
-            if s is None:
+        def verify(s):
+            whole = oracle_hashes(("stream", s), streams[s])
+            if not multi:
+                if per_stream.get(s, []) != whole:
+                    failed.append(s)
                 return
-            verify(s)
+            # sharded by GOP: every unit is what its decoder was given -- the oracle decodes exactly that; and the whole
+            # stream beside it, to COUNT the pictures where a unit decoded alone differs from the unsplit stream (a
+            # macroblock never written in a unit's first two pictures shows the GOP before in the unsplit stream: header, part 4)
+            got, pos = got_of(s), 0
+            for g, unit in enumerate(my_units[s]):
+                want = oracle_hashes(("unit", s, g), unit)
+                if got[g] != want:
+                    failed.append((s, g))
+                with dev_lock:
+                    deviating[0] += sum(1 for a, bb in zip(want, whole[pos:pos + len(want)]) if a != bb)
+                pos += len(want)
 
-    ts = [threading.Thread(target=runner) for _ in range(max(1, min(len(check), (os.cpu_count() or 8), 32)))]
-    [t.start() for t in ts]
-    [t.join() for t in ts]
-    log("rank %d: parity of %d streams against the oracle in %.1fs" % (rank, len(check), time.perf_counter() - t_par))
-    if failed:
-        raise SystemExit("rank %d: PARITY FAILURE against the oracle on streams %r -- no number reported" % (rank, sorted(failed)))
+        t_par = time.perf_counter()
+        idx = iter(check)
+        lock = threading.Lock()
+
+        def runner():
+            while True:
+                with lock:
+                    s = next(idx, None)
+                if s is None:
+                    return
+                verify(s)
+
+        ts = [threading.Thread(target=runner) for _ in range(max(1, min(len(check), (os.cpu_count() or 8), 32)))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        log("rank %d: parity (%s) of %d streams against the oracle in %.1fs" % (rank, what, len(check), time.perf_counter() - t_par))
+        if failed:
+            raise SystemExit("rank %d: PARITY FAILURE (%s) against the oracle on streams %r -- no number reported" % (rank, what, sorted(failed)))
+        return deviating[0]
+
+    deviating = parity_gate(X["units_of_rank"] if multi else None, "single source" if multi else "whole streams")
+
+    # ---- N > 1: the same job with every rank ingesting its own streams (only the imbalance travels), its own timed run
+    # and its own parity gate; reported beside the headline, never as `value` ----
+    local_ingest = None
+    if multi:
+        saved_phase, saved_levels = dict(phase), list(level_ms)
+        for kk in phase:
+            phase[kk] = 0.0
+        X = modes["local_ingest"]
+        n_pictures = X["n_pictures"]
+        dt = timed_run(args.steps, 1)
+        parity_gate(X["units_of_rank"], "every rank its own streams")
+        tot = torch.tensor([float(n_pictures)], dtype=torch.float64)
+        dist.all_reduce(tot)
+        local_ingest = {"value": round(float(tot.item()) * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                        "bytes_leaving_busiest_rank_per_step": max(sent_by_rank), "bytes_leaving_each_rank_per_step": sent_by_rank,
+                        "units_this_rank": X["n_units"], "exchange_ms_avg_rank0": round(sum(X["ms"]) / max(1, len(X["ms"])), 3),
+                        "phases_ms_rank0": {kk: round(v / args.steps, 4) for kk, v in phase.items()},
+                        "note": "every rank cuts and keeps the streams that arrived on it; jsmpeg_hip_plan_rebalance moves units only "
+                                "where that narrows the gap between the most and the least loaded rank; jsmpeg_hip_dist_exchange "
+                                "carries them rank to rank (one RCCL group) beside the previous step's kernels; parity-gated like the headline"}
+        phase.update(saved_phase)
+        level_ms[:] = saved_levels
+        X = modes["single_source"]
+        n_pictures = X["n_pictures"]
 
     # ---- the variant that starts from host memory (SURVEY.md 8d: both stated) -- N = 1 only, after the headline run ----
     value_incl_h2d = None
@@ -653,8 +723,9 @@ def main():
     if value_incl_h2d:
         line["value_incl_h2d"] = value_incl_h2d
     if multi:
-        sm = exchange.pop("scatter_ms")
+        sm = modes["single_source"]["ms"]
         exchange["scatter_ms_avg_rank0"] = round(sum(sm) / max(1, len(sm)), 3)
+        exchange["local_ingest"] = local_ingest
         exchange["note"] = ("scatter of step k+1 runs on its own HIP stream beside the kernels of step k; its time is inside "
                             "ms_per_step only where it is not hidden")
         exchange["pictures_differing_from_unsplit_streams"] = int(deviating)

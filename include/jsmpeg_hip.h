@@ -313,6 +313,10 @@ int jsmpeg_hip_split_gops(const uint8_t *es, uint64_t es_bytes, jsmpeg_hip_gop_u
                           uint64_t *header_offset, uint64_t *header_bytes);
 /* Balanced assignment of n units (weights = compressed bytes) to `world` ranks: owner[i] = rank of unit i. */
 int jsmpeg_hip_plan_shards(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner);
+/* The same for units that ARRIVED on the ranks (every rank ingests its own streams; home[i] = the rank that holds unit
+ * i): a unit stays where it is unless moving it from the most to the least loaded rank narrows the gap between the
+ * two -- about half the imbalance travels, a balanced job moves nothing. */
+int jsmpeg_hip_plan_rebalance(const uint64_t *weights, const uint32_t *home, uint32_t n, uint32_t world, uint32_t *owner);
 
 /* One RCCL communicator over the ranks of a job (one process per GPU).  The 128-byte id is made on one rank
  * (jsmpeg_hip_dist_unique_id) and handed to the others by whatever launched them (torch.distributed, MPI, a file). */
@@ -328,6 +332,12 @@ int32_t jsmpeg_hip_dist_world(jsmpeg_hip_dist_t *d);
  * carry their pieces at once.  Enqueued on `hip_stream` (void* hipStream_t).  Returns 0 or < 0. */
 int jsmpeg_hip_dist_scatter(jsmpeg_hip_dist_t *d, int32_t src_rank, const void *src_dev, const uint64_t *offset,
                             const uint64_t *bytes, void *dst_dev, void *hip_stream);
+/* The exchange step when every rank holds units (jsmpeg_hip_plan_rebalance): rank to rank, only what the plan moved.
+ * To rank r go send_bytes[r] bytes from src_dev + send_offset[r]; from rank r come recv_bytes[r] bytes to dst_dev +
+ * recv_offset[r] (THIS rank's arrays of `world` entries; its own entry is a device copy).  One group of sends and
+ * receives.  Enqueued on `hip_stream`.  Returns 0 or < 0. */
+int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_dev, const uint64_t *send_offset, const uint64_t *send_bytes,
+                             void *dst_dev, const uint64_t *recv_offset, const uint64_t *recv_bytes, void *hip_stream);
 /* The reverse (set-up: streams that arrived on several ranks are collected where they are distributed from). */
 int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, const void *src_dev, const uint64_t *offset,
                            const uint64_t *bytes, void *dst_dev, void *hip_stream);

@@ -132,6 +132,37 @@ extern "C" int jsmpeg_hip_plan_shards(const uint64_t *weights, uint32_t n, uint3
 	return 0;
 }
 
+/* Units that ARRIVED on the ranks themselves (every rank ingests its own streams: `home[i]` = the rank that holds unit
+ * i): only the imbalance moves.  owner = home, then units leave the most loaded rank for the least loaded one while
+ * that narrows the gap between the two -- the unit whose weight is closest to half the gap, never more than the gap --
+ * so the bytes that travel are about half the imbalance and a balanced job moves nothing. */
+extern "C" int jsmpeg_hip_plan_rebalance(const uint64_t *weights, const uint32_t *home, uint32_t n, uint32_t world, uint32_t *owner) {
+	jm_clear_error();
+	if (world == 0 || (n && (!weights || !home || !owner))) return sfail("bad rebalance arguments");
+	std::vector<uint64_t> load(world, 0);
+	for (uint32_t i = 0; i < n; i++) {
+		if (home[i] >= world) return sfail("unit %u: home rank %u outside the job", i, home[i]);
+		owner[i] = home[i];
+		load[home[i]] += weights[i];
+	}
+	for (uint32_t guard = 0; guard < n; guard++) {
+		const uint32_t hi = (uint32_t)(std::max_element(load.begin(), load.end()) - load.begin());
+		const uint32_t lo = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+		const uint64_t gap = load[hi] - load[lo];
+		uint32_t best = n;
+		uint64_t best_d = ~0ull;
+		for (uint32_t i = 0; i < n; i++) {
+			if (owner[i] != hi || weights[i] == 0 || weights[i] >= gap) continue;      /* moving it must narrow the gap */
+			const uint64_t d = weights[i] * 2 > gap ? weights[i] * 2 - gap : gap - weights[i] * 2;
+			if (d < best_d) { best_d = d; best = i; }
+		}
+		if (best == n) break;
+		owner[best] = lo;
+		load[hi] -= weights[best]; load[lo] += weights[best];
+	}
+	return 0;
+}
+
 /* ------------------------------------------------------------------ RCCL */
 
 struct RcclApi {
@@ -274,6 +305,35 @@ extern "C" int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, co
 	} else if (bytes[d->rank]) {
 		if (!src_dev) return sfail("null send buffer");
 		RCCL_TRY(g_rccl.Send(src_dev, bytes[d->rank], ncclUint8, dst_rank, d->comm, st));
+	}
+	return 0;
+}
+
+/* The exchange step when every rank holds units: rank -> rank, only what the plan moved.  To rank r go
+ * send_bytes[r] bytes from src_dev + send_offset[r]; from rank r come recv_bytes[r] bytes to dst_dev +
+ * recv_offset[r] (this rank's arrays; what it sends to r is what r receives from it).  The rank's own entry is a
+ * device copy.  One group: every link of every rank works at once.  Enqueued on `hip_stream`. */
+extern "C" int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_dev, const uint64_t *send_offset, const uint64_t *send_bytes,
+                                        void *dst_dev, const uint64_t *recv_offset, const uint64_t *recv_bytes, void *hip_stream) {
+	jm_clear_error();
+	if (!d || !send_offset || !send_bytes || !recv_offset || !recv_bytes) return sfail("bad exchange arguments");
+	SHIP_TRY(hipSetDevice(d->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	uint64_t out = 0, in = 0;
+	for (int r = 0; r < d->world; r++) { out += send_bytes[r]; in += recv_bytes[r]; }
+	if ((out && !src_dev) || (in && !dst_dev)) return sfail("null exchange buffer");
+	if (send_bytes[d->rank] != recv_bytes[d->rank]) return sfail("the rank's own entry must be the same on both sides");
+	if (send_bytes[d->rank])
+		SHIP_TRY(hipMemcpyAsync((uint8_t *)dst_dev + recv_offset[d->rank], (const uint8_t *)src_dev + send_offset[d->rank], send_bytes[d->rank],
+		                        hipMemcpyDeviceToDevice, st));
+	if (d->world > 1) {
+		RCCL_TRY(g_rccl.GroupStart());
+		for (int r = 0; r < d->world; r++) {
+			if (r == d->rank) continue;
+			if (send_bytes[r]) RCCL_TRY(g_rccl.Send((const uint8_t *)src_dev + send_offset[r], send_bytes[r], ncclUint8, r, d->comm, st));
+			if (recv_bytes[r]) RCCL_TRY(g_rccl.Recv((uint8_t *)dst_dev + recv_offset[r], recv_bytes[r], ncclUint8, r, d->comm, st));
+		}
+		RCCL_TRY(g_rccl.GroupEnd());
 	}
 	return 0;
 }

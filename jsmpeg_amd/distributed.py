@@ -20,9 +20,9 @@ class GopUnit(ctypes.Structure):
 
 
 DIST_ID_BYTES = 128
-SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_dist_unique_id", "jsmpeg_hip_dist_create",
-                 "jsmpeg_hip_dist_destroy", "jsmpeg_hip_dist_rank", "jsmpeg_hip_dist_world", "jsmpeg_hip_dist_scatter",
-                 "jsmpeg_hip_dist_gather", "jsmpeg_hip_dist_allgather")
+SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_plan_rebalance", "jsmpeg_hip_dist_unique_id",
+                 "jsmpeg_hip_dist_create", "jsmpeg_hip_dist_destroy", "jsmpeg_hip_dist_rank", "jsmpeg_hip_dist_world",
+                 "jsmpeg_hip_dist_scatter", "jsmpeg_hip_dist_exchange", "jsmpeg_hip_dist_gather", "jsmpeg_hip_dist_allgather")
 _bound = False
 
 
@@ -35,6 +35,10 @@ def _lib():
         L.jsmpeg_hip_split_gops.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(GopUnit), ctypes.c_uint32, u64p, u64p]
         L.jsmpeg_hip_plan_shards.restype = ctypes.c_int
         L.jsmpeg_hip_plan_shards.argtypes = [u64p, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.jsmpeg_hip_plan_rebalance.restype = ctypes.c_int
+        L.jsmpeg_hip_plan_rebalance.argtypes = [u64p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.jsmpeg_hip_dist_exchange.restype = ctypes.c_int
+        L.jsmpeg_hip_dist_exchange.argtypes = [vp, vp, u64p, u64p, vp, u64p, u64p, vp]
         L.jsmpeg_hip_dist_unique_id.restype = ctypes.c_int
         L.jsmpeg_hip_dist_unique_id.argtypes = [vp]
         L.jsmpeg_hip_dist_create.restype = vp
@@ -83,6 +87,17 @@ def plan_shards_c(weights, world):
     return list(owner)
 
 
+def plan_rebalance_c(weights, home, world):
+    """plan_rebalance() through the C ABI: owner rank per unit, starting from where the units arrived."""
+    L = _lib()
+    w = (ctypes.c_uint64 * len(weights))(*[int(x) for x in weights])
+    h = (ctypes.c_uint32 * len(weights))(*[int(x) for x in home])
+    owner = (ctypes.c_uint32 * len(weights))()
+    if L.jsmpeg_hip_plan_rebalance(w, h, len(weights), world, owner) != 0:
+        raise RuntimeError(_batch.last_error())
+    return list(owner)
+
+
 def unique_id():
     """128 bytes that name a new communicator: made on one rank, handed to the others by the launcher."""
     buf = (ctypes.c_uint8 * DIST_ID_BYTES)()
@@ -120,6 +135,11 @@ class Dist:
         if self.L.jsmpeg_hip_dist_scatter(self.h, src_rank, src_ptr, self._arr(offsets), self._arr(sizes), dst_ptr, stream) != 0:
             raise RuntimeError(_batch.last_error())
 
+    def exchange(self, src_ptr, send_offsets, send_sizes, dst_ptr, recv_offsets, recv_sizes, stream=None):
+        if self.L.jsmpeg_hip_dist_exchange(self.h, src_ptr, self._arr(send_offsets), self._arr(send_sizes), dst_ptr,
+                                           self._arr(recv_offsets), self._arr(recv_sizes), stream) != 0:
+            raise RuntimeError(_batch.last_error())
+
     def gather(self, dst_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
         if self.L.jsmpeg_hip_dist_gather(self.h, dst_rank, src_ptr, self._arr(offsets), self._arr(sizes), dst_ptr, stream) != 0:
             raise RuntimeError(_batch.last_error())
@@ -142,6 +162,95 @@ def plan_shards(weights, world):
         owner[i] = r
         load[r] += int(weights[i])
     return [[i for i in range(len(weights)) if owner[i] == r] for r in range(world)]
+
+
+def plan_rebalance(weights, home, world):
+    """Restatement of jsmpeg_hip_plan_rebalance: units stay on the rank they arrived on unless moving one from the most to
+    the least loaded rank narrows the gap between the two (the unit closest to half the gap, first such unit on a tie)."""
+    owner = [int(h) for h in home]
+    load = [0] * world
+    for w, h in zip(weights, home):
+        load[h] += int(w)
+    for _ in range(len(weights)):
+        hi = max(range(world), key=lambda r: (load[r], -r))
+        lo = min(range(world), key=lambda r: (load[r], r))
+        gap = load[hi] - load[lo]
+        best, best_d = None, None
+        for i, w in enumerate(weights):
+            w = int(w)
+            if owner[i] != hi or w == 0 or w >= gap:
+                continue
+            d = abs(2 * w - gap)
+            if best is None or d < best_d:
+                best, best_d = i, d
+        if best is None:
+            break
+        owner[best] = lo
+        load[hi] -= int(weights[best])
+        load[lo] += int(weights[best])
+    return owner
+
+
+def layout_local(table, home, owner, world, gap=16):
+    """Every rank ingests its own streams.  Rank r's WORK buffer = the units it keeps, then what it receives (rank by
+    rank, in global unit order); its SEND buffer = the units it gives away, destination by destination.  Returns per
+    rank dict(units, begin, end, size  -- the work buffer, what jsmpeg_hip_batch_upload_device takes --
+    send_units, send_pos (offset of each sent unit in the send buffer), send_offset[world], send_bytes[world],
+    recv_offset[world] (in the work buffer), recv_bytes[world])."""
+    ranks = []
+    for r in range(world):
+        kept = [u for u in range(len(table)) if home[u] == r and owner[u] == r]
+        got = [[u for u in range(len(table)) if home[u] == s and owner[u] == r] for s in range(world)]
+        gave = [[u for u in range(len(table)) if home[u] == r and owner[u] == s] for s in range(world)]
+        d = dict(units=[], begin=[], end=[], size=gap, send_units=[], send_pos=[], send_offset=[0] * world, send_bytes=[0] * world,
+                 recv_offset=[0] * world, recv_bytes=[0] * world)
+
+        def place(u):
+            off = (d["size"] + 15) & ~15
+            d["units"].append(u)
+            d["begin"].append(off)
+            d["end"].append(off + table[u][2])
+            d["size"] = off + table[u][2] + gap
+
+        for u in kept:
+            place(u)
+        for s in range(world):
+            if s == r or not got[s]:
+                continue
+            start = (d["size"] + 15) & ~15
+            d["size"] = start
+            # the sender packs these units back to back from a 16-byte aligned start with `gap` bytes between them: the
+            # received run lands as one block, unit positions follow from the sizes
+            pos = start
+            for u in got[s]:
+                pos = (pos + 15) & ~15
+                d["units"].append(u)
+                d["begin"].append(pos)
+                d["end"].append(pos + table[u][2])
+                pos += table[u][2] + gap
+            d["recv_offset"][s] = start
+            d["recv_bytes"][s] = pos - start
+            d["size"] = pos
+        soff = 0
+        for s in range(world):
+            if s == r or not gave[s]:
+                continue
+            soff = (soff + 15) & ~15
+            d["send_offset"][s] = soff
+            pos = soff
+            for u in gave[s]:
+                pos = (pos + 15) & ~15
+                d["send_units"].append(u)
+                d["send_pos"].append(pos)
+                pos += table[u][2] + gap
+            d["send_bytes"][s] = pos - soff
+            soff = pos
+        d["send_size"] = (soff + 64 + 15) & ~15
+        d["size"] = (d["size"] + 64 + 15) & ~15
+        d["begin"] = np.array(d["begin"], np.uint32)
+        d["end"] = np.array(d["end"], np.uint32)
+        ranks.append(d)
+    return ranks
 
 
 def pack_streams(streams, gap=16):

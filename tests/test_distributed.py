@@ -110,6 +110,123 @@ def test_two_rank_gop_shards_decode_like_whole_streams(libs, hip_lib):
         assert sum(counts) == WORLD * STREAMS_PER_RANK * (FRAMES // GOP) and min(counts) > 0
 
 
+# ---- every rank ingests its own streams: only the imbalance travels (jsmpeg_hip_plan_rebalance, jsmpeg_hip_dist_exchange) ----
+
+LOCAL_STREAMS = (3, 1)       # streams that arrive on rank 0 / rank 1: uneven, so that units must move
+
+
+def _local_streams_of(rank):
+    from jsmpeg_amd import synth
+    first = sum(LOCAL_STREAMS[:rank])
+    return [synth.generate_config("cfg1_720p", n_frames=FRAMES, stream=first + k, width=176, height=144, gop=GOP)[0]
+            for k in range(LOCAL_STREAMS[rank])]
+
+
+def _worker_local(rank, port, oracle_path, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from jsmpeg_amd import cabi, distributed as jd, hashing
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        mine = [jd.split_gops_c(es) for es in _local_streams_of(rank)]
+        sizes = [None] * WORLD
+        dist.all_gather_object(sizes, [[len(u) for u in units] for units in mine])
+        table = jd.unit_table([units for r in sizes for units in r])
+        home = [r for r in range(WORLD) for units in sizes[r] for _ in units]
+        owner = jd.plan_rebalance_c([n for _, _, n in table], home, WORLD)
+        lay = jd.layout_local(table, home, owner, WORLD)[rank]
+        first_unit = sum(len(units) for r in range(rank) for units in sizes[r])
+        my_bytes = {first_unit + k: u for k, u in enumerate(u for units in mine for u in units)}
+        # the send buffer: what this rank gives away, destination by destination (the library: one jsmpeg_hip_dist_exchange)
+        send = np.full(lay["send_size"], 0xFF, dtype=np.uint8)
+        for u, pos in zip(lay["send_units"], lay["send_pos"]):
+            send[pos:pos + len(my_bytes[u])] = my_bytes[u]
+        work = np.full(lay["size"], 0xFF, dtype=np.uint8)
+        for u, b, e in zip(lay["units"], lay["begin"], lay["end"]):
+            if u in my_bytes and owner[u] == rank:
+                work[int(b):int(e)] = my_bytes[u]
+        reqs = []
+        for r in range(WORLD):
+            if r == rank:
+                continue
+            if lay["send_bytes"][r]:
+                o = lay["send_offset"][r]
+                reqs.append(dist.isend(torch.from_numpy(send[o:o + lay["send_bytes"][r]].copy()), dst=r))
+        for r in range(WORLD):
+            if r != rank and lay["recv_bytes"][r]:
+                buf = torch.empty(lay["recv_bytes"][r], dtype=torch.uint8)
+                dist.recv(buf, src=r)
+                o = lay["recv_offset"][r]
+                work[o:o + lay["recv_bytes"][r]] = buf.numpy()
+        [x.wait() for x in reqs]
+        local = {}
+        for u, b, e in zip(lay["units"], lay["begin"], lay["end"]):
+            frames, _, _ = cabi.decode_stream(oracle_path, work[int(b):int(e)], keep="planes")
+            local[u] = [hashing.frame_hash(*f) for f in frames]
+        everything = [None] * WORLD
+        dist.all_gather_object(everything, local)
+        merged = {}
+        for d in everything:
+            merged.update(d)
+        per_stream = {}
+        for u, (s, g, _) in enumerate(table):
+            per_stream.setdefault(s, []).extend(merged[u])
+        moved = sum(table[u][2] for u in range(len(table)) if home[u] != owner[u])
+        q.put((rank, per_stream, [sum(1 for u in range(len(table)) if owner[u] == r) for r in range(WORLD)], moved,
+               sum(lay["send_bytes"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_ingest_their_own_streams_and_move_only_the_imbalance(libs, hip_lib):
+    import torch.multiprocessing as mp
+    from jsmpeg_amd import cabi, hashing
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local, args=(r, port, libs["oracle"], q)) for r in range(WORLD)]
+    [p.start() for p in procs]
+    results = [q.get(timeout=180) for _ in range(WORLD)]
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    want, k = {}, 0
+    for r in range(WORLD):
+        for es in _local_streams_of(r):
+            frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+            want[k] = [hashing.frame_hash(*f) for f in frames]
+            k += 1
+    for rank, per_stream, counts, moved, sent in results:
+        assert per_stream == want, "rank %d" % rank
+        # 3 + 1 streams of 3 units each: 9 + 3 -> 6 + 6, three units leave rank 0 and nothing leaves rank 1
+        assert counts == [6, 6] and moved > 0
+        assert (sent > 0) == (rank == 0)
+
+
+def test_rebalance_plan_equals_its_restatement_and_moves_nothing_when_balanced(hip_lib):
+    import random
+    from jsmpeg_amd import distributed as jd
+    rnd = random.Random(7)
+    for _ in range(200):
+        world, n = rnd.randint(1, 8), rnd.randint(0, 50)
+        w = [rnd.choice([0, 1, 7, 100, rnd.randint(1, 10 ** 6)]) for _ in range(n)]
+        home = [rnd.randrange(world) for _ in range(n)]
+        owner = jd.plan_rebalance_c(w, home, world)
+        assert owner == jd.plan_rebalance(w, home, world)
+        before, after = [0] * world, [0] * world
+        for i in range(n):
+            before[home[i]] += w[i]
+            after[owner[i]] += w[i]
+        assert max(after) - min(after) <= max(before) - min(before)
+    # the benchmark's shape: the same number of like streams on every rank -> nothing travels
+    w = [60000 + (i * 37) % 500 for i in range(8 * 640)]
+    home = [i // 640 for i in range(8 * 640)]
+    owner = jd.plan_rebalance_c(w, home, 8)
+    assert sum(w[i] for i in range(len(w)) if owner[i] != home[i]) < 0.001 * sum(w)
+
+
 def test_c_abi_cut_and_plan_equal_the_numpy_restatements(hip_lib):
     from jsmpeg_amd import distributed as jd, synth
     for kw in (dict(gop=6, custom_quant=1), dict(gop=1), dict(gop=12)):
