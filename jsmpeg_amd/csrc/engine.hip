@@ -98,8 +98,8 @@ struct jsmpeg_hip_batch_t {
 	uint32_t sc_cap;
 	uint64_t *d_scan_state;
 	uint32_t *d_sc_pos; uint8_t *d_sc_code; uint32_t *d_sc_owner; uint32_t *d_pic_sc; uint32_t *d_slice_sc; uint32_t *d_slice_order; uint32_t *d_order_hist; uint32_t *d_counters;
-	JmPic *d_pics; std::vector<JmPic> h_pics;
-	JmReconDesc *d_desc; std::vector<JmReconDesc> h_desc;
+	JmPic *d_pics; JmPic *h_pics;                 /* h_pics, h_desc: pinned host memory (copies of pageable memory stall on the runtime's staging path) */
+	JmReconDesc *d_desc; JmReconDesc *h_desc;
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
 	uint32_t desc_cap, n_uncovered;
 	hipEvent_t ev_cov;
@@ -131,6 +131,8 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
 	if (b->h_covered) hipHostFree(b->h_covered);
+	if (b->h_pics) hipHostFree(b->h_pics);
+	if (b->h_desc) hipHostFree(b->h_desc);
 	if (b->ev_cov) hipEventDestroy(b->ev_cov);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	for (auto &e : b->ev_level) if (e) hipEventDestroy(e);
@@ -160,6 +162,8 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
 	HIP_TRY(jm_malloc(&b->d_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc(&b->h_pics, sizeof(JmPic) * std::max(1u, c.max_pictures), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc(&b->h_desc, sizeof(JmReconDesc) * b->desc_cap, hipHostMallocDefault));
 	HIP_TRY(hipEventCreate(&b->ev_cov));
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
 	HIP_TRY(jm_malloc(&b->d_mb, mb_bytes));
@@ -191,7 +195,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
-	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
+	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
@@ -500,6 +504,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
 	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * std::max(1u, b->cfg.max_pictures), hipMemcpyDeviceToHost, st));
 	tr.mark("index-enqueued");
 	HIP_TRY(hipStreamSynchronize(st));
 	tr.mark("index-done");
@@ -507,10 +512,9 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
 	b->n_sc = b->h_counters[0]; b->n_pics = b->h_counters[1]; b->n_levels = b->h_counters[3];
 	b->n_slice_codes = std::min(b->h_counters[4], b->sc_cap);
-	b->h_pics.resize(b->n_pics);
-	if (b->n_pics) HIP_TRY(hipMemcpy(b->h_pics.data(), b->d_pics, sizeof(JmPic) * b->n_pics, hipMemcpyDeviceToHost));
+	/* (the picture table came over with the counters: one copy of the whole table, one turn-around) */
 	tr.mark("pics-copied");
-	for (const JmPic &p : b->h_pics) if (p.decoded) { b->n_decoded++; b->n_slices += p.n_slices; }
+	for (uint32_t i = 0; i < b->n_pics; i++) if (b->h_pics[i].decoded) { b->n_decoded++; b->n_slices += b->h_pics[i].n_slices; }
 	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
 	/* The reconstruct plan.  A picture comes after its forward reference -- and, if it leaves macroblocks UNWRITTEN,
 	 * after the frame those keep showing: the reference keeps two plane sets and rotates them after every picture
@@ -522,12 +526,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * reference are reconstructed right behind it (step 4a: intra pictures hardly ever have such macroblocks), the
 	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs. */
 	std::vector<int32_t> stale;
-	const uint32_t n_roots = jm_plan_stale(b->h_pics.data(), b->n_pics, b->n_streams, stale);
+	const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
 	{
-		b->h_desc.resize(std::max<size_t>(1, (size_t)b->n_decoded + n_roots));
+		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
 		uint32_t k = 0;
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
-		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc.data(), sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
+		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
 	}
 	if (++b->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
@@ -584,7 +588,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	tr.mark("parse-done");
 	{
 		std::vector<int32_t> level;
-		const uint32_t n_levels = jm_plan_levels(b->h_pics.data(), b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
+		const uint32_t n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
 		b->n_levels = n_levels;
 		std::vector<uint32_t> off(n_levels + 1, 0);
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;
@@ -596,7 +600,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		if (n_later) {
 			std::vector<uint32_t> cur(off.begin(), off.end());
 			for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) fill_desc(b, b->h_desc[n_roots + cur[level[p]]++], p, stale[p]);
-			HIP_TRY(hipMemcpyAsync(b->d_desc + n_roots, b->h_desc.data() + n_roots, sizeof(JmReconDesc) * n_later, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(b->d_desc + n_roots, b->h_desc + n_roots, sizeof(JmReconDesc) * n_later, hipMemcpyHostToDevice, st));
 			for (uint32_t l = 1; l < n_levels; l++) {
 				rb.desc = b->d_desc + n_roots + off[l];
 				rb.n_level_pics = off[l + 1] - off[l];
