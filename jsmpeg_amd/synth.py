@@ -116,7 +116,17 @@ def stuff_zero_bytes(es, pic_offsets, before_pictures=0, before_slices=0):
     return out, new_offs.astype(np.uint32)
 
 
+ENCODED_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
 def generate_config(name, n_frames=None, stream=0, stuff_pictures=0, stuff_slices=0, **overrides):
+    if name.startswith("enc:"):
+        # not generated here: a stream written by the independent test-side encoder (tests/enc/mpeg1_enc.py), committed as
+        # tests/golden/<name>.m1v + .offsets.npy so that fixtures made from it mean the same bytes everywhere
+        es = np.fromfile(os.path.join(ENCODED_DIR, name[4:] + ".m1v"), dtype=np.uint8)
+        offs = np.load(os.path.join(ENCODED_DIR, name[4:] + ".offsets.npy")).astype(np.uint32)
+        assert n_frames in (None, len(offs) - 1) and not overrides, "an encoded stream is what it is"
+        return es, offs
     c = dict(CONFIGS[name])
     cfg = c.pop("cfg")
     frames = c.pop("frames")

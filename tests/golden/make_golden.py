@@ -82,6 +82,12 @@ PROBES = {
     "slice_stuffing_352x288": ("cfg1_720p", 14, dict(width=352, height=288, stuff_slices=3)),
 }
 CASES.update(PROBES)
+# Streams from the independent encoder (tests/enc/mpeg1_enc.py: real motion search, DCT, quantisation, skipped / not-coded /
+# intra decisions on procedural pictures), committed as tests/golden/enc_*.m1v: the same four-way agreement, the same fixture.
+sys.path.insert(0, os.path.join(ROOT, "tests", "enc"))
+import mpeg1_enc  # noqa: E402
+for _name, _kw in mpeg1_enc.CASES.items():
+    CASES["" + _name] = ("enc:" + _name, _kw["n_frames"], {})
 
 
 def disagreement_record(name, cfg, n, ov, es, runs, why):

@@ -93,3 +93,17 @@ def test_reference_under_node_matches_golden(impl, libs):
         os.unlink(f.name)
     assert out["hashes"] == fx["frame_md5"]
     assert out["sizes"] == [[fx["info"]["width"], fx["info"]["height"]]]
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="container only: pins the test-side encoder to the streams it committed")
+def test_encoder_script_reproduces_the_committed_streams():
+    """tests/golden/enc_*.m1v are what tests/enc/mpeg1_enc.py writes (float DCT: checked where the fixtures were made)."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "enc"))
+    import mpeg1_enc
+    name = "enc_coarse_fullpel_160x128"
+    es, offs = mpeg1_enc.encode(**mpeg1_enc.CASES[name])
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_%s.json" % name)))
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"] and len(offs) == fx["n_frames"] + 1
