@@ -193,6 +193,14 @@ int jsmpeg_hip_batch_render_rgba(jsmpeg_hip_batch_t *b, uint32_t first_picture, 
                                  void *dev_rgba, void *hip_stream);
 /* Same conversion for ONE picture, copied to host memory (width * height * 4 bytes). */
 int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba);
+/* The reference's OTHER renderer form, WebGL (src/webgl.js:259-281): chroma sampled bilinearly from the
+ * half-size planes (GL_LINEAR, CLAMP_TO_EDGE, weights 0.75 / 0.25), (y, cr, cb, 1) times the shader's BT.601 matrix in
+ * float32, framebuffer conversion round(c * 255), alpha 255; display size, rows packed.  A browser's result depends on its
+ * GPU's shader precision and filter hardware, so this form carries a tolerance (1 LSB against the float64 restatement),
+ * not the bit-exact contract of the Canvas2D form above. */
+int jsmpeg_hip_batch_render_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t first_picture, uint32_t count,
+                                    void *dev_rgba, void *hip_stream);
+int jsmpeg_hip_batch_read_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba);
 /* hipEvent timings of the last decode, milliseconds: [0] start-code index +
  * tables, [1] host table turn-around, [2] slice parse, [3] reconstruct,
  * [4] total.  Valid after jsmpeg_hip_batch_sync. */

@@ -25,7 +25,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
-                 "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
+                 "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
                  "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
@@ -214,6 +214,15 @@ class Batch:
         """Picture p as RGBA uint8[height, width, 4]: device conversion, then a copy to the host."""
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self._ok(self.L.jsmpeg_hip_batch_read_rgba(self.h, p, out.ctypes.data))
+        return out
+
+    def read_rgba_gl(self, p):
+        """Picture p in the reference's WebGL renderer's arithmetic (bilinear chroma, float matrix): uint8[height, width, 4]."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        fn = self.L.jsmpeg_hip_batch_read_rgba_gl
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        self._ok(fn(self.h, p, out.ctypes.data))
         return out
 
     def timings(self):

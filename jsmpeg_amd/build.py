@@ -108,7 +108,7 @@ def build_oracle(force=False):
     deps = [os.path.join(ORACLE, "mpeg1_oracle.h"), os.path.join(CSRC, "mp2_window.h")]
     if force or _newer(LIB_ORACLE, src + deps):
         # -ffp-contract=off: the MP2 restatement's float products must round as written (oracle/mp2_oracle.c header)
-        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-o", LIB_ORACLE] + src)
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-o", LIB_ORACLE] + src + ["-lm"])
     return LIB_ORACLE
 
 

@@ -689,6 +689,35 @@ extern "C" int jsmpeg_hip_batch_render_rgba(jsmpeg_hip_batch_t *b, uint32_t firs
 	return 0;
 }
 
+/* The same in the reference's WebGL renderer's arithmetic (src/webgl.js:259-281). */
+extern "C" int jsmpeg_hip_batch_render_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t first_picture, uint32_t count,
+                                               void *dev_rgba, void *hip_stream) {
+	g_err[0] = 0;
+	if (!b || !dev_rgba) return fail("null argument");
+	if ((uint64_t)first_picture + count > b->n_pics) return fail("picture range [%u, %u) outside the %u decoded pictures", first_picture, first_picture + count, b->n_pics);
+	HIP_TRY(hipSetDevice(b->device));
+	JmRgbaBufs r;
+	r.frames = b->d_pool; r.first_frame = first_picture; r.n_frames = count;
+	r.frame_stride = b->g.frame_bytes; r.luma_bytes = b->g.luma_bytes; r.chroma_bytes = b->g.chroma_bytes;
+	r.coded_width = b->g.coded_width; r.coded_height = b->g.coded_height; r.width = b->cfg.width; r.height = b->cfg.height;
+	r.rgba = (uint8_t *)dev_rgba; r.rgba_stride = (uint64_t)b->cfg.width * b->cfg.height * 4;
+	HIP_TRY(jm_launch_rgba_gl(r, (hipStream_t)hip_stream));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_read_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba) {
+	g_err[0] = 0;
+	if (!b || !host_rgba) return fail("null argument");
+	if (picture >= b->n_pics) return fail("bad picture index");
+	HIP_TRY(hipSetDevice(b->device));
+	const size_t bytes = (size_t)b->cfg.width * b->cfg.height * 4;
+	if (!b->d_rgba) HIP_TRY(jm_malloc(&b->d_rgba, bytes));
+	if (jsmpeg_hip_batch_render_rgba_gl(b, picture, 1, b->d_rgba, b->stream) < 0) return -1;
+	HIP_TRY(hipMemcpyAsync(host_rgba, b->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
 /* One picture as RGBA in host memory (device conversion into a scratch frame, then a copy). */
 extern "C" int jsmpeg_hip_batch_read_rgba(jsmpeg_hip_batch_t *b, uint32_t picture, void *host_rgba) {
 	g_err[0] = 0;

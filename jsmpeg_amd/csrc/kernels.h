@@ -136,6 +136,8 @@ struct JmRgbaBufs {
 	uint64_t rgba_stride;
 };
 hipError_t jm_launch_rgba(const JmRgbaBufs &b, hipStream_t st);
+/* the same frames in the reference's WebGL form (src/webgl.js:259-281: bilinear chroma, float BT.601 matrix) */
+hipError_t jm_launch_rgba_gl(const JmRgbaBufs &b, hipStream_t st);
 
 /* ---- ingest side: MPEG-TS -> elementary streams (ts_kernels.hip; reference src/ts.js) ---- */
 struct JmTsRec {                 /* what one 188-byte packet says by itself, 16 bytes */

@@ -814,6 +814,52 @@ __global__ __launch_bounds__(JM_WG) void k_rgba_any(JmRgbaBufs b, uint32_t block
 	reinterpret_cast<uint32_t *>(b.rgba + (uint64_t)f * b.rgba_stride)[p] = v;
 }
 
+/* The reference's OTHER renderer, WebGL (src/webgl.js:259-281): three LUMINANCE textures with LINEAR filtering, a
+ * viewport of coded width x display height, and a fragment shader that multiplies (y, cr, cb, 1) by a BT.601 matrix in
+ * floating point.  One lane per output pixel.  The luma texel centre coincides with the pixel centre (weights 1 / 0); the
+ * half-size chroma textures are sampled at (x + 0.5) / 2 - 0.5 = x / 2 - 0.25: bilinear, weights 0.75 / 0.25, clamped to
+ * the edge (webgl.js:126-141); textures hold the first `height` (chroma: height >> 1) rows of the coded planes
+ * (webgl.js:203-215).  float32 arithmetic, framebuffer conversion round(c * 255).  What a browser's GPU computes depends on
+ * its precision (`mediump`) and filter hardware: this form has a tolerance (1 LSB against the float64 restatement in
+ * oracle/ycbcr_oracle.c), not a bit-exact contract like the Canvas2D form above. */
+__global__ __launch_bounds__(JM_WG) void k_rgba_gl(JmRgbaBufs b, uint32_t blocks_per_frame) {
+	const uint32_t f = blockIdx.x / blocks_per_frame;
+	const uint32_t p = (blockIdx.x % blocks_per_frame) * JM_WG + threadIdx.x;
+	const uint32_t w = (uint32_t)b.width, h = (uint32_t)b.height;
+	if (p >= w * h) return;
+	const uint32_t py = p / w, px = p - py * w;
+	const uint8_t *frame = b.frames + (uint64_t)(b.first_frame + f) * b.frame_stride;
+	const uint32_t cw = (uint32_t)b.coded_width, cw2 = cw >> 1, h2 = h >> 1;
+	const float yv = (float)frame[(size_t)py * cw + px] * (1.0f / 255.0f);
+	float cr = 0.5f, cb = 0.5f;
+	if (h2 > 0) {
+		/* texel coordinates of the sample in the half-size textures (cw2 x h2), GL_LINEAR + CLAMP_TO_EDGE */
+		const float u = ((float)px + 0.5f) / (float)cw * (float)cw2 - 0.5f, v = ((float)py + 0.5f) / (float)h * (float)h2 - 0.5f;
+		const float fu = floorf(u), fv = floorf(v), ax = u - fu, ay = v - fv;
+		const int x0 = max((int)fu, 0), x1 = min((int)fu + 1, (int)cw2 - 1), y0 = max((int)fv, 0), y1 = min((int)fv + 1, (int)h2 - 1);
+		const uint8_t *Cr = frame + b.luma_bytes, *Cb = Cr + b.chroma_bytes;
+		const float k = 1.0f / 255.0f;
+		const float r00 = Cr[(size_t)y0 * cw2 + x0] * k, r10 = Cr[(size_t)y0 * cw2 + x1] * k, r01 = Cr[(size_t)y1 * cw2 + x0] * k, r11 = Cr[(size_t)y1 * cw2 + x1] * k;
+		const float b00 = Cb[(size_t)y0 * cw2 + x0] * k, b10 = Cb[(size_t)y0 * cw2 + x1] * k, b01 = Cb[(size_t)y1 * cw2 + x0] * k, b11 = Cb[(size_t)y1 * cw2 + x1] * k;
+		cr = (1.0f - ay) * ((1.0f - ax) * r00 + ax * r10) + ay * ((1.0f - ax) * r01 + ax * r11);
+		cb = (1.0f - ay) * ((1.0f - ax) * b00 + ax * b10) + ay * ((1.0f - ax) * b01 + ax * b11);
+	}
+	/* the shader's matrix product (its `cb` variable holds true Cr and vice versa: webgl.js:189, 279) */
+	const float R = 1.16438f * yv + 1.59603f * cr - 0.87079f;
+	const float G = 1.16438f * yv - 0.39176f * cb - 0.81297f * cr + 0.52959f;
+	const float B = 1.16438f * yv + 2.01723f * cb - 1.08139f;
+	const uint32_t r8 = (uint32_t)(fminf(fmaxf(R, 0.0f), 1.0f) * 255.0f + 0.5f), g8 = (uint32_t)(fminf(fmaxf(G, 0.0f), 1.0f) * 255.0f + 0.5f),
+	               b8 = (uint32_t)(fminf(fmaxf(B, 0.0f), 1.0f) * 255.0f + 0.5f);
+	reinterpret_cast<uint32_t *>(b.rgba + (uint64_t)f * b.rgba_stride)[p] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+}
+
+hipError_t jm_launch_rgba_gl(const JmRgbaBufs &b, hipStream_t st) {
+	if (b.n_frames == 0 || b.width <= 0 || b.height <= 0) return hipSuccess;
+	const uint32_t bpf = ((uint32_t)b.width * (uint32_t)b.height + JM_WG - 1) / JM_WG;
+	hipLaunchKernelGGL(k_rgba_gl, dim3(b.n_frames * bpf), dim3(JM_WG), 0, st, b, bpf);
+	return hipGetLastError();
+}
+
 hipError_t jm_launch_rgba(const JmRgbaBufs &b, hipStream_t st) {
 	if (b.n_frames == 0 || b.width <= 0 || b.height <= 0) return hipSuccess;
 	if ((b.width & 3) == 0 && (b.height & 1) == 0) {

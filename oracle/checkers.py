@@ -20,6 +20,19 @@ def oracle_rgba(oracle_path, y, cr, cb, width, height):
     return out
 
 
+def oracle_rgba_gl(oracle_path, y, cr, cb, width, height):
+    """CHECKER ONLY: the reference's WebGL colour conversion (bilinear chroma, float BT.601 matrix) restated in float64
+    (oracle/ycbcr_oracle.c; unpinned: no WebGL runs here); uint8[height, width, 4]."""
+    lib = ctypes.CDLL(oracle_path)
+    fn = lib.ycbcr_oracle_to_rgba_gl
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    y, cr, cb = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cr, cb))
+    out = np.empty((height, width, 4), dtype=np.uint8)
+    fn(y.ctypes.data, cr.ctypes.data, cb.ctypes.data, width, height, out.ctypes.data)
+    return out
+
+
 class _TsWrite(ctypes.Structure):
     _fields_ = [("pts", ctypes.c_double), ("offset", ctypes.c_uint32), ("length", ctypes.c_uint32)]
 

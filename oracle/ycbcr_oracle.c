@@ -46,3 +46,38 @@ void ycbcr_oracle_to_rgba(const uint8_t *y, const uint8_t *cr, const uint8_t *cb
 		c_index += c_next;
 	}
 }
+
+/* The reference's WebGL renderer (src/webgl.js), restated in float64: textures of coded width x display height (luma) and
+ * half that (chroma, height >> 1 rows) with GL_LINEAR / CLAMP_TO_EDGE (webgl.js:126-141, 203-215), viewport coded width x
+ * height (webgl.js:122-124), texCoord = vertex (webgl.js:293-301), fragment shader webgl.js:259-281:
+ * gl_FragColor = vec4(y, cr, cb, 1) * rec601 with the shader's `cb` holding the true Cr plane (render(y, cb, cr) is
+ * called with (Y, Cr, Cb)).  PARITY UNPINNED for this form: no WebGL implementation runs in the build container, and a
+ * browser's output depends on its GPU (shader precision `mediump`, filter precision); the GPU test compares the device
+ * kernel with this restatement within 1 LSB. */
+#include <math.h>
+void ycbcr_oracle_to_rgba_gl(const uint8_t *y, const uint8_t *cr, const uint8_t *cb, int width, int height, uint8_t *rgba) {
+	const int cw = ((width + 15) >> 4) << 4, cw2 = cw >> 1, h2 = height >> 1;
+	for (int py = 0; py < height; py++)
+		for (int px = 0; px < width; px++) {
+			const double yv = y[(size_t)py * cw + px] / 255.0;
+			double c_r = 0.5, c_b = 0.5;
+			if (h2 > 0) {
+				const double u = (px + 0.5) / cw * cw2 - 0.5, v = (py + 0.5) / height * h2 - 0.5;
+				const double fu = floor(u), fv = floor(v), ax = u - fu, ay = v - fv;
+				int x0 = (int)fu, x1 = x0 + 1, y0 = (int)fv, y1 = y0 + 1;
+				if (x0 < 0) x0 = 0;
+				if (x1 > cw2 - 1) x1 = cw2 - 1;
+				if (y0 < 0) y0 = 0;
+				if (y1 > h2 - 1) y1 = h2 - 1;
+#define SAMPLE(P) ((1.0 - ay) * ((1.0 - ax) * P[(size_t)y0 * cw2 + x0] + ax * P[(size_t)y0 * cw2 + x1]) + ay * ((1.0 - ax) * P[(size_t)y1 * cw2 + x0] + ax * P[(size_t)y1 * cw2 + x1])) / 255.0
+				c_r = SAMPLE(cr); c_b = SAMPLE(cb);
+#undef SAMPLE
+			}
+			double R = 1.16438 * yv + 1.59603 * c_r - 0.87079;
+			double G = 1.16438 * yv - 0.39176 * c_b - 0.81297 * c_r + 0.52959;
+			double B = 1.16438 * yv + 2.01723 * c_b - 1.08139;
+			R = R < 0 ? 0 : (R > 1 ? 1 : R); G = G < 0 ? 0 : (G > 1 ? 1 : G); B = B < 0 ? 0 : (B > 1 ? 1 : B);
+			uint8_t *o = rgba + ((size_t)py * width + px) * 4;
+			o[0] = (uint8_t)(R * 255.0 + 0.5); o[1] = (uint8_t)(G * 255.0 + 0.5); o[2] = (uint8_t)(B * 255.0 + 0.5); o[3] = 255;
+		}
+}

@@ -91,3 +91,66 @@ def test_batch_render_rgba(path, hip_lib):
         assert [md5(b.read_rgba(p)) for p in range(n)] == fx["rgba_md5"]
         with pytest.raises(RuntimeError):
             b.read_rgba(n)
+
+
+# ---- the reference's other renderer form: WebGL (src/webgl.js:259-281).  No WebGL implementation runs in the build
+# container and a browser's result depends on its GPU (shader precision, filter hardware): the restatement is float64 and
+# UNPINNED; what is checked is its arithmetic against a plain numpy statement of the shader (CPU) and the device kernel
+# against it within 1 LSB (GPU) ----
+
+def _numpy_webgl(y, cr, cb, width, height):
+    cw, h2 = ((width + 15) >> 4) << 4, height >> 1
+    cw2 = cw >> 1
+    Y = y.reshape(-1, cw)[:height, :width].astype(np.float64) / 255.0
+    px, py = np.meshgrid(np.arange(width), np.arange(height))
+    u, v = (px + 0.5) / cw * cw2 - 0.5, (py + 0.5) / height * h2 - 0.5
+    fu, fv = np.floor(u), np.floor(v)
+    ax, ay = u - fu, v - fv
+    x0, x1 = np.clip(fu, 0, cw2 - 1).astype(int), np.clip(fu + 1, 0, cw2 - 1).astype(int)
+    y0, y1 = np.clip(fv, 0, h2 - 1).astype(int), np.clip(fv + 1, 0, h2 - 1).astype(int)
+
+    def sample(P):
+        P = P.reshape(-1, cw2).astype(np.float64)
+        return ((1 - ay) * ((1 - ax) * P[y0, x0] + ax * P[y0, x1]) + ay * ((1 - ax) * P[y1, x0] + ax * P[y1, x1])) / 255.0
+    CR, CB = sample(cr), sample(cb)
+    M = np.array([[1.16438, 0.0, 1.59603, -0.87079], [1.16438, -0.39176, -0.81297, 0.52959], [1.16438, 2.01723, 0.0, -1.08139]])
+    # gl_FragColor = vec4(y, cr, cb, 1) * rec601, the shader's cr = true Cb, its cb = true Cr
+    vec = np.stack([Y, CB, CR, np.ones_like(Y)], axis=-1)
+    rgb = np.clip(vec @ M.T, 0.0, 1.0)
+    out = np.full((height, width, 4), 255, np.uint8)
+    out[..., :3] = np.floor(rgb * 255.0 + 0.5).astype(np.uint8)
+    return out
+
+
+def test_webgl_restatement_is_the_shader(libs):
+    rng = np.random.default_rng(5)
+    for w, h in ((32, 16), (17, 33), (352, 288), (30, 2)):
+        cw, ch = ((w + 15) >> 4) << 4, ((h + 15) >> 4) << 4
+        y = rng.integers(0, 256, cw * ch, dtype=np.uint8)
+        cr = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
+        cb = rng.integers(0, 256, cw * ch // 4, dtype=np.uint8)
+        got = checkers.oracle_rgba_gl(libs["oracle"], y, cr, cb, w, h)
+        want = _numpy_webgl(y, cr, cb, w, h)
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.999
+    # a grey ramp with chroma 128: nearly grey (the shader's offsets are exact for 128 / 255 only to 0.006), black at 16, white at 235
+    y = np.tile(np.arange(256, dtype=np.uint8), 16)
+    neutral = np.full(256 * 16 // 4, 128, np.uint8)
+    out = checkers.oracle_rgba_gl(libs["oracle"], y, neutral, neutral, 256, 16)
+    assert (np.abs(out[..., 0].astype(int) - out[..., 1]) <= 2).all() and out[0, 16, 0] <= 1 and out[0, 235, 0] >= 254
+
+
+@pytest.mark.gpu
+def test_batch_render_rgba_webgl_form(hip_lib, libs):
+    """k_rgba_gl through the C ABI against the float64 restatement: at most 1 LSB apart, almost everywhere equal."""
+    from jsmpeg_amd import batch as jb
+    for w, h, n in ((352, 288, 4), (17, 33, 3), (1280, 96, 2)):
+        es, _ = synth.generate_config("cfg1_720p", n_frames=n, width=w, height=h)
+        frames, _, info = cabi.decode_stream(libs["oracle"], es, keep="planes")
+        with jb.Batch(w, h, 1, n + 2, len(es) + 1024) as b:
+            b.upload([es])
+            assert b.decode() == n
+            for p, (y, cr, cb) in enumerate(frames):
+                got = b.read_rgba_gl(p)
+                want = checkers.oracle_rgba_gl(libs["oracle"], y, cr, cb, w, h)
+                d = np.abs(got.astype(int) - want.astype(int))
+                assert d.max() <= 1 and (d == 0).mean() > 0.99, (w, h, p, d.max(), (d == 0).mean())
