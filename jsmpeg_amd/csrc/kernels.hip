@@ -518,14 +518,18 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
  * All tiles of a picture are dispatched to the same XCD (workgroup b runs on
  * XCD b % 8) so the forward frame's prediction reads hit one L2.
  *
- * What bounds it (round 2, profiles/r02_recon_notes.md): with the synthetic
- * streams' random vectors the P levels run at the speed of a kernel that does
- * nothing but this kernel's loads and stores (tools/ubench_pred.hip) -- L1
- * misses in flight per CU, not HBM bandwidth and not the arithmetic.  A
+ * What bounds it (profiles/r02_recon_notes.md, r03_recon_notes.md): two
+ * throughput limits that overlap imperfectly.  The arithmetic alone (no
+ * prediction loads, no plane stores) takes 0.69 ms per level of cfg2 -- ~870
+ * VALU instructions per wavefront at the 1.0-1.8 ns the power-limited chip
+ * sustains -- and the memory side alone 0.75-0.85 ms (4.06 GB at this GPU's
+ * device-copy rate); the kernel takes 0.94.  Removing a tenth of either side
+ * buys 2-3 %: perfectly coalesced vectors -7 %, no record load -2 %.  A
  * persistent-workgroup form (tile tickets, records prefetched a tile ahead,
- * stores deferred a tile) was built and measured slower: a wavefront that
- * loops pays for its own store acknowledgements (one in-order counter for
- * loads and stores), which a workgroup that simply ends never waits for.
+ * stores deferred a tile) was built in round 2 and measured slower: a
+ * wavefront that loops pays for its own store acknowledgements (one in-order
+ * counter for loads and stores), which a workgroup that simply ends never
+ * waits for.  Workgroups of 2 / 8 wavefronts: 0.98 / 1.15 ms.
  * ---------------------------------------------------------------------- */
 #define JM_RECON_WG (64 * JM_RECON_WAVES)   /* 4 wavefronts = 8 block rows of a tile */
 #define JM_SLOT_HALVES 72 /* 144 bytes per slot: 36-dword stride => conflict-free ds_read_b128 / ds_write_b128 */
