@@ -245,9 +245,16 @@ JM_HD void jm_recon_locate(const JmGeom &G, JM_GLOBAL const JmMbRec *mb, int g, 
  * most 16 blocks are left, `rows16` of them: 1080p luma is 7 columns + 16 blocks, 128 tiles instead of 136 with the
  * last column's lanes half idle. */
 struct JmPlaneTiles { int full, rows, rem, rem16, rows16, count; };
+/* NARROW PICTURES (luma plane less than 64 blocks = 512 pixels wide): 32-block-wide tiles leave a third of the lanes of a
+ * 40-block plane without a block (320 x 240: 70 % lane use over a picture).  There the tiles are LINEAR: a workgroup takes
+ * JM_RECON_WG consecutive blocks of the plane's block raster (a wavefront: 64 consecutive blocks, still whole row pieces
+ * per store), the two chroma planes as one raster of 2 x (bw / 2) x (bh / 2) blocks -- 8 workgroups instead of 10 for
+ * 320 x 240.  Wide pictures keep the 2-D tiles: their shared prediction window is worth more than the last lanes. */
 struct JmTiles {
 	JmPlaneTiles y, c;             /* luma, each chroma plane */
-	int per_picture;               /* y.count + 2 * c.count */
+	int per_picture;               /* y.count + 2 * c.count; linear: y.count + c.count (c.count covers both chroma planes) */
+	int linear;
+	uint32_t rcp_ybw, rcp_cbw;     /* ceil(2^32 / blocks per luma / chroma row): g / bw == mulhi(g, rcp) */
 };
 JM_HD void jm_plane_tiles_init(JmPlaneTiles &P, int bw, int bh) {
 	/* tile edges at multiples of 256 bytes, so that a wavefront's row pieces are whole 32-byte sectors (30-block tiles,
@@ -258,14 +265,50 @@ JM_HD void jm_plane_tiles_init(JmPlaneTiles &P, int bw, int bh) {
 	P.rows16 = (bh + JM_TILE16_ROWS - 1) / JM_TILE16_ROWS;
 	P.count = P.full * P.rows + (P.rem ? (P.rem16 ? P.rows16 : P.rows) : 0);
 }
+#ifndef JM_LINEAR_BELOW
+#define JM_LINEAR_BELOW 64                      /* luma blocks per row below which a picture takes linear tiles */
+#endif
 JM_HD void jm_tiles_init(JmTiles &T, const JmGeom &G) {
 	jm_plane_tiles_init(T.y, 2 * G.mb_width, 2 * G.mb_height);
 	jm_plane_tiles_init(T.c, G.mb_width, G.mb_height);
 	T.per_picture = T.y.count + 2 * T.c.count;
+	T.linear = 2 * G.mb_width < JM_LINEAR_BELOW;
+	T.rcp_ybw = G.rcp_bw; T.rcp_cbw = G.rcp_mbw;
+	if (T.linear) {
+		const int per = 64 * JM_RECON_WAVES;
+		T.y.count = (4 * G.mb_size + per - 1) / per;
+		T.c.count = (2 * G.mb_size + per - 1) / per;
+		T.per_picture = T.y.count + T.c.count;
+	}
 }
 /* lane `lane` of wavefront `wave` of tile `tile` of a picture: where its block is; false: no block (past the
  * plane's edge or the tile's width) -- Q then describes a neighbouring block, so that every lane has loads to issue */
 JM_HD bool jm_recon_where_tile(const JmGeom &G, const JmTiles &T, int tile, int wave, int lane, JmLoc &Q) {
+	if (T.linear) {
+		const int per = 64 * JM_RECON_WAVES;
+		const bool luma = tile < T.y.count;
+		int g = (luma ? tile : tile - T.y.count) * per + wave * 64 + lane;
+		const int n = luma ? 4 * G.mb_size : 2 * G.mb_size;
+		const bool ok = g < n;
+		if (!ok) g = n - 1;                          /* a lane without a block looks at the last block (loads coalesce with that lane's) */
+		int pl = 0;
+		if (!luma && g >= G.mb_size) { pl = 1; g -= G.mb_size; }
+		const int bw = luma ? 2 * G.mb_width : G.mb_width;
+		const int by = bw == 1 ? g : (int)jm_mulhi((uint32_t)g, luma ? T.rcp_ybw : T.rcp_cbw), bx = g - by * bw;
+		if (luma) {
+			Q.mbaddr = (by >> 1) * G.mb_width + (bx >> 1);
+			Q.bnum = ((by & 1) << 1) | (bx & 1);
+			Q.stride = G.coded_width; Q.ph = G.coded_height;
+			Q.plane_off = 0;
+		} else {
+			Q.mbaddr = by * G.mb_width + bx;
+			Q.bnum = 4 + pl;
+			Q.stride = G.coded_width >> 1; Q.ph = G.coded_height >> 1;
+			Q.plane_off = G.luma_bytes + (pl == 0 ? G.chroma_bytes : 0u);   /* block 4 -> the Cb plane (third), block 5 -> Cr: mpeg1.c:1571 */
+		}
+		Q.x0 = bx << 3; Q.y0 = by << 3;
+		return ok;
+	}
 	int pl = 0, t = tile;                                      /* pl: 0 luma, 1 / 2 the chroma planes in block-number order (block 4, block 5) */
 	if (tile >= T.y.count) { pl = tile >= T.y.count + T.c.count ? 2 : 1; t = tile - T.y.count - (pl - 1) * T.c.count; }
 	const JmPlaneTiles &P = pl ? T.c : T.y;
