@@ -58,8 +58,9 @@ class Bits:
         self.out += bytes([0, 0, 1, c])
 
 
-def content(width, height, n_frames, seed):
-    """Procedural pictures: a panning textured background, two moving textured rectangles, a little noise."""
+def content(width, height, n_frames, seed, pan=1.5, noise=1.5):
+    """Procedural pictures: a panning textured background (pan = pixels per picture; 0: a static one, whose macroblocks an
+    encoder skips), two moving textured rectangles, a little noise."""
     rng = np.random.RandomState(seed)
     big = 64
     yy, xx = np.mgrid[0:height + 2 * big, 0:width + 2 * big].astype(np.float64)
@@ -68,7 +69,7 @@ def content(width, height, n_frames, seed):
     tex_v = 128 + 40 * np.cos(xx / 27.0) - 25 * np.sin(yy / 13.0 + 2)
     frames = []
     for t in range(n_frames):
-        ox, oy = big + int(round(1.5 * t)), big + int(round(0.5 * t * ((t // 4) % 2 * 2 - 1)))
+        ox, oy = big + int(round(pan * t)), big + int(round(pan / 3.0 * t * ((t // 4) % 2 * 2 - 1)))
         y = tex[oy:oy + height, ox:ox + width].copy()
         u = tex_u[oy:oy + height:2, ox:ox + width:2].copy()
         v = tex_v[oy:oy + height:2, ox:ox + width:2].copy()
@@ -78,7 +79,7 @@ def content(width, height, n_frames, seed):
             y[y0:y0 + h0, x0:x0 + w0] = lum + 25 * np.sin(np.arange(w0) / 3.0)[None, :] * np.cos(np.arange(h0) / 4.0)[:, None]
             u[y0 // 2:(y0 + h0) // 2, x0 // 2:(x0 + w0) // 2] = 90 + 60 * k
             v[y0 // 2:(y0 + h0) // 2, x0 // 2:(x0 + w0) // 2] = 170 - 70 * k
-        y += 1.5 * rng.randn(*y.shape)
+        y += noise * rng.randn(*y.shape)
         frames.append((np.clip(y, 0, 255), np.clip(u, 0, 255), np.clip(v, 0, 255)))
     return frames
 
@@ -157,10 +158,10 @@ def put_motion(w, d, r_size):
     w.put(ad & (f - 1), r_size)
 
 
-def encode(width, height, n_frames, gop=6, qscale=6, f_code=1, seed=1, half_pel=True, quant_changes=True):
+def encode(width, height, n_frames, gop=6, qscale=6, f_code=1, seed=1, half_pel=True, quant_changes=True, pan=1.5, noise=1.5):
     mbw, mbh = (width + 15) >> 4, (height + 15) >> 4
     cw, ch = mbw * 16, mbh * 16
-    frames = [pad_planes(f, cw, ch) for f in content(width, height, n_frames, seed)]
+    frames = [pad_planes(f, cw, ch) for f in content(width, height, n_frames, seed, pan, noise)]
     rng = np.random.RandomState(seed + 1000)
     w = Bits()
     r_size = f_code - 1
@@ -336,6 +337,9 @@ CASES = {
     "enc_pan_176x144": dict(width=176, height=144, n_frames=13, gop=6, qscale=6, f_code=1, seed=1),
     "enc_wide_search_208x160": dict(width=208, height=160, n_frames=10, gop=5, qscale=4, f_code=2, seed=2),
     "enc_coarse_fullpel_160x128": dict(width=160, height=128, n_frames=12, gop=12, qscale=12, f_code=1, seed=3, half_pel=False),
+    # full size, a STATIC background behind the moving rectangles: rows of skipped macroblocks (increments beyond 33:
+    # macroblock_escape), zero vectors, the 2-D tiles and the 16-wide remainder column of a 1080p plane with coded video in them
+    "enc_static_1920x1080": dict(width=1920, height=1080, n_frames=3, gop=3, qscale=8, f_code=1, seed=4, pan=0.0, noise=0.0),
 }
 
 if __name__ == "__main__":
