@@ -21,7 +21,9 @@
 static __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
 /* one lane per 8x8 block of one plane of one frame; workgroup = tile of 32 x 8 blocks (wavefront: 2 block rows) */
+template <int STAGE>   /* 0: every lane gathers its rows from global memory; 1: chroma tiles stage their window in LDS; 2: luma tiles too */
 __global__ __launch_bounds__(256) void k_mem(const uint8_t *src, uint8_t *dst, uint32_t frame_bytes, uint32_t n_frames, int range) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t win[];
 	const int LW = 1920, LH = 1088;
 	/* tiles per frame: luma 8 x 17, each chroma plane 4 x 9 (960 x 544: 120 x 68 blocks) */
 	const uint32_t per = 8 * 17 + 2 * 4 * 9;
@@ -36,7 +38,6 @@ __global__ __launch_bounds__(256) void k_mem(const uint8_t *src, uint8_t *dst, u
 	else { t -= 8 * 17; W = LW / 2; H = LH / 2; cols = 4; plane_off = (uint32_t)(LW * LH); if (t >= 36) { t -= 36; plane_off += (uint32_t)(W * H); } }
 	const int ty = t / cols, tx = t - ty * cols;
 	const int bx = tx * 32 + (lane & 31), by = ty * 8 + wave * 2 + (lane >> 5);
-	if (bx >= W / 8 || by >= H / 8) return;
 	const int mbx = W == LW ? bx >> 1 : bx, mby = W == LW ? by >> 1 : by;
 	const uint32_t h = hash32((uint32_t)(f * 8160 + mby * 120 + mbx));
 	int mvx = (int)(h % (2 * range + 1)) - range, mvy = (int)((h >> 12) % (2 * range + 1)) - range;
@@ -45,11 +46,33 @@ __global__ __launch_bounds__(256) void k_mem(const uint8_t *src, uint8_t *dst, u
 	sx = sx < 0 ? 0 : (sx > W - 12 ? W - 12 : sx);
 	sy = sy < 0 ? 0 : (sy > H - 9 ? H - 9 : sy);
 	const uint8_t *fs = src + (size_t)f * frame_bytes + plane_off;
-	const uint32_t off = (uint32_t)(sy * W + sx);
-	const uint32_t *w = reinterpret_cast<const uint32_t *>(fs + (off & ~3u));
 	uint32_t R[27], a0 = 0, a1 = 0;
+	const bool staged = STAGE == 2 || (STAGE == 1 && W != LW);
+	if (staged) {
+		/* the tile's window: (256 + 2 r + 16) x (64 + 2 r + 1) bytes, x origin 16-byte aligned, clamped into the plane */
+		const int r = W == LW ? range : range / 2;
+		const int WW = (256 + 2 * r + 16 + 15) & ~15, WH = 64 + 2 * r + 1;
+		int wx0 = tx * 256 - r; wx0 = wx0 < 0 ? 0 : wx0; wx0 &= ~15; if (wx0 + WW > W) wx0 = W - WW;
+		int wy0 = ty * 64 - r; wy0 = wy0 < 0 ? 0 : wy0; if (wy0 + WH > H) wy0 = H - WH;
+		for (int i = threadIdx.x; i < WH * (WW / 16); i += 256) {
+			const int rr = i / (WW / 16), c = i - rr * (WW / 16);
+			*reinterpret_cast<uint4 *>(win + rr * WW + c * 16) = *reinterpret_cast<const uint4 *>(fs + (size_t)(wy0 + rr) * W + wx0 + c * 16);
+		}
+		__syncthreads();
+		if (bx >= W / 8 || by >= H / 8) return;
+		sx = sx < wx0 ? wx0 : (sx > wx0 + WW - 12 ? wx0 + WW - 12 : sx);
+		sy = sy < wy0 ? wy0 : (sy > wy0 + WH - 9 ? wy0 + WH - 9 : sy);
+		const uint32_t off = (uint32_t)((sy - wy0) * WW + (sx - wx0));
+		const uint32_t *w = reinterpret_cast<const uint32_t *>(win + (off & ~3u));
 #pragma unroll
-	for (int j = 0; j < 9; j++) { const uint32_t *wr = w + j * (W / 4); R[3 * j] = wr[0]; R[3 * j + 1] = wr[1]; R[3 * j + 2] = wr[2]; }
+		for (int j = 0; j < 9; j++) { const uint32_t *wr = w + j * (WW / 4); R[3 * j] = wr[0]; R[3 * j + 1] = wr[1]; R[3 * j + 2] = wr[2]; }
+	} else {
+		if (bx >= W / 8 || by >= H / 8) return;
+		const uint32_t off = (uint32_t)(sy * W + sx);
+		const uint32_t *w = reinterpret_cast<const uint32_t *>(fs + (off & ~3u));
+#pragma unroll
+		for (int j = 0; j < 9; j++) { const uint32_t *wr = w + j * (W / 4); R[3 * j] = wr[0]; R[3 * j + 1] = wr[1]; R[3 * j + 2] = wr[2]; }
+	}
 #pragma unroll
 	for (int j = 0; j < 9; j++) { a0 ^= R[3 * j] + R[3 * j + 2]; a1 += R[3 * j + 1]; }
 	uint8_t *o = dst + (size_t)f * frame_bytes + plane_off + (size_t)(by * 8) * W + bx * 8;
@@ -87,7 +110,7 @@ int main() {
 	const uint32_t per = 8 * 17 + 2 * 4 * 9, groups_m = (n_frames / 8) * 8 * per;
 	const uint32_t groups_v = 128000;               /* k_recon's 512 k wavefronts per level */
 	const int range = 16;
-	auto mem = [&](hipStream_t s) { hipLaunchKernelGGL(k_mem, dim3(groups_m), dim3(256), 0, s, src, dst, frame_bytes, n_frames, range); };
+	auto mem = [&](hipStream_t s) { hipLaunchKernelGGL(k_mem<0>, dim3(groups_m), dim3(256), 0, s, src, dst, frame_bytes, n_frames, range); };
 	auto valu = [&](hipStream_t s, int iters) { hipLaunchKernelGGL(k_valu, dim3(groups_v), dim3(256), 0, s, sink, iters, 1u); };
 	auto time1 = [&](auto fn) {
 		float best = 1e9f;
@@ -100,6 +123,17 @@ int main() {
 		}
 		return best;
 	};
+	/* the memory side at the occupancy k_recon's LDS leaves it (dynamic LDS as padding: 5 / 4 / 3 workgroups per CU) */
+	for (uint32_t pad : { 0u, 31u * 1024u, 39u * 1024u, 52u * 1024u, 79u * 1024u }) {
+		(void)hipFuncSetAttribute((const void *)k_mem<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+		(void)hipFuncSetAttribute((const void *)k_mem<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pad < 24u * 1024u ? 24u * 1024u : pad));
+		(void)hipFuncSetAttribute((const void *)k_mem<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pad < 31u * 1024u ? 31u * 1024u : pad));
+		const float t0 = time1([&](hipStream_t s) { hipLaunchKernelGGL(k_mem<0>, dim3(groups_m), dim3(256), pad, s, src, dst, frame_bytes, n_frames, range); });
+		const float t1 = time1([&](hipStream_t s) { hipLaunchKernelGGL(k_mem<1>, dim3(groups_m), dim3(256), pad < 24u * 1024u ? 24u * 1024u : pad, s, src, dst, frame_bytes, n_frames, range); });
+		const float t2 = time1([&](hipStream_t s) { hipLaunchKernelGGL(k_mem<2>, dim3(groups_m), dim3(256), pad < 31u * 1024u ? 31u * 1024u : pad, s, src, dst, frame_bytes, n_frames, range); });
+		printf("memory side alone, %2u KB of LDS per workgroup (%s workgroups per CU): direct gather %.3f ms | chroma windows through LDS %.3f | all windows through LDS %.3f\n",
+		       pad / 1024, pad == 0 ? "8 / 6 / 5" : pad < 32768 ? "5" : pad < 40960 ? "4" : pad < 60000 ? "3" : "2", t0, t1, t2);
+	}
 	const float t_mem = time1([&](hipStream_t s) { mem(s); });
 	printf("memory side alone (k_recon's prediction reads + plane stores, 640 pictures, +-%d px): %.3f ms  (%.2f GB algorithmic)\n", range, t_mem,
 	       2.0 * n_frames * frame_bytes / 1e9);
