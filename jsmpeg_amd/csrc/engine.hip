@@ -516,23 +516,6 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	tr.mark("pics-copied");
 	for (uint32_t i = 0; i < b->n_pics; i++) if (b->h_pics[i].decoded) { b->n_decoded++; b->n_slices += b->h_pics[i].n_slices; }
 	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
-	/* The reconstruct plan.  A picture comes after its forward reference -- and, if it leaves macroblocks UNWRITTEN,
-	 * after the frame those keep showing: the reference keeps two plane sets and rotates them after every picture
-	 * (mpeg1.c:986-994), so a macroblock a picture never writes -- e.g. a last macroblock of 6 bits (forward vector
-	 * repeated, nothing coded: common in a pan) that hides in the slack of the slice's last byte, so that
-	 * next_bytes_are_start_code ends the slice before it (mpeg1.c:1018-1020) -- keeps the decoded picture before
-	 * last.  Here every picture has its own frame, so such a block is copied from that picture's frame (`stale`).
-	 * Whether a picture has unwritten macroblocks is only known after the parse: the pictures without a forward
-	 * reference are reconstructed right behind it (step 4a: intra pictures hardly ever have such macroblocks), the
-	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs. */
-	std::vector<int32_t> stale;
-	const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
-	{
-		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
-		uint32_t k = 0;
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
-		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
-	}
 	if (++b->epoch == 0) {
 		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
 		b->epoch = 1;
@@ -571,6 +554,24 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	if (b->n_pics) HIP_TRY(hipMemcpyAsync(b->h_covered, b->d_covered, sizeof(uint32_t) * b->n_pics, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(b->ev_cov, st));
 
+	/* The reconstruct plan.  A picture comes after its forward reference -- and, if it leaves macroblocks UNWRITTEN,
+	 * after the frame those keep showing: the reference keeps two plane sets and rotates them after every picture
+	 * (mpeg1.c:986-994), so a macroblock a picture never writes -- e.g. a last macroblock of 6 bits (forward vector
+	 * repeated, nothing coded: common in a pan) that hides in the slack of the slice's last byte, so that
+	 * next_bytes_are_start_code ends the slice before it (mpeg1.c:1018-1020) -- keeps the decoded picture before
+	 * last.  Here every picture has its own frame, so such a block is copied from that picture's frame (`stale`).
+	 * Whether a picture has unwritten macroblocks is only known after the parse: the pictures without a forward
+	 * reference are reconstructed right behind it (step 4a: intra pictures hardly ever have such macroblocks), the
+	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs.
+	 * (Laid out here, while the GPU is busy with the parse: the descriptors are only read by the reconstruct.) */
+	std::vector<int32_t> stale;
+	const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+	{
+		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
+		uint32_t k = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
+		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
+	}
 	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
