@@ -436,9 +436,13 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * loop ends; the bound is a backstop against a wedged wavefront, not a code path */
 #ifdef JM_PARSE_STATS   /* diagnostics build (tools/parse_stats.py): turn statistics per wavefront into b.dbg */
 	uint32_t st_turns = 0, st_cold = 0, st_coef1 = 0, st_coef2 = 0, st_blocked = 0, st_dc = 0, st_slow = 0, st_live = 0, st_service = 0;
+	uint64_t ck_service = 0, ck_cold = 0, ck_dc = 0, ck_coef1 = 0, ck_slow = 0, ck_coef2 = 0, ck_t = 0;   /* shader clocks inside each part of the turn */
+	const uint64_t ck_begin = __builtin_readcyclecounter();
 #define JM_STAT(x) x
+#define JM_CK(acc, body) { ck_t = __builtin_readcyclecounter(); body; acc += __builtin_readcyclecounter() - ck_t; }
 #else
 #define JM_STAT(x)
+#define JM_CK(acc, body) { body; }
 #endif
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
 		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, its token slots) */
@@ -447,24 +451,26 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		const uint64_t blocked = __ballot(live && !ready);
 		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
 		if (n_cold == 0 && !others) break;
-		if (blocked) { JM_STAT(st_service++;) if (live) jm_lane_service(L); }
+		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_service(L)) }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
-		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { JM_STAT(st_cold++;) if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c); }
+		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { JM_STAT(st_cold++;) JM_CK(ck_cold, if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c)) }
 		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
-		if (ready && L.state == JM_ST_DC) jm_step_dc(L, c);
+		JM_CK(ck_dc, if (ready && L.state == JM_ST_DC) jm_step_dc(L, c))
 		JM_STAT(st_coef1 += __popcll(__ballot(ready && L.state == JM_ST_COEF));)
-		if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+		JM_CK(ck_coef1, if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c))
 		JM_STAT(st_slow += __popcll(__ballot(ready && L.state == JM_ST_SLOW));)
-		if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c);
+		JM_CK(ck_slow, if (ready && L.state == JM_ST_SLOW) jm_step_slow(L, c))
 #pragma unroll
 		for (int k = 1; k < JM_COEF_REPEAT; k++) {
-			JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c);
+			JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) JM_CK(ck_coef2, if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c))
 		}
 	}
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {
-		uint32_t *o = b.dbg + (size_t)batch * 8;
+		uint32_t *o = b.dbg + (size_t)batch * 16;
 		o[0] = st_turns; o[1] = st_cold; o[2] = st_coef1; o[3] = st_coef2; o[4] = st_blocked; o[5] = st_dc; o[6] = st_slow; o[7] = st_live | (st_service << 20);
+		o[8] = (uint32_t)(__builtin_readcyclecounter() - ck_begin); o[9] = (uint32_t)ck_service; o[10] = (uint32_t)ck_cold; o[11] = (uint32_t)ck_dc;
+		o[12] = (uint32_t)ck_coef1; o[13] = (uint32_t)ck_slow; o[14] = (uint32_t)ck_coef2; o[15] = 0;
 	}
 #endif
 	if (mine) {

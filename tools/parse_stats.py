@@ -23,8 +23,8 @@ with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, to
     b.upload(streams)
     b.decode()
     n_slices = b.counters()["slices"]
-    n_waves = n_slices        # at most one entry per slice (small passes take fewer than 64 slices per wavefront)
-    a = np.zeros((n_waves, 8), np.uint32)
+    n_waves = max(1, n_slices // 4)   # 16 words per wavefront in a buffer of 4 words per start code (passes of 64 slices per wavefront)
+    a = np.zeros((n_waves, 16), np.uint32)
     assert L.jsmpeg_hip_batch_debug_read(b.h, 8, a.ctypes.data, 0, a.nbytes) == 0, jb.last_error()
     a = a[a[:, 0] != 0xeeeeeeee]
     service = (a[:, 7] >> 20).astype(np.float64)
@@ -35,4 +35,10 @@ with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, to
     print("header steps per turn %.3f, ring services per turn %.3f" % (a[:, 1].sum() / t.sum(), service.sum() / t.sum()))
     for name, col in (("live", 7), ("blocked", 4), ("DC ready", 5), ("COEF ready (1st)", 2), ("SLOW ready", 6), ("COEF ready (2nd)", 3)):
         print("%-18s lanes per turn %.1f" % (name, a[:, col].sum() / t.sum()))
+    ck = a[:, 8:15]
+    if ck[:, 0].sum() > 0:      # shader clocks (s_memtime) of the turn loop and inside each of its parts, per wavefront
+        tot = ck[:, 0].sum()
+        print("shader clocks per turn %.0f; share of the turn loop: " % (tot / t.sum())
+              + ", ".join("%s %.1f %%" % (n, 100.0 * ck[:, k].sum() / tot) for k, n in ((1, "ring service"), (2, "COLD"), (3, "DC"), (4, "COEF 1st"), (5, "SLOW"), (6, "COEF 2nd")))
+              + ", rest (scheduling, waits between steps) %.1f %%" % (100.0 * (tot - ck[:, 1:7].sum()) / tot))
     print(b.timings())
