@@ -672,10 +672,12 @@ def main():
         peak = 1024 / 1.15             # G wavefront-instructions/s: 1024 SIMDs, 1.15 ns per two-operand instruction at 8 wavefronts per SIMD
         ach = n_inst / (parse_ms * 1e-3) / 1e9
         parse_roof = {"kernel": "k_parse", "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
-                      "unit": "G wavefront-instructions/s", "frac": round(ach / peak, 4), "avg_launch_ms": round(parse_ms, 4),
+                      "unit": "G wavefront-instructions/s", "frac": round(ach / peak, 4),
+                      "frac_at_slow_class_rate": round(ach / (1024 / 1.8), 4), "avg_launch_ms": round(parse_ms, 4),
                       "instructions_per_pass": int(n_inst), "instructions_source": "static: profiles/pmc_valu.json (%s), SQ_INSTS_VALU, not measured in this run" % vj.get("source", "?"),
                       "peak_note": "1024 SIMDs / 1.15 ns per two-operand VALU instruction (tools/ubench.hip, 8 wavefronts per SIMD: the chip holds "
-                                   "1.2-1.5 GHz under that load); three-operand forms, 24-bit multiplies and byte permutes issue at 1.8 ns",
+                                   "1.2-1.5 GHz under that load); three-operand forms, 24-bit multiplies and byte permutes issue at 1.8 ns "
+                                   "(frac_at_slow_class_rate prices every instruction at that): the pass's VALU is between the two busy",
                       "hbm_fetch_over_es": round(tj.get("fetch_bytes", {}).get("k_parse", 0) / max(1, es_bytes), 2) or None,
                       "hbm_traffic_over_es": round(tj.get("k_parse", 0) / max(1, es_bytes), 2) or None}
     except Exception as e:
