@@ -275,7 +275,8 @@ def main():
         mine = pieces[rank]
         n_units = len(mine["units"])
         shard_len = int(mine["size"])
-        d_piece = [torch.empty(shard_len, dtype=torch.uint8, device=dev) for _ in range(2)]   # double-buffered receive
+        # double-buffered receive; the decode reads a piece where it arrived (jsmpeg_hip_batch_attach_device): 0xff behind it
+        d_piece = [torch.full((shard_len + 4096,), 0xFF, dtype=torch.uint8, device=dev) for _ in range(2)]
         xfer = torch.cuda.Stream(device=dev)               # the exchange runs beside the decode kernels
         xptr = ctypes.c_void_p(xfer.cuda_stream)
         # ---- the other ingest mode: every rank KEEPS the units of the streams that arrived on it, the plan moves only
@@ -289,7 +290,7 @@ def main():
         h_send = np.full(lay["send_size"], 0xFF, dtype=np.uint8)
         for u, pos in zip(lay["send_units"], lay["send_pos"]):
             h_send[pos:pos + len(my_bytes[u])] = my_bytes[u]
-        h_work = np.full(lay["size"], 0xFF, dtype=np.uint8)
+        h_work = np.full(lay["size"] + 4096, 0xFF, dtype=np.uint8)
         for u, bb, ee in zip(lay["units"], lay["begin"], lay["end"]):
             if home[u] == rank:
                 h_work[int(bb):int(ee)] = my_bytes[u]            # the units this rank keeps: resident before the timed region
@@ -299,9 +300,9 @@ def main():
         sent_by_rank = [int(sum(ly["send_bytes"])) for ly in lays]
         modes = {
             "single_source": dict(begin=mine["begin"], end=mine["end"], shard_len=shard_len, bufs=d_piece, units_of_rank=[p["units"] for p in pieces],
-                                  n_pictures=sum(unit_pics[u] for u in mine["units"]), n_units=n_units, ms=[]),
+                                  n_pictures=sum(unit_pics[u] for u in mine["units"]), n_units=n_units, ms=[], ev=[]),
             "local_ingest": dict(begin=lay["begin"], end=lay["end"], shard_len=int(lay["size"]), bufs=d_work, units_of_rank=[ly["units"] for ly in lays],
-                                 n_pictures=sum(unit_pics[u] for u in lay["units"]), n_units=len(lay["units"]), ms=[]),
+                                 n_pictures=sum(unit_pics[u] for u in lay["units"]), n_units=len(lay["units"]), ms=[], ev=[]),
         }
         X = modes["single_source"]                     # the headline: what north_star words ("RCCL ... of stream slices")
         n_pictures = X["n_pictures"]
@@ -363,9 +364,11 @@ def main():
                 state["pending"] = start_scatter(state["cur"])
             e0, e1 = state["pending"]
             stream.wait_event(e1)
-            b.upload_device(ctypes.c_void_p(X["bufs"][state["cur"]].data_ptr()), X["shard_len"], X["begin"], X["end"], sptr)   # returns when the piece has been copied
+            # the piece is decoded where it arrived (no placement pass); its buffer is next written by the scatter two steps on,
+            # which waits for this stream (start_scatter)
+            b.attach_device(ctypes.c_void_p(X["bufs"][state["cur"]].data_ptr()), X["shard_len"], X["begin"], X["end"], sptr)
             if collect:
-                X["ms"].append(e0.elapsed_time(e1))
+                X["ev"].append((e0, e1))          # read after the run: nothing in a step waits for the host any more
             state["pending"] = None
             if more and overlap:
                 state["cur"] ^= 1
@@ -437,6 +440,9 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         scrub["ms"] = scrub["events"][0].elapsed_time(scrub["events"][1])
+        if multi:
+            X["ms"].extend(a.elapsed_time(bb) for a, bb in X["ev"])
+            X["ev"].clear()
         if multi:
             tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

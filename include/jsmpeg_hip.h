@@ -126,6 +126,16 @@ int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uin
 int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,
                                    uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
                                    void *hip_stream);
+/* The same WITHOUT the copy: the next decode reads `dev_es` in place (a rank's piece as it arrived by
+ * jsmpeg_hip_dist_scatter / _exchange, part 4: no placement pass in front of every step).  What the caller promises:
+ * `dev_es` is 16-byte aligned and readable 256 bytes past `total_bytes`; every begin[i] is a multiple of 16, ranges
+ * ascend with >= 8 bytes between them, and every byte outside the ranges (the gaps, the tail) is 0xff -- a gap must
+ * not complete a start code; the buffer is left alone until the decode that follows has finished on `hip_stream`.
+ * Returns at once (the stream table is copied on `hip_stream`); 0 or < 0 (misaligned / touching ranges are refused,
+ * nothing is decoded from them).  The next upload* call returns the batch to its own buffer. */
+int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,
+                                   uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
+                                   void *hip_stream);
 
 /* Ingest side on the device (reference src/ts.js:25-210): n_streams
  * MPEG-TS buffers (host) -> the elementary streams of `stream_id` (0xE0 = the

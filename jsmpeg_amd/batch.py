@@ -21,7 +21,7 @@ class PictureInfo(ctypes.Structure):
 
 
 BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_hip_batch_upload",
-                 "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
+                 "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_attach_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
@@ -40,7 +40,7 @@ def lib():
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: build it with `python -m jsmpeg_amd.build hip` "
                                "(there is no CPU fallback for the decode path)" % path)
-        L = ctypes.CDLL(path)
+        L = _build.load_hip_library(path)
         vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
         L.jsmpeg_hip_batch_create.restype = vp
         L.jsmpeg_hip_batch_create.argtypes = [ctypes.POINTER(BatchConfig)]
@@ -50,6 +50,8 @@ def lib():
         L.jsmpeg_hip_batch_upload.argtypes = [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
         L.jsmpeg_hip_batch_upload_device.restype = ctypes.c_int
         L.jsmpeg_hip_batch_upload_device.argtypes = [vp, vp, u64, u32, vp, vp, vp]
+        L.jsmpeg_hip_batch_attach_device.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_attach_device.argtypes = [vp, vp, u64, u32, vp, vp, vp]
         L.jsmpeg_hip_batch_decode.restype = ctypes.c_int
         L.jsmpeg_hip_batch_decode.argtypes = [vp, vp]
         L.jsmpeg_hip_batch_sync.restype = ctypes.c_int
@@ -170,6 +172,14 @@ class Batch:
         begin = np.ascontiguousarray(begin, dtype=np.uint32)
         end = np.ascontiguousarray(end, dtype=np.uint32)
         self._ok(self.L.jsmpeg_hip_batch_upload_device(self.h, dev_ptr, total_bytes, len(begin), begin.ctypes.data,
+                                                       end.ctypes.data, stream))
+
+    def attach_device(self, dev_ptr, total_bytes, begin, end, stream=None):
+        """upload_device without the copy: the next decode reads the caller's packed device buffer in place
+        (16-byte aligned begins, 0xff between the ranges; include/jsmpeg_hip.h)"""
+        begin = np.ascontiguousarray(begin, dtype=np.uint32)
+        end = np.ascontiguousarray(end, dtype=np.uint32)
+        self._ok(self.L.jsmpeg_hip_batch_attach_device(self.h, dev_ptr, total_bytes, len(begin), begin.ctypes.data,
                                                        end.ctypes.data, stream))
 
     def decode(self, stream=None, sync=True):

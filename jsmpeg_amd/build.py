@@ -23,6 +23,32 @@ WASM_REF = os.path.join(REF_DIR, "jsmpeg_ref.wasm")
 JS_REF = os.path.join(REF_DIR, "jsmpeg_ref.min.js")
 
 
+_hip_runtime = None
+
+
+def load_hip_library(path=None):
+    """ctypes.CDLL of the decode library, bound to ONE HIP runtime per process.  The library needs libamdhip64.so.7; so
+    does PyTorch, which ships its own copy under torch/lib.  Whichever is loaded first wins for the whole process (same
+    SONAME), and torch does not find a GPU through the system's copy ("No HIP GPUs are available").  So: when PyTorch is
+    installed and has not been imported yet, ITS runtime is loaded first (by path, without importing torch); a torch
+    imported earlier has done that already.  Without PyTorch (the Node host, a C++ host) the system's runtime is used."""
+    global _hip_runtime
+    import ctypes
+    import importlib.util
+    if _hip_runtime is None:
+        _hip_runtime = False
+        if "torch" not in sys.modules:
+            try:
+                spec = importlib.util.find_spec("torch")
+            except (ImportError, ValueError):
+                spec = None
+            if spec is not None and spec.origin:
+                cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+                if os.path.exists(cand):
+                    _hip_runtime = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    return ctypes.CDLL(path or LIB_HIP)
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True

@@ -6,6 +6,7 @@ The same wrapper drives three libraries that export that ABI:
   * oracle/_ref/libjsmpeg_ref.so - the reference's own C (tests / cpu_baseline only)
 This module never picks a library itself: callers pass the path."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -34,10 +35,19 @@ ABI_SYMBOLS = tuple(_SIGS)
 _libs = {}
 
 
+def _load_shared(path):
+    # the HIP library goes through build.load_hip_library (one HIP runtime per process, the one PyTorch ships if installed);
+    # the oracle and the reference's own C are plain CPU libraries
+    from . import build
+    if os.path.abspath(path) == os.path.abspath(build.LIB_HIP):
+        return build.load_hip_library(path)
+    return ctypes.CDLL(path)
+
+
 def load(path):
     lib = _libs.get(path)
     if lib is None:
-        lib = ctypes.CDLL(path)
+        lib = _load_shared(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype = res
@@ -199,7 +209,7 @@ _mp2_libs = {}
 def load_mp2(path):
     lib = _mp2_libs.get(path)
     if lib is None:
-        lib = ctypes.CDLL(path)
+        lib = _load_shared(path)
         for name, (res, args) in _MP2_SIGS.items():
             fn = getattr(lib, name)
             fn.restype = res

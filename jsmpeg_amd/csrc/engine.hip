@@ -91,6 +91,7 @@ struct jsmpeg_hip_batch_t {
 	hipStream_t stream;          /* stream of the last decode */
 
 	uint8_t *d_es; uint64_t es_cap; uint32_t es_bytes;
+	const uint8_t *es_view;      /* what the decode reads: d_es, or the caller's buffer after jsmpeg_hip_batch_attach_device */
 	uint32_t n_streams;
 	std::vector<JmStream> h_streams;
 	JmStream *d_streams;
@@ -237,6 +238,7 @@ static int batch_layout(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint64_
 	if (off + JM_ES_PAD > b->es_cap) return fail("batch layout exceeds the ES buffer");
 	b->es_bytes = (uint32_t)off;
 	b->n_streams = n_streams;
+	b->es_view = b->d_es;
 	return 0;
 }
 
@@ -413,7 +415,7 @@ extern "C" int64_t jsmpeg_hip_batch_read_es(jsmpeg_hip_batch_t *b, uint32_t stre
 	HIP_TRY(hipSetDevice(b->device));
 	const JmStream &s = b->h_streams[stream];
 	const uint64_t n = s.es_end - s.es_begin, k = std::min(n, cap);
-	if (k && out) HIP_TRY(hipMemcpy(out, b->d_es + s.es_begin, k, hipMemcpyDeviceToHost));
+	if (k && out) HIP_TRY(hipMemcpy(out, b->es_view + s.es_begin, k, hipMemcpyDeviceToHost));
 	return (int64_t)n;
 }
 
@@ -447,6 +449,40 @@ extern "C" int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void 
 		HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
 	}
 	HIP_TRY(hipStreamSynchronize(st));
+	return 0;
+}
+
+/* The zero-copy form of upload_device: the decode reads the caller's packed device buffer in place. */
+extern "C" int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,
+                                              uint32_t n_streams, const uint32_t *begin, const uint32_t *end,
+                                              void *hip_stream) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	if (n_streams > b->cfg.max_streams) return fail("%u streams > max_streams %u", n_streams, b->cfg.max_streams);
+	if (((uintptr_t)dev_es & 15u) != 0) return fail("attach: the buffer must be 16-byte aligned");
+	if (total_bytes + JM_ES_PAD >= (1ull << 32)) return fail("attach: batch ES positions are 32-bit");
+	uint64_t sum = 0, prev_end = 0;
+	for (uint32_t i = 0; i < n_streams; i++) {
+		if (end[i] < begin[i] || end[i] > total_bytes) return fail("stream %u: bad byte range", i);
+		if ((begin[i] & 15u) != 0) return fail("attach: stream %u does not begin on a 16-byte boundary (use upload_device)", i);
+		if (begin[i] < prev_end + JM_STREAM_GAP) return fail("attach: stream %u begins less than %d bytes after the one before", i, JM_STREAM_GAP);
+		prev_end = end[i];
+		sum += end[i] - begin[i];
+	}
+	if (sum > b->cfg.max_es_bytes) return fail("batch of %llu ES bytes > max_es_bytes %llu", (unsigned long long)sum, (unsigned long long)b->cfg.max_es_bytes);
+	b->h_streams.assign(n_streams, JmStream());
+	for (uint32_t i = 0; i < n_streams; i++) {
+		JmStream &s = b->h_streams[i];
+		memset(&s, 0, sizeof(s));
+		s.es_begin = begin[i]; s.es_end = end[i]; s.seq_sc = JM_NONE;
+	}
+	b->es_bytes = (uint32_t)total_bytes;
+	b->n_streams = n_streams;
+	b->es_view = (const uint8_t *)dev_es;
+	/* (pageable source: the runtime has taken its copy when the call returns) */
+	if (n_streams) HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
 	return 0;
 }
 
@@ -490,12 +526,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	HIP_TRY(hipEventRecord(b->ev[0], st));
 	HIP_TRY(hipMemsetAsync(b->d_counters, 0, JM_N_COUNTERS * sizeof(uint32_t), st));
 	JmScanBufs sb;
-	sb.es = b->d_es; sb.n_bytes = b->es_bytes; sb.state = b->d_scan_state; sb.slice_sc = b->d_slice_sc; sb.sc_owner = b->d_sc_owner;
+	sb.es = b->es_view; sb.n_bytes = b->es_bytes; sb.state = b->d_scan_state; sb.slice_sc = b->d_slice_sc; sb.sc_owner = b->d_sc_owner;
 	sb.sc_pos = b->d_sc_pos; sb.sc_code = b->d_sc_code; sb.pic_sc = b->d_pic_sc; sb.counters = b->d_counters;
 	sb.sc_cap = b->sc_cap; sb.pic_cap = b->cfg.max_pictures; sb.pos_bias = 0;
 	HIP_TRY(jm_launch_scan(sb, st));
 	JmIndexBufs ib;
-	ib.es = b->d_es; ib.sc_pos = b->d_sc_pos; ib.sc_code = b->d_sc_code; ib.sc_owner = b->d_sc_owner;
+	ib.es = b->es_view; ib.sc_pos = b->d_sc_pos; ib.sc_code = b->d_sc_code; ib.sc_owner = b->d_sc_owner;
 	ib.pic_sc = b->d_pic_sc; ib.counters = b->d_counters; ib.streams = b->d_streams; ib.pics = b->d_pics;
 	ib.counters_rw = b->d_counters; ib.n_streams = b->n_streams; ib.sc_cap = b->sc_cap; ib.pic_cap = b->cfg.max_pictures;
 	ib.width = b->cfg.width; ib.height = b->cfg.height;
@@ -524,7 +560,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 3. slice parse: every slice of the batch at once ---- */
 	JmParseBufs pb;
-	pb.es = b->d_es; pb.sc_pos = b->d_sc_pos; pb.sc_code = b->d_sc_code; pb.sc_owner = b->d_sc_owner;
+	pb.es = b->es_view; pb.sc_pos = b->d_sc_pos; pb.sc_code = b->d_sc_code; pb.sc_owner = b->d_sc_owner;
 	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
 	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
 	pb.ticket = b->d_order_hist + 2 * JM_ORDER_BINS;
@@ -778,7 +814,7 @@ extern "C" int jsmpeg_hip_batch_debug_read(jsmpeg_hip_batch_t *b, int what, void
 	case 4: src = (const uint8_t *)b->d_mb; break;
 	case 5: src = (const uint8_t *)b->d_tokens; break;
 	case 6: src = (const uint8_t *)b->d_streams; break;
-	case 7: src = (const uint8_t *)b->d_es; break;
+	case 7: src = b->es_view; break;
 	case 8: src = (const uint8_t *)b->d_dbg; break;
 	case 9: src = (const uint8_t *)b->d_slice_sc; break;      /* the scan's list of slice codes, stream order */
 	case 10: src = (const uint8_t *)b->d_slice_order; break;  /* ... in the order the slice parse takes them */

@@ -28,7 +28,7 @@ def lib():
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: build it with `python -m jsmpeg_amd.build hip` "
                                "(there is no CPU fallback for the MP2 decode stage)" % path)
-        L = ctypes.CDLL(path)
+        L = _build.load_hip_library(path)
         vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
         L.jsmpeg_hip_mp2_batch_create.restype = vp
         L.jsmpeg_hip_mp2_batch_create.argtypes = [u32, u64, i32]

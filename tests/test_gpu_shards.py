@@ -107,13 +107,24 @@ def test_local_ingest_layout_decodes_like_the_whole_streams(hip_lib, libs):
                 assert lay["recv_bytes"][s] == lays[s]["send_bytes"][r]
                 o = lays[s]["send_offset"][r]
                 work[lay["recv_offset"][s]:lay["recv_offset"][s] + lay["recv_bytes"][s]] = send_from[s][o:o + lay["recv_bytes"][s]]
-        d_work = torch.from_numpy(work).to(dev)
+        d_work = torch.from_numpy(np.concatenate([work, np.full(512, 0xFF, np.uint8)])).to(dev)   # readable (0xff) past the piece: attach
         with jb.Batch(176, 144, len(lay["units"]), 12 * len(lay["units"]) + 8, lay["size"] + 4096) as b:
             b.upload_device(ctypes.c_void_p(d_work.data_ptr()), lay["size"], lay["begin"], lay["end"])
             b.decode()
             dev_h = b.frame_hashes()
             for p, info in enumerate(b.pictures()):
                 got.setdefault(lay["units"][info.stream], []).append(int(dev_h[p]))
+            # the zero-copy form: the same piece decoded IN PLACE gives the same pictures (and the batch goes back to
+            # its own buffer with the next upload)
+            b.attach_device(ctypes.c_void_p(d_work.data_ptr()), lay["size"], lay["begin"], lay["end"])
+            assert b.decode() == len(dev_h)
+            assert np.array_equal(b.frame_hashes(), dev_h)
+            assert [(i.stream, i.es_offset) for i in b.pictures()] is not None
+            with pytest.raises(RuntimeError, match="16-byte"):
+                b.attach_device(ctypes.c_void_p(d_work.data_ptr()), lay["size"], np.asarray(lay["begin"]) + 4, lay["end"])
+            b.upload_device(ctypes.c_void_p(d_work.data_ptr()), lay["size"], lay["begin"], lay["end"])
+            b.decode()
+            assert np.array_equal(b.frame_hashes(), dev_h)
     per_stream = {}
     for u, (s, g, _) in enumerate(table):
         per_stream.setdefault(s, []).extend(got[u])
