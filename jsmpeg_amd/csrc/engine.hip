@@ -463,6 +463,9 @@ extern "C" int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void 
 	if (n_streams > b->cfg.max_streams) return fail("%u streams > max_streams %u", n_streams, b->cfg.max_streams);
 	if (((uintptr_t)dev_es & 15u) != 0) return fail("attach: the buffer must be 16-byte aligned");
 	if (total_bytes + JM_ES_PAD >= (1ull << 32)) return fail("attach: batch ES positions are 32-bit");
+	/* the start-code tables and the scan's state were sized for the batch's own buffer */
+	if (total_bytes + JM_ES_PAD > b->es_cap) return fail("attach: %llu bytes > the %llu the batch was created for",
+	                                                    (unsigned long long)total_bytes, (unsigned long long)(b->es_cap - JM_ES_PAD));
 	uint64_t sum = 0, prev_end = 0;
 	for (uint32_t i = 0; i < n_streams; i++) {
 		if (end[i] < begin[i] || end[i] > total_bytes) return fail("stream %u: bad byte range", i);
