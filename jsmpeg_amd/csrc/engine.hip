@@ -568,6 +568,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
 	pb.ticket = b->d_order_hist + 2 * JM_ORDER_BINS;
 	pb.slice_sc = b->d_slice_sc; pb.n_lanes = std::min(b->h_counters[4], b->sc_cap);   /* a lane per slice code (not per start code) */
+	pb.long_slices = 0;
 	if (!getenv("JSMPEG_HIP_STREAM_ORDER")) {   /* (the variable: slices in stream order, for measurements) */
 		JmOrderBufs ob;
 		ob.slice_sc = b->d_slice_sc; ob.sc_pos = b->d_sc_pos; ob.sc_owner = b->d_sc_owner;
@@ -578,6 +579,20 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		ob.hist = b->d_order_hist; ob.order = b->d_slice_order;
 		HIP_TRY(jm_launch_order(ob, st));
 		pb.slice_sc = b->d_slice_order;
+		/* how many slices are much longer than the mean (the intra pictures' in an I + P batch), from the picture table:
+		 * a picture's bytes / its slices against the batch's.  The slices come longest first; jm_launch_parse gives that
+		 * many fewer lanes per wavefront when the pass is of a size where it pays. */
+		if (pb.n_lanes) {
+			uint64_t longs = 0;
+			for (uint32_t p = 0; p < b->n_pics; p++) {
+				const JmPic &pic = b->h_pics[p];
+				if (!pic.decoded || !pic.n_slices || pic.stream >= b->n_streams) continue;
+				const uint32_t end = p + 1 < b->n_pics && b->h_pics[p + 1].stream == pic.stream ? b->h_pics[p + 1].pos : b->h_streams[pic.stream].es_end;
+				const uint64_t bytes = end > pic.pos ? end - pic.pos : 0;
+				if (bytes * 2 * pb.n_lanes >= (uint64_t)3 * b->es_bytes * pic.n_slices) longs += pic.n_slices;   /* >= 1.5 x the mean slice */
+			}
+			pb.long_slices = (uint32_t)std::min<uint64_t>(longs + longs / 8, pb.n_lanes);                  /* + 1/8: the estimate is by picture, the order by slice */
+		}
 	}
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
@@ -1185,7 +1200,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	JmParseBufs pb;
 	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
 	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
-	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.ticket = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
+	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.long_slices = 0; pb.ticket = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;

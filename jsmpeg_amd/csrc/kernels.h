@@ -91,6 +91,10 @@ struct JmParseBufs {
 	uint8_t epoch;
 	uint32_t lanes_per_wave;     /* set by jm_launch_parse: slices a wavefront takes (64, fewer for small batches) */
 	int cold_threshold;          /* ... and the lanes that must queue for the header step before it runs */
+	uint32_t long_slices;        /* caller's estimate of how many slices are much longer than the mean (those of the intra pictures), 0: none
+	                                -- with the slices in longest-first order, jm_launch_parse gives the first ones fewer lanes per wavefront */
+	uint32_t head_batches[2], head_lanes[2], head_first[3];   /* set by jm_launch_parse: batches [0, hb0) take hl0 slices each from slice 0,
+	                                the next hb1 take hl1 each from head_first[1], the rest lanes_per_wave each from head_first[2] */
 	int debug_flags;             /* diagnostics only: 4 = per-slice abort records, 8 = always 64 slices per wavefront */
 	uint32_t *dbg;               /* diagnostics only: 4 words per start-code entry, or null */
 };

@@ -397,7 +397,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * a wavefront that is through starts on the next slices at once instead of waiting for the seven others of its
 	 * workgroup, and the pass has no rounds of workgroups to fall between. */
 	for (uint32_t batch = blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave; batch < b.n_batches;) {
-	const uint32_t j = (uint32_t)lane < b.lanes_per_wave ? batch * b.lanes_per_wave + (uint32_t)lane : 0xffffffffu;
+	/* (mid-size passes: the batches of the longest slices take fewer of them, jm_launch_parse) */
+	uint32_t lanes = b.lanes_per_wave, first = b.head_first[2] + (batch - b.head_batches[0] - b.head_batches[1]) * b.lanes_per_wave;
+	if (batch < b.head_batches[0]) { lanes = b.head_lanes[0]; first = batch * lanes; }
+	else if (batch < b.head_batches[0] + b.head_batches[1]) { lanes = b.head_lanes[1]; first = b.head_first[1] + (batch - b.head_batches[0]) * lanes; }
+	const int cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+	const uint32_t j = (uint32_t)lane < lanes ? first + (uint32_t)lane : 0xffffffffu;
 	uint32_t i = 0xffffffffu;
 	if (b.slice_sc) { if (j < b.n_lanes) i = b.slice_sc[j]; }
 	else i = j;
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		if (n_cold == 0 && !others) break;
 		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_service(L)) }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
-		if (jm_run_cold(n_cold, others ? 1 : 0, b.cold_threshold)) { JM_STAT(st_cold++;) JM_CK(ck_cold, if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c)) }
+		if (jm_run_cold(n_cold, others ? 1 : 0, cold_threshold)) { JM_STAT(st_cold++;) JM_CK(ck_cold, if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c)) }
 		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
 		JM_CK(ck_dc, if (ready && L.state == JM_ST_DC) jm_step_dc(L, c))
 		JM_STAT(st_coef1 += __popcll(__ballot(ready && L.state == JM_ST_COEF));)
@@ -499,11 +504,58 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 		while (lanes < 64 && (uint64_t)lanes * JM_PARSE_FILL_WAVES < b.n_lanes) lanes <<= 1;
 	}
 	if (b.debug_flags & 8) lanes = 64;
+	bool lanes_forced = false;
 	{ static const int forced = getenv("JSMPEG_HIP_PARSE_LANES") ? atoi(getenv("JSMPEG_HIP_PARSE_LANES")) : 0;   /* tuning only */
-	  if (forced >= 1 && forced <= 64) lanes = (uint32_t)forced; }
+	  if (forced >= 1 && forced <= 64) { lanes = (uint32_t)forced; lanes_forced = true; } }
 	b.lanes_per_wave = lanes;
 	b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
-	b.n_batches = (b.n_lanes + lanes - 1) / lanes;
+	/* Mid-size passes with a few LONG slices (16 x 24 pictures of 4K: the 8 % of the slices that belong to intra pictures
+	 * are three times the others): the pass lasts as long as the wavefront that holds the longest slices walks, and a
+	 * wavefront with one or two slices walks about twice as fast as one with 16+ (its turns run only the step kinds those
+	 * lanes need).  The slices come longest first, so: the first `long_slices` of them at a few per wavefront, the rest at
+	 * `lanes`. */
+	b.head_batches[0] = b.head_batches[1] = 0; b.head_lanes[0] = b.head_lanes[1] = 1;
+	b.head_first[0] = b.head_first[1] = b.head_first[2] = 0;
+	uint32_t H = b.long_slices, seg_a = 0;
+	bool forced = false;
+	if (const char *e = getenv("JSMPEG_HIP_PARSE_HEAD")) {   /* tests / tuning: "a,l0,h,l1" = the first a slices l0 per wavefront, up to slice h l1 per wavefront */
+		unsigned a = 0, l0 = 1, h = 0, l1 = 1;
+		if (sscanf(e, "%u,%u,%u,%u", &a, &l0, &h, &l1) == 4 && l0 >= 1 && l0 <= 64 && l1 >= 1 && l1 <= 64 && a <= h) {
+			H = std::min<uint32_t>(h, b.n_lanes); seg_a = std::min<uint32_t>(a, H); seg_a -= seg_a % l0;
+			b.head_lanes[0] = l0; b.head_lanes[1] = l1; forced = true;
+		}
+	}
+	if (!forced) {
+		/* measured (profiles/r03_parse_head.txt; 16 / 8 streams x 24 pictures of 4K, one 720p stream of 360 pictures): what
+		 * a wavefront's walk costs grows with its slices (1 .. ~16: more step kinds per turn) AND with the wavefronts that
+		 * share its SIMD.  So: as few long slices per wavefront as keeps the whole pass at two (then three) wavefronts per
+		 * SIMD, the short ones packed as tightly as that needs.  16 x 24 of 4K: 4 + 64 per wavefront, parse 6.36 -> 5.08 ms;
+		 * 8 x 24: 2 + 64, 5.77 -> 4.0; one 720p stream: 1 + 32, 0.97 -> 0.8 */
+		uint32_t lh = 0, lt = 0;
+		if (H > 0 && (uint64_t)H * 3 <= b.n_lanes && !(b.debug_flags & 8) && !lanes_forced) {
+			for (uint32_t w = JM_PARSE_FILL_WAVES / 2; w <= JM_PARSE_FILL_WAVES * 3 / 4 && !lh; w += JM_PARSE_FILL_WAVES / 4)
+				for (uint32_t l = 1; l <= 16 && !lh; l <<= 1) {
+					const uint32_t head_w = (H + l - 1) / l;
+					if (head_w > w * 3 / 4) continue;
+					for (uint32_t t = 16; t <= 64; t <<= 1)
+						if (t > l && (b.n_lanes - H + t - 1) / t <= w - head_w) { lh = l; lt = t; break; }
+				}
+		}
+		if (lh) {
+			seg_a = H - H % lh;
+			b.head_lanes[0] = b.head_lanes[1] = lh;
+			lanes = lt;
+			b.lanes_per_wave = lanes;
+			b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+		} else H = 0;
+	}
+	if (H) {
+		b.head_batches[0] = seg_a / b.head_lanes[0];
+		b.head_first[1] = seg_a;
+		b.head_batches[1] = (H - seg_a + b.head_lanes[1] - 1) / b.head_lanes[1];
+		b.head_first[2] = std::min<uint32_t>(seg_a + b.head_batches[1] * b.head_lanes[1], b.n_lanes);
+	}
+	b.n_batches = b.head_batches[0] + b.head_batches[1] + (b.n_lanes - b.head_first[2] + lanes - 1) / lanes;
 	/* as many workgroups as there are batches -- or, for large passes, as the GPU holds at a time (2 per CU: 80 KB of
 	 * LDS each), their wavefronts drawing further batches by ticket */
 	uint32_t groups = (b.n_batches + JM_PARSE_WAVES - 1) / JM_PARSE_WAVES;

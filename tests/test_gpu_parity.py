@@ -159,11 +159,16 @@ def test_damaged_input_neither_faults_nor_hangs(hip_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(JSMPEG_HIP_PARSE_RESIDENT="1", JSMPEG_HIP_PARSE_LANES="64"),
-                                 dict(JSMPEG_HIP_PARSE_RESIDENT="2", JSMPEG_HIP_PARSE_LANES="4")])
+                                 dict(JSMPEG_HIP_PARSE_RESIDENT="2", JSMPEG_HIP_PARSE_LANES="4"),
+                                 dict(JSMPEG_HIP_PARSE_HEAD="5,1,23,2"), dict(JSMPEG_HIP_PARSE_HEAD="64,4,1000,8"),
+                                 dict(JSMPEG_HIP_PARSE_HEAD="9,3,9,3", JSMPEG_HIP_PARSE_RESIDENT="1")])
 def test_parse_wavefronts_draw_batches_by_ticket(env):
     """Large passes launch as many parse workgroups as the GPU holds and their wavefronts draw further batches of slices
     from a ticket counter; small inputs never get there -- here they do (the environment limits the workgroups: the
-    library reads it once per process, hence the subprocess), golden fixtures through the batch interface."""
+    library reads it once per process, hence the subprocess), golden fixtures through the batch interface.
+    JSMPEG_HIP_PARSE_HEAD: the batches of the longest slices take fewer slices per wavefront than the rest (what
+    jm_launch_parse does by itself for passes with a few long slices) -- here forced on every fixture, in segmentations
+    that do not divide the slice count."""
     import subprocess
     import sys
     code = r'''
