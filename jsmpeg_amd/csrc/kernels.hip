@@ -500,8 +500,11 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	 * wavefronts are fastest at 64) */
 	uint32_t lanes = 64;
 	if (b.n_lanes <= 512u * 64u) {
+		/* ... within 2048 wavefronts, two per SIMD: a wavefront walks faster the fewer others share its SIMD (late round 3,
+		 * profiles/r03_parse_head.txt: all-intra 1080p 16 x 24 pictures 2.15 -> 1.66 ms of parse at 16 instead of 8 slices per
+		 * wavefront, 4 x 24 1.55 -> 1.41 at 4 instead of 2, 320x240 4 x 300 0.58 -> 0.46 at 16 instead of 8) */
 		lanes = 1;
-		while (lanes < 64 && (uint64_t)lanes * JM_PARSE_FILL_WAVES < b.n_lanes) lanes <<= 1;
+		while (lanes < 64 && (uint64_t)lanes * (JM_PARSE_FILL_WAVES / 2) < b.n_lanes) lanes <<= 1;
 	}
 	if (b.debug_flags & 8) lanes = 64;
 	bool lanes_forced = false;
