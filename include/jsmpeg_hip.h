@@ -217,13 +217,22 @@ int jsmpeg_hip_batch_read_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t picture, void 
 int jsmpeg_hip_batch_timings(jsmpeg_hip_batch_t *b, float out_ms[5]);
 /* hipEvent timings of the reconstruct launches of the last decode, one per dependency level in launch order ([0]: the
  * pictures without a forward reference), milliseconds; at most `cap` (and at most 64) are written.  Returns the
- * number written or < 0.  Valid after jsmpeg_hip_batch_sync. */
+ * number written or < 0.  Valid after jsmpeg_hip_batch_sync.  An ordered launch (jsmpeg_hip_batch_recon_info) is ONE entry. */
 int jsmpeg_hip_batch_level_timings(jsmpeg_hip_batch_t *b, float *out_ms, uint32_t cap);
 /* Counters of the last decode: [0] start codes, [1] pictures, [2] decoded
  * pictures, [3] dependency levels, [4] slices parsed, [5] macroblocks per picture,
  * [6] pictures with macroblocks the stream never writes (they keep the decoded
  * picture before last, see part 4), [7] slice start codes found (01 .. AF; [4] counts the ones a picture owns). */
 int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]);
+/* How the last decode reconstructed (waits for the stream): [0] reconstruct launches -- 1: the ORDERED launch (one launch
+ * for the whole batch: every eighth of the GPU walks its streams in lockstep and a picture's tiles wait for the picture
+ * before it in its stream; batches of >= 8 streams that fill eight classes evenly), else one launch per dependency
+ * level; [1] streams a class walks in lockstep (0: level by level; environment JSMPEG_HIP_RECON_ORDER = 0 / n);
+ * [2] waits of the ordered launch that found their picture unfinished at the first look; [3] its status (0: clean;
+ * non-zero: the launch flagged itself, the frames were reconstructed a second time level by level before
+ * jsmpeg_hip_batch_sync returned, and the batch stays with per-level launches).  Frames of an ordered launch are final
+ * once jsmpeg_hip_batch_sync (or any call that reads them back) has returned. */
+int jsmpeg_hip_batch_recon_info(jsmpeg_hip_batch_t *b, uint32_t out[4]);
 
 /* ------------------------------------------------------------------ part 3
  * MP2 audio (MPEG-1 Audio Layer II) -- the sibling decoder of the reference's

@@ -24,7 +24,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_attach_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
-                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_render_rgba",
+                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_recon_info", "jsmpeg_hip_batch_render_rgba",
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
@@ -254,6 +254,15 @@ class Batch:
         self._ok(self.L.jsmpeg_hip_batch_counters(self.h, c))
         return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5],
                     uncovered_pictures=c[6], slice_codes=c[7])
+
+    def recon_info(self):
+        """how the last decode reconstructed: launches (1 = the ordered launch), lockstep group, waits, status"""
+        c = (ctypes.c_uint32 * 4)()
+        fn = self.L.jsmpeg_hip_batch_recon_info
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        self._ok(fn(self.h, c))
+        return dict(launches=c[0], group=c[1], waits=c[2], status=c[3])
 
     @property
     def frame_pool_ptr(self):

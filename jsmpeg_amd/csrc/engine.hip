@@ -77,6 +77,12 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 
 static void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g, width, height); }
 
+/* Streams a class of the ordered reconstruct walks in lockstep (recon_plan.h): 8 x this many frames are written per
+ * step and read back by the next.  JSMPEG_HIP_RECON_ORDER overrides (0: one launch per dependency level, always). */
+#ifndef JM_ORDER_GROUP_DEFAULT
+#define JM_ORDER_GROUP_DEFAULT 2
+#endif
+#define JM_DONE_STRIDE 32   /* words between two pictures' tile counts: k_recon's first look at one goes through the L1 */
 #define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
 
 /* =========================================================================
@@ -104,6 +110,15 @@ struct jsmpeg_hip_batch_t {
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
 	uint32_t desc_cap, n_uncovered;
 	hipEvent_t ev_cov;
+	/* ordered reconstruct (one launch per batch, recon_plan.h jm_plan_ordered): per-picture tile counts, the launch's
+	 * status words (kernels.h JM_RECON_STATUS_WORDS; h_: pinned), and how the last decode went */
+	uint32_t *d_done, *d_rstatus, *h_rstatus;
+	uint32_t last_group;         /* lockstep width of the last decode's launch, 0: it went level by level */
+	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level */
+	bool ordered;                /* the last decode used the ordered launch (its status is checked at the next sync) */
+	bool stats_pending;          /* n_levels / n_uncovered of the last decode not worked out yet (needs the parse's counts) */
+	uint32_t ordered_status;     /* status of the last checked ordered launch (non-zero: it was done over) */
+	uint32_t ordered_waits;      /* polls of the last checked ordered launch that found their picture unfinished */
 	JmMbRec *d_mb; uint16_t *d_tokens; uint8_t *d_pool_alloc, *d_pool;
 	uint64_t *d_hashes;
 	uint8_t *d_rgba;             /* one RGBA frame: scratch of jsmpeg_hip_batch_read_rgba */
@@ -128,6 +143,8 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	hipFree(b->d_es); hipFree(b->d_streams); hipFree(b->d_scan_state); hipFree(b->d_sc_pos);
 	hipFree(b->d_sc_code); hipFree(b->d_sc_owner); hipFree(b->d_pic_sc); hipFree(b->d_slice_sc); hipFree(b->d_slice_order); hipFree(b->d_order_hist); hipFree(b->d_counters);
 	hipFree(b->d_pics); hipFree(b->d_desc); hipFree(b->d_covered); hipFree(b->d_mb); hipFree(b->d_tokens);
+	hipFree(b->d_done); hipFree(b->d_rstatus);
+	if (b->h_rstatus) hipHostFree(b->h_rstatus);
 	hipFree(b->d_pool_alloc); hipFree(b->d_hashes); hipFree(b->d_dbg); hipFree(b->d_rgba);
 	hipFree(b->d_ts); hipFree(b->d_ts_rec); hipFree(b->d_ts_es_off); hipFree(b->d_ts_cand); hipFree(b->d_ts_writes); hipFree(b->d_ts_begin); hipFree(b->d_ts_len); hipFree(b->d_ts_small);
 	if (b->h_counters) hipHostFree(b->h_counters);
@@ -159,8 +176,11 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * (2 * JM_ORDER_BINS + 16)));   /* + the parse pass's ticket counter */
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
-	b->desc_cap = 2 * std::max(1u, c.max_pictures);   /* every picture once, the ones without a forward reference twice (steps 4a, 4b) */
+	b->desc_cap = 2 * std::max(1u, c.max_pictures) + 64;   /* every picture once, the ones without a forward reference twice (steps 4a, 4b); ordered: padding of up to 8 % */
 	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
+	HIP_TRY(jm_malloc(&b->d_done, (size_t)JM_DONE_STRIDE * sizeof(uint32_t) * std::max(1u, c.max_pictures)));   /* a 128-byte line per picture's count */
+	HIP_TRY(jm_malloc(&b->d_rstatus, sizeof(uint32_t) * JM_RECON_STATUS_WORDS));
+	HIP_TRY(hipHostMalloc(&b->h_rstatus, sizeof(uint32_t) * JM_RECON_STATUS_WORDS, hipHostMallocDefault));
 	HIP_TRY(jm_malloc(&b->d_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures), hipHostMallocDefault));
 	HIP_TRY(hipHostMalloc(&b->h_pics, sizeof(JmPic) * std::max(1u, c.max_pictures), hipHostMallocDefault));
@@ -196,7 +216,9 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
-	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0; b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
+	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0;
+	b->d_done = nullptr; b->d_rstatus = nullptr; b->h_rstatus = nullptr; b->ordered = false; b->stats_pending = false; b->ordered_waits = 0; b->ordered_status = 0; b->last_group = 0;
+	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_GROUP_DEFAULT; } b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
@@ -497,7 +519,7 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	D.fwd = pic.fwd >= 0 ? b->d_pool + (uint64_t)pic.fwd * b->g.frame_bytes : nullptr;
 	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes : nullptr;
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
-	D.pad_[0] = D.pad_[1] = 0;
+	D.done = nullptr; D.wait = nullptr;
 }
 
 /* JSMPEG_HIP_TRACE=1: where the HOST's time goes in one decode call (stderr, ms since the call began) */
@@ -513,6 +535,54 @@ struct HostTrace {
 	}
 	~HostTrace() { if (on) fprintf(stderr, "decode host trace (ms):%s\n", line); }
 };
+
+/* Reconstruct level by level: the pictures that wait for nothing right behind the parse (step 4a), then -- once the
+ * parse has reported which pictures wrote every macroblock -- one launch per dependency level (step 4b).  The form
+ * for batches that do not fill eight classes (recon_plan.h), the one-off fallback of an ordered launch that flagged
+ * itself, and JSMPEG_HIP_RECON_ORDER=0. */
+static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::vector<int32_t> &stale, uint32_t n_roots, hipStream_t st, HostTrace &tr) {
+	{
+		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
+		uint32_t k = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
+		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
+	}
+	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
+	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
+		HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
+	HIP_TRY(jm_launch_recon(rb, st));
+
+	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4a meanwhile):
+	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
+	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
+	tr.mark("roots-enqueued");
+	HIP_TRY(hipEventSynchronize(b->ev_cov));
+	tr.mark("parse-done");
+	{
+		std::vector<int32_t> level;
+		const uint32_t n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
+		b->n_levels = n_levels;
+		std::vector<uint32_t> off(n_levels + 1, 0);
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;
+		for (uint32_t l = 0; l < n_levels; l++) off[l + 1] += off[l];
+		const uint32_t n_later = off[n_levels];
+		if ((size_t)n_roots + n_later > b->desc_cap) return fail("internal: descriptor table too small");
+		if (getenv("JSMPEG_HIP_DEBUG_COVER"))
+			fprintf(stderr, "cover: %u of %u pictures with unwritten macroblocks, %u levels, %u pictures behind the first\n", b->n_uncovered, b->n_pics, n_levels, n_later);
+		if (n_later) {
+			std::vector<uint32_t> cur(off.begin(), off.end());
+			for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) fill_desc(b, b->h_desc[n_roots + cur[level[p]]++], p, stale[p]);
+			HIP_TRY(hipMemcpyAsync(b->d_desc + n_roots, b->h_desc + n_roots, sizeof(JmReconDesc) * n_later, hipMemcpyHostToDevice, st));
+			for (uint32_t l = 1; l < n_levels; l++) {
+				rb.desc = b->d_desc + n_roots + off[l];
+				rb.n_level_pics = off[l + 1] - off[l];
+				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
+				HIP_TRY(jm_launch_recon(rb, st));
+			}
+		}
+	}
+	return 0;
+}
 
 extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) {
 	g_err[0] = 0;
@@ -620,50 +690,42 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * (Laid out here, while the GPU is busy with the parse: the descriptors are only read by the reconstruct.) */
 	std::vector<int32_t> stale;
 	const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
-	{
-		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
-		uint32_t k = 0;
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && b->h_pics[p].fwd < 0) fill_desc(b, b->h_desc[k++], p, stale[p]);
-		if (n_roots) HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * n_roots, hipMemcpyHostToDevice, st));
-	}
-	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
-	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr;
 	b->n_level_ev = 0;
-	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
-	HIP_TRY(jm_launch_recon(rb, st));
-
-	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4a meanwhile):
-	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
-	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
-	tr.mark("roots-enqueued");
-	HIP_TRY(hipEventSynchronize(b->ev_cov));
-	tr.mark("parse-done");
-	{
-		std::vector<int32_t> level;
-		const uint32_t n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
-		b->n_levels = n_levels;
-		std::vector<uint32_t> off(n_levels + 1, 0);
-		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;
-		for (uint32_t l = 0; l < n_levels; l++) off[l + 1] += off[l];
-		const uint32_t n_later = off[n_levels];
-		if ((size_t)n_roots + n_later > b->desc_cap) return fail("internal: descriptor table too small");
-		if (getenv("JSMPEG_HIP_DEBUG_COVER"))
-			fprintf(stderr, "cover: %u of %u pictures with unwritten macroblocks, %u levels, %u pictures behind the first\n", b->n_uncovered, b->n_pics, n_levels, n_later);
-		if (n_later) {
-			std::vector<uint32_t> cur(off.begin(), off.end());
-			for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) fill_desc(b, b->h_desc[n_roots + cur[level[p]]++], p, stale[p]);
-			HIP_TRY(hipMemcpyAsync(b->d_desc + n_roots, b->h_desc + n_roots, sizeof(JmReconDesc) * n_later, hipMemcpyHostToDevice, st));
-			for (uint32_t l = 1; l < n_levels; l++) {
-				rb.desc = b->d_desc + n_roots + off[l];
-				rb.n_level_pics = off[l + 1] - off[l];
-				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
-				HIP_TRY(jm_launch_recon(rb, st));
-			}
+	b->ordered = false; b->stats_pending = false; b->last_group = 0; b->ordered_status = 0; b->ordered_waits = 0;
+	JmOrderedPlan plan;
+	if (b->order_group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, b->order_group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap) {
+		/* ---- 4. ONE launch: every class walks its streams in lockstep, a picture's tiles wait for the picture before
+		 * it in its stream (its forward reference and the frame its unwritten macroblocks show are both behind that
+		 * one), so nothing here needs the parse's counts: no host turn-around between parse and reconstruct ---- */
+		for (size_t i = 0; i < plan.seq.size(); i++) {
+			JmReconDesc &D = b->h_desc[i];
+			const int32_t p = plan.seq[i];
+			if (p < 0) { memset(&D, 0, sizeof(D)); continue; }
+			fill_desc(b, D, (uint32_t)p, stale[p]);
+			D.done = b->d_done + (size_t)JM_DONE_STRIDE * p;
+			D.wait = plan.prev[p] >= 0 ? b->d_done + (size_t)JM_DONE_STRIDE * plan.prev[p] : nullptr;
 		}
-	}
+		if (const char *e = getenv("JSMPEG_HIP_RECON_BREAK")) {   /* tests: picture n of the plan never reports, its successor's wait runs out */
+			const size_t i = (size_t)atoi(e);
+			if (i < plan.seq.size() && plan.seq[i] >= 0) b->h_desc[i].done = nullptr;
+		}
+		if (const char *e = getenv("JSMPEG_HIP_RECON_PATIENCE")) rb.patience = (uint32_t)atoi(e);
+		HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * plan.seq.size(), hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemsetAsync(b->d_done, 0, (size_t)JM_DONE_STRIDE * sizeof(uint32_t) * b->n_pics, st));
+		HIP_TRY(hipMemsetAsync(b->d_rstatus, 0, sizeof(uint32_t) * 8, st));
+		HIP_TRY(hipMemsetAsync(b->d_rstatus + 8, 0xff, sizeof(uint32_t) * 8, st));
+		rb.desc = b->d_desc; rb.n_level_pics = (uint32_t)plan.seq.size();
+		rb.need = 1; rb.status = b->d_rstatus;      /* (jm_launch_recon puts the workgroups per picture there) */
+		HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
+		HIP_TRY(jm_launch_recon(rb, st));
+		HIP_TRY(hipMemcpyAsync(b->h_rstatus, b->d_rstatus, sizeof(uint32_t) * JM_RECON_STATUS_WORDS, hipMemcpyDeviceToHost, st));
+		b->ordered = true; b->stats_pending = true; b->last_group = b->order_group;
+		tr.mark("ordered-enqueued");
+	} else if (recon_by_levels(b, rb, stale, n_roots, st, tr) < 0) return -1;
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], st));
 	HIP_TRY(hipEventRecord(b->ev[4], st));
 	tr.mark("levels-enqueued");
@@ -671,12 +733,46 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	return (int)b->n_pics;
 }
 
+/* What is left of a decode once its stream has drained: the ordered launch's status (a launch that gave a wait up, or
+ * met a class on two XCDs, is done over level by level -- once; the batch then stays with per-level launches), and
+ * the statistics that need the parse's counts. */
+static int batch_settle(jsmpeg_hip_batch_t *b) {
+	if (b->ordered) {
+		b->ordered = false;
+		b->ordered_waits = b->h_rstatus[1];
+		b->ordered_status = b->h_rstatus[0];
+		if (b->h_rstatus[0]) {
+			fprintf(stderr, "jsmpeg_hip: the ordered reconstruct flagged itself (status %u: %s); reconstructing level by level, and from now on\n",
+			        b->h_rstatus[0], (b->h_rstatus[0] & 2) ? "a class of workgroups ran on two XCDs" : "a picture's wait ran out of patience");
+			b->order_group = 0; b->last_group = 0;
+			std::vector<int32_t> stale;
+			const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+			JmReconBufs rb;
+			rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr;
+			HostTrace tr;
+			b->n_level_ev = 0;
+			if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
+			HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], b->stream));
+			HIP_TRY(hipStreamSynchronize(b->stream));
+			b->stats_pending = false;
+		}
+	}
+	if (b->stats_pending) {
+		b->stats_pending = false;
+		HIP_TRY(hipEventSynchronize(b->ev_cov));
+		std::vector<int32_t> stale, level;
+		jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+		b->n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
+	}
+	return 0;
+}
+
 extern "C" int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b) {
 	g_err[0] = 0;
 	if (!b) return fail("null batch");
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
-	return 0;
+	return batch_settle(b);
 }
 
 extern "C" uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b) { return b ? b->n_pics : 0; }
@@ -708,6 +804,7 @@ extern "C" int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t pictu
 	if (!b || picture >= b->n_pics) return fail("bad picture index");
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (batch_settle(b) < 0) return -1;
 	const uint8_t *f = b->d_pool + (uint64_t)picture * b->g.frame_bytes;
 	if (y) HIP_TRY(hipMemcpy(y, f, b->g.luma_bytes, hipMemcpyDeviceToHost));
 	if (cr) HIP_TRY(hipMemcpy(cr, f + b->g.luma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
@@ -720,6 +817,7 @@ extern "C" int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *ou
 	if (!b || !out) return fail("null argument");
 	HIP_TRY(hipSetDevice(b->device));
 	if (!b->n_pics) return 0;
+	if (b->ordered) { HIP_TRY(hipStreamSynchronize(b->stream)); if (batch_settle(b) < 0) return -1; }
 	HIP_TRY(jm_launch_hash(b->d_pool, b->g.frame_bytes, b->g.luma_bytes + 2 * b->g.chroma_bytes, b->n_pics,
 	                       b->d_hashes, b->stream));
 	HIP_TRY(hipMemcpyAsync(out, b->d_hashes, sizeof(uint64_t) * b->n_pics, hipMemcpyDeviceToHost, b->stream));
@@ -810,9 +908,18 @@ extern "C" int jsmpeg_hip_batch_level_timings(jsmpeg_hip_batch_t *b, float *out_
 
 extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]) {
 	if (!b) return fail("null batch");
+	if (b->ordered || b->stats_pending) { HIP_TRY(hipSetDevice(b->device)); HIP_TRY(hipStreamSynchronize(b->stream)); if (batch_settle(b) < 0) return -1; }
 	out[0] = b->n_sc; out[1] = b->n_pics; out[2] = b->n_decoded; out[3] = b->n_levels; out[4] = b->n_slices;
 	out[5] = (uint64_t)b->g.mb_size;
 	out[6] = b->n_uncovered; out[7] = b->n_slice_codes;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_recon_info(jsmpeg_hip_batch_t *b, uint32_t out[4]) {
+	g_err[0] = 0;
+	if (!b || !out) return fail("null argument");
+	if (b->ordered || b->stats_pending) { HIP_TRY(hipSetDevice(b->device)); HIP_TRY(hipStreamSynchronize(b->stream)); if (batch_settle(b) < 0) return -1; }
+	out[0] = b->n_level_ev; out[1] = b->last_group; out[2] = b->ordered_waits; out[3] = b->ordered_status;
 	return 0;
 }
 
@@ -1183,7 +1290,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	desc.dst = d->d_pool + (uint64_t)d->cur * d->g.frame_bytes; desc.fwd = d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes;
 	desc.stale = nullptr;
 	desc.qm = reinterpret_cast<const uint8_t *>(d->d_stream) + offsetof(JmStream, intra_q);
-	desc.pad_[0] = desc.pad_[1] = 0;
+	desc.done = nullptr; desc.wait = nullptr;
 
 	hipStream_t st = d->stream;
 	HIP_TRY(hipMemcpyAsync(d->d_sc_pos, d->stage_pos.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
@@ -1206,6 +1313,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
+	rb.need = 0; rb.patience = 0; rb.status = nullptr;
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));

@@ -112,8 +112,14 @@ struct alignas(64) JmReconDesc {
 	                                mpeg1.c:986-994): macroblocks the picture never writes keep showing it.  Null: zeros
 	                                (the JS typed arrays start zeroed, mpeg1.js:131-152) */
 	const uint8_t *qm;           /* the stream's quantiser matrices: intra | non-intra, 128 bytes (JmStream::intra_q) */
-	uint64_t pad_[2];
+	/* ordered launches (JmReconBufs::need != 0; kernels.hip, k_recon): `done` counts the picture's finished tiles;
+	 * `wait` is the `done` word of the picture that comes before this one in its stream -- its forward reference, the
+	 * frame its unwritten macroblocks keep showing, and everything those depended on are complete once that word
+	 * reads JmReconBufs::need.  Null: nothing to wait for / nobody waits (per-level launches, the one-picture ABI). */
+	uint32_t *done;
+	const uint32_t *wait;
 };
+static_assert(sizeof(JmReconDesc) == 64, "JmReconDesc: one 64-byte line, two scalar loads");
 
 struct JmReconBufs {
 	JmGeom g;
@@ -122,7 +128,16 @@ struct JmReconBufs {
 	const JmVlcLuts *luts;       /* device global copy (zig-zag order) */
 	uint8_t epoch;
 	int zero_uncovered;
+	/* ORDERED launch (one launch for a whole batch instead of one per dependency level): desc[8 i + c] is the i-th
+	 * picture of CLASS c's sequence (workgroup b belongs to class b % 8: one XCD, one dispatcher walking its blocks in
+	 * order); a picture's dependencies all lie earlier in ITS class's sequence.  need: non-zero = ordered (the launch wrapper
+	 * replaces it by the workgroups per picture: what a finished picture's `done` word reads), 0: per-level launch.  Entries with dst == null are padding. */
+	uint32_t need;
+	uint32_t patience;           /* polls (~1 us each) before a wait is given up and the launch flags itself; 0: JM_RECON_PATIENCE */
+	uint32_t *status;            /* ordered launches: [0] error flags (1: a wait ran out of patience, 2: a class met two XCDs),
+	                                [1] polls that found their picture unfinished, [8 + c] XCC id class c ran on (preset 0xffffffff) */
 };
+#define JM_RECON_STATUS_WORDS 16
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 
 /* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */

@@ -602,6 +602,9 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 #ifndef JM_RECON_SLOTS
 #define JM_RECON_SLOTS (55 * JM_RECON_WAVES)
 #endif
+#ifndef JM_RECON_PATIENCE
+#define JM_RECON_PATIENCE (1u << 19)        /* polls (~1 us each with the sleep) before an ordered launch gives a wait up: about a second */
+#endif
 #define JM_RECON_PASS (JM_RECON_SLOTS < JM_RECON_WG / 2 ? JM_RECON_SLOTS : JM_RECON_WG / 2)
 static_assert(JM_RECON_SLOTS >= 32 && JM_RECON_SLOTS <= JM_RECON_WG, "a wavefront round takes 32 slots");
 
@@ -635,11 +638,60 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	const uint32_t tile = q % (uint32_t)T.per_picture, k = (q / (uint32_t)T.per_picture) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
 	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
+	if (D.dst == nullptr) return;                    /* ordered launch: a class with fewer pictures than the longest */
+#ifdef JM_T_VWAVE
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#else
+	/* the wavefront's number as a scalar: what depends on (tile, wavefront) alone -- the tile's place in its plane, the
+	 * rows this wavefront takes -- is then scalar arithmetic, not 64 lanes' */
+	const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
 	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>((JM_GLOBAL const JmMbRec *)D.mb + Q.mbaddr);
+	/* ORDERED launch: the picture before this one in its stream must be complete before anything of a frame is read.
+	 * The word is polled past the vector L1 (agent-scope relaxed load = `sc1`); in the common case -- the producer is
+	 * hundreds of workgroups back in this class's dispatch order -- the first look finds it, and its latency lies
+	 * behind the record's.  Nothing of an unfinished frame has been touched by this CU before (k_recon never reads a
+	 * frame ahead of its picture's `wait`: lanes without prediction read the stream's matrix table, not the frame), so
+	 * the L1 holds no line of it; producer and consumer are workgroups of one class = one XCD = one L2 (checked:
+	 * status[8 + class]), so the rows come out of the L2 the stores were acknowledged by. */
+#ifndef JM_T_NOPOLL
+	if (D.wait != nullptr) {
+		/* FIRST a plain load: the word has a 128-byte line to itself and only ever counts up to `need`, so a cached
+		 * `need` is final -- and in the common case that is what the first workgroup of this CU that asked brought
+		 * in: one request to the L2 per CU and picture.  (Every wavefront polling past the L1 -- 4 x 1.5 M `sc1` loads
+		 * per step on a handful of addresses -- doubled the reconstruct's time: an L2 channel serves one word at
+		 * ~15 ns per request.)  A cached count below `need` says nothing (the L1 is never refreshed): then ONE lane
+		 * polls past the L1 (agent-scope relaxed load = `sc1`) and the wavefront follows it. */
+		JM_GLOBAL const uint32_t *w = (JM_GLOBAL const uint32_t *)D.wait;
+		uint32_t spins = 0;
+		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*w) < b.need) for (;;) {
+			uint32_t seen = 0;
+			if (lane == 0) seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) >= b.need) break;
+			__builtin_amdgcn_s_sleep(16);
+			if (spins == 0 && threadIdx.x == 0) atomicAdd(b.status + 1, 1u);
+			/* never hang: a wait that runs out flags the launch (the host then reconstructs level by level), and a
+			 * flagged launch waits for nothing any more -- the frames are being done over anyway */
+			if ((spins & 63u) == 63u) {
+				uint32_t flagged = 0;
+				if (lane == 0) flagged = __hip_atomic_load((JM_GLOBAL const uint32_t *)b.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (__builtin_amdgcn_readfirstlane((int)flagged) != 0) break;
+			}
+			if (++spins > b.patience) { if (threadIdx.x == 0) atomicOr(b.status, 1u); break; }
+		}
+		asm volatile("" ::: "memory");
+	}
+#endif
+	if (b.need != 0 && tile == 0 && threadIdx.x == 0) {
+		/* which XCD this class runs on (HW_REG_XCC_ID): one answer per class, or the launch is flagged */
+		uint32_t xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+		const uint32_t seen = atomicCAS(b.status + 8 + xcd, 0xffffffffu, xcc);
+		if (seen != 0xffffffffu && seen != xcc) atomicOr(b.status, 2u);
+	}
 	/* quantiser matrices (128 contiguous bytes of the stream's table) and the zig-zag order: twelve 16-byte loads */
 	uint4 tq = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];
@@ -652,7 +704,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	c.tok = (JM_GLOBAL const uint16_t *)D.tok;
 	c.has_fwd = D.fwd != nullptr;
 	c.dst = (JM_GLOBAL uint8_t *)D.dst;
-	c.fwd = (JM_GLOBAL const uint8_t *)(c.has_fwd ? D.fwd : D.dst);
+	/* lanes without prediction read twelve bytes all the same (no branch around the loads): of the forward frame when
+	 * there is one, else of the stream's matrix table -- never of a frame that is not complete (ordered launches) */
+	c.fwd = (JM_GLOBAL const uint8_t *)(c.has_fwd ? D.fwd : D.qm);
 	c.stale = (JM_GLOBAL const uint8_t *)D.stale;
 	c.qm = qm; c.zz = qm + 128;
 	c.epoch = b.epoch;
@@ -742,6 +796,15 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 			if (X.store) jm_recon_store(c, B2, X);
 		}
 	}
+	/* ORDERED launch: this tile's rows are in the L2 (every wavefront's stores acknowledged), then the picture's count
+	 * goes up -- one atomic per workgroup */
+	if (D.done != nullptr) {
+#ifndef JM_T_NOEPIWAIT
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		__syncthreads();
+		if (threadIdx.x == 0) __hip_atomic_fetch_add((JM_GLOBAL uint32_t *)D.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
@@ -749,7 +812,10 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	JmTiles T;
 	jm_tiles_init(T, b.g);
 	const uint32_t groups = (b.n_level_pics + 7) / 8;
-	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), 0, st, b, T);
+	JmReconBufs a = b;
+	if (a.need) a.need = (uint32_t)T.per_picture;      /* ordered launch: what a finished picture's `done` word reads */
+	if (a.patience == 0) a.patience = JM_RECON_PATIENCE;
+	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), 0, st, a, T);
 	return hipGetLastError();
 }
 

@@ -124,7 +124,9 @@ struct JmGeom {
 	int32_t mb_width, mb_height, mb_size;
 	int32_t coded_width, coded_height;
 	uint32_t luma_bytes, chroma_bytes; /* per plane */
-	uint64_t frame_bytes;              /* luma + 2 chroma, rounded up to 256 */
+	uint64_t frame_bytes;              /* luma + 2 chroma + 16, rounded up to 256: a frame's first 128-byte line holds nothing of the frame before
+	                                      it, not even the (up to 4) bytes an aligned 12-byte prediction load reads past that frame's last row --
+	                                      an ordered launch's CU must never have a line of a frame in its L1 before the frame is complete */
 	uint32_t rcp_bw, rcp_mbw;          /* ceil(2^32 / (2 * mb_width)), ceil(2^32 / mb_width): n / d == mulhi(n, rcp) for n < 2^32 / d */
 };
 JM_HD void jm_geom_init(JmGeom &g, int width, int height) {
@@ -135,7 +137,7 @@ JM_HD void jm_geom_init(JmGeom &g, int width, int height) {
 	g.coded_height = g.mb_height << 4;
 	g.luma_bytes = (uint32_t)(g.coded_width * g.coded_height);
 	g.chroma_bytes = g.luma_bytes >> 2;
-	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 255) & ~255ull;
+	g.frame_bytes = ((uint64_t)g.luma_bytes + 2ull * g.chroma_bytes + 16 + 255) & ~255ull;
 	g.rcp_bw = g.mb_width > 0 ? (uint32_t)(((1ull << 32) + 2 * g.mb_width - 1) / (uint64_t)(2 * g.mb_width)) : 0;
 	g.rcp_mbw = g.mb_width > 1 ? (uint32_t)(((1ull << 32) + g.mb_width - 1) / (uint64_t)g.mb_width) : 0xffffffffu;
 }

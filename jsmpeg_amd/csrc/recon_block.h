@@ -626,7 +626,7 @@ JM_HD void jm_recon_store(const JmReconCtx &c, const JmBlk &B, const JmPix &X) {
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		JM_GLOBAL uint32_t *o = (JM_GLOBAL uint32_t *)(c.dst + (B.out + (uint32_t)(r * B.stride)));
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JM_RECON_PLAIN_STORES)
 		/* the plane is read back a whole launch later, long after the 32 MB of L2 have turned over: stream it out */
 		__builtin_nontemporal_store(X.p[2 * r], o); __builtin_nontemporal_store(X.p[2 * r + 1], o + 1);
 #else

@@ -53,4 +53,63 @@ static inline uint32_t jm_plan_levels(const JmPic *pics, uint32_t n_pics, const 
 	return n_levels;
 }
 
+/* THE ORDERED PLAN: one reconstruct launch for the whole batch (kernels.h, JmReconBufs::need).  Streams are dealt to
+ * eight CLASSES (a class = the workgroups b with b % 8 == c = one XCD: one dispatcher that starts its blocks in order,
+ * one L2); a class takes its streams `group` at a time and walks them in lockstep -- picture i of stream A, picture i of
+ * stream B, picture i + 1 of A ... -- so that (1) a picture's predecessor in its stream lies `group` pictures back in
+ * the class's dispatch order (hundreds of workgroups: finished, or about to be, when the picture's first tile looks),
+ * and (2) the frames a step writes are read back by the next step while they are still in the 256 MB memory-side
+ * cache: 8 x group frames per step instead of a whole level's (640 for the benchmark batch: 2 GB).
+ *   seq[8 i + c] = the i-th picture of class c, -1 = padding;   prev[p] = the decoded picture before p in its stream.
+ * A picture waits for prev[p] only: its forward reference and the frame its unwritten macroblocks keep showing
+ * (jm_plan_stale) are both earlier pictures of its stream, and every picture waited for ITS predecessor.
+ * Returns false when the batch does not fill eight classes evenly (fewer than eight streams, or a class more than
+ * `slack_pct` percent above the mean): the caller then launches level by level. */
+struct JmOrderedPlan { std::vector<int32_t> seq, prev; uint32_t rows; };
+static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, uint32_t group, uint32_t slack_pct, JmOrderedPlan &out) {
+	out.seq.clear(); out.prev.assign(n_pics, -1); out.rows = 0;
+	if (n_streams < 8 || group == 0) return false;
+	std::vector<std::vector<int32_t>> of(n_streams);
+	uint64_t total = 0;
+	for (uint32_t p = 0; p < n_pics; p++) {
+		const JmPic &pic = pics[p];
+		if (!pic.decoded || pic.stream >= n_streams) continue;
+		if (!of[pic.stream].empty()) out.prev[p] = of[pic.stream].back();
+		of[pic.stream].push_back((int32_t)p);
+		total++;
+	}
+	if (total == 0) return false;
+	/* longest stream first onto the class with the least so far (equal streams: round robin) */
+	std::vector<uint32_t> by(n_streams);
+	for (uint32_t s = 0; s < n_streams; s++) by[s] = s;
+	std::stable_sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) { return of[a].size() > of[b].size(); });
+	std::vector<uint32_t> cls[8];
+	uint64_t load[8] = { 0 };
+	for (uint32_t s : by) {
+		if (of[s].empty()) continue;
+		uint32_t best = 0;
+		for (uint32_t c = 1; c < 8; c++) if (load[c] < load[best]) best = c;
+		cls[best].push_back(s); load[best] += of[s].size();
+	}
+	const uint64_t most = *std::max_element(load, load + 8);
+	if (most * 8 * 100 > total * (100 + slack_pct)) return false;
+	out.rows = (uint32_t)most;
+	out.seq.assign((size_t)8 * out.rows, -1);
+	for (uint32_t c = 0; c < 8; c++) {
+		std::vector<uint32_t> active, at;            /* the streams walked in lockstep, and where each one is */
+		size_t next = 0, i = 0;
+		while (active.size() < group && next < cls[c].size()) { active.push_back(cls[c][next++]); at.push_back(0); }
+		while (!active.empty()) {
+			for (size_t a = 0; a < active.size();) {
+				const std::vector<int32_t> &l = of[active[a]];
+				out.seq[8 * i++ + c] = l[at[a]++];
+				if (at[a] < l.size()) { a++; continue; }
+				if (next < cls[c].size()) { active[a] = cls[c][next++]; at[a] = 0; a++; }   /* the next stream takes the place */
+				else { active.erase(active.begin() + (long)a); at.erase(at.begin() + (long)a); }
+			}
+		}
+	}
+	return true;
+}
+
 #endif

@@ -1,0 +1,141 @@
+"""The ORDERED reconstruct (one launch per batch: every eighth of the GPU walks its streams in lockstep, a picture's tiles
+wait for the picture before it in its stream; csrc/recon_plan.h jm_plan_ordered, kernels.hip k_recon) against the golden
+fixtures and the oracle: same frames as one launch per dependency level, for every lockstep width, with streams of
+unequal length, with pictures whose unwritten macroblocks show the decoded picture before last across a GOP boundary --
+and the launch that flags itself is done over level by level before anybody reads a frame.  Needs an MI355X."""
+import glob
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from jsmpeg_amd import batch as jb
+from jsmpeg_amd import cabi, hashing, synth
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "frames_*.json")))
+
+
+def md5_planes(planes):
+    h = hashlib.md5()
+    for p in planes:
+        h.update(p.tobytes())
+    return h.hexdigest()
+
+
+class order_env:
+    """JSMPEG_HIP_RECON_ORDER is read when a batch is created"""
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_ordered_launch_matches_golden(group, hip_lib):
+    """every fixture of moderate size as 16 streams of one batch (two per class), every frame against the golden md5"""
+    seen = 0
+    for path in FIXTURES:
+        fx = json.load(open(path))
+        if fx["n_frames"] * fx["info"]["coded_size"] > 12e6 or "abi_frame_md5" in fx:
+            continue
+        es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+        n_streams = 16
+        with order_env(JSMPEG_HIP_RECON_ORDER=group):
+            b = jb.Batch(fx["info"]["width"], fx["info"]["height"], n_streams, n_streams * fx["n_frames"] + 4, n_streams * (len(es) + 64) + 8192)
+        with b:
+            b.upload([es] * n_streams)
+            for rep in range(2):          # the second pass: the counts are reset, the epoch moves on
+                assert b.decode() == n_streams * fx["n_frames"]
+                info = b.recon_info()
+                assert info["launches"] == 1 and info["group"] == group and info["status"] == 0, (path, info)
+                for p in range(n_streams * fx["n_frames"]):
+                    if rep == 0 or p % 7 == 0:
+                        assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], (os.path.basename(path), p)
+        seen += 1
+    assert seen >= 10
+
+
+def test_ordered_equals_level_by_level_on_ragged_streams(hip_lib, libs):
+    """24 streams with different seeds and different lengths (cut at picture boundaries), two GOP lengths: the ordered
+    launch, the per-level launches and the oracle agree on every frame"""
+    streams, want = [], []
+    for s in range(24):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=26, stream=s, width=176, height=144, gop=(6 if s % 2 else 13))
+        n = 26 - s % 3
+        cut = es[:int(offs[n])] if n < 26 else es
+        streams.append(cut)
+        frames, _, _ = cabi.decode_stream(libs["oracle"], cut, keep="planes")
+        want.append([hashing.frame_hash(*f) for f in frames])
+    total = sum(len(w) for w in want)
+    got = {}
+    for order in (2, 0):
+        with order_env(JSMPEG_HIP_RECON_ORDER=order):
+            b = jb.Batch(176, 144, 24, total + 8, sum(len(s) for s in streams) + 8192)
+        with b:
+            b.upload(streams)
+            assert b.decode() == total
+            dev = b.frame_hashes()
+            info = b.recon_info()
+            assert (info["launches"] == 1) == (order != 0) and info["status"] == 0
+            per = {}
+            for p, pic in enumerate(b.pictures()):
+                per.setdefault(pic.stream, []).append(int(dev[p]))
+            got[order] = per
+    for s in range(24):
+        assert got[2][s] == want[s] and got[0][s] == want[s], "stream %d" % s
+
+
+def test_batches_that_do_not_fill_eight_classes_go_level_by_level(hip_lib):
+    es, _ = synth.generate_config("cfg1_720p", n_frames=13, stream=1, width=176, height=144)
+    for n_streams, ordered in ((1, False), (7, False), (8, True), (9, False), (15, True), (16, True)):
+        # 9 streams: one class carries two, 2 / (9 / 8) is far over the 8 % slack; 15: seven classes of two and one of one, 2 / (15 / 8) = 1.067
+        with jb.Batch(176, 144, n_streams, n_streams * 13 + 4, n_streams * (len(es) + 64) + 8192) as b:
+            b.upload([es] * n_streams)
+            assert b.decode() == n_streams * 13
+            assert (b.recon_info()["launches"] == 1) == ordered, n_streams
+
+
+def test_a_launch_that_flags_itself_is_done_over(hip_lib):
+    """JSMPEG_HIP_RECON_BREAK: one picture of the plan never reports, its successor's wait runs out of (shortened)
+    patience, the launch flags itself -- the frames are rebuilt level by level before the sync returns, the result is
+    the golden one, and the batch stays with per-level launches"""
+    code = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %r)
+from jsmpeg_amd import batch as jb, synth
+fx = json.load(open(os.path.join(%r, "tests", "golden", "frames_long_gop_p_chain.json")))
+es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+with jb.Batch(fx["info"]["width"], fx["info"]["height"], 8, 8 * fx["n_frames"] + 4, 8 * (len(es) + 64) + 8192) as b:
+    b.upload([es] * 8)
+    for rep in range(2):
+        assert b.decode() == 8 * fx["n_frames"]
+        info = b.recon_info()
+        print("INFO", rep, info)
+        assert (info["status"] != 0) == (rep == 0) and info["launches"] > 1
+        for p in range(8 * fx["n_frames"]):
+            h = hashlib.md5()
+            for plane in b.read_frame(p):
+                h.update(plane.tobytes())
+            assert h.hexdigest() == fx["frame_md5"][p %% fx["n_frames"]], p
+print("DONE")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, JSMPEG_HIP_RECON_BREAK="8", JSMPEG_HIP_RECON_PATIENCE="2000", JSMPEG_HIP_RECON_ORDER="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "flagged itself" in r.stderr

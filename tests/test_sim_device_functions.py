@@ -123,3 +123,85 @@ def test_reconstruct_plan_random(sim):
         assert st == st_ref and lv == lv_ref
         assert nl == (max(lv_ref[p] for p in range(n) if decoded[p]) + 1 if any(decoded) else 0)
         assert unc == sum(1 for p in range(n) if decoded[p] and covered[p] < 10)
+
+
+def run_plan_ordered(sim, decoded, fwd, stream, n_streams, group, slack=8):
+    n = len(decoded)
+    cap = 8 * (n + 8)
+    seq = (ctypes.c_int32 * cap)()
+    prev = (ctypes.c_int32 * max(1, n))()
+    rows = sim.sim_plan_ordered(n, n_streams, (ctypes.c_uint8 * n)(*decoded), (ctypes.c_int32 * n)(*fwd), (ctypes.c_uint32 * n)(*stream),
+                                group, slack, seq, cap, prev)
+    return rows, [seq[i] for i in range(8 * rows)], list(prev)[:n]
+
+
+def test_ordered_plan_properties(sim):
+    """The one-launch plan (recon_plan.h): every decoded picture once; a class = whole streams; a picture's predecessor in
+    its stream comes earlier in the SAME class, `group` places back while the class still has that many streams going;
+    no class more than the slack above the mean; batches that cannot fill eight classes are refused."""
+    rng = np.random.default_rng(11)
+    for case in range(150):
+        n_streams = int(rng.integers(1, 40))
+        per = [int(rng.integers(1, 30)) if rng.random() < 0.3 else 24 for _ in range(n_streams)]
+        decoded, fwd, stream, last = [], [], [], {}
+        for s_, n_ in enumerate(per):
+            for i in range(n_):
+                p = len(decoded)
+                d = int(rng.random() < 0.9)
+                is_p = d and s_ in last and i % 6 != 0
+                decoded.append(d); stream.append(s_); fwd.append(last[s_] if is_p else -1)
+                if d:
+                    last[s_] = p
+        group = int(rng.integers(1, 5))
+        rows, seq, prev = run_plan_ordered(sim, decoded, fwd, stream, n_streams, group)
+        n_dec = sum(decoded)
+        loads = {}
+        for s_ in range(n_streams):
+            loads[s_] = sum(1 for p in range(len(decoded)) if decoded[p] and stream[p] == s_)
+        # the deal, restated: longest stream first onto the class with the least so far
+        cls = [0] * 8
+        for n_ in sorted((v for v in loads.values() if v), reverse=True):
+            cls[cls.index(min(cls))] += n_
+        fits = n_streams >= 8 and n_dec > 0 and max(cls) * 8 * 100 <= n_dec * 108
+        assert (rows != 0) == fits
+        if rows == 0:
+            continue
+        assert n_streams >= 8
+        pos = {}
+        for i, p in enumerate(seq):
+            if p >= 0:
+                assert p not in pos and decoded[p]
+                pos[p] = i
+        assert len(pos) == n_dec
+        cls_of_stream = {}
+        for p, i in pos.items():
+            assert cls_of_stream.setdefault(stream[p], i % 8) == i % 8          # whole streams per class
+        for c in range(8):
+            col = [p for p in seq[c::8]]
+            assert all(x < 0 for x in col[len([x for x in col if x >= 0]):])   # padding only at the end
+        for p, i in pos.items():
+            q = prev[p]
+            want = max((x for x in range(p) if decoded[x] and stream[x] == stream[p]), default=-1)
+            assert q == want
+            if q >= 0:
+                assert pos[q] % 8 == i % 8 and pos[q] < i
+                # every picture of its stream in between the two is impossible; the distance is the streams in lockstep
+                assert (i - pos[q]) // 8 <= group
+        cls_load = [sum(1 for x in seq[c::8] if x >= 0) for c in range(8)]
+        assert max(cls_load) == rows and max(cls_load) * 8 * 100 <= n_dec * 108
+
+
+def test_ordered_plan_benchmark_shape(sim):
+    """64 equal streams x 120 pictures, GOP 12, two streams in lockstep per class: 960 rows, no padding, predecessor exactly
+    two places back except where a class moves on to its next pair of streams"""
+    decoded, fwd, stream = [], [], []
+    for s_ in range(64):
+        for i in range(120):
+            p = len(decoded)
+            decoded.append(1); stream.append(s_); fwd.append(-1 if i % 12 == 0 else p - 1)
+    rows, seq, prev = run_plan_ordered(sim, decoded, fwd, stream, 64, 2)
+    assert rows == 960 and all(p >= 0 for p in seq)
+    pos = {p: i for i, p in enumerate(seq)}
+    for p in range(len(decoded)):
+        if prev[p] >= 0:
+            assert (pos[p] - pos[prev[p]]) // 8 == 2

@@ -23,21 +23,35 @@ if os.environ.get("JSMPEG_SYNTH_MV_JITTER"):       # coherent motion: one vector
 gen = bench.generate_streams(0, n_streams, frames)
 streams = [g[0] for g in gen]
 total = sum(len(s) for s in streams)
-with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, total + 64 * n_streams + 4096) as b:
-    b.upload(streams)
-    acc = None
-    for r in range(reps):
-        b.decode()
-        t = b.timings()
-        if r >= warm:
-            acc = t if acc is None else {k: acc[k] + t[k] for k in t}
-    lv = b.counters()["levels"]
-    try:
-        lt = b.level_timings()
-        print("recon launches ms:", " ".join("%.3f" % x for x in lt))
-    except Exception as e:  # an older library under JSMPEG_HIP_LIB
-        print("no level timings:", e)
-    ms = acc["total_ms"] / (reps - warm)
-    print({k: round(v / (reps - warm), 3) for k, v in acc.items()}, "recon per level %.3f" % (acc["recon_ms"] / (reps - warm) / lv),
-          "| %s %d x %d: %.0f frames/s, %.0f Mpixel/s" % (bench.CONFIG, n_streams, frames, n_streams * frames / ms * 1e3,
-                                                         n_streams * frames / ms * 1e3 * cfg["width"] * cfg["height"] / 1e6))
+def run(order):
+    if order is not None:
+        os.environ["JSMPEG_HIP_RECON_ORDER"] = order
+    with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, total + 64 * n_streams + 4096) as b:
+        b.upload(streams)
+        acc = None
+        for r in range(reps):
+            b.decode()
+            t = b.timings()
+            if r >= warm:
+                acc = t if acc is None else {k: acc[k] + t[k] for k in t}
+        lv = b.counters()["levels"]
+        try:
+            lt = b.level_timings()
+            print("recon launches ms:", " ".join("%.3f" % x for x in lt))
+        except Exception as e:  # an older library under JSMPEG_HIP_LIB
+            print("no level timings:", e)
+        try:
+            print("reconstruct:", b.recon_info())
+        except Exception as e:
+            print("no recon info:", e)
+        ms = acc["total_ms"] / (reps - warm)
+        print(("order %s: " % order if order is not None else "") + str({k: round(v / (reps - warm), 3) for k, v in acc.items()}),
+              "recon per level %.3f" % (acc["recon_ms"] / (reps - warm) / lv),
+              "| %s %d x %d: %.0f frames/s, %.0f Mpixel/s" % (bench.CONFIG, n_streams, frames, n_streams * frames / ms * 1e3,
+                                                             n_streams * frames / ms * 1e3 * cfg["width"] * cfg["height"] / 1e6), flush=True)
+
+
+# JSMPEG_KBENCH_ORDERS=0,1,2,4: one batch per value of JSMPEG_HIP_RECON_ORDER (streams a class walks in lockstep; 0 = level by level)
+orders = os.environ.get("JSMPEG_KBENCH_ORDERS")
+for o in (orders.split(",") if orders else [None]):
+    run(o)
