@@ -128,9 +128,11 @@ int jsmpeg_hip_batch_upload_device(jsmpeg_hip_batch_t *b, const void *dev_es, ui
                                    void *hip_stream);
 /* The same WITHOUT the copy: the next decode reads `dev_es` in place (a rank's piece as it arrived by
  * jsmpeg_hip_dist_scatter / _exchange, part 4: no placement pass in front of every step).  What the caller promises:
- * `dev_es` is 16-byte aligned and readable 256 bytes past `total_bytes`; every begin[i] is a multiple of 16, ranges
- * ascend with >= 8 bytes between them, and every byte outside the ranges (the gaps, the tail) is 0xff -- a gap must
- * not complete a start code; the buffer is left alone until the decode that follows has finished on `hip_stream`.
+ * `dev_es` is 16-byte aligned and readable 256 bytes past `total_bytes`; every begin[i] is a multiple of 16, the first
+ * one >= 16 (the buffer BEGINS with a gap), ranges ascend with >= 8 bytes between them, and every byte outside the
+ * ranges (the leading gap, the gaps, the tail) is 0xff -- unchecked: a stale byte in a gap can complete a start code
+ * and change the decode; the buffer stays valid and untouched for as long as it is attached: until the next upload*
+ * / attach call (jsmpeg_hip_batch_read_es and the debug read-backs look at it too, not only the decode).
  * Returns at once (the stream table is copied on `hip_stream`); 0 or < 0 (misaligned / touching ranges are refused,
  * nothing is decoded from them).  The next upload* call returns the batch to its own buffer. */
 int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void *dev_es, uint64_t total_bytes,

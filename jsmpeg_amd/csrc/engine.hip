@@ -492,6 +492,7 @@ extern "C" int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void 
 	for (uint32_t i = 0; i < n_streams; i++) {
 		if (end[i] < begin[i] || end[i] > total_bytes) return fail("stream %u: bad byte range", i);
 		if ((begin[i] & 15u) != 0) return fail("attach: stream %u does not begin on a 16-byte boundary (use upload_device)", i);
+		if (i == 0 && begin[0] < 16) return fail("attach: the first stream must begin at byte 16 or later (the buffer starts with a gap of 0xff bytes like the ones between streams)");
 		if (begin[i] < prev_end + JM_STREAM_GAP) return fail("attach: stream %u begins less than %d bytes after the one before", i, JM_STREAM_GAP);
 		prev_end = end[i];
 		sum += end[i] - begin[i];
@@ -667,8 +668,11 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	{ const char *dbg = getenv("JSMPEG_HIP_DEBUG"); pb.debug_flags = dbg ? atoi(dbg) : 0; }
 	pb.dbg = nullptr;
 	if (pb.debug_flags & 4) {   /* diagnostics: per-slice abort record, parked in the (unused) hash buffer's neighbour */
-		if (!b->d_dbg) { HIP_TRY(jm_malloc(&b->d_dbg, (size_t)b->sc_cap * 16)); }
-		HIP_TRY(hipMemsetAsync(b->d_dbg, 0xee, (size_t)b->sc_cap * 16, st));
+		/* 4 words per start code (abort records) -- or, in a -DJM_PARSE_STATS build, 16 words per BATCH of slices: a head
+		 * batch may hold a single slice, so up to one batch per slice code */
+		const size_t dbg_bytes = (size_t)b->sc_cap * 64;
+		if (!b->d_dbg) { HIP_TRY(jm_malloc(&b->d_dbg, dbg_bytes)); }
+		HIP_TRY(hipMemsetAsync(b->d_dbg, 0xee, dbg_bytes, st));
 		pb.dbg = b->d_dbg;
 	}
 	tr.mark("plan1");

@@ -77,8 +77,32 @@
  * detached when the decoder is destroyed (the pinned host planes are freed then: a late read by a renderer must
  * see an empty view, not freed memory), and where the host forbids external buffers (V8 sandbox builds, Electron
  * >= 21: napi_no_external_buffers_allowed) they are JS-owned buffers that every getPlanes() refreshes by a copy. */
+/* WHO KEEPS A DECODER ALIVE.  Zero-copy views are external ArrayBuffers over the decoder's pinned host memory, and JS
+ * may keep them longer than the handle (a renderer holds the last planes).  So the decoder belongs to a small counted
+ * owner: one claim for the handle, one for every external ArrayBuffer made over its memory (released by that buffer's
+ * own finalizer).  destroy() ends the decoder at once (it detaches the views first); a handle that is simply dropped
+ * gives up its claim when it is collected, and the decoder goes with the LAST claim -- no view ever looks at freed
+ * memory, and nothing stays behind once the views are gone. */
+typedef struct {
+	void *d;                     /* mpeg1_decoder_t / mp2_decoder_t, NULL once destroyed */
+	void (*destroy)(void *);
+	int claims;
+} dec_owner_t;
+static int g_live_decoders = 0;   /* decoders (video + audio) created through this addon and not destroyed yet: liveDecoders() */
+static void owner_kill(dec_owner_t *o) { if (o->d) { o->destroy(o->d); o->d = NULL; g_live_decoders--; } }
+static void owner_release(dec_owner_t *o) { if (--o->claims == 0) { owner_kill(o); free(o); } }
+static void owner_release_buffer(napi_env env, void *data, void *hint) { (void)env; (void)data; owner_release((dec_owner_t *)hint); }
+static void destroy_mpeg1(void *d) { mpeg1_decoder_destroy((mpeg1_decoder_t *)d); }
+static void destroy_mp2(void *d) { mp2_decoder_destroy((mp2_decoder_t *)d); }
+static dec_owner_t *owner_new(void *d, void (*destroy)(void *)) {
+	dec_owner_t *o = (dec_owner_t *)calloc(1, sizeof(dec_owner_t));
+	if (o) { o->d = d; o->destroy = destroy; o->claims = 1; g_live_decoders++; }
+	return o;
+}
+
 typedef struct {
 	mpeg1_decoder_t *d;
+	dec_owner_t *own;
 	napi_ref views;              /* {y, cr, cb} or NULL */
 	void *views_ptr;             /* the Y pointer the cached views were made for */
 	size_t views_n;
@@ -101,12 +125,10 @@ static mpeg1_decoder_t *handle_arg(napi_env env, napi_value v) {
 static void wrap_finalize(napi_env env, void *data, void *hint) {
 	(void)hint;
 	dec_wrap_t *w = (dec_wrap_t *)data;
-	/* a handle dropped without destroy().  Views that look at the decoder's pinned planes may outlive the handle (the
-	 * renderer keeps them), and a finalizer may not detach ArrayBuffers: the decoder then keeps its memory (a leak
-	 * bounded by one decoder, chosen over views into freed memory); destroy() is the way to give it back. */
-	const int views_alive = w->views && !w->copied;
+	/* a handle dropped without destroy(): its claim goes; views JS still holds keep the decoder until they are collected
+	 * (a finalizer may not detach ArrayBuffers) */
 	if (w->views) napi_delete_reference(env, w->views);
-	if (w->d && !views_alive) mpeg1_decoder_destroy(w->d);
+	if (w->own) owner_release(w->own);
 	free(w);
 }
 /* forget the cached views; detach their buffers when they look at decoder memory */
@@ -140,10 +162,11 @@ static napi_value fn_create(napi_env env, napi_callback_info info) {
 		return NULL;
 	}
 	dec_wrap_t *w = (dec_wrap_t *)calloc(1, sizeof(dec_wrap_t));
-	if (!w) { mpeg1_decoder_destroy(d); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
-	w->d = d;
+	dec_owner_t *own = w ? owner_new(d, destroy_mpeg1) : NULL;
+	if (!w || !own) { mpeg1_decoder_destroy(d); free(w); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
+	w->d = d; w->own = own;
 	if (napi_create_external(env, w, wrap_finalize, NULL, &out) != napi_ok) {
-		mpeg1_decoder_destroy(d); free(w);
+		mpeg1_decoder_destroy(d); free(own); free(w);
 		napi_throw_error(env, NULL, "jsmpeg_hip: N-API call failed: napi_create_external");
 		return NULL;
 	}
@@ -156,9 +179,9 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info) {
 	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
 	dec_wrap_t *w = wrap_arg(env, argv[0]);
 	if (!w) return NULL;
-	wrap_drop_views(env, w);
-	mpeg1_decoder_destroy(w->d);
-	w->d = NULL;                 /* the wrapper itself goes with the handle (wrap_finalize) */
+	wrap_drop_views(env, w);     /* detached: nothing looks at the planes any more */
+	owner_kill(w->own);
+	w->d = NULL;                 /* the wrapper itself goes with the handle (wrap_finalize), the owner with the last claim */
 	return NULL;
 }
 
@@ -248,9 +271,10 @@ static napi_value fn_decode(napi_env env, napi_callback_info info) {
 
 /* one plane as a Uint8Array: over the decoder's pinned host memory, or (external buffers forbidden) over a JS-owned
  * copy whose address comes back in *copy_dst */
-static napi_value plane_view(napi_env env, void *ptr, size_t len, int *copied, void **copy_dst) {
+static napi_value plane_view(napi_env env, dec_owner_t *own, void *ptr, size_t len, int *copied, void **copy_dst) {
 	napi_value ab, view;
-	if (*copied || napi_create_external_arraybuffer(env, ptr, len, NULL, NULL, &ab) != napi_ok) {
+	if (!*copied && napi_create_external_arraybuffer(env, ptr, len, owner_release_buffer, own, &ab) == napi_ok) own->claims++;
+	else {
 		napi_value pending;
 		bool is_pending = false;
 		if (napi_is_exception_pending(env, &is_pending) == napi_ok && is_pending) napi_get_and_clear_last_exception(env, &pending);
@@ -283,9 +307,9 @@ static napi_value fn_get_planes(napi_env env, napi_callback_info info) {
 	}
 	wrap_drop_views(env, w);
 	int copied = 0;
-	y = plane_view(env, py, n, &copied, &w->copy_dst[0]);
-	cr = y ? plane_view(env, pcr, n >> 2, &copied, &w->copy_dst[1]) : NULL;
-	cb = cr ? plane_view(env, pcb, n >> 2, &copied, &w->copy_dst[2]) : NULL;
+	y = plane_view(env, w->own, py, n, &copied, &w->copy_dst[0]);
+	cr = y ? plane_view(env, w->own, pcr, n >> 2, &copied, &w->copy_dst[1]) : NULL;
+	cb = cr ? plane_view(env, w->own, pcb, n >> 2, &copied, &w->copy_dst[2]) : NULL;
 	if (copied && y && !w->copy_dst[0]) { w->copy_dst[0] = NULL; }
 	if (!y || !cr || !cb) { napi_throw_error(env, NULL, "jsmpeg_hip: cannot create plane views"); return NULL; }
 	NAPI_OK(napi_create_object(env, &out));
@@ -294,6 +318,14 @@ static napi_value fn_get_planes(napi_env env, napi_callback_info info) {
 	NAPI_OK(napi_set_named_property(env, out, "cb", cb));
 	NAPI_OK(napi_create_reference(env, out, 1, &w->views));
 	w->views_ptr = py; w->views_n = n; w->copied = copied;
+	return out;
+}
+
+/* diagnostics: decoders created through the addon that still hold their device and pinned memory */
+static napi_value fn_live_decoders(napi_env env, napi_callback_info info) {
+	(void)info;
+	napi_value out;
+	NAPI_OK(napi_create_int32(env, g_live_decoders, &out));
 	return out;
 }
 
@@ -550,6 +582,7 @@ static napi_value fn_last_error(napi_env env, napi_callback_info info) {
 /* the MP2 handle: the decoder and its cached {left, right} views (same rules as dec_wrap_t) */
 typedef struct {
 	mp2_decoder_t *d;
+	dec_owner_t *own;
 	napi_ref views;
 	void *views_ptr;
 	int copied;
@@ -570,9 +603,8 @@ static mp2_decoder_t *mp2_handle_arg(napi_env env, napi_value v) {
 static void mp2_wrap_finalize(napi_env env, void *data, void *hint) {
 	(void)hint;
 	mp2_wrap_t *w = (mp2_wrap_t *)data;
-	const int views_alive = w->views && !w->copied;      /* same rule as wrap_finalize */
 	if (w->views) napi_delete_reference(env, w->views);
-	if (w->d && !views_alive) mp2_decoder_destroy(w->d);
+	if (w->own) owner_release(w->own);       /* same rule as wrap_finalize */
 	free(w);
 }
 static void mp2_wrap_drop_views(napi_env env, mp2_wrap_t *w) {
@@ -599,10 +631,11 @@ static napi_value fn_mp2_create(napi_env env, napi_callback_info info) {
 		return NULL;
 	}
 	mp2_wrap_t *w = (mp2_wrap_t *)calloc(1, sizeof(mp2_wrap_t));
-	if (!w) { mp2_decoder_destroy(d); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
-	w->d = d;
+	dec_owner_t *own = w ? owner_new(d, destroy_mp2) : NULL;
+	if (!w || !own) { mp2_decoder_destroy(d); free(w); napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
+	w->d = d; w->own = own;
 	if (napi_create_external(env, w, mp2_wrap_finalize, NULL, &out) != napi_ok) {
-		mp2_decoder_destroy(d); free(w);
+		mp2_decoder_destroy(d); free(own); free(w);
 		napi_throw_error(env, NULL, "jsmpeg_hip: N-API call failed: napi_create_external");
 		return NULL;
 	}
@@ -616,7 +649,7 @@ static napi_value fn_mp2_destroy(napi_env env, napi_callback_info info) {
 	mp2_wrap_t *w = mp2_wrap_arg(env, argv[0]);
 	if (!w) return NULL;
 	mp2_wrap_drop_views(env, w);
-	mp2_decoder_destroy(w->d);
+	owner_kill(w->own);
 	w->d = NULL;
 	return NULL;
 }
@@ -695,7 +728,8 @@ static napi_value fn_mp2_get_channels(napi_env env, napi_callback_info info) {
 	}
 	mp2_wrap_drop_views(env, w);
 	int copied = 0;
-	if (napi_create_external_arraybuffer(env, l, bytes, NULL, NULL, &ab) != napi_ok) {
+	if (napi_create_external_arraybuffer(env, l, bytes, owner_release_buffer, w->own, &ab) == napi_ok) w->own->claims++;
+	else {
 		napi_value pending;
 		bool is_pending = false;
 		if (napi_is_exception_pending(env, &is_pending) == napi_ok && is_pending) napi_get_and_clear_last_exception(env, &pending);
@@ -871,7 +905,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "hasSequenceHeader", fn_has_sequence_header }, { "getFrameRate", fn_get_frame_rate },
 		{ "getCodedSize", fn_get_coded_size }, { "getWidth", fn_get_width }, { "getHeight", fn_get_height },
 		{ "decode", fn_decode }, { "getPlanes", fn_get_planes }, { "renderRGBA", fn_render_rgba },
-		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error },
+		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error }, { "liveDecoders", fn_live_decoders },
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
 		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },

@@ -209,6 +209,13 @@ static int rccl_load(void) {
 		ncclResult_t r_ = (call);                                             \
 		if (r_ != ncclSuccess) return sfail("%s: %s", #call, g_rccl.GetErrorString(r_)); \
 	} while (0)
+/* inside a ncclGroupStart / ncclGroupEnd bracket: a failing call must not leave the group open on this thread (every
+ * later RCCL call, on any communicator, would queue into a group that never ends) */
+#define RCCL_TRY_IN_GROUP(call)                                               \
+	do {                                                                      \
+		ncclResult_t r_ = (call);                                             \
+		if (r_ != ncclSuccess) { (void)g_rccl.GroupEnd(); return sfail("%s: %s", #call, g_rccl.GetErrorString(r_)); } \
+	} while (0)
 #define SHIP_TRY(call)                                                        \
 	do {                                                                      \
 		hipError_t e_ = (call);                                               \
@@ -273,7 +280,7 @@ extern "C" int jsmpeg_hip_dist_scatter(jsmpeg_hip_dist_t *d, int32_t src_rank, c
 			RCCL_TRY(g_rccl.GroupStart());
 			for (int r = 0; r < d->world; r++)
 				if (r != d->rank && bytes[r])
-					RCCL_TRY(g_rccl.Send((const uint8_t *)src_dev + offset[r], bytes[r], ncclUint8, r, d->comm, st));
+					RCCL_TRY_IN_GROUP(g_rccl.Send((const uint8_t *)src_dev + offset[r], bytes[r], ncclUint8, r, d->comm, st));
 			RCCL_TRY(g_rccl.GroupEnd());
 		}
 	} else if (bytes[d->rank]) {
@@ -299,7 +306,7 @@ extern "C" int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, co
 			RCCL_TRY(g_rccl.GroupStart());
 			for (int r = 0; r < d->world; r++)
 				if (r != d->rank && bytes[r])
-					RCCL_TRY(g_rccl.Recv((uint8_t *)dst_dev + offset[r], bytes[r], ncclUint8, r, d->comm, st));
+					RCCL_TRY_IN_GROUP(g_rccl.Recv((uint8_t *)dst_dev + offset[r], bytes[r], ncclUint8, r, d->comm, st));
 			RCCL_TRY(g_rccl.GroupEnd());
 		}
 	} else if (bytes[d->rank]) {
@@ -330,8 +337,8 @@ extern "C" int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_de
 		RCCL_TRY(g_rccl.GroupStart());
 		for (int r = 0; r < d->world; r++) {
 			if (r == d->rank) continue;
-			if (send_bytes[r]) RCCL_TRY(g_rccl.Send((const uint8_t *)src_dev + send_offset[r], send_bytes[r], ncclUint8, r, d->comm, st));
-			if (recv_bytes[r]) RCCL_TRY(g_rccl.Recv((uint8_t *)dst_dev + recv_offset[r], recv_bytes[r], ncclUint8, r, d->comm, st));
+			if (send_bytes[r]) RCCL_TRY_IN_GROUP(g_rccl.Send((const uint8_t *)src_dev + send_offset[r], send_bytes[r], ncclUint8, r, d->comm, st));
+			if (recv_bytes[r]) RCCL_TRY_IN_GROUP(g_rccl.Recv((uint8_t *)dst_dev + recv_offset[r], recv_bytes[r], ncclUint8, r, d->comm, st));
 		}
 		RCCL_TRY(g_rccl.GroupEnd());
 	}

@@ -34,7 +34,7 @@ enum { COEFF_EOB_OR_ONE = 0x0001, COEFF_ESCAPE = 0xffff };       /* mpeg1.js:144
 
 /* ------------------------------------------------- VLC prefix tables */
 
-typedef struct { int maxlen; uint8_t *len; int32_t *val; } vlc_t;
+typedef struct { int maxlen; uint8_t *len; int32_t *val; int32_t invalid; /* what a bit string that is no code reads as: the reference tree's T[1], see read_vlc */ } vlc_t;
 
 static void vlc_add(vlc_t *t, const char *bits, int32_t value) {
 	int n = (int)strlen(bits);
@@ -47,6 +47,7 @@ static void vlc_init(vlc_t *t, int maxlen) {
 	t->maxlen = maxlen;
 	t->len = calloc((size_t)1 << maxlen, 1);
 	t->val = calloc((size_t)1 << maxlen, sizeof(int32_t));
+	t->invalid = 6;
 }
 
 static vlc_t T_MBA, T_MBTYPE_I, T_MBTYPE_P, T_CBP, T_MOTION, T_DCL, T_DCC, T_COEFF;
@@ -67,6 +68,10 @@ static void tables_init(void) {
 	cur = &T_COEFF; vlc_init(cur, 16); MPEG1_VLC_DCT_COEFF(ADD2)
 	vlc_add(cur, "1", COEFF_EOB_OR_ONE);
 	vlc_add(cur, MPEG1_VLC_DCT_ESCAPE_BITS, COEFF_ESCAPE);
+	/* T[1] of the reference's trees: 2*3 = 6 where the table begins "1*3, 2*3, 0" (MACROBLOCK_ADDRESS_INCREMENT,
+	 * MACROBLOCK_TYPE_*, MOTION, DCT_COEFF: mpeg1.c:123, 164-190, 360, 446), 1*3 = 3 where it begins "2*3, 1*3, 0"
+	 * (CODE_BLOCK_PATTERN mpeg1.c:202, DCT_DC_SIZE_LUMINANCE :401, DCT_DC_SIZE_CHROMINANCE :422) */
+	T_CBP.invalid = T_DCL.invalid = T_DCC.invalid = 3;
 	tables_ready = 1;
 }
 
@@ -111,12 +116,16 @@ static uint32_t read_bits(mpeg1_decoder_t *d, int n) { uint32_t v = peek_bits(d,
 
 /* readHuffman: mpeg1.js:66-72 / mpeg1.c:1742-1748, table-driven here.
  * A bit string that is no code: the reference walks its tree one bit at a time, `state = T[state + bit]`, and a
- * missing branch is -1 -- the loop ends on `state >= 0` and the function returns T[state + 2] = T[1], which is 6 in
- * every one of its tables (they all begin 1*3, 2*3, 0).  So an invalid string consumes its bits up to and including
- * the first one no code continues with, and yields 6 -- in JS, wasm and C alike.  Valid MPEG-1 runs into this: with
- * zero_byte stuffing between a picture's last slice and the next start code decode_slice keeps calling
- * decode_macroblock (mpeg1.c:1018-1020), each call reads eight zero bits as an "increment of 6", finds it illegal at
- * the end of the picture (mpeg1.c:1053-1057) and returns -- a byte per call until the start code is aligned. */
+ * missing branch is -1 -- the loop ends on `state >= 0` and the function returns T[state + 2] = T[1]: the SECOND entry
+ * of the table, which is 6 in the tables that begin "1*3, 2*3, 0" (address increment, macroblock types, motion,
+ * coefficients) and 3 in the three that begin "2*3, 1*3, 0" (coded block pattern, both dct_dc_size tables) --
+ * vlc_t::invalid.  So an invalid string consumes its bits up to and including the first one no code continues with,
+ * and yields that value -- in JS, wasm and C alike.  Valid MPEG-1 runs into the first kind: with zero_byte stuffing
+ * between a picture's last slice and the next start code decode_slice keeps calling decode_macroblock
+ * (mpeg1.c:1018-1020), each call reads eight zero bits as an "increment of 6", finds it illegal at the end of the
+ * picture (mpeg1.c:1053-1057) and returns -- a byte per call until the start code is aligned.  The second kind
+ * (cbp 3, dct_dc_size 3 for `0000 0000x` / `1111 111x`) only damaged streams reach; tests/test_oracle_pin.py holds it
+ * against the reference's own build all the same. */
 static int32_t read_vlc(mpeg1_decoder_t *d, const vlc_t *t) {
 	uint32_t idx = peek_bits(d, t->maxlen);
 	int len = t->len[idx];
@@ -126,10 +135,10 @@ static int32_t read_vlc(mpeg1_decoder_t *d, const vlc_t *t) {
 			const uint32_t lo = (idx >> (t->maxlen - n)) << (t->maxlen - n), hi = lo + (1u << (t->maxlen - n));
 			int any = 0;
 			for (uint32_t k = lo; k < hi && !any; k++) any = t->len[k] != 0;
-			if (!any) { d->index += (unsigned)n; return 6; }
+			if (!any) { d->index += (unsigned)n; return t->invalid; }
 		}
 		d->index += (unsigned)t->maxlen;
-		return 6;
+		return t->invalid;
 	}
 	d->index += (unsigned)len;
 	return t->val[idx];

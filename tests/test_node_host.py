@@ -187,3 +187,21 @@ def test_player_hip_over_the_real_addon(mode, hip_lib):
     assert out["video"] == want
     assert out["sizes"] == [[176, 144]] and abs(out["frameRate"] - 30.0) < 1e-6
     assert out["audio"] == afx["frame_md5"] and out["sampleRate"] == afx["sample_rate"]
+
+
+@pytest.mark.gpu
+def test_dropped_handles_give_their_decoders_back(hip_lib):
+    """A handle that is garbage-collected without destroy() must neither free memory its plane views still look at nor
+    keep the decoder for ever: the decoder goes with the last of {handle, external ArrayBuffers} (napi_addon.c, dec_owner_t)."""
+    build.build_addon()
+    fx, ts = _ts_for("cfg0_240p_intra")
+    try:
+        out = json.loads(subprocess.check_output([NODE, "--expose-gc", os.path.join(ROOT, "tests", "js", "hip_handle_lifetime.js"), ts]))
+    finally:
+        os.unlink(ts)
+    assert out["start"] == 0 and out["afterCreate"] == 12
+    assert out["afterDrop"] == 0, out                       # nothing leaks
+    assert out["viewsStillReadable"], out                   # nothing dangles
+    assert out["viewsKeepDecoder"] in (0, 1), out           # 1: zero-copy views (external buffers); 0: the host copies planes
+    assert out["afterViewsGone"] == 0 and out["afterDestroy"] == 0, out
+    assert out["detachedLength"] == 0 or out["viewsKeepDecoder"] == 0, out

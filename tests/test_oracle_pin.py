@@ -107,3 +107,62 @@ def test_encoder_script_reproduces_the_committed_streams():
     es, offs = mpeg1_enc.encode(**mpeg1_enc.CASES[name])
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_%s.json" % name)))
     assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"] and len(offs) == fx["n_frames"] + 1
+
+
+def _stream_with_invalid_cbp_and_dc_size():
+    """32 x 16, two pictures written bit by bit: an I picture whose first luma block has the dct_dc_size code 1111111 (no
+    such code), and a P picture whose first macroblock has the coded_block_pattern 00000000 (no code begins like that).
+    The reference's tree walk returns its table's T[1] for both: size 3 and pattern 3 (mpeg1.c:202, 401, 1742-1748)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "enc"))
+    import mpeg1_enc as E
+    w = E.Bits()
+    w.start_code(0xB3)
+    w.put(32, 12); w.put(16, 12); w.put(1, 4); w.put(5, 4); w.put(0x3FFFF, 18); w.put(1, 1); w.put(20, 10); w.put(0, 1); w.put(0, 1); w.put(0, 1)
+    w.start_code(0xB8)
+    w.put(0, 1); w.put(0, 5); w.put(0, 6); w.put(1, 1); w.put(0, 6); w.put(0, 6); w.put(1, 1); w.put(0, 1)
+    # ---- I picture ----
+    w.start_code(0x00)
+    w.put(0, 10); w.put(1, 3); w.put(0xFFFF, 16); w.put(0, 1)
+    w.start_code(0x01)
+    w.put(8, 5); w.put(0, 1)
+    for mb in range(2):
+        w.code(E.INV["MBA"][1]); w.code(E.INV["MBTYPE_I"][0x01])
+        for b in range(6):
+            if mb == 0 and b == 0:
+                w.code("1111111")            # no dct_dc_size_luminance code: read as size 3
+                w.put(0b101, 3)              # its three differential bits: +5
+            else:
+                w.code(E.INV["DCSIZE_LUMA" if b < 4 else "DCSIZE_CHROMA"][0])
+            w.code("10")                     # end_of_block
+    # ---- P picture ----
+    w.start_code(0x00)
+    w.put(1, 10); w.put(2, 3); w.put(0xFFFF, 16); w.put(0, 1); w.put(1, 3); w.put(0, 1)
+    w.start_code(0x01)
+    w.put(8, 5); w.put(0, 1)
+    w.code(E.INV["MBA"][1]); w.code(E.INV["MBTYPE_P"][0x02])
+    w.code("00000000")                       # no coded_block_pattern code: read as pattern 3 = blocks 4 and 5
+    for b in range(2):
+        w.code("1"); w.put(b, 1); w.code("10")   # (0, +1) / (0, -1), end_of_block
+    # the second macroblock intra (31 bits: one of 6 bits would hide in the slice's last byte and never be decoded, mpeg1.c:1018-1020)
+    w.code(E.INV["MBA"][1]); w.code(E.INV["MBTYPE_P"][0x01])
+    for b in range(6):
+        w.code(E.INV["DCSIZE_LUMA" if b < 4 else "DCSIZE_CHROMA"][0]); w.code("10")
+    w.start_code(0xB7)
+    return np.frombuffer(bytes(w.out), dtype=np.uint8).copy()
+
+
+def test_invalid_cbp_and_dc_size_read_as_the_reference_reads_them(libs):
+    """read_huffman returns T[1] for a bit string that is no code -- 3, not 6, in the three tables that begin
+    2*3, 1*3, 0.  Only damaged streams get there; the restatement is held against the reference's own build all the same."""
+    if not libs["ref"] or not os.path.exists(libs["ref"]):
+        pytest.skip("oracle/_ref not built (needs /root/reference once)")
+    es = _stream_with_invalid_cbp_and_dc_size()
+    want, want_idx, _ = cabi.decode_stream(libs["ref"], es)
+    got, got_idx, _ = cabi.decode_stream(libs["oracle"], es)
+    assert len(want) == 2 and got == want and got_idx == want_idx
+    # and the values really are in play: the +5 differential moved the first block's DC, blocks 4 / 5 of the P picture got their +-1
+    frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+    (y0, cr0, cb0), (y1, cr1, cb1) = frames
+    assert int(y0.reshape(16, 32)[0, 0]) == 128 + 5          # (the predictor carries it to the blocks behind)
+    assert not np.array_equal(cr1.reshape(8, 16)[:, :8], cr0.reshape(8, 16)[:, :8]) and not np.array_equal(cb1.reshape(8, 16)[:, :8], cb0.reshape(8, 16)[:, :8])
