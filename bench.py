@@ -51,15 +51,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def generate_streams(first_stream, count, frames):
+def generate_streams(first_stream, count, frames, config=None):
     """`count` synthetic streams with global indices first_stream.. (distinct seeds), in parallel threads
     (the generator is C and releases the GIL)."""
     from jsmpeg_amd import synth
     synth.lib()
     out = [None] * count
+    config = config or CONFIG
 
     def work(k):
-        out[k] = synth.generate_config(CONFIG, n_frames=frames, stream=first_stream + k, with_stats=True)
+        out[k] = synth.generate_config(config, n_frames=frames, stream=first_stream + k, with_stats=True)
 
     n_threads = max(1, min(count, (os.cpu_count() or 8), 32))
     idx = iter(range(count))
@@ -157,6 +158,79 @@ def cpu_baseline(sample_streams, width, height):
     return res
 
 
+OTHER_CONFIGS = (
+    # (BASELINE.json config it stands for, generator config, streams, pictures per stream, streams checked against the oracle)
+    ("configs[0] shape: 320x240 I-frame-only", "cfg0_240p_intra", 64, 300, 2),
+    ("configs[1]: 1280x720 I+P, single stream", "cfg1_720p", 1, 360, 1),
+    ("configs[1] content, 64 streams batched", "cfg1_720p", 64, 120, 2),
+    ("configs[4] content (3840x2160 high bitrate), 16 streams", "cfg4_2160p", 16, 24, 1),
+    ("configs[4] content (3840x2160 high bitrate), 64 streams", "cfg4_2160p", 64, 24, 1),
+)
+
+
+def other_configs(device, passes=5):
+    """The other BASELINE.json configurations as witnessed timings (never `value`): each one generated, decoded through the
+    batch interface (`passes` timed passes after two warm-up passes, host clock around decode + sync, median), and
+    parity-gated on a sample of its streams against the oracle before its numbers are reported."""
+    import statistics
+    import torch
+    from jsmpeg_amd import batch as jb, build, cabi, hashing, synth
+    lib_oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
+    out = []
+    for what, config, n_streams, frames, n_check in OTHER_CONFIGS:
+        cfg = synth.CONFIGS[config]
+        t_gen = time.perf_counter()
+        gen = generate_streams(0, n_streams, frames, config)
+        streams = [g[0] for g in gen]
+        stats = {k: sum(g[2][k] for g in gen) for k in gen[0][2]}
+        es_bytes = sum(len(s) for s in streams)
+        entry = {"stands_for": what, "workload": "%s: %d streams x %d pictures %dx%d" % (config, n_streams, frames, cfg["width"], cfg["height"])}
+        try:
+            with jb.Batch(cfg["width"], cfg["height"], n_streams, n_streams * frames + 8, es_bytes + 64 * n_streams + 4096, device=device) as b:
+                b.upload(streams)
+                ms, phases = [], None
+                for r in range(passes + 2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n = b.decode()              # decode + sync
+                    dt = (time.perf_counter() - t0) * 1e3
+                    if n != n_streams * frames:
+                        raise RuntimeError("decoded %d pictures, expected %d" % (n, n_streams * frames))
+                    if r >= 2:
+                        ms.append(dt)
+                        phases = b.timings()
+                dev = b.frame_hashes()
+                per = {}
+                for p, i in enumerate(b.pictures()):
+                    per.setdefault(i.stream, []).append(int(dev[p]))
+                checked = sorted(set([0, n_streams - 1][:n_check]))
+                for s_ in checked:
+                    want = []
+                    with cabi.Mpeg1Decoder(lib_oracle, len(streams[s_]) + 1024, cabi.MODE_EXPAND) as dec:
+                        dec.write(streams[s_])
+                        while dec.decode():
+                            want.append(hashing.frame_hash(*dec.planes()))
+                    if per.get(s_, []) != want:
+                        raise RuntimeError("PARITY FAILURE against the oracle on stream %d" % s_)
+                info = b.recon_info()
+            med = statistics.median(ms)
+            alg = es_bytes + 384 * stats["macroblocks"] + 384 * stats["predicted"]
+            entry.update({"ms_per_pass": round(med, 3), "ms_per_pass_min": round(min(ms), 3), "passes": passes,
+                          "frames_per_s": round(n_streams * frames / med * 1e3, 1),
+                          "mpixel_per_s": round(n_streams * frames / med * 1e3 * cfg["width"] * cfg["height"] / 1e6, 1),
+                          "algorithmic_bytes_per_pass": int(alg),
+                          "whole_step_frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "gpu_phases_ms": {k: round(v, 3) for k, v in phases.items()},
+                          "reconstruct_launches": info["launches"],
+                          "parity": "streams %s of %d, every picture: device hash == oracle" % (checked, n_streams),
+                          "clock": "host clock around decode + sync, median of %d passes after 2 warm-up passes" % passes})
+        except Exception as e:  # a reported extra: never fatal for the headline line, but never a number without its gate either
+            entry["error"] = repr(e)[:300]
+        log("other config %s: %s (generated in %.1fs)" % (entry["workload"], entry.get("ms_per_pass", entry.get("error")), time.perf_counter() - t_gen))
+        out.append(entry)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +243,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="testing: run the multi-rank code path (GOP units, RCCL scatter / all-gather) with the ranks present, even one")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra run that starts every step from host memory (value_incl_h2d)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the witnessed timings of the other BASELINE.json configurations (other_configs)")
     args = ap.parse_args()
     args.h2d = False
 
@@ -316,6 +391,7 @@ def main():
     phase = {"index_ms": 0.0, "host_ms": 0.0, "parse_ms": 0.0, "recon_ms": 0.0, "total_ms": 0.0}
     levels = 0
     level_ms = []        # reconstruct launches of the last timed step, HIP events on the launch stream
+    recon_how = {}       # ... and how it launched them (jsmpeg_hip_batch_recon_info)
     h2d_ms = []
 
     if not multi:
@@ -397,6 +473,7 @@ def main():
                 phase[k] += t[k]
             levels = b.counters()["levels"]
             level_ms[:] = b.level_timings()
+            recon_how.update(b.recon_info())
 
     # ---- what the parity gate certifies (it hashes the frame pool once, after the last timed step): the whole pool is
     # overwritten with a pattern between the warm-up and the timed region (untimed), so every plane the gate sees was
@@ -639,8 +716,11 @@ def main():
     if parse_ms >= recon_ms:
         dom = dict(kernel="k_parse", launches_per_step=1, avg_launch_ms=parse_ms, bytes_per_launch=alg_bytes_rank)
     else:
-        dom = dict(kernel="k_recon", launches_per_step=levels, avg_launch_ms=recon_ms / max(1, levels),
-                   bytes_per_launch=alg_bytes_rank / max(1, levels))
+        # one launch per dependency level -- or ONE for the whole step (the ordered launch): bytes and time of a launch
+        # change together, the rate is the same figure
+        launches = max(1, int(recon_how.get("launches", 0)) or levels)
+        dom = dict(kernel="k_recon", launches_per_step=launches, avg_launch_ms=recon_ms / launches,
+                   bytes_per_launch=alg_bytes_rank / launches)
     achieved = dom["bytes_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
     # HBM traffic of the dominant kernel from the PMC counters: NOT measured in this run (counter passes need rocprofv3
     # around the process) -- the figure of the last committed profile, with its source, or null
@@ -655,11 +735,16 @@ def main():
             traffic = None
     # the read-only share of the algorithmic bytes (north_star words the target as an "HBM-read roofline"): predicted
     # macroblocks (k_recon) or the compressed bytes (k_parse); and the measured HBM traffic as a rate
-    read_bytes = (384 * pred_rank / max(1, levels)) if dom["kernel"] == "k_recon" else es_bytes
+    read_bytes = (384 * pred_rank / dom["launches_per_step"]) if dom["kernel"] == "k_recon" else es_bytes
     # per level: what a reconstruct launch takes by what it holds (the first launch = the pictures without a forward
     # reference: planes written, nothing read back)
     lv = None
-    if level_ms:
+    if level_ms and len(level_ms) == 1 and levels > 1:
+        lv = {"ms": [round(level_ms[0], 4)], "level_equivalent_ms": round(level_ms[0] / levels, 4), "dependency_levels": levels,
+              "note": "the ordered launch: one launch for all %d dependency levels (every eighth of the GPU walks its streams in lockstep, "
+                      "a picture's tiles wait for the picture before it in its stream); JSMPEG_HIP_RECON_ORDER=0 launches level by level "
+                      "(per-level figures: profiles/r04_*)" % levels}
+    elif level_ms:
         rest = level_ms[1:] or level_ms
         intra_bytes = (alg_bytes_rank - 2 * 384 * pred_rank) / max(1, levels)       # its share of ES + planes, no prediction reads
         lv = {"ms": [round(x, 4) for x in level_ms], "intra_ms": round(level_ms[0], 4), "predicted_min_ms": round(min(rest), 4),
@@ -688,6 +773,18 @@ def main():
                       "hbm_traffic_over_es": round(tj.get("k_parse", 0) / max(1, es_bytes), 2) or None}
     except Exception as e:
         log("k_parse roofline not attached: %r" % (e,))
+    # how far from what THIS GPU can give (next to, never instead of, `frac` against the 8 TB/s spec): (1) a plain device copy's
+    # rate in this run / spec -- no kernel that reads and writes in k_recon's proportions gets more out of the HBM; (2) the
+    # dominant kernel's arithmetic alone (timing build without prediction loads and plane stores, 0.686 ms per level of this
+    # workload: profiles/r03_recon_notes.md) priced in the same bytes -- VALU issue bounds the kernel below its memory side
+    skeleton_ms_per_level = 0.686
+    ceilings = {"device_copy": round(copy_gbs / HBM_PEAK_GBS, 4) if copy_gbs else None,
+                "device_copy_source": "measured in this run (device_copy_measured)",
+                "valu_skeleton": round(alg_bytes_rank / max(1, levels) / (skeleton_ms_per_level * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if dom["kernel"] == "k_recon" and n_streams == STREAMS_PER_GPU and frames == FRAMES_PER_STREAM else None,
+                "valu_skeleton_source": "static: %.3f ms per level for the kernel without its prediction loads and plane stores "
+                                        "(profiles/r03_recon_notes.md), not measured in this run" % skeleton_ms_per_level,
+                "note": "ceilings of this design on this GPU, as fractions of the same 8 TB/s: frac / min(ceilings) is the distance left"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_rate": round(traffic / (dom["avg_launch_ms"] * 1e-3) / 1e9, 1) if traffic else None,
@@ -700,6 +797,8 @@ def main():
                                "note": "all kernels + host turn-around of a step, per-GPU peak x n_gpus"},
                 "phases_ms": {kk: round(v / k, 4) for kk, v in phase.items()},
                 "levels": lv,
+                "reconstruct": dict(recon_how) or None,
+                "ceiling_frac": ceilings,
                 "peak_measured_achievable": 6290.0,
                 "device_copy_measured": {"value": copy_gbs, "unit": "GB/s",
                                          "note": "read + write traffic of a 2 GiB torch device-to-device copy on this GPU, same run: "
@@ -739,10 +838,16 @@ def main():
         exchange["pictures_differing_from_unsplit_streams"] = int(deviating)
         exchange["pictures_with_unwritten_macroblocks"] = int(uncovered)
         line["exchange"] = exchange
-    if not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_baseline(streams[:2], width, height)
-    else:
-        line["cpu_baseline"] = None
+    # rank 0, after the timed runs, at every N: the baseline is per host core and does not scale with the GPUs
+    line["cpu_baseline"] = cpu_baseline(streams[:2], width, height) if not args.no_cpu_baseline else None
+    if world == 1 and not args.no_other_configs:
+        try:
+            b.close()                       # the headline batch's 24 GB frame pool, before the other shapes take theirs
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(local_rank)
+        except Exception as e:
+            log("other configurations failed: %r" % (e,))
+            line["other_configs"] = {"error": repr(e)[:300]}
     # the sibling stage: MP2 audio of the same batch, its own figure beside the headline metric;
     # a reported extra, never fatal for the line
     if world == 1 and not args.no_audio:

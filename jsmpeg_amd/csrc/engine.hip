@@ -77,12 +77,16 @@ static int luts_for_device(int dev, JmVlcLuts **out) {
 
 static void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g, width, height); }
 
-/* Streams a class of the ordered reconstruct walks in lockstep (recon_plan.h): 8 x this many frames are written per
- * step and read back by the next.  JSMPEG_HIP_RECON_ORDER overrides (0: one launch per dependency level, always). */
-#ifndef JM_ORDER_GROUP_DEFAULT
-#define JM_ORDER_GROUP_DEFAULT 2
-#endif
-#define JM_DONE_STRIDE 32   /* words between two pictures' tile counts: k_recon's first look at one goes through the L1 */
+/* The ordered reconstruct (recon_plan.h): how far back, in workgroups of its class's dispatch order, the LAST tile of a
+ * picture's forward reference should lie behind the picture's FIRST tile: (streams in lockstep - 1) x tiles per picture.
+ * A class (32 CUs) holds 160 workgroups at a time; 200 back is finished but for stragglers (cfg2, 200 tiles per picture,
+ * two streams in lockstep: 0-1000 unfinished first looks in 1.5 M; one stream in lockstep, distance 1: 1.16 M, three times
+ * the time; 4K, 816 tiles, one stream: 0.87 M).  Below the residency the per-level launches are the better form (small
+ * pictures with few streams per class).
+ * JSMPEG_HIP_RECON_ORDER: 0 = always level by level, n = n streams in lockstep whatever the picture size (tests). */
+#define JM_ORDER_DISTANCE 200u
+#define JM_ORDER_MIN_DISTANCE 160u
+#define JM_ORDER_AUTO 0xffffffffu
 #define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
 
 /* =========================================================================
@@ -114,7 +118,7 @@ struct jsmpeg_hip_batch_t {
 	 * status words (kernels.h JM_RECON_STATUS_WORDS; h_: pinned), and how the last decode went */
 	uint32_t *d_done, *d_rstatus, *h_rstatus;
 	uint32_t last_group;         /* lockstep width of the last decode's launch, 0: it went level by level */
-	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level */
+	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level; JM_ORDER_AUTO: by the picture size */
 	bool ordered;                /* the last decode used the ordered launch (its status is checked at the next sync) */
 	bool stats_pending;          /* n_levels / n_uncovered of the last decode not worked out yet (needs the parse's counts) */
 	uint32_t ordered_status;     /* status of the last checked ordered launch (non-zero: it was done over) */
@@ -218,7 +222,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0;
 	b->d_done = nullptr; b->d_rstatus = nullptr; b->h_rstatus = nullptr; b->ordered = false; b->stats_pending = false; b->ordered_waits = 0; b->ordered_status = 0; b->last_group = 0;
-	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_GROUP_DEFAULT; } b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
+	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_AUTO; } b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
@@ -520,7 +524,7 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	D.fwd = pic.fwd >= 0 ? b->d_pool + (uint64_t)pic.fwd * b->g.frame_bytes : nullptr;
 	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes : nullptr;
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
-	D.done = nullptr; D.wait = nullptr;
+	D.done_pic = D.wait_fwd = D.wait_stale = JM_NONE; D.pad_ = 0;
 }
 
 /* JSMPEG_HIP_TRACE=1: where the HOST's time goes in one decode call (stderr, ms since the call began) */
@@ -697,25 +701,29 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
-	rb.need = 0; rb.patience = 0; rb.status = nullptr;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
 	b->n_level_ev = 0;
 	b->ordered = false; b->stats_pending = false; b->last_group = 0; b->ordered_status = 0; b->ordered_waits = 0;
 	JmOrderedPlan plan;
-	if (b->order_group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, b->order_group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap) {
-		/* ---- 4. ONE launch: every class walks its streams in lockstep, a picture's tiles wait for the picture before
-		 * it in its stream (its forward reference and the frame its unwritten macroblocks show are both behind that
-		 * one), so nothing here needs the parse's counts: no host turn-around between parse and reconstruct ---- */
+	const uint32_t per_picture = jm_recon_tiles_per_picture(b->g);
+	const uint32_t group = b->order_group == JM_ORDER_AUTO ? 1 + (JM_ORDER_DISTANCE + per_picture - 1) / per_picture : b->order_group;
+	if (group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap &&
+	    (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE)) {
+		/* ---- 4. ONE launch: every class walks its streams in lockstep; a picture's tiles wait for its forward reference,
+		 * and a tile with a macroblock the picture never wrote for the frame that keeps showing there -- decided by the
+		 * tile itself, so nothing here needs the parse's counts: no host turn-around between parse and reconstruct ---- */
 		for (size_t i = 0; i < plan.seq.size(); i++) {
 			JmReconDesc &D = b->h_desc[i];
 			const int32_t p = plan.seq[i];
 			if (p < 0) { memset(&D, 0, sizeof(D)); continue; }
 			fill_desc(b, D, (uint32_t)p, stale[p]);
-			D.done = b->d_done + (size_t)JM_DONE_STRIDE * p;
-			D.wait = plan.prev[p] >= 0 ? b->d_done + (size_t)JM_DONE_STRIDE * plan.prev[p] : nullptr;
+			D.done_pic = (uint32_t)p;
+			D.wait_fwd = b->h_pics[p].fwd >= 0 ? (uint32_t)b->h_pics[p].fwd : JM_NONE;
+			D.wait_stale = stale[p] >= 0 ? (uint32_t)stale[p] : JM_NONE;
 		}
 		if (const char *e = getenv("JSMPEG_HIP_RECON_BREAK")) {   /* tests: picture n of the plan never reports, its successor's wait runs out */
 			const size_t i = (size_t)atoi(e);
-			if (i < plan.seq.size() && plan.seq[i] >= 0) b->h_desc[i].done = nullptr;
+			if (i < plan.seq.size() && plan.seq[i] >= 0) b->h_desc[i].done_pic = JM_NONE;
 		}
 		if (const char *e = getenv("JSMPEG_HIP_RECON_PATIENCE")) rb.patience = (uint32_t)atoi(e);
 		HIP_TRY(hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(JmReconDesc) * plan.seq.size(), hipMemcpyHostToDevice, st));
@@ -723,11 +731,11 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		HIP_TRY(hipMemsetAsync(b->d_rstatus, 0, sizeof(uint32_t) * 8, st));
 		HIP_TRY(hipMemsetAsync(b->d_rstatus + 8, 0xff, sizeof(uint32_t) * 8, st));
 		rb.desc = b->d_desc; rb.n_level_pics = (uint32_t)plan.seq.size();
-		rb.need = 1; rb.status = b->d_rstatus;      /* (jm_launch_recon puts the workgroups per picture there) */
+		rb.need = 1; rb.status = b->d_rstatus; rb.done = b->d_done;     /* (jm_launch_recon puts the workgroups per picture into `need`) */
 		HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 		HIP_TRY(jm_launch_recon(rb, st));
 		HIP_TRY(hipMemcpyAsync(b->h_rstatus, b->d_rstatus, sizeof(uint32_t) * JM_RECON_STATUS_WORDS, hipMemcpyDeviceToHost, st));
-		b->ordered = true; b->stats_pending = true; b->last_group = b->order_group;
+		b->ordered = true; b->stats_pending = true; b->last_group = plan.lockstep;
 		tr.mark("ordered-enqueued");
 	} else if (recon_by_levels(b, rb, stale, n_roots, st, tr) < 0) return -1;
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], st));
@@ -752,7 +760,7 @@ static int batch_settle(jsmpeg_hip_batch_t *b) {
 			std::vector<int32_t> stale;
 			const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
 			JmReconBufs rb;
-			rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr;
+			rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
 			HostTrace tr;
 			b->n_level_ev = 0;
 			if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
@@ -1294,7 +1302,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	desc.dst = d->d_pool + (uint64_t)d->cur * d->g.frame_bytes; desc.fwd = d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes;
 	desc.stale = nullptr;
 	desc.qm = reinterpret_cast<const uint8_t *>(d->d_stream) + offsetof(JmStream, intra_q);
-	desc.done = nullptr; desc.wait = nullptr;
+	desc.done_pic = desc.wait_fwd = desc.wait_stale = JM_NONE; desc.pad_ = 0;
 
 	hipStream_t st = d->stream;
 	HIP_TRY(hipMemcpyAsync(d->d_sc_pos, d->stage_pos.data(), sizeof(uint32_t) * n_entries, hipMemcpyHostToDevice, st));
@@ -1317,7 +1325,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
-	rb.need = 0; rb.patience = 0; rb.status = nullptr;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));

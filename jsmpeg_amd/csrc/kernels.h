@@ -112,12 +112,11 @@ struct alignas(64) JmReconDesc {
 	                                mpeg1.c:986-994): macroblocks the picture never writes keep showing it.  Null: zeros
 	                                (the JS typed arrays start zeroed, mpeg1.js:131-152) */
 	const uint8_t *qm;           /* the stream's quantiser matrices: intra | non-intra, 128 bytes (JmStream::intra_q) */
-	/* ordered launches (JmReconBufs::need != 0; kernels.hip, k_recon): `done` counts the picture's finished tiles;
-	 * `wait` is the `done` word of the picture that comes before this one in its stream -- its forward reference, the
-	 * frame its unwritten macroblocks keep showing, and everything those depended on are complete once that word
-	 * reads JmReconBufs::need.  Null: nothing to wait for / nobody waits (per-level launches, the one-picture ABI). */
-	uint32_t *done;
-	const uint32_t *wait;
+	/* ordered launches (JmReconBufs::need != 0; kernels.hip, k_recon), as picture numbers into JmReconBufs::done (JM_NONE:
+	 * none): `done_pic` = this picture, whose finished tiles are counted; `wait_fwd` = its forward reference, complete
+	 * before any of this picture's tiles reads a frame; `wait_stale` = the picture whose frame `stale` is, waited for only by
+	 * a tile that really has a macroblock the picture never wrote (known once the tile's records are in). */
+	uint32_t done_pic, wait_fwd, wait_stale, pad_;
 };
 static_assert(sizeof(JmReconDesc) == 64, "JmReconDesc: one 64-byte line, two scalar loads");
 
@@ -130,15 +129,19 @@ struct JmReconBufs {
 	int zero_uncovered;
 	/* ORDERED launch (one launch for a whole batch instead of one per dependency level): desc[8 i + c] is the i-th
 	 * picture of CLASS c's sequence (workgroup b belongs to class b % 8: one XCD, one dispatcher walking its blocks in
-	 * order); a picture's dependencies all lie earlier in ITS class's sequence.  need: non-zero = ordered (the launch wrapper
+	 * order); a picture's dependencies (JmReconDesc::wait_fwd, wait_stale) all lie earlier in ITS class's sequence.  need: non-zero = ordered (the launch wrapper
 	 * replaces it by the workgroups per picture: what a finished picture's `done` word reads), 0: per-level launch.  Entries with dst == null are padding. */
 	uint32_t need;
+	uint32_t *done;              /* ordered launches: picture p's count of finished tiles at done[JM_DONE_STRIDE * p] (a 128-byte line each) */
 	uint32_t patience;           /* polls (~1 us each) before a wait is given up and the launch flags itself; 0: JM_RECON_PATIENCE */
 	uint32_t *status;            /* ordered launches: [0] error flags (1: a wait ran out of patience, 2: a class met two XCDs),
 	                                [1] polls that found their picture unfinished, [8 + c] XCC id class c ran on (preset 0xffffffff) */
 };
 #define JM_RECON_STATUS_WORDS 16
+#define JM_DONE_STRIDE 32     /* words between two pictures' tile counts: k_recon's first look at one goes through the L1 */
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
+/* workgroups (tiles) k_recon takes per picture of this geometry */
+uint32_t jm_recon_tiles_per_picture(const JmGeom &g);
 
 /* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */
 hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,

@@ -630,6 +630,33 @@ struct LdsSlot {
 	}
 };
 
+/* ORDERED launch: wait until picture `pic` is complete (its count of finished tiles reads b.need).
+ * FIRST a plain load: the word has a 128-byte line to itself and only ever counts up to `need`, so a cached `need` is
+ * final -- and in the common case that is what the first workgroup of this CU that asked brought in: one request to the
+ * L2 per CU and picture.  (Every wavefront polling past the L1 -- 4 x 1.5 M `sc1` loads per step on a handful of
+ * addresses -- doubled the reconstruct's time: an L2 channel serves one word at ~15 ns per request.)  A cached count
+ * below `need` says nothing (the L1 is never refreshed): then ONE lane polls past the L1 (agent-scope relaxed load =
+ * `sc1`) and the wavefront follows it.  Bounded: a wait that runs out flags the launch (the host then reconstructs
+ * level by level), and a flagged launch waits for nothing any more -- the frames are being done over anyway. */
+static __device__ __forceinline__ void jm_recon_wait(const JmReconBufs &b, uint32_t pic, uint32_t lane) {
+	JM_GLOBAL const uint32_t *w = (JM_GLOBAL const uint32_t *)b.done + (size_t)JM_DONE_STRIDE * pic;
+	uint32_t spins = 0;
+	if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*w) < b.need) for (;;) {
+		uint32_t seen = 0;
+		if (lane == 0) seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) >= b.need) break;
+		__builtin_amdgcn_s_sleep(16);
+		if (spins == 0 && lane == 0) atomicAdd(b.status + 1, 1u);
+		if ((spins & 63u) == 63u) {
+			uint32_t flagged = 0;
+			if (lane == 0) flagged = __hip_atomic_load((JM_GLOBAL const uint32_t *)b.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (__builtin_amdgcn_readfirstlane((int)flagged) != 0) break;
+		}
+		if (++spins > b.patience) { if (lane == 0) atomicOr(b.status, 1u); break; }
+	}
+	asm volatile("" ::: "memory");
+}
+
 __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
@@ -639,52 +666,21 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	if (k >= b.n_level_pics) return;
 	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
 	if (D.dst == nullptr) return;                    /* ordered launch: a class with fewer pictures than the longest */
-#ifdef JM_T_VWAVE
-	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#else
 	/* the wavefront's number as a scalar: what depends on (tile, wavefront) alone -- the tile's place in its plane, the
 	 * rows this wavefront takes -- is then scalar arithmetic, not 64 lanes' */
 	const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#endif
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
 	Q.rw = *reinterpret_cast<JM_GLOBAL const uint4_like_t *>((JM_GLOBAL const JmMbRec *)D.mb + Q.mbaddr);
-	/* ORDERED launch: the picture before this one in its stream must be complete before anything of a frame is read.
-	 * The word is polled past the vector L1 (agent-scope relaxed load = `sc1`); in the common case -- the producer is
-	 * hundreds of workgroups back in this class's dispatch order -- the first look finds it, and its latency lies
-	 * behind the record's.  Nothing of an unfinished frame has been touched by this CU before (k_recon never reads a
-	 * frame ahead of its picture's `wait`: lanes without prediction read the stream's matrix table, not the frame), so
-	 * the L1 holds no line of it; producer and consumer are workgroups of one class = one XCD = one L2 (checked:
-	 * status[8 + class]), so the rows come out of the L2 the stores were acknowledged by. */
-#ifndef JM_T_NOPOLL
-	if (D.wait != nullptr) {
-		/* FIRST a plain load: the word has a 128-byte line to itself and only ever counts up to `need`, so a cached
-		 * `need` is final -- and in the common case that is what the first workgroup of this CU that asked brought
-		 * in: one request to the L2 per CU and picture.  (Every wavefront polling past the L1 -- 4 x 1.5 M `sc1` loads
-		 * per step on a handful of addresses -- doubled the reconstruct's time: an L2 channel serves one word at
-		 * ~15 ns per request.)  A cached count below `need` says nothing (the L1 is never refreshed): then ONE lane
-		 * polls past the L1 (agent-scope relaxed load = `sc1`) and the wavefront follows it. */
-		JM_GLOBAL const uint32_t *w = (JM_GLOBAL const uint32_t *)D.wait;
-		uint32_t spins = 0;
-		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*w) < b.need) for (;;) {
-			uint32_t seen = 0;
-			if (lane == 0) seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) >= b.need) break;
-			__builtin_amdgcn_s_sleep(16);
-			if (spins == 0 && threadIdx.x == 0) atomicAdd(b.status + 1, 1u);
-			/* never hang: a wait that runs out flags the launch (the host then reconstructs level by level), and a
-			 * flagged launch waits for nothing any more -- the frames are being done over anyway */
-			if ((spins & 63u) == 63u) {
-				uint32_t flagged = 0;
-				if (lane == 0) flagged = __hip_atomic_load((JM_GLOBAL const uint32_t *)b.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (__builtin_amdgcn_readfirstlane((int)flagged) != 0) break;
-			}
-			if (++spins > b.patience) { if (threadIdx.x == 0) atomicOr(b.status, 1u); break; }
-		}
-		asm volatile("" ::: "memory");
-	}
-#endif
+	/* ORDERED launch: the forward reference must be complete before anything of its frame is read.  In the common case
+	 * -- the producer is hundreds of workgroups back in this class's dispatch order -- the first look finds it, and its
+	 * latency lies behind the record's.  Nothing of an unfinished frame has been touched by this CU before (k_recon never
+	 * reads a frame ahead of its picture's count: lanes without prediction read the stream's matrix table, not a frame;
+	 * frames are padded so that no aligned load behind one frame's end reaches the next one's first line), so the L1
+	 * holds no line of it; producer and consumer are workgroups of one class = one XCD = one L2 (checked: status[8 +
+	 * class]), so the rows come out of the L2 the stores were acknowledged by. */
+	if (b.need != 0 && D.wait_fwd != JM_NONE) jm_recon_wait(b, D.wait_fwd, lane);
 	if (b.need != 0 && tile == 0 && threadIdx.x == 0) {
 		/* which XCD this class runs on (HW_REG_XCC_ID): one answer per class, or the launch is flagged */
 		uint32_t xcc;
@@ -762,6 +758,8 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	JmPix X;
 	X.store = false;
 	if (later) B.idct = false;           /* for now the prediction alone (an idct block's konst is 0) */
+	/* ordered launch: a tile with a macroblock its picture never wrote copies it from the `stale` frame -- complete? */
+	if (D.wait_stale != JM_NONE && __ballot(valid && !B.live) != 0) jm_recon_wait(b, D.wait_stale, lane);
 	if (valid) X = jm_recon_pixels(c, B, mine);
 	if (X.store && !later) jm_recon_store(c, B, X);
 
@@ -798,13 +796,17 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	}
 	/* ORDERED launch: this tile's rows are in the L2 (every wavefront's stores acknowledged), then the picture's count
 	 * goes up -- one atomic per workgroup */
-	if (D.done != nullptr) {
-#ifndef JM_T_NOEPIWAIT
+	if (b.need != 0 && D.done_pic != JM_NONE) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 		__syncthreads();
-		if (threadIdx.x == 0) __hip_atomic_fetch_add((JM_GLOBAL uint32_t *)D.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (threadIdx.x == 0) __hip_atomic_fetch_add((JM_GLOBAL uint32_t *)b.done + (size_t)JM_DONE_STRIDE * D.done_pic, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
+}
+
+uint32_t jm_recon_tiles_per_picture(const JmGeom &g) {
+	JmTiles T;
+	jm_tiles_init(T, g);
+	return (uint32_t)T.per_picture;
 }
 
 hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {

@@ -56,25 +56,23 @@ static inline uint32_t jm_plan_levels(const JmPic *pics, uint32_t n_pics, const 
 /* THE ORDERED PLAN: one reconstruct launch for the whole batch (kernels.h, JmReconBufs::need).  Streams are dealt to
  * eight CLASSES (a class = the workgroups b with b % 8 == c = one XCD: one dispatcher that starts its blocks in order,
  * one L2); a class takes its streams `group` at a time and walks them in lockstep -- picture i of stream A, picture i of
- * stream B, picture i + 1 of A ... -- so that (1) a picture's predecessor in its stream lies `group` pictures back in
- * the class's dispatch order (hundreds of workgroups: finished, or about to be, when the picture's first tile looks),
- * and (2) the frames a step writes are read back by the next step while they are still in the 256 MB memory-side
- * cache: 8 x group frames per step instead of a whole level's (640 for the benchmark batch: 2 GB).
- *   seq[8 i + c] = the i-th picture of class c, -1 = padding;   prev[p] = the decoded picture before p in its stream.
- * A picture waits for prev[p] only: its forward reference and the frame its unwritten macroblocks keep showing
- * (jm_plan_stale) are both earlier pictures of its stream, and every picture waited for ITS predecessor.
+ * stream B, picture i + 1 of A ... -- so that a picture's forward reference (the picture before it in its stream) lies
+ * `group` pictures back in the class's dispatch order: far enough, in workgroups, to be finished or about to be when the
+ * picture's first tile looks (the caller picks `group` by the tiles a picture has).
+ *   seq[8 i + c] = the i-th picture of class c, -1 = padding;   lockstep = the narrowest class's streams in lockstep.
+ * A picture's dependencies -- its forward reference, and for a tile with a macroblock the picture never wrote the
+ * frame that keeps showing there (jm_plan_stale) -- are earlier pictures of its own stream: earlier in its class.
  * Returns false when the batch does not fill eight classes evenly (fewer than eight streams, or a class more than
  * `slack_pct` percent above the mean): the caller then launches level by level. */
-struct JmOrderedPlan { std::vector<int32_t> seq, prev; uint32_t rows; };
+struct JmOrderedPlan { std::vector<int32_t> seq; uint32_t rows, lockstep; };
 static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, uint32_t group, uint32_t slack_pct, JmOrderedPlan &out) {
-	out.seq.clear(); out.prev.assign(n_pics, -1); out.rows = 0;
+	out.seq.clear(); out.rows = 0; out.lockstep = 0;
 	if (n_streams < 8 || group == 0) return false;
 	std::vector<std::vector<int32_t>> of(n_streams);
 	uint64_t total = 0;
 	for (uint32_t p = 0; p < n_pics; p++) {
 		const JmPic &pic = pics[p];
 		if (!pic.decoded || pic.stream >= n_streams) continue;
-		if (!of[pic.stream].empty()) out.prev[p] = of[pic.stream].back();
 		of[pic.stream].push_back((int32_t)p);
 		total++;
 	}
@@ -95,6 +93,8 @@ static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t 
 	if (most * 8 * 100 > total * (100 + slack_pct)) return false;
 	out.rows = (uint32_t)most;
 	out.seq.assign((size_t)8 * out.rows, -1);
+	out.lockstep = group;
+	for (uint32_t c = 0; c < 8; c++) out.lockstep = std::min<uint32_t>(out.lockstep, (uint32_t)cls[c].size());
 	for (uint32_t c = 0; c < 8; c++) {
 		std::vector<uint32_t> active, at;            /* the streams walked in lockstep, and where each one is */
 		size_t next = 0, i = 0;

@@ -288,16 +288,16 @@ int sim_plan(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded, const 
 	return (int)n;
 }
 
-// The ordered plan (recon_plan.h, jm_plan_ordered) on plain arrays: seq[8 * rows] (-1 = padding) and prev[] out; returns
-// the rows, 0 when the batch does not qualify.
+// The ordered plan (recon_plan.h, jm_plan_ordered) on plain arrays: seq[8 * rows] (-1 = padding) out, *out_lockstep = the
+// narrowest class's streams in lockstep; returns the rows, 0 when the batch does not qualify.
 int sim_plan_ordered(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded, const int32_t *fwd, const uint32_t *stream,
-                     uint32_t group, uint32_t slack_pct, int32_t *out_seq, uint32_t seq_cap, int32_t *out_prev) {
+                     uint32_t group, uint32_t slack_pct, int32_t *out_seq, uint32_t seq_cap, uint32_t *out_lockstep) {
 	std::vector<JmPic> pics(n_pics);
 	for (uint32_t p = 0; p < n_pics; p++) { pics[p] = JmPic(); pics[p].decoded = decoded[p]; pics[p].fwd = fwd[p]; pics[p].stream = stream[p]; }
 	JmOrderedPlan plan;
 	if (!jm_plan_ordered(pics.data(), n_pics, n_streams, group, slack_pct, plan) || plan.seq.size() > seq_cap) return 0;
 	for (size_t i = 0; i < plan.seq.size(); i++) out_seq[i] = plan.seq[i];
-	for (uint32_t p = 0; p < n_pics; p++) out_prev[p] = plan.prev[p];
+	*out_lockstep = plan.lockstep;
 	return (int)plan.rows;
 }
 

@@ -63,7 +63,7 @@ def test_ordered_launch_matches_golden(group, hip_lib):
             for rep in range(2):          # the second pass: the counts are reset, the epoch moves on
                 assert b.decode() == n_streams * fx["n_frames"]
                 info = b.recon_info()
-                assert info["launches"] == 1 and info["group"] == group and info["status"] == 0, (path, info)
+                assert info["launches"] == 1 and info["group"] == min(group, 2) and info["status"] == 0, (path, info)
                 for p in range(n_streams * fx["n_frames"]):
                     if rep == 0 or p % 7 == 0:
                         assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], (os.path.basename(path), p)
@@ -105,10 +105,33 @@ def test_batches_that_do_not_fill_eight_classes_go_level_by_level(hip_lib):
     es, _ = synth.generate_config("cfg1_720p", n_frames=13, stream=1, width=176, height=144)
     for n_streams, ordered in ((1, False), (7, False), (8, True), (9, False), (15, True), (16, True)):
         # 9 streams: one class carries two, 2 / (9 / 8) is far over the 8 % slack; 15: seven classes of two and one of one, 2 / (15 / 8) = 1.067
-        with jb.Batch(176, 144, n_streams, n_streams * 13 + 4, n_streams * (len(es) + 64) + 8192) as b:
+        with order_env(JSMPEG_HIP_RECON_ORDER=2):         # (forced: by itself a batch of pictures this small never takes the ordered launch)
+            b = jb.Batch(176, 144, n_streams, n_streams * 13 + 4, n_streams * (len(es) + 64) + 8192)
+        with b:
             b.upload([es] * n_streams)
             assert b.decode() == n_streams * 13
             assert (b.recon_info()["launches"] == 1) == ordered, n_streams
+
+
+def test_the_lockstep_width_follows_the_picture_size(hip_lib):
+    """by itself the engine walks as many streams in lockstep as put the last tile of a picture's forward reference ~200
+    workgroups behind the picture's first tile in its class's dispatch order, and launches level by level where the batch
+    cannot give that (small pictures, few streams per class): 1080p x 16 streams -> two in lockstep (200 tiles each), one
+    launch; 176x144 x 16 -> per level"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_enc_static_1920x1080.json")))
+    es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    with jb.Batch(1920, 1080, 16, 16 * fx["n_frames"] + 4, 16 * (len(es) + 64) + 8192) as b:
+        b.upload([es] * 16)
+        assert b.decode() == 16 * fx["n_frames"]
+        info = b.recon_info()
+        assert info["launches"] == 1 and info["group"] == 2 and info["status"] == 0, info
+        for p in range(16 * fx["n_frames"]):
+            assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], p
+    es, _ = synth.generate_config("cfg1_720p", n_frames=13, stream=1, width=176, height=144)
+    with jb.Batch(176, 144, 16, 16 * 13 + 4, 16 * (len(es) + 64) + 8192) as b:
+        b.upload([es] * 16)
+        assert b.decode() == 16 * 13
+        assert b.recon_info()["launches"] == 12
 
 
 def test_a_launch_that_flags_itself_is_done_over(hip_lib):

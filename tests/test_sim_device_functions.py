@@ -129,10 +129,15 @@ def run_plan_ordered(sim, decoded, fwd, stream, n_streams, group, slack=8):
     n = len(decoded)
     cap = 8 * (n + 8)
     seq = (ctypes.c_int32 * cap)()
-    prev = (ctypes.c_int32 * max(1, n))()
+    lock = ctypes.c_uint32(0)
     rows = sim.sim_plan_ordered(n, n_streams, (ctypes.c_uint8 * n)(*decoded), (ctypes.c_int32 * n)(*fwd), (ctypes.c_uint32 * n)(*stream),
-                                group, slack, seq, cap, prev)
-    return rows, [seq[i] for i in range(8 * rows)], list(prev)[:n]
+                                group, slack, seq, cap, ctypes.byref(lock))
+    prev, last = [-1] * n, {}
+    for p in range(n):
+        if decoded[p]:
+            prev[p] = last.get(stream[p], -1)
+            last[stream[p]] = p
+    return rows, [seq[i] for i in range(8 * rows)], prev, lock.value
 
 
 def test_ordered_plan_properties(sim):
@@ -153,7 +158,7 @@ def test_ordered_plan_properties(sim):
                 if d:
                     last[s_] = p
         group = int(rng.integers(1, 5))
-        rows, seq, prev = run_plan_ordered(sim, decoded, fwd, stream, n_streams, group)
+        rows, seq, prev, lockstep = run_plan_ordered(sim, decoded, fwd, stream, n_streams, group)
         n_dec = sum(decoded)
         loads = {}
         for s_ in range(n_streams):
@@ -180,15 +185,14 @@ def test_ordered_plan_properties(sim):
             col = [p for p in seq[c::8]]
             assert all(x < 0 for x in col[len([x for x in col if x >= 0]):])   # padding only at the end
         for p, i in pos.items():
-            q = prev[p]
-            want = max((x for x in range(p) if decoded[x] and stream[x] == stream[p]), default=-1)
-            assert q == want
+            q = prev[p]          # the picture before it in its stream: what its forward reference / stale frame can be at the latest
             if q >= 0:
                 assert pos[q] % 8 == i % 8 and pos[q] < i
                 # every picture of its stream in between the two is impossible; the distance is the streams in lockstep
                 assert (i - pos[q]) // 8 <= group
         cls_load = [sum(1 for x in seq[c::8] if x >= 0) for c in range(8)]
         assert max(cls_load) == rows and max(cls_load) * 8 * 100 <= n_dec * 108
+        assert lockstep == min(group, min(len({stream[p] for p in seq[c::8] if p >= 0}) for c in range(8)))
 
 
 def test_ordered_plan_benchmark_shape(sim):
@@ -199,8 +203,8 @@ def test_ordered_plan_benchmark_shape(sim):
         for i in range(120):
             p = len(decoded)
             decoded.append(1); stream.append(s_); fwd.append(-1 if i % 12 == 0 else p - 1)
-    rows, seq, prev = run_plan_ordered(sim, decoded, fwd, stream, 64, 2)
-    assert rows == 960 and all(p >= 0 for p in seq)
+    rows, seq, prev, lockstep = run_plan_ordered(sim, decoded, fwd, stream, 64, 2)
+    assert rows == 960 and all(p >= 0 for p in seq) and lockstep == 2
     pos = {p: i for i, p in enumerate(seq)}
     for p in range(len(decoded)):
         if prev[p] >= 0:
