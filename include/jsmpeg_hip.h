@@ -235,6 +235,18 @@ int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]);
  * jsmpeg_hip_batch_sync returned, and the batch stays with per-level launches).  Frames of an ordered launch are final
  * once jsmpeg_hip_batch_sync (or any call that reads them back) has returned. */
 int jsmpeg_hip_batch_recon_info(jsmpeg_hip_batch_t *b, uint32_t out[4]);
+/* Streams that CONTINUE other streams (part 4: the units a sharded job cuts its streams into).  prev[s] >= 0: stream s
+ * of the uploaded batch goes on where stream prev[s] (< s) ended -- its unwritten macroblocks show that stream's last
+ * pictures (the reference's plane rotation, mpeg1.c:986-994) instead of zeros; -1: a stream of its own.  `n` = the
+ * uploaded streams; prev == NULL clears.  Every upload* / attach call clears links and seeds: set them after it. */
+int jsmpeg_hip_batch_link_streams(jsmpeg_hip_batch_t *b, const int32_t *prev, uint32_t n);
+/* ... and a stream whose predecessor was decoded ELSEWHERE (another rank, an earlier batch): the frames (Y | Cr | Cb,
+ * jsmpeg_hip_batch_geometry's layout, device memory, complete before the decode starts and left alone until it has
+ * finished) of the decoded picture last / before last in front of the stream; either may be NULL (zeros). */
+int jsmpeg_hip_batch_seed_stream(jsmpeg_hip_batch_t *b, uint32_t stream, const void *dev_frame_last, const void *dev_frame_before_last);
+/* out[p] = 1 where picture p of the last decode was decoded and left macroblocks unwritten (they show the stream's
+ * decoded picture before last); at most `cap` entries; waits for the decode.  Returns the entries written or < 0. */
+int jsmpeg_hip_batch_uncovered(jsmpeg_hip_batch_t *b, uint8_t *out, uint32_t cap);
 
 /* ------------------------------------------------------------------ part 3
  * MP2 audio (MPEG-1 Audio Layer II) -- the sibling decoder of the reference's
@@ -323,10 +335,16 @@ int jsmpeg_hip_mp2_batch_timings(jsmpeg_hip_mp2_batch_t *b, float out_ms[5]);
  * -- so the one exchange step of the path moves compressed bytes: the rank that holds the streams sends every rank
  * the units it owns (RCCL over xGMI), each rank decodes its piece with its own jsmpeg_hip_batch_t as that many
  * independent streams.
- * One difference to decoding the whole stream in one piece exists and is inherent to the reference's plane rotation
- * (mpeg1.c:986-994): a macroblock a picture never writes keeps showing the decoded picture BEFORE LAST; for the first
- * two pictures of a unit that picture belongs to the GOP before, which the unit's decoder never saw (it shows zeros,
- * like the reference fed the unit alone).  jsmpeg_hip_batch_counters()[6] counts the pictures with such macroblocks. */
+ * ONE THING CROSSES A CUT, and the results are bit-exact to the unsplit stream all the same: the reference rotates two
+ * plane sets (mpeg1.c:986-994), so a macroblock a picture never writes keeps showing the decoded picture BEFORE LAST --
+ * for the first two pictures of a unit that is a picture of the GOP before.  A unit therefore CONTINUES its
+ * predecessor: in the same batch by jsmpeg_hip_batch_link_streams (costs nothing: a pointer per picture, and a
+ * dependency only for a picture that really has such a macroblock); across ranks or batches by
+ * jsmpeg_hip_batch_seed_stream with the predecessor's last two frames -- needed only when
+ * jsmpeg_hip_batch_uncovered() says one of the unit's first two decoded pictures has such macroblocks (none in the
+ * benchmark's content, ~1 picture in 8 with coherent motion).  jsmpeg_hip_plan_contiguous keeps a stream's units on one
+ * rank wherever the balance allows: at most world - 1 cuts of the whole job cross ranks.  jsmpeg_amd/distributed.py
+ * (resolve_history) is the procedure: decode, ask, ship 2 frames per needy cross-rank cut, decode those ranks again. */
 
 typedef struct jsmpeg_hip_gop_unit_t {
 	uint64_t offset, bytes;     /* byte range of the unit in the elementary stream */
@@ -342,6 +360,10 @@ int jsmpeg_hip_split_gops(const uint8_t *es, uint64_t es_bytes, jsmpeg_hip_gop_u
                           uint64_t *header_offset, uint64_t *header_bytes);
 /* Balanced assignment of n units (weights = compressed bytes) to `world` ranks: owner[i] = rank of unit i. */
 int jsmpeg_hip_plan_shards(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner);
+/* The same as CONTIGUOUS ranges of the unit list (units in job order: stream after stream, GOP after GOP): rank r takes
+ * the units whose middle byte falls into the r-th of `world` equal shares of the job's bytes -- balanced to within one
+ * unit, and consecutive units of a stream stay together except at the <= world - 1 range boundaries. */
+int jsmpeg_hip_plan_contiguous(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner);
 /* The same for units that ARRIVED on the ranks (every rank ingests its own streams; home[i] = the rank that holds unit
  * i): a unit stays where it is unless moving it from the most to the least loaded rank narrows the gap between the
  * two -- about half the imbalance travels, a balanced job moves nothing. */

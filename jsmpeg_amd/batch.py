@@ -24,7 +24,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_attach_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
-                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_recon_info", "jsmpeg_hip_batch_render_rgba",
+                 "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_recon_info", "jsmpeg_hip_batch_link_streams", "jsmpeg_hip_batch_seed_stream", "jsmpeg_hip_batch_uncovered", "jsmpeg_hip_batch_render_rgba",
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
@@ -254,6 +254,34 @@ class Batch:
         self._ok(self.L.jsmpeg_hip_batch_counters(self.h, c))
         return dict(start_codes=c[0], pictures=c[1], decoded=c[2], levels=c[3], slices=c[4], mb_per_picture=c[5],
                     uncovered_pictures=c[6], slice_codes=c[7])
+
+    def link_streams(self, prev):
+        """stream s continues stream prev[s] (< s) of the uploaded batch, -1: a stream of its own; None clears.  After upload / attach."""
+        fn = self.L.jsmpeg_hip_batch_link_streams
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32]
+        if prev is None:
+            self._ok(fn(self.h, None, 0))
+        else:
+            arr = (ctypes.c_int32 * len(prev))(*[int(x) for x in prev])
+            self._ok(fn(self.h, arr, len(prev)))
+
+    def seed_stream(self, stream, frame_last, frame_before_last):
+        """device addresses (ints / None) of the frames of the decoded picture last / before last in front of `stream`"""
+        fn = self.L.jsmpeg_hip_batch_seed_stream
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        self._ok(fn(self.h, stream, frame_last, frame_before_last))
+
+    def uncovered(self):
+        """per picture of the last decode: decoded and left macroblocks unwritten"""
+        n = self.picture_count
+        out = (ctypes.c_uint8 * max(1, n))()
+        fn = self.L.jsmpeg_hip_batch_uncovered
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32]
+        k = self._ok(fn(self.h, out, n))
+        return [int(out[i]) for i in range(k)]
 
     def recon_info(self):
         """how the last decode reconstructed: launches (1 = the ordered launch), lockstep group, waits, status"""

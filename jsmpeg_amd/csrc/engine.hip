@@ -117,6 +117,10 @@ struct jsmpeg_hip_batch_t {
 	/* ordered reconstruct (one launch per batch, recon_plan.h jm_plan_ordered): per-picture tile counts, the launch's
 	 * status words (kernels.h JM_RECON_STATUS_WORDS; h_: pinned), and how the last decode went */
 	uint32_t *d_done, *d_rstatus, *h_rstatus;
+	/* streams that continue other streams (jsmpeg_hip_batch_link_streams / _seed_stream; recon_plan.h): cleared by every upload / attach */
+	std::vector<int32_t> link_prev;
+	std::vector<uint8_t> seeded;
+	std::vector<const uint8_t *> seed_frames;   /* [2 * stream + which] */
 	uint32_t last_group;         /* lockstep width of the last decode's launch, 0: it went level by level */
 	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level; JM_ORDER_AUTO: by the picture size */
 	bool ordered;                /* the last decode used the ordered launch (its status is checked at the next sync) */
@@ -265,6 +269,7 @@ static int batch_layout(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint64_
 	b->es_bytes = (uint32_t)off;
 	b->n_streams = n_streams;
 	b->es_view = b->d_es;
+	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear();
 	return 0;
 }
 
@@ -511,9 +516,15 @@ extern "C" int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void 
 	b->es_bytes = (uint32_t)total_bytes;
 	b->n_streams = n_streams;
 	b->es_view = (const uint8_t *)dev_es;
+	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear();
 	/* (pageable source: the runtime has taken its copy when the call returns) */
 	if (n_streams) HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
 	return 0;
+}
+
+static uint32_t batch_plan_stale(const jsmpeg_hip_batch_t *b, std::vector<int32_t> &stale) {
+	return jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr,
+	                     b->seeded.size() == b->n_streams ? b->seeded.data() : nullptr);
 }
 
 static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, int32_t stale) {
@@ -522,7 +533,8 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	D.mb = b->d_mb + (size_t)p * b->g.mb_size;
 	D.dst = b->d_pool + (uint64_t)p * b->g.frame_bytes;
 	D.fwd = pic.fwd >= 0 ? b->d_pool + (uint64_t)pic.fwd * b->g.frame_bytes : nullptr;
-	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes : nullptr;
+	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes
+	                     : (jm_stale_is_seed(stale) && jm_stale_seed_slot(stale) < b->seed_frames.size() ? b->seed_frames[jm_stale_seed_slot(stale)] : nullptr);
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
 	D.done_pic = D.wait_fwd = D.wait_stale = JM_NONE; D.pad_ = 0;
 }
@@ -697,7 +709,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * levels of all the others are laid out once the parse has reported (step 4b), while 4a runs.
 	 * (Laid out here, while the GPU is busy with the parse: the descriptors are only read by the reconstruct.) */
 	std::vector<int32_t> stale;
-	const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+	const uint32_t n_roots = batch_plan_stale(b, stale);
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
@@ -707,7 +719,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmOrderedPlan plan;
 	const uint32_t per_picture = jm_recon_tiles_per_picture(b->g);
 	const uint32_t group = b->order_group == JM_ORDER_AUTO ? 1 + (JM_ORDER_DISTANCE + per_picture - 1) / per_picture : b->order_group;
-	if (group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap &&
+	if (group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) && (size_t)8 * plan.rows <= b->desc_cap &&
 	    (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE)) {
 		/* ---- 4. ONE launch: every class walks its streams in lockstep; a picture's tiles wait for its forward reference,
 		 * and a tile with a macroblock the picture never wrote for the frame that keeps showing there -- decided by the
@@ -758,7 +770,7 @@ static int batch_settle(jsmpeg_hip_batch_t *b) {
 			        b->h_rstatus[0], (b->h_rstatus[0] & 2) ? "a class of workgroups ran on two XCDs" : "a picture's wait ran out of patience");
 			b->order_group = 0; b->last_group = 0;
 			std::vector<int32_t> stale;
-			const uint32_t n_roots = jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+			const uint32_t n_roots = batch_plan_stale(b, stale);
 			JmReconBufs rb;
 			rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
 			HostTrace tr;
@@ -773,7 +785,7 @@ static int batch_settle(jsmpeg_hip_batch_t *b) {
 		b->stats_pending = false;
 		HIP_TRY(hipEventSynchronize(b->ev_cov));
 		std::vector<int32_t> stale, level;
-		jm_plan_stale(b->h_pics, b->n_pics, b->n_streams, stale);
+		batch_plan_stale(b, stale);
 		b->n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
 	}
 	return 0;
@@ -925,6 +937,41 @@ extern "C" int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8])
 	out[5] = (uint64_t)b->g.mb_size;
 	out[6] = b->n_uncovered; out[7] = b->n_slice_codes;
 	return 0;
+}
+
+/* Streams that continue other streams: the (stream, GOP) units of a sharded job (include/jsmpeg_hip.h part 4). */
+extern "C" int jsmpeg_hip_batch_link_streams(jsmpeg_hip_batch_t *b, const int32_t *prev, uint32_t n) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	if (!prev) { b->link_prev.clear(); return 0; }
+	if (n != b->n_streams) return fail("link: %u entries for %u uploaded streams", n, b->n_streams);
+	for (uint32_t s = 0; s < n; s++)
+		if (prev[s] >= 0 && (uint32_t)prev[s] >= s) return fail("link: stream %u can only continue an EARLIER stream of the batch (got %d)", s, prev[s]);
+	b->link_prev.assign(prev, prev + n);
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_seed_stream(jsmpeg_hip_batch_t *b, uint32_t stream, const void *dev_frame_last, const void *dev_frame_before_last) {
+	g_err[0] = 0;
+	if (!b) return fail("null batch");
+	if (stream >= b->n_streams) return fail("seed: stream %u of %u", stream, b->n_streams);
+	if (b->seeded.size() != b->n_streams) { b->seeded.assign(b->n_streams, 0); b->seed_frames.assign(2 * (size_t)b->n_streams, nullptr); }
+	b->seeded[stream] = (uint8_t)((dev_frame_last ? 1 : 0) | (dev_frame_before_last ? 2 : 0));
+	b->seed_frames[2 * (size_t)stream] = (const uint8_t *)dev_frame_last;
+	b->seed_frames[2 * (size_t)stream + 1] = (const uint8_t *)dev_frame_before_last;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_batch_uncovered(jsmpeg_hip_batch_t *b, uint8_t *out, uint32_t cap) {
+	g_err[0] = 0;
+	if (!b || !out) return fail("null argument");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (batch_settle(b) < 0) return -1;
+	if (b->n_pics) HIP_TRY(hipEventSynchronize(b->ev_cov));
+	const uint32_t n = std::min(cap, b->n_pics);
+	for (uint32_t p = 0; p < n; p++) out[p] = b->h_pics[p].decoded && b->h_covered[p] < (uint32_t)b->g.mb_size;
+	return (int)n;
 }
 
 extern "C" int jsmpeg_hip_batch_recon_info(jsmpeg_hip_batch_t *b, uint32_t out[4]) {

@@ -16,17 +16,42 @@
 
 #include "mpeg1_dev.h"
 
-/* stale[p]: the decoded picture before last of p's stream (what p's unwritten macroblocks show), -1: none (zeros).
- * Returns the number of decoded pictures without a forward reference. */
-static inline uint32_t jm_plan_stale(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, std::vector<int32_t> &stale) {
-	stale.assign(n_pics, -1);
-	std::vector<int64_t> last1(n_streams, -1), last2(n_streams, -1);      /* the stream's last two decoded pictures */
+/* What a stream's unwritten macroblocks may keep showing that is NOT a picture of this stream in this batch
+ * (jsmpeg_hip_batch_link_streams / _seed_stream: a stream that CONTINUES another -- the (stream, GOP) units a sharded
+ * job cuts its streams into):
+ *   link_prev[s] >= 0: stream s continues stream link_prev[s] of this batch (link_prev[s] < s): its plane rotation goes on
+ *                      where that stream's ended;
+ *   seeded[s] bit 0 / 1: the caller gave the frame of the decoded picture last / before last in front of stream s
+ *                      (decoded elsewhere: another rank, an earlier batch).
+ * Both null: every stream starts with zeroed planes (the JS typed arrays start zeroed, mpeg1.js:131-152). */
+#define JM_STALE_NONE (-1)
+static inline int32_t jm_stale_seed(uint32_t stream, int which) { return -2 - (int32_t)(2 * stream + (uint32_t)which); }   /* which: 0 last, 1 before last */
+static inline bool jm_stale_is_seed(int32_t v) { return v <= -2; }
+static inline uint32_t jm_stale_seed_slot(int32_t v) { return (uint32_t)(-2 - v); }                                         /* 2 * stream + which */
+
+/* stale[p]: what p's unwritten macroblocks show -- the decoded picture before last of p's stream (>= 0), a seeded frame
+ * (jm_stale_is_seed), or JM_STALE_NONE (zeros).  Returns the number of decoded pictures without a forward reference. */
+static inline uint32_t jm_plan_stale(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, std::vector<int32_t> &stale,
+                                     const int32_t *link_prev = nullptr, const uint8_t *seeded = nullptr) {
+	stale.assign(n_pics, JM_STALE_NONE);
+	std::vector<int32_t> last1(n_streams, JM_STALE_NONE), last2(n_streams, JM_STALE_NONE);      /* the stream's last two decoded pictures */
+	std::vector<uint8_t> begun(n_streams, 0);
 	uint32_t n_roots = 0;
 	for (uint32_t p = 0; p < n_pics; p++) {
 		const JmPic &pic = pics[p];
 		if (!pic.decoded) continue;
 		if (pic.fwd < 0) n_roots++;
-		if (pic.stream < n_streams) { stale[p] = (int32_t)last2[pic.stream]; last2[pic.stream] = last1[pic.stream]; last1[pic.stream] = p; }
+		const uint32_t s = pic.stream;
+		if (s >= n_streams) continue;
+		if (!begun[s]) {
+			begun[s] = 1;
+			if (link_prev && link_prev[s] >= 0 && (uint32_t)link_prev[s] < s) { last1[s] = last1[link_prev[s]]; last2[s] = last2[link_prev[s]]; }
+			else if (seeded) {
+				if (seeded[s] & 1) last1[s] = jm_stale_seed(s, 0);
+				if (seeded[s] & 2) last2[s] = jm_stale_seed(s, 1);
+			}
+		}
+		stale[p] = last2[s]; last2[s] = last1[s]; last1[s] = (int32_t)p;
 	}
 	return n_roots;
 }
@@ -65,15 +90,25 @@ static inline uint32_t jm_plan_levels(const JmPic *pics, uint32_t n_pics, const 
  * Returns false when the batch does not fill eight classes evenly (fewer than eight streams, or a class more than
  * `slack_pct` percent above the mean): the caller then launches level by level. */
 struct JmOrderedPlan { std::vector<int32_t> seq; uint32_t rows, lockstep; };
-static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, uint32_t group, uint32_t slack_pct, JmOrderedPlan &out) {
+static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, uint32_t group, uint32_t slack_pct, JmOrderedPlan &out,
+                                   const int32_t *link_prev = nullptr) {
 	out.seq.clear(); out.rows = 0; out.lockstep = 0;
 	if (n_streams < 8 || group == 0) return false;
+	/* streams that continue one another (link_prev) are ONE stream here: the chain's first stream carries them all, in
+	 * order -- a chain stays in its class, and a continuing stream's `stale` frames lie earlier in it */
+	std::vector<uint32_t> root(n_streams);
+	uint32_t n_chains = 0;
+	for (uint32_t s = 0; s < n_streams; s++) {
+		root[s] = link_prev && link_prev[s] >= 0 && (uint32_t)link_prev[s] < s ? root[link_prev[s]] : s;
+		n_chains += root[s] == s;
+	}
+	if (n_chains < 8) return false;
 	std::vector<std::vector<int32_t>> of(n_streams);
 	uint64_t total = 0;
 	for (uint32_t p = 0; p < n_pics; p++) {
 		const JmPic &pic = pics[p];
 		if (!pic.decoded || pic.stream >= n_streams) continue;
-		of[pic.stream].push_back((int32_t)p);
+		of[root[pic.stream]].push_back((int32_t)p);
 		total++;
 	}
 	if (total == 0) return false;

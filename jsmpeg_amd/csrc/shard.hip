@@ -132,6 +132,24 @@ extern "C" int jsmpeg_hip_plan_shards(const uint64_t *weights, uint32_t n, uint3
 	return 0;
 }
 
+/* Contiguous ranges of the unit list: a stream's units stay on one rank except where a range boundary falls inside the
+ * stream -- what is left of the cuts that cross ranks is <= world - 1 for the whole job (include/jsmpeg_hip.h part 4:
+ * a unit continues its predecessor; across ranks that costs two frames when the unit needs them). */
+extern "C" int jsmpeg_hip_plan_contiguous(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner) {
+	jm_clear_error();
+	if (world == 0 || (n && (!weights || !owner))) return sfail("bad shard plan arguments");
+	long double total = 0;
+	for (uint32_t i = 0; i < n; i++) total += (long double)weights[i];
+	long double before = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		const long double mid = before + (long double)weights[i] / 2;
+		uint32_t r = total > 0 ? (uint32_t)(mid * world / total) : (uint32_t)((uint64_t)i * world / n);
+		owner[i] = r < world ? r : world - 1;
+		before += (long double)weights[i];
+	}
+	return 0;
+}
+
 /* Units that ARRIVED on the ranks themselves (every rank ingests its own streams: `home[i]` = the rank that holds unit
  * i): only the imbalance moves.  owner = home, then units leave the most loaded rank for the least loaded one while
  * that narrows the gap between the two -- the unit whose weight is closest to half the gap, never more than the gap --

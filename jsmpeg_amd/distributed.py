@@ -20,7 +20,7 @@ class GopUnit(ctypes.Structure):
 
 
 DIST_ID_BYTES = 128
-SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_plan_rebalance", "jsmpeg_hip_dist_unique_id",
+SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_plan_contiguous", "jsmpeg_hip_plan_rebalance", "jsmpeg_hip_dist_unique_id",
                  "jsmpeg_hip_dist_create", "jsmpeg_hip_dist_destroy", "jsmpeg_hip_dist_rank", "jsmpeg_hip_dist_world",
                  "jsmpeg_hip_dist_scatter", "jsmpeg_hip_dist_exchange", "jsmpeg_hip_dist_gather", "jsmpeg_hip_dist_allgather")
 _bound = False
@@ -35,6 +35,8 @@ def _lib():
         L.jsmpeg_hip_split_gops.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(GopUnit), ctypes.c_uint32, u64p, u64p]
         L.jsmpeg_hip_plan_shards.restype = ctypes.c_int
         L.jsmpeg_hip_plan_shards.argtypes = [u64p, ctypes.c_uint32, ctypes.c_uint32, u32p]
+        L.jsmpeg_hip_plan_contiguous.restype = ctypes.c_int
+        L.jsmpeg_hip_plan_contiguous.argtypes = [u64p, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.jsmpeg_hip_plan_rebalance.restype = ctypes.c_int
         L.jsmpeg_hip_plan_rebalance.argtypes = [u64p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.jsmpeg_hip_dist_exchange.restype = ctypes.c_int
@@ -83,6 +85,16 @@ def plan_shards_c(weights, world):
     w = (ctypes.c_uint64 * len(weights))(*[int(x) for x in weights])
     owner = (ctypes.c_uint32 * len(weights))()
     if L.jsmpeg_hip_plan_shards(w, len(weights), world, owner) != 0:
+        raise RuntimeError(_batch.last_error())
+    return list(owner)
+
+
+def plan_contiguous_c(weights, world):
+    """plan_contiguous() through the C ABI: owner rank per unit, contiguous ranges of the unit list."""
+    L = _lib()
+    w = (ctypes.c_uint64 * len(weights))(*[int(x) for x in weights])
+    owner = (ctypes.c_uint32 * len(weights))()
+    if L.jsmpeg_hip_plan_contiguous(w, len(weights), world, owner) != 0:
         raise RuntimeError(_batch.last_error())
     return list(owner)
 
@@ -162,6 +174,19 @@ def plan_shards(weights, world):
         owner[i] = r
         load[r] += int(weights[i])
     return [[i for i in range(len(weights)) if owner[i] == r] for r in range(world)]
+
+
+def plan_contiguous(weights, world):
+    """Restatement of jsmpeg_hip_plan_contiguous: rank r takes the units whose middle byte falls into the r-th of `world`
+    equal shares of the job's bytes (exact integer arithmetic here, long double there: the tests use sizes where both agree)."""
+    total = sum(int(w) for w in weights)
+    owner, before = [], 0
+    for i, w in enumerate(weights):
+        w = int(w)
+        r = ((2 * before + w) * world) // (2 * total) if total else i * world // len(weights)
+        owner.append(min(r, world - 1))
+        before += w
+    return owner
 
 
 def plan_rebalance(weights, home, world):
@@ -357,3 +382,121 @@ def fill_source(buf, pieces, offsets, unit_bytes):
     for p, base in zip(pieces, offsets):
         for u, b, e in zip(p["units"], p["begin"], p["end"]):
             buf[base + int(b):base + int(e)] = unit_bytes[u]
+
+
+# ---- a unit CONTINUES its predecessor (include/jsmpeg_hip.h part 4): links inside a rank's batch, two frames across ranks ----
+# The reference rotates two plane sets (src/wasm/mpeg1.c:986-994): a macroblock a picture never writes keeps showing the
+# decoded picture before last -- for a unit's first two pictures a picture of the unit before.  Units of one stream that
+# sit in the same batch are LINKED (jsmpeg_hip_batch_link_streams: free); a unit whose predecessor was decoded by
+# another rank is exact by itself unless one of its first two decoded pictures has such macroblocks
+# (jsmpeg_hip_batch_uncovered) -- then it is SEEDED with the predecessor's last two frames and its rank decodes again.
+
+class HistoryRank:
+    """One rank's piece: `units` = the job's unit numbers in the order the rank's batch holds them as streams.
+    prev_local[i]: the batch stream unit i continues (-1: none here); remote[i]: the unit it continues on ANOTHER rank."""
+
+    def __init__(self, table, units):
+        self.units = [int(u) for u in units]
+        self.index = {u: i for i, u in enumerate(self.units)}
+        self.prev_local, self.remote = [], {}
+        for i, u in enumerate(self.units):
+            gop = table[u][1]
+            prev = -1
+            if gop > 0:                                  # unit u - 1 is the same stream's GOP before (the table is stream after stream)
+                j = self.index.get(u - 1, -1)
+                if 0 <= j < i:
+                    prev = j
+                else:
+                    self.remote[i] = u - 1
+            self.prev_local.append(prev)
+
+    def chain_head(self, i):
+        while self.prev_local[i] >= 0:
+            i = self.prev_local[i]
+        return i
+
+
+def needy_streams(pictures, uncovered, n_streams):
+    """per batch stream: one of its first two DECODED pictures left macroblocks unwritten (what shows there belongs to the
+    stream it continues).  `pictures`: (stream, decoded) per picture of the batch, `uncovered`: jsmpeg_hip_batch_uncovered."""
+    seen, needy = [0] * n_streams, [False] * n_streams
+    for (s, dec), unc in zip(pictures, uncovered):
+        if dec and s < n_streams and seen[s] < 2:
+            seen[s] += 1
+            needy[s] = needy[s] or bool(unc)
+    return needy
+
+
+def final_states(pictures, n_streams, prev_local, seeds, frame_of):
+    """(last, before last) of every batch stream once it is through: frame_of(p) for a picture of the batch, what the
+    stream started from otherwise (its predecessor's state by link, the seeded frames, or None).  seeds: {stream: (last, before)}."""
+    state = [None] * n_streams
+    by_stream = [[] for _ in range(n_streams)]
+    for p, (s, dec) in enumerate(pictures):
+        if dec and s < n_streams:
+            by_stream[s].append(p)
+    for s in range(n_streams):
+        l1, l2 = state[prev_local[s]] if prev_local[s] >= 0 else seeds.get(s, (None, None))
+        for p in by_stream[s]:
+            l1, l2 = frame_of(p), l1
+        state[s] = (l1, l2)
+    return state
+
+
+def history_transfers(hists, owner, unresolved):
+    """One round of the resolution, computed alike by every rank: `unresolved[r]` = the batch streams of rank r that need
+    their remote predecessor's frames and do not have them yet.  A predecessor can hand its frames over once nothing it
+    depends on inside its own batch is itself unresolved.  Returns [(src_rank, src_stream, dst_rank, dst_stream)]."""
+    moves = []
+    for r, hist in enumerate(hists):
+        for i in sorted(unresolved[r]):
+            pred = hist.remote[i]
+            pr = owner[pred]
+            j = hists[pr].index[pred]
+            k, final = j, True
+            while True:                                   # walk the predecessor's chain inside its batch
+                if k in unresolved[pr]:
+                    final = False
+                    break
+                if hists[pr].prev_local[k] < 0:
+                    break
+                k = hists[pr].prev_local[k]
+            if final:
+                moves.append((pr, j, r, i))
+    return moves
+
+
+def resolve_history_emulated(ranks, table, owner, max_rounds=64):
+    """The whole procedure with every rank in THIS process (tests, one GPU): ranks[r] = dict(batch, hist, redecode) where
+    redecode() uploads the rank's piece again, links it, applies ranks[r]["seeds"] and decodes.  Frames travel as device
+    addresses into the source batch's frame pool (the real thing ships 2 x frame bytes through jsmpeg_hip_dist_exchange:
+    bench.py).  Returns the number of decodes done over again."""
+    again = 0
+    for rk in ranks:
+        rk.setdefault("seeds", {})
+    hists = [rk["hist"] for rk in ranks]
+
+    def look(rk):
+        b = rk["batch"]
+        pics = [(i.stream, i.decoded) for i in b.pictures()]
+        n = len(rk["hist"].units)
+        needy = needy_streams(pics, b.uncovered(), n)
+        stride, pool = b.frame_stride, b.frame_pool_ptr
+        rk["states"] = final_states(pics, n, rk["hist"].prev_local, rk["seeds"], lambda p: pool + p * stride)
+        return {i for i in rk["hist"].remote if needy[i] and i not in rk["seeds"]}
+
+    for _ in range(max_rounds):
+        unresolved = [look(rk) for rk in ranks]
+        if not any(unresolved):
+            return again
+        moves = history_transfers(hists, owner, unresolved)
+        if not moves:
+            raise RuntimeError("history resolution is stuck: %r" % (unresolved,))
+        touched = set()
+        for pr, j, r, i in moves:
+            ranks[r]["seeds"][i] = ranks[pr]["states"][j]
+            touched.add(r)
+        for r in sorted(touched):
+            ranks[r]["redecode"]()
+            again += 1
+    raise RuntimeError("history resolution did not converge")

@@ -265,3 +265,71 @@ def test_split_gops_units_decode_like_the_whole_stream(libs):
         frames, _, _ = cabi.decode_stream(libs["oracle"], u)
         parts += frames
     assert parts == whole
+
+
+# ---- a unit continues its predecessor: the bookkeeping (jsmpeg_amd/distributed.py), no GPU ----
+
+def test_contiguous_plan_equals_its_restatement_and_keeps_streams_together(hip_lib):
+    from jsmpeg_amd import distributed as jd
+    rng = np.random.default_rng(7)
+    for case in range(200):
+        n_streams = int(rng.integers(1, 12))
+        sizes = [[int(rng.integers(50_000, 900_000)) for _ in range(int(rng.integers(1, 14)))] for _ in range(n_streams)]
+        table = jd.unit_table(sizes)
+        w = [n for _, _, n in table]
+        world = int(rng.integers(1, 9))
+        owner = jd.plan_contiguous_c(w, world)
+        assert owner == jd.plan_contiguous(w, world)
+        assert owner == sorted(owner) and all(0 <= r < world for r in owner)
+        loads = [sum(x for x, r in zip(w, owner) if r == k) for k in range(world)]
+        assert max(loads) - sum(w) / world <= max(w)                     # balanced to within one unit
+        # cuts that cross ranks: consecutive units of ONE stream with different owners -- at most world - 1 in the job
+        crossing = sum(1 for u in range(1, len(table)) if table[u][1] > 0 and owner[u] != owner[u - 1])
+        assert crossing <= world - 1
+
+
+def test_history_resolution_converges_to_the_unsplit_result():
+    """A model of the procedure without a decoder: a unit's pictures are 'right' iff it does not need its predecessor, or
+    started from its predecessor's RIGHT final state.  Random placements and needs; every rank links what it holds,
+    needy units with a remote predecessor are seeded round by round (history_transfers); in the end every unit is right,
+    and a unit is only ever seeded from a predecessor that was right at that moment."""
+    from jsmpeg_amd import distributed as jd
+    rng = np.random.default_rng(11)
+    for case in range(300):
+        n_streams = int(rng.integers(1, 6))
+        table = jd.unit_table([[1000] * int(rng.integers(1, 9)) for _ in range(n_streams)])
+        world = int(rng.integers(1, 5))
+        mode = case % 3
+        if mode == 0:
+            owner = [int(rng.integers(0, world)) for _ in table]
+        elif mode == 1:
+            owner = [k % world for k in range(len(table))]
+        else:
+            owner = jd.plan_contiguous([n for _, _, n in table], world)
+        needs = [bool(table[u][1] > 0 and rng.random() < 0.5) for u in range(len(table))]
+        hists = [jd.HistoryRank(table, [u for u in range(len(table)) if owner[u] == r]) for r in range(world)]
+        seeded = [dict() for _ in range(world)]             # stream -> was the state it was seeded with right?
+
+        def evaluate():
+            right = {}
+            for r, h in enumerate(hists):
+                for i, u in enumerate(h.units):            # batch order = job order inside a rank: a link's target comes first
+                    if not needs[u]:
+                        right[u] = True
+                    elif h.prev_local[i] >= 0:
+                        right[u] = right[h.units[h.prev_local[i]]]
+                    else:
+                        right[u] = seeded[r].get(i, False)
+            return right
+
+        for _ in range(len(table) + 2):
+            right = evaluate()
+            unresolved = [{i for i in h.remote if needs[h.units[i]] and i not in seeded[r]} for r, h in enumerate(hists)]
+            if not any(unresolved):
+                break
+            moves = jd.history_transfers(hists, owner, unresolved)
+            assert moves, "stuck"
+            for pr, j, r, i in moves:
+                assert right[hists[pr].units[j]], "seeded from a predecessor that was not final"
+                seeded[r][i] = True
+        assert all(evaluate().values())

@@ -129,3 +129,119 @@ def test_local_ingest_layout_decodes_like_the_whole_streams(hip_lib, libs):
     for u, (s, g, _) in enumerate(table):
         per_stream.setdefault(s, []).extend(got[u])
     assert per_stream == want
+
+
+# ---- a unit continues its predecessor: the sharded decode equals the WHOLE-stream golden pictures ----
+
+HISTORY_CASES = ["uncovered_first_p_118x197", "uncovered_last_mb_118x197", "coherent_pan_352x288"]
+
+
+def _golden(case):
+    import hashlib
+    import json
+    import os
+    from conftest import ROOT
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_%s.json" % case)))
+    es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"]
+    return fx, es
+
+
+def _md5(planes):
+    import hashlib
+    h = hashlib.md5()
+    for p in planes:
+        h.update(p.tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("case", HISTORY_CASES)
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_linked_units_of_one_batch_decode_like_the_whole_stream(case, order, hip_lib):
+    """streams whose pictures leave macroblocks unwritten (they show the decoded picture before last -- across GOP
+    boundaries too), cut at EVERY GOP, all units in one batch: decoded as independent streams some pictures differ from
+    the whole stream's; LINKED (jsmpeg_hip_batch_link_streams) every picture has the golden md5 -- with per-level
+    launches and (16 copies: 16 chains) with the ordered launch"""
+    import os
+    fx, es = _golden(case)
+    units = jd.split_gops_c(es)
+    assert len(units) >= 2
+    copies = 16
+    os.environ["JSMPEG_HIP_RECON_ORDER"] = order
+    try:
+        b = jb.Batch(fx["info"]["width"], fx["info"]["height"], copies * len(units), copies * fx["n_frames"] + 8,
+                     copies * (sum(len(u) for u in units) + 64 * len(units)) + 8192)
+    finally:
+        del os.environ["JSMPEG_HIP_RECON_ORDER"]
+    with b:
+        b.upload(units * copies)
+        assert b.decode() == copies * fx["n_frames"]
+        alone = [_md5(b.read_frame(p)) for p in range(fx["n_frames"])]
+        b.upload(units * copies)
+        b.link_streams([(-1 if s % len(units) == 0 else s - 1) for s in range(copies * len(units))])
+        assert b.decode() == copies * fx["n_frames"]
+        assert (b.recon_info()["launches"] == 1) == (order != "0")
+        for p in range(copies * fx["n_frames"]):
+            assert _md5(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], (case, p)
+        if case != "uncovered_last_mb_118x197":
+            assert alone != fx["frame_md5"], "the case does not exercise the cut"
+        with pytest.raises(RuntimeError, match="EARLIER"):
+            b.link_streams([1] + [-1] * (copies * len(units) - 1))
+
+
+@pytest.mark.parametrize("case", HISTORY_CASES)
+@pytest.mark.parametrize("placement", ["alternating", "contiguous"])
+def test_two_emulated_ranks_resolve_history_across_the_cut(case, placement, hip_lib):
+    """two ranks emulated on one GPU, every stream cut at every GOP: with `alternating` every cut crosses ranks (each unit's
+    predecessor was decoded by the OTHER rank), with jsmpeg_hip_plan_contiguous at most one does.  Units are linked inside
+    a rank's batch; a unit that needs its remote predecessor (jsmpeg_hip_batch_uncovered on its first two pictures) is
+    seeded with that unit's last two frames and its rank decodes again (jd.resolve_history_emulated).  Result: the
+    whole-stream golden pictures, exactly."""
+    import torch
+    fx, es = _golden(case)
+    streams = [es, es, es]
+    per_stream = [jd.split_gops_c(s) for s in streams]
+    table = jd.unit_table([[len(u) for u in us] for us in per_stream])
+    flat = [u for us in per_stream for u in us]
+    if placement == "alternating":
+        owner = [k % 2 for k in range(len(table))]
+    else:
+        owner = jd.plan_contiguous_c([n for _, _, n in table], 2)
+        assert owner == jd.plan_contiguous([n for _, _, n in table], 2) and owner == sorted(owner) and set(owner) == {0, 1}
+    pics_per_unit = [u[2] for us in streams for u in jd.gop_units(us)[0]]
+    ranks = []
+    for r in range(2):
+        mine = [u for u in range(len(table)) if owner[u] == r]
+        hist = jd.HistoryRank(table, mine)
+        b = jb.Batch(fx["info"]["width"], fx["info"]["height"], len(mine), sum(pics_per_unit[u] for u in mine) + 8,
+                     sum(len(flat[u]) + 64 for u in mine) + 8192)
+        rk = dict(batch=b, hist=hist, seeds={})
+
+        def redecode(rk=rk, mine=mine):
+            bb = rk["batch"]
+            bb.upload([flat[u] for u in mine])
+            bb.link_streams(rk["hist"].prev_local)
+            for i, (last, before) in rk["seeds"].items():
+                bb.seed_stream(i, last, before)
+            bb.decode()
+        rk["redecode"] = redecode
+        redecode()
+        ranks.append(rk)
+    try:
+        again = jd.resolve_history_emulated(ranks, table, owner)
+        got = {}
+        for r, rk in enumerate(ranks):
+            b = rk["batch"]
+            for p, info in enumerate(b.pictures()):
+                if info.decoded:
+                    got.setdefault(rk["hist"].units[info.stream], []).append(_md5(b.read_frame(p)))
+        per = {}
+        for u, (s, g, _) in enumerate(table):
+            per.setdefault(s, []).extend(got[u])
+        for s in range(len(streams)):
+            assert per[s] == fx["frame_md5"], (case, placement, s)
+        if case != "uncovered_last_mb_118x197" and placement == "alternating":
+            assert again >= 1, "no cut needed its history: the case does not exercise the exchange"
+    finally:
+        for rk in ranks:
+            rk["batch"].close()
