@@ -75,6 +75,18 @@ void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *self);
  * failure must never read as "no more pictures". */
 bool mpeg1_decoder_decode(mpeg1_decoder_t *self);
 
+/* DECODE-AHEAD.  The reference decodes one picture per call; so does this function, as far as a caller can tell.  But
+ * when several COMPLETE pictures are buffered behind the cursor (a file written in one piece, EXPAND mode; never the
+ * streaming case of one picture written, one pulled) and the caller is pulling them one after the other (the first
+ * picture after a write or a seek comes the plain way, at the plain latency), a call decodes up to 48 of them (as many as fit 160 MB of frames) in ONE pass of the batch engine
+ * (part 2: all their slices parsed at once, the P chain reconstructed launch by launch, frames left in HBM) and the
+ * following calls are served from those frames: planes, cursor (mpeg1_decoder_get_index) and plane rotation exactly as
+ * if each call had decoded its picture.  A cursor that is not where the next such picture begins
+ * (mpeg1_decoder_set_index: a seek) drops what is left; the last buffered picture (nothing behind it yet) is always
+ * decoded the plain way.  Environment JSMPEG_HIP_DECODE_AHEAD = pictures per pass (0 / 1: off).
+ * out[0] = passes of the batch engine so far, out[1] = pictures served from them. */
+int jsmpeg_hip_decoder_ahead_stats(mpeg1_decoder_t *self, uint64_t out[2]);
+
 /* Additive: DEVICE pointer to the most recently decoded frame (Y | Cr | Cb
  * contiguous, 1.5 * coded_size bytes), for consumers that stay on the GPU. */
 void *jsmpeg_hip_decoder_get_device_frame(mpeg1_decoder_t *self);

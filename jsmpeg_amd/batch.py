@@ -28,7 +28,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
-                 "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame")
+                 "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame", "jsmpeg_hip_decoder_ahead_stats")
 
 _lib = None
 

@@ -127,6 +127,16 @@ class Mpeg1Decoder:
     def height(self):
         return self.lib.mpeg1_decoder_get_height(self.h)
 
+    def ahead_stats(self):
+        """Product only: (passes of the batch engine, pictures served from them) of the decode-ahead (include/jsmpeg_hip.h)"""
+        fn = self.lib.jsmpeg_hip_decoder_ahead_stats
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        out = (ctypes.c_uint64 * 2)()
+        if fn(self.h, out) != 0:
+            raise RuntimeError("jsmpeg_hip_decoder_ahead_stats failed")
+        return int(out[0]), int(out[1])
+
     def render_rgba(self):
         """Product only (libjsmpeg_hip.so): the most recently decoded picture as RGBA, converted on the
         device (jsmpeg_hip_decoder_render_rgba); uint8[height, width, 4]."""

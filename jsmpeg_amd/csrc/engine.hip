@@ -87,6 +87,10 @@ static void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g, width,
 #define JM_ORDER_DISTANCE 200u
 #define JM_ORDER_MIN_DISTANCE 160u
 #define JM_ORDER_AUTO 0xffffffffu
+/* pictures the one-picture interface decodes per pass of the batch engine when that many are buffered (mpeg1_decoder_t::ahead) */
+#ifndef JM_DECODE_AHEAD
+#define JM_DECODE_AHEAD 48u        /* ... at most, and no more than fit 160 MB of frames (1080p: 48, 2160p: 12): dec_sequence_header */
+#endif
 #define POOL_GUARD 256 /* bytes before/after a frame pool: aligned 12-byte prediction loads may straddle */
 
 /* =========================================================================
@@ -533,6 +537,11 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	D.mb = b->d_mb + (size_t)p * b->g.mb_size;
 	D.dst = b->d_pool + (uint64_t)p * b->g.frame_bytes;
 	D.fwd = pic.fwd >= 0 ? b->d_pool + (uint64_t)pic.fwd * b->g.frame_bytes : nullptr;
+	/* a P picture in front of which the stream has no decoded picture of its own, in a stream seeded with the frame that
+	 * was decoded last before it (jsmpeg_hip_batch_seed_stream): that frame is its forward reference */
+	if (pic.fwd < 0 && pic.type == JM_PIC_PREDICTIVE && pic.stream < b->seeded.size() && (b->seeded[pic.stream] & 1) &&
+	    (pic.stream >= b->link_prev.size() || b->link_prev[pic.stream] < 0))
+		D.fwd = b->seed_frames[2 * (size_t)pic.stream];
 	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes
 	                     : (jm_stale_is_seed(stale) && jm_stale_seed_slot(stale) < b->seed_frames.size() ? b->seed_frames[jm_stale_seed_slot(stale)] : nullptr);
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
@@ -1048,6 +1057,22 @@ struct mpeg1_decoder_t {
 	uint8_t *d_rgba; size_t rgba_cap; /* renderer stage scratch (jsmpeg_hip_decoder_render_rgba) */
 	uint8_t epoch;
 	std::vector<uint32_t> stage_pos; std::vector<uint8_t> stage_code;
+
+	/* DECODE-AHEAD: when several complete pictures are buffered (a file in EXPAND mode; never the streaming case of one
+	 * picture written, one pulled) decode() runs the BATCH engine over the next `ahead_max` of them in one pass -- all
+	 * their slices parsed at once, the P chain reconstructed launch by launch, frames left in the batch's pool -- and the
+	 * following decode() calls are served from there: a device copy into the two rotating frames (so that the
+	 * one-at-a-time path, the device-frame pointer and the RGBA stage see exactly what they would have), a copy to the
+	 * pinned host planes, the cursor where the reference would leave it.  set_index / a cursor that is not where the next
+	 * served picture begins drops what is left. */
+	struct Ahead { unsigned index_before, index_after; uint32_t picture; };
+	jsmpeg_hip_batch_t *ahead;      /* made on first use for the stream's size */
+	std::vector<Ahead> ahead_q; size_t ahead_next;
+	std::vector<uint8_t> seq_bytes; /* the sequence header as it stood in the stream (the batch engine reads size and matrices from it) */
+	uint8_t *ahead_stage; size_t ahead_stage_cap;   /* pinned: header + the run's bytes on their way into the batch */
+	unsigned ahead_max;
+	unsigned last_after;            /* cursor the last decode() that returned a picture left behind (decode-ahead waits for a caller that PULLS) */
+	uint64_t ahead_served, ahead_passes;
 };
 
 static int dec_fail_cleanup(mpeg1_decoder_t *d);
@@ -1068,6 +1093,8 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 	d->capacity = buffer_size ? buffer_size : 1; d->length = 0; d->index = 0; d->mode = (int)buffer_mode;
 	d->d_es_cap = 0; d->mirrored = 0; d->scan_cap = 0; d->tokens_cap = 0;
 	d->has_sequence_header = 0; d->frame_rate = 0; d->width = d->height = 0; d->cur = 0; d->epoch = 0;
+	d->ahead = nullptr; d->ahead_next = 0; d->ahead_served = d->ahead_passes = 0; d->ahead_stage = nullptr; d->ahead_stage_cap = 0; d->last_after = ~0u;
+	{ const char *e = getenv("JSMPEG_HIP_DECODE_AHEAD"); d->ahead_max = e ? (unsigned)atoi(e) : JM_DECODE_AHEAD; }
 	memset(&d->g, 0, sizeof(d->g)); memset(&d->h_stream, 0, sizeof(d->h_stream));
 	bool ok = hipGetDevice(&d->device) == hipSuccess && luts_for_device(d->device, &d->d_luts) == 0 &&
 	          hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1087,6 +1114,8 @@ extern "C" mpeg1_decoder_t *mpeg1_decoder_create(unsigned int buffer_size, bit_b
 static int dec_fail_cleanup(mpeg1_decoder_t *d) {
 	if (!d) return -1;
 	if (d->stream) hipStreamSynchronize(d->stream);
+	if (d->ahead) jsmpeg_hip_batch_destroy(d->ahead);
+	hipHostFree(d->ahead_stage);
 	hipHostFree(d->bytes); hipFree(d->d_es); hipFree(d->d_scan_state); hipFree(d->d_sc_pos); hipFree(d->d_sc_code);
 	hipFree(d->d_sc_owner); hipFree(d->d_pic_sc); hipFree(d->d_counters); hipHostFree(d->h_scan_pos);
 	hipHostFree(d->h_scan_code); hipHostFree(d->h_counters); hipFree(d->d_stream); hipFree(d->d_pic); hipFree(d->d_desc);
@@ -1105,6 +1134,7 @@ static void store_evict(mpeg1_decoder_t *d, unsigned needed) {
 	 * but only traps inside the wasm sandbox): nothing to keep */
 	if (byte_pos >= d->length || needed > available + byte_pos) {
 		d->length = 0; d->index = 0; d->codes.clear(); d->mirrored = 0;
+		d->ahead_q.clear(); d->ahead_next = 0;
 		return;
 	}
 	if (byte_pos == 0) return;
@@ -1115,6 +1145,7 @@ static void store_evict(mpeg1_decoder_t *d, unsigned needed) {
 	for (const StartCode &c : d->codes) if (c.pos >= byte_pos) d->codes[k++] = StartCode{ c.pos - byte_pos, c.code };
 	d->codes.resize(k);
 	d->mirrored = 0; /* device mirror is re-sent on the next did_write */
+	for (size_t i = d->ahead_next; i < d->ahead_q.size(); i++) { d->ahead_q[i].index_before -= byte_pos << 3; d->ahead_q[i].index_after -= byte_pos << 3; }
 }
 
 /* buffer.c:48-65 */
@@ -1256,6 +1287,13 @@ static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
 	HIP_TRY(hipHostMalloc(&d->h_frame, d->g.frame_bytes, hipHostMallocDefault));
 	memset(d->h_frame, 0, d->g.frame_bytes);
 	d->has_sequence_header = 1;
+	if (!getenv("JSMPEG_HIP_DECODE_AHEAD"))
+		d->ahead_max = (unsigned)std::min<uint64_t>(JM_DECODE_AHEAD, std::max<uint64_t>(8, (160ull << 20) / std::max<uint64_t>(1, d->g.frame_bytes)));
+	{   /* the header's bytes, up to the next start code (decode-ahead hands them to the batch engine) */
+		size_t k = first_code_from(d, pos + 4);
+		const unsigned end = k < d->codes.size() ? d->codes[k].pos : d->length;
+		d->seq_bytes.assign(d->bytes + pos, d->bytes + std::max(end, pos));
+	}
 	return 0;
 }
 
@@ -1381,32 +1419,158 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	return 0;
 }
 
+/* What decode() finds from a cursor: the next picture start code, its header, the run of slices behind it
+ * (mpeg1.c:853-864 + decode_picture's control flow, mpeg1.c:947-995).  No state is changed. */
+struct PicScan {
+	bool found;                  /* a picture start code at or after the cursor */
+	bool skipped;                /* B / D / unknown type, or P with forward_f_code 0: consumed, not decoded */
+	size_t k, first, j;          /* codes[k] = the picture, slices [first, j) */
+	int type, full_pel, f_code;
+	unsigned index_header;       /* cursor after the header fields the reference reads */
+	unsigned index_after;        /* cursor when decode() returns */
+};
+static PicScan dec_scan_picture(const mpeg1_decoder_t *d, unsigned from_index) {
+	PicScan r;
+	memset(&r, 0, sizeof(r));
+	size_t k = first_code_from(d, (from_index + 7) >> 3);
+	while (k < d->codes.size() && d->codes[k].code != JM_CODE_PICTURE) k++;
+	if (k == d->codes.size()) { r.index_after = d->length << 3; return r; }
+	r.found = true; r.k = k;
+	uint64_t bit = ((uint64_t)d->codes[k].pos + 4) * 8 + 10;
+	r.type = (int)host_bits(d, bit, 3); bit += 3 + 16;
+	const uint64_t end_bits = (uint64_t)d->length << 3;          /* a chunk that ends inside a picture header: the cursor never passes the data (store_evict's arithmetic relies on it) */
+	r.index_header = (unsigned)std::min(bit, end_bits);
+	if (r.type <= 0 || r.type >= 3) { r.skipped = true; r.index_after = r.index_header; return r; }   /* B, D, unknown: skipped */
+	if (r.type == JM_PIC_PREDICTIVE) {
+		r.full_pel = (int)host_bits(d, bit, 1);
+		r.f_code = (int)host_bits(d, bit + 1, 3);
+		bit += 4;
+		r.index_header = (unsigned)std::min(bit, end_bits);
+		if (r.f_code == 0) { r.skipped = true; r.index_after = r.index_header; return r; }
+	}
+	/* next start code from the cursor; skip extension / user data; take the run of slices */
+	size_t j = first_code_from(d, (r.index_header + 7) >> 3);
+	while (j < d->codes.size() && (d->codes[j].code == JM_CODE_EXTENSION || d->codes[j].code == JM_CODE_USER_DATA)) j++;
+	r.first = j;
+	while (j < d->codes.size() && d->codes[j].code >= JM_CODE_SLICE_FIRST && d->codes[j].code <= JM_CODE_SLICE_LAST) j++;
+	r.j = j;
+	/* cursor: rewound onto the code that ended the picture, or end of data (mpeg1.c:980-984) */
+	r.index_after = j < d->codes.size() ? d->codes[j].pos << 3 : d->length << 3;
+	return r;
+}
+
+/* DECODE-AHEAD (mpeg1_decoder_t::ahead): the batch engine over the run of pictures `run` -- complete (the start code that
+ * ends each one is buffered), of a decoded type, with slices.  The batch gets one stream: the sequence header as it
+ * stood in the stream + the bytes from the first picture's start code to the code that ends the last one, seeded with
+ * the two rotating frames (the run's first P picture predicts from the frame decoded last; macroblocks its first two
+ * pictures never write show the frames before).  0: the queue is filled; -1: not this time (the caller decodes one
+ * picture the plain way; g_err says why if it was a HIP failure). */
+static int dec_ahead_build(mpeg1_decoder_t *d, const std::vector<PicScan> &run) {
+	const unsigned begin = d->codes[run.front().k].pos, end = d->codes[run.back().j].pos;
+	const size_t bytes = d->seq_bytes.size() + (end - begin);
+	if (d->seq_bytes.empty() || end <= begin) return -1;
+	if (d->ahead && (d->ahead->cfg.max_es_bytes < bytes || d->ahead->cfg.max_pictures < run.size())) { jsmpeg_hip_batch_destroy(d->ahead); d->ahead = nullptr; }
+	if (!d->ahead) {
+		jsmpeg_hip_batch_config_t c;
+		c.width = d->width; c.height = d->height; c.max_streams = 1; c.max_pictures = std::max<uint32_t>(d->ahead_max, (uint32_t)run.size());
+		c.max_es_bytes = std::max<uint64_t>(2 * bytes, 4u << 20); c.device = d->device;
+		d->ahead = jsmpeg_hip_batch_create(&c);
+		if (!d->ahead) return -1;
+	}
+	if (d->ahead_stage_cap < bytes) {
+		hipHostFree(d->ahead_stage); d->ahead_stage = nullptr; d->ahead_stage_cap = 0;
+		if (hipHostMalloc(&d->ahead_stage, 2 * bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		d->ahead_stage_cap = 2 * bytes;
+	}
+	memcpy(d->ahead_stage, d->seq_bytes.data(), d->seq_bytes.size());
+	memcpy(d->ahead_stage + d->seq_bytes.size(), d->bytes + begin, end - begin);
+	const uint8_t *ptr = d->ahead_stage;
+	const uint64_t len = bytes;
+	if (jsmpeg_hip_batch_upload(d->ahead, 1, &ptr, &len) < 0) return -1;
+	if (jsmpeg_hip_batch_seed_stream(d->ahead, 0, d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes) < 0) return -1;
+	const int n = jsmpeg_hip_batch_decode(d->ahead, d->stream);
+	if (n < 0 || jsmpeg_hip_batch_sync(d->ahead) < 0) return -1;
+	/* the engine must have found exactly the pictures the scan found, every one of them decoded, where the scan saw them */
+	if ((size_t)n != run.size()) return -1;
+	for (size_t i = 0; i < run.size(); i++) {
+		const JmPic &pic = d->ahead->h_pics[i];
+		if (!pic.decoded || pic.pos - d->ahead->h_streams[0].es_begin != d->seq_bytes.size() + (d->codes[run[i].k].pos - begin)) return -1;
+	}
+	d->ahead_q.clear(); d->ahead_next = 0;
+	unsigned before = d->index;
+	for (size_t i = 0; i < run.size(); i++) {
+		d->ahead_q.push_back(mpeg1_decoder_t::Ahead{ before, run[i].index_after, (uint32_t)i });
+		before = run[i].index_after;
+	}
+	d->ahead_passes++;
+	return 0;
+}
+
+/* the next queued picture: into the rotating frame that is due (a device copy), to the pinned host planes, cursor on */
+static int dec_ahead_serve(mpeg1_decoder_t *d) {
+	const mpeg1_decoder_t::Ahead e = d->ahead_q[d->ahead_next];
+	const uint8_t *src = d->ahead->d_pool + (uint64_t)e.picture * d->ahead->g.frame_bytes;
+	const size_t planes = (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes;
+	HIP_TRY(hipMemcpyAsync(d->d_pool + (uint64_t)d->cur * d->g.frame_bytes, src, planes, hipMemcpyDeviceToDevice, d->stream));
+	HIP_TRY(hipMemcpyAsync(d->h_frame, src, planes, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	d->cur ^= 1;                                    /* plane rotation, mpeg1.c:986-994 */
+	d->index = e.index_after;
+	d->last_after = d->index;
+	d->ahead_served++;
+	if (++d->ahead_next == d->ahead_q.size()) { d->ahead_q.clear(); d->ahead_next = 0; }
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_decoder_ahead_stats(mpeg1_decoder_t *d, uint64_t out[2]) {
+	if (!d || !out) return fail("null argument");
+	out[0] = d->ahead_passes; out[1] = d->ahead_served;
+	return 0;
+}
+
 /* mpeg1.c:853-864 + decode_picture's control flow, mpeg1.c:947-995 */
 extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
 	g_err[0] = 0;               /* first: "false + a message" is this call's failure, never one an earlier call left behind */
 	if (!d || !d->has_sequence_header) return false;
 	if (hipSetDevice(d->device) != hipSuccess) { fail("hipSetDevice(%d) failed", d->device); return false; }
-	size_t k = first_code_from(d, (d->index + 7) >> 3);
-	while (k < d->codes.size() && d->codes[k].code != JM_CODE_PICTURE) k++;
-	if (k == d->codes.size()) { d->index = d->length << 3; return false; }
-	uint64_t bit = ((uint64_t)d->codes[k].pos + 4) * 8 + 10;
-	int type = (int)host_bits(d, bit, 3); bit += 3 + 16;
-	const uint64_t end_bits = (uint64_t)d->length << 3;          /* a chunk that ends inside a picture header: the cursor never passes the data (store_evict's arithmetic relies on it) */
-	d->index = (unsigned)std::min(bit, end_bits);
-	if (type <= 0 || type >= 3) return true;                       /* B, D, unknown: skipped */
-	int full_pel = 0, f_code = 0;
-	if (type == JM_PIC_PREDICTIVE) {
-		full_pel = (int)host_bits(d, bit, 1);
-		f_code = (int)host_bits(d, bit + 1, 3);
-		bit += 4;
-		d->index = (unsigned)std::min(bit, end_bits);
-		if (f_code == 0) return true;
+	/* served from the pictures decoded ahead -- if the cursor is where the next of them begins (a seek, or anything else
+	 * that moved it, drops what is left) */
+	if (d->ahead_next < d->ahead_q.size()) {
+		if (d->ahead_q[d->ahead_next].index_before == d->index) {
+			if (dec_ahead_serve(d) == 0) return true;
+			d->ahead_q.clear(); d->ahead_next = 0;
+			return false;                                                   /* a HIP failure: g_err says which; the cursor has not moved */
+		}
+		d->ahead_q.clear(); d->ahead_next = 0;
 	}
-	/* next start code from the cursor; skip extension / user data; take the run of slices */
-	size_t j = first_code_from(d, (d->index + 7) >> 3);
-	while (j < d->codes.size() && (d->codes[j].code == JM_CODE_EXTENSION || d->codes[j].code == JM_CODE_USER_DATA)) j++;
-	size_t first = j;
-	while (j < d->codes.size() && d->codes[j].code >= JM_CODE_SLICE_FIRST && d->codes[j].code <= JM_CODE_SLICE_LAST) j++;
+	const PicScan sc = dec_scan_picture(d, d->index);
+	if (!sc.found) { d->index = sc.index_after; return false; }
+	if (sc.skipped) { d->index = sc.index_after; return true; }
+	/* several complete pictures buffered (never the streaming case): the batch engine takes up to ahead_max of them in
+	 * one pass and this call and the next ones are served from its frames */
+	if (d->ahead_max >= 2 && d->index == d->last_after && sc.j > sc.first && sc.j < d->codes.size()) {   /* (a caller that is pulling: the first picture after a write or a seek comes the plain way, at the plain latency) */
+		std::vector<PicScan> run(1, sc);
+		while (run.size() < d->ahead_max) {
+			const PicScan nx = dec_scan_picture(d, run.back().index_after);
+			if (!nx.found || nx.skipped || nx.j == nx.first || nx.j >= d->codes.size()) break;
+			run.push_back(nx);
+		}
+		if (run.size() >= 2) {
+			if (dec_ahead_build(d, run) == 0) {
+				if (dec_ahead_serve(d) == 0) return true;
+				d->ahead_q.clear(); d->ahead_next = 0;
+				return false;
+			}
+			/* not this time -- and not again for this decoder: whatever kept the batch engine from the run (a picture it
+			 * reads differently, an allocation) would keep it from the next one; the plain path below reports a HIP failure
+			 * of its own if the device is the reason */
+			d->ahead_max = 0;
+			g_err[0] = 0;
+		}
+	}
+	d->index = sc.index_header;
+	const size_t k = sc.k, first = sc.first, j = sc.j;
+	const int type = sc.type, full_pel = sc.full_pel, f_code = sc.f_code;
 	if (j > first) {
 		if (dec_picture_gpu(d, k, first, j, type, full_pel, f_code) != 0) {
 			/* a HIP error (allocation, device reset ...): never hand back a stale picture, never take the host process
@@ -1423,5 +1587,6 @@ extern "C" bool mpeg1_decoder_decode(mpeg1_decoder_t *d) {
 		hipMemcpy(d->h_frame, d->d_pool + (uint64_t)(d->cur ^ 1) * d->g.frame_bytes,
 		          (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost);
 	}
+	d->last_after = d->index;
 	return true;
 }

@@ -196,3 +196,66 @@ assert not bad
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- decode-ahead in the one-picture ABI (include/jsmpeg_hip.h): the batch engine behind decode(), invisible to the caller ----
+
+def test_decode_ahead_serves_buffered_streams_and_is_invisible(hip_lib, libs):
+    """a buffered stream (everything written, decode() until false): the pictures come from passes of the batch engine --
+    and planes, cursor after every call and picture count are what the oracle gives one picture at a time.  Then seeks
+    (set_index back onto earlier pictures, in the middle of a pass) against the oracle doing the same."""
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_cfg1_720p.json"))
+    with cabi.Mpeg1Decoder(hip_lib, len(es) + 1024, cabi.MODE_EXPAND) as d, cabi.Mpeg1Decoder(libs["oracle"], len(es) + 1024, cabi.MODE_EXPAND) as o:
+        d.write(es)
+        o.write(es)
+        n = 0
+        while True:
+            a, b = d.decode(), o.decode()
+            assert a == b
+            if not a:
+                break
+            assert d.index == o.index and md5_planes(d.planes()) == md5_planes(o.planes()), n
+            n += 1
+        assert n == fx["n_frames"]
+        passes, served = d.ahead_stats()
+        assert passes >= 1 and served >= n - 3            # the first picture and a last one with nothing behind it come the plain way
+        # seeks: back to picture 7 (a pass is dropped half way), on for five pictures, back to picture 3, to the end
+        for target, count in ((7, 5), (3, 1000), (12, 2), (0, 3)):
+            d.index = int(offs[target]) * 8
+            o.index = int(offs[target]) * 8
+            for k in range(count):
+                a, b = d.decode(), o.decode()
+                assert a == b
+                if not a:
+                    break
+                assert d.index == o.index and md5_planes(d.planes()) == md5_planes(o.planes()), (target, k)
+        assert d.ahead_stats()[0] > passes
+
+
+def test_decode_ahead_stays_out_of_streaming_and_can_be_switched_off(hip_lib):
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_long_gop_p_chain.json"))
+    # streaming: a picture written, a picture pulled -- nothing is ever buffered ahead
+    with cabi.Mpeg1Decoder(hip_lib, 64 * 1024, cabi.MODE_EVICT) as dec:
+        got, n = [], len(offs) - 1
+        for k in range(n):
+            end = len(es) if k == n - 1 else int(offs[k + 1])
+            dec.write(es[int(offs[k]):end])
+            while dec.decode():
+                got.append(md5_planes(dec.planes()))
+        assert got == fx["frame_md5"] and dec.ahead_stats() == (0, 0)
+    # EVICT with several pictures per write: passes of the batch engine, the store evicting underneath them
+    with cabi.Mpeg1Decoder(hip_lib, 48 * 1024, cabi.MODE_EVICT) as dec:
+        got, n = [], len(offs) - 1
+        for k in range(0, n, 5):
+            hi = min(n, k + 5)
+            end = len(es) if hi == n else int(offs[hi])
+            dec.write(es[int(offs[k]):end])
+            while dec.decode():
+                got.append(md5_planes(dec.planes()))
+        assert got == fx["frame_md5"] and dec.ahead_stats()[1] > 0
+    os.environ["JSMPEG_HIP_DECODE_AHEAD"] = "0"
+    try:
+        frames, idx, _ = cabi.decode_stream(hip_lib, es)
+    finally:
+        del os.environ["JSMPEG_HIP_DECODE_AHEAD"]
+    assert frames == fx["frame_md5"] and idx == fx["bit_index_after_decode"]

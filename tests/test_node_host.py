@@ -205,3 +205,32 @@ def test_dropped_handles_give_their_decoders_back(hip_lib):
     assert out["viewsKeepDecoder"] in (0, 1), out           # 1: zero-copy views (external buffers); 0: the host copies planes
     assert out["afterViewsGone"] == 0 and out["afterDestroy"] == 0, out
     assert out["detachedLength"] == 0 or out["viewsKeepDecoder"] == 0, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["static", "streaming"])
+def test_the_references_own_player_drives_the_hip_classes_on_the_gpu(mode, hip_lib):
+    """The reference's own JSMpeg.Player, Demuxer.TS, Decoder.Base and Canvas2D renderer -- from its shipped bundle
+    (oracle/_ref/jsmpeg_ref.min.js, placed there unmodified by oracle/Makefile; it travels to the GPU box) -- drive
+    MPEG1VideoHIP / MP2AudioHIP over the real addon (JSMpeg.PlayerHIP), and in the SAME Node process the bundle's own
+    decoders check them live: the event log (every Canvas2D frame, every audio buffer and its start time, the clock,
+    the seek) equals the reference Player's with its wasm decoders, and every rendered (Y, Cr, Cb) equals both the wasm
+    decoder's and the pure-JS JSMpeg.Decoder.MPEG1Video's (reference src/player.js:30-46, 195-294)."""
+    bundle = build.JS_REF
+    if not os.path.exists(bundle):
+        pytest.skip("oracle/_ref/jsmpeg_ref.min.js not there (made from /root/reference by oracle/Makefile)")
+    from test_mp2_gpu import _av_ts
+    build.build_addon()
+    ts, es, afx, _ = _av_ts(30, "stereo_44k_192", 3)
+    f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+    f.write(ts.tobytes())
+    f.close()
+    try:
+        args = [NODE, os.path.join(ROOT, "tests", "js", "player_bundle_gpu.js"), bundle, f.name] + (["streaming"] if mode == "streaming" else [])
+        out = json.loads(subprocess.check_output(args, timeout=300))
+    finally:
+        os.unlink(f.name)
+    assert out["selected"] and out["restored"] and out["realParts"] and out["referenceRunsUsedWasmAndJs"], out
+    assert out["sameLogAsWasmPlayer"], out
+    assert out["samePlanesAsWasm"] and out["samePlanesAsJsDecoder"], out
+    assert out["frames"] >= 15 and out["audio"] >= 10 and out["pictures"] >= 15
