@@ -817,7 +817,9 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	JmReconBufs a = b;
 	if (a.need) a.need = (uint32_t)T.per_picture;      /* ordered launch: what a finished picture's `done` word reads */
 	if (a.patience == 0) a.patience = JM_RECON_PATIENCE;
-	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), 0, st, a, T);
+	/* JSMPEG_HIP_RECON_LDSPAD (measurements): bytes of unused dynamic LDS per workgroup -- fewer workgroups per CU */
+	static const uint32_t pad = getenv("JSMPEG_HIP_RECON_LDSPAD") ? (uint32_t)atoi(getenv("JSMPEG_HIP_RECON_LDSPAD")) : 0u;
+	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
 	return hipGetLastError();
 }
 
