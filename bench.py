@@ -543,6 +543,7 @@ def main():
         [int(x) for x in os.environ["JSMPEG_BENCH_PARITY_STREAMS"].split(",")]
     oracle_cache = {}            # what the oracle says is decoded once per stream / unit, whatever the mode that is checked
     needing = [[]]               # the job's units that need their cross-rank predecessor's frames (last gate)
+    history_info = {}            # ... and what resolving them took
 
     def device_hashes_by_unit(units_of_rank):
         """exchange step 2 (reporting, once per run, outside the timed steps): 8 bytes per picture to every rank, through
@@ -584,22 +585,51 @@ def main():
     def parity_gate(units_of_rank, what):
         """Every stream of this rank against the oracle; no number is reported unless all of them match.  Returns the
         pictures where a unit decoded alone differs from the unsplit stream (multi-rank only)."""
-        per_stream, got_of, excused = {}, None, set()
+        per_stream, got_of = {}, None
         if multi:
             got_of = device_hashes_by_unit(units_of_rank)
             # this rank's units whose predecessor was decoded elsewhere and that need it (first two decoded pictures with
-            # unwritten macroblocks); every rank learns all of them, a stream's owner excuses them and everything behind
-            # them in the stream
+            # unwritten macroblocks); every rank learns all of them
             hist = X["hists"][rank]
             needy = jd.needy_streams([(i.stream, i.decoded) for i in b.pictures()], b.uncovered(), len(hist.units))
             mine_needy = [hist.units[i] for i in hist.remote if needy[i]]
             all_needy = [None] * world
             dist.all_gather_object(all_needy, mine_needy)
             needing[0] = sorted(u for lst in all_needy for u in lst)
-            for u in needing[0]:
-                s_g, g_ = table[u][0], table[u][1]           # the table numbers the job's streams rank after rank
-                if s_g // n_streams == rank:
-                    excused.update((s_g - rank * n_streams, gg) for gg in range(g_, len(my_units[s_g - rank * n_streams])))
+            if needing[0]:
+                # ... and resolved: two frames per such cut travel rank to rank (the library's RCCL exchange), the ranks
+                # that received some decode again (jsmpeg_amd/distributed.py; tests/test_gpu_shards.py runs it with two
+                # ranks as threads).  Outside the timed steps: this content has none.
+                t_h = time.perf_counter()
+
+                class _Comm:
+                    def allgather(self, obj):
+                        out = [None] * world
+                        dist.all_gather_object(out, obj)
+                        return out
+
+                    def exchange(self, sa, so, sn, ra, ro, rn):
+                        D.exchange(ctypes.c_void_p(sa), so, sn, ctypes.c_void_p(ra), ro, rn, sptr)
+                        torch.cuda.synchronize()
+
+                def _view(addr, n):
+                    return torch.as_tensor(_DevMem(addr, n), device=dev)
+
+                def _alloc(n):
+                    t = torch.zeros(n, dtype=torch.uint8, device=dev)
+                    return t.data_ptr(), t
+
+                def _redecode(seeds):
+                    b.attach_device(ctypes.c_void_p(X["bufs"][state["cur"]].data_ptr()), X["shard_len"], X["begin"], X["end"], sptr)
+                    b.link_streams(hist.prev_local)
+                    for i, (last, before) in seeds.items():
+                        b.seed_stream(i, last, before)
+                    b.decode(stream=sptr, sync=True)
+
+                rounds, _, history_keep = jd.resolve_history_dist(b, hist, X["hists"], X["owner"], rank, world, _Comm(), _redecode, frame_stride, _alloc,
+                                                                  lambda dst, src: _view(dst, frame_stride).copy_(_view(src, frame_stride)))
+                history_info.update(rounds=int(rounds), ms=round((time.perf_counter() - t_h) * 1e3, 2))
+                got_of = device_hashes_by_unit(units_of_rank)
         else:
             dev_hashes = b.frame_hashes()
             for p, i in enumerate(b.pictures()):
@@ -613,19 +643,15 @@ def main():
                 if per_stream.get(s, []) != whole:
                     failed.append(s)
                 return
-            # sharded by GOP, and still the WHOLE stream's pictures: a unit continues its predecessor (linked inside a rank's
-            # batch).  The one thing left open by this run: a unit whose predecessor sits on ANOTHER rank and whose first
-            # two decoded pictures leave macroblocks unwritten needs that unit's last two frames (jd.resolve_history_*):
-            # such units are counted (cross_rank_units_needing_history) and excused here -- there are none in this content
+            # sharded by GOP, and still the WHOLE stream's pictures: a unit continues its predecessor -- linked inside a rank's
+            # batch, seeded with two shipped frames across ranks where it needs them (resolved above)
             got, pos = got_of(s), 0
             for g, unit in enumerate(my_units[s]):
                 want = whole[pos:pos + len(got[g])]
                 if got[g] != want:
-                    if (s, g) in excused:
-                        with dev_lock:
-                            deviating[0] += sum(1 for a, bb in zip(got[g], want) if a != bb)
-                    else:
-                        failed.append((s, g))
+                    failed.append((s, g))
+                    with dev_lock:
+                        deviating[0] += sum(1 for a, bb in zip(got[g], want) if a != bb)
                 pos += len(got[g])
             if pos != len(whole):
                 failed.append((s, "picture count"))
@@ -862,11 +888,13 @@ def main():
                             "ms_per_step only where it is not hidden")
         exchange["pictures_differing_from_unsplit_streams"] = int(deviating)
         exchange["cross_rank_units_needing_history"] = len(needing[0])
+        exchange["history_resolution"] = dict(history_info) or None
         exchange["history_note"] = ("units are planned as contiguous ranges of the job's unit list (jsmpeg_hip_plan_contiguous) and linked inside a "
                                     "rank's batch (jsmpeg_hip_batch_link_streams): the parity gate holds every unit against the UNSPLIT stream's "
                                     "pictures.  A unit behind one of the <= n_gpus - 1 cross-rank cuts needs its predecessor's last two frames only "
-                                    "when its first two decoded pictures leave macroblocks unwritten (jsmpeg_amd/distributed.py, resolve_history_*: "
-                                    "tests/test_gpu_shards.py); this run counts such units and excuses them in the gate -- 0 in this content")
+                                    "when its first two decoded pictures leave macroblocks unwritten: then two frames travel rank to rank and the receiving rank decodes "
+                                    "again (jsmpeg_amd/distributed.py resolve_history_dist, tests/test_gpu_shards.py), here after the timed steps, "
+                                    "before the gate -- 0 such units in this content")
         exchange["pictures_with_unwritten_macroblocks"] = int(uncovered)
         line["exchange"] = exchange
     # rank 0, after the timed runs, at every N: the baseline is per host core and does not scale with the GPUs

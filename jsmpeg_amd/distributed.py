@@ -500,3 +500,56 @@ def resolve_history_emulated(ranks, table, owner, max_rounds=64):
             ranks[r]["redecode"]()
             again += 1
     raise RuntimeError("history resolution did not converge")
+
+
+def resolve_history_dist(b, hist, hists, owner, rank, world, comm, redecode, frame_bytes, alloc, copy_frame, max_rounds=64):
+    """The same procedure with one rank per process (bench.py; tests/test_gpu_shards.py runs two ranks as threads over a
+    stand-in `comm`).  Every rank calls this after its decode:
+      comm.allgather(obj) -> [obj of rank 0, ...]; comm.exchange(send_addr, send_offset, send_bytes, recv_addr, recv_offset,
+      recv_bytes) = jsmpeg_hip_dist_exchange (device addresses, per-rank byte tables), synchronised on return;
+      alloc(n) -> (device address, keep-alive) of n zeroed bytes; copy_frame(dst_addr, src_addr) copies one frame on the device;
+      redecode(seeds) uploads / attaches this rank's piece again, links it, seeds {stream: (last, before)} and decodes.
+    Frames travel two per move (the predecessor's last and the one before, zeros where it has none).  Returns (rounds, the
+    seeds this rank ended up with); the receive buffers stay alive in the returned seeds' keep list."""
+    seeds, keep = {}, []
+    n = len(hist.units)
+    for rounds in range(max_rounds):
+        pics = [(i.stream, i.decoded) for i in b.pictures()]
+        needy = needy_streams(pics, b.uncovered(), n)
+        mine = sorted(i for i in hist.remote if needy[i] and i not in seeds)
+        unresolved = [set(x) for x in comm.allgather(mine)]
+        if not any(unresolved):
+            return rounds, seeds, keep
+        moves = history_transfers(hists, owner, unresolved)
+        if not moves:
+            raise RuntimeError("history resolution is stuck: %r" % (unresolved,))
+        stride, pool = b.frame_stride, b.frame_pool_ptr
+        states = final_states(pics, n, hist.prev_local, seeds, lambda p: pool + p * stride)
+        out = [m for m in moves if m[0] == rank]          # what this rank gives, in the order every rank computes
+        inc = [m for m in moves if m[2] == rank]          # what it gets
+        send_off, send_n, recv_off, recv_n = [0] * world, [0] * world, [0] * world, [0] * world
+        for m in out:
+            send_n[m[2]] += 2 * frame_bytes
+        for m in inc:
+            recv_n[m[0]] += 2 * frame_bytes
+        for r in range(1, world):
+            send_off[r] = send_off[r - 1] + send_n[r - 1]
+            recv_off[r] = recv_off[r - 1] + recv_n[r - 1]
+        send_addr, send_keep = alloc(max(1, sum(send_n)))
+        recv_addr, recv_keep = alloc(max(1, sum(recv_n)))
+        keep.append(recv_keep)
+        cur = list(send_off)
+        for pr, j, r, i in out:                           # per destination in move order
+            for f in states[j]:
+                if f is not None:
+                    copy_frame(send_addr + cur[r], f)
+                cur[r] += frame_bytes
+        comm.exchange(send_addr, send_off, send_n, recv_addr, recv_off, recv_n)
+        del send_keep
+        cur = list(recv_off)
+        for pr, j, r, i in inc:
+            seeds[i] = (recv_addr + cur[pr], recv_addr + cur[pr] + frame_bytes)
+            cur[pr] += 2 * frame_bytes
+        if inc:
+            redecode(seeds)
+    raise RuntimeError("history resolution did not converge")

@@ -245,3 +245,106 @@ def test_two_emulated_ranks_resolve_history_across_the_cut(case, placement, hip_
     finally:
         for rk in ranks:
             rk["batch"].close()
+
+
+@pytest.mark.parametrize("case", ["uncovered_first_p_118x197", "coherent_pan_352x288"])
+def test_history_resolution_one_rank_per_thread(case, hip_lib):
+    """jd.resolve_history_dist -- the function bench.py's ranks run -- with two ranks as two THREADS of this process over a
+    stand-in communicator (all-gather by barrier, the frame exchange as device copies with jsmpeg_hip_dist_exchange's
+    arguments): every cut crosses ranks (alternating placement), the result is the whole stream's golden pictures."""
+    import threading
+    import torch
+    dev = torch.device("cuda", 0)
+    fx, es = _golden(case)
+    streams = [es, es]
+    per_stream = [jd.split_gops_c(s) for s in streams]
+    table = jd.unit_table([[len(u) for u in us] for us in per_stream])
+    flat = [u for us in per_stream for u in us]
+    owner = [k % 2 for k in range(len(table))]
+    pics_per_unit = [u[2] for us in streams for u in jd.gop_units(us)[0]]
+    hists = [jd.HistoryRank(table, [u for u in range(len(table)) if owner[u] == r]) for r in range(2)]
+
+    class Mem:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+    def view(addr, n):
+        return torch.as_tensor(Mem(addr, n), device=dev)
+
+    barrier, box, lock = threading.Barrier(2), {}, threading.Lock()
+
+    class Comm:
+        def __init__(self, rank):
+            self.rank = rank
+
+        def allgather(self, obj):
+            box[("g", self.rank)] = obj
+            barrier.wait()
+            out = [box[("g", 0)], box[("g", 1)]]
+            barrier.wait()
+            return out
+
+        def exchange(self, send_addr, send_off, send_n, recv_addr, recv_off, recv_n):
+            box[("x", self.rank)] = (send_addr, send_off, send_n)
+            barrier.wait()
+            for src in range(2):
+                if src != self.rank and recv_n[src]:
+                    s_addr, s_off, s_n = box[("x", src)]
+                    assert s_n[self.rank] == recv_n[src]
+                    with lock:
+                        view(recv_addr + recv_off[src], recv_n[src]).copy_(view(s_addr + s_off[self.rank], recv_n[src]))
+                        torch.cuda.synchronize()
+            barrier.wait()
+
+    results, errors = {}, []
+
+    def rank_main(r):
+        try:
+            mine = hists[r].units
+            b = jb.Batch(fx["info"]["width"], fx["info"]["height"], len(mine), sum(pics_per_unit[u] for u in mine) + 8,
+                         sum(len(flat[u]) + 64 for u in mine) + 8192)
+            fb = b.frame_stride
+
+            def redecode(seeds):
+                with lock:
+                    b.upload([flat[u] for u in mine])
+                    b.link_streams(hists[r].prev_local)
+                    for i, (last, before) in seeds.items():
+                        b.seed_stream(i, last, before)
+                    b.decode()
+
+            def alloc(n):
+                t = torch.zeros(n, dtype=torch.uint8, device=dev)
+                return t.data_ptr(), t
+
+            def copy_frame(dst, src):
+                with lock:
+                    view(dst, fb).copy_(view(src, fb))
+                    torch.cuda.synchronize()
+
+            redecode({})
+            rounds, seeds, keep = jd.resolve_history_dist(b, hists[r], hists, owner, r, 2, Comm(r), redecode, fb, alloc, copy_frame)
+            got = {}
+            with lock:
+                for p, info in enumerate(b.pictures()):
+                    if info.decoded:
+                        got.setdefault(mine[info.stream], []).append(_md5(b.read_frame(p)))
+            results[r] = (got, rounds)
+            b.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((r, repr(e)))
+            barrier.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errors, errors
+    merged = {}
+    for r in range(2):
+        merged.update(results[r][0])
+    per = {}
+    for u, (s, g, _) in enumerate(table):
+        per.setdefault(s, []).extend(merged[u])
+    for s in range(len(streams)):
+        assert per[s] == fx["frame_md5"], (case, s)
+    assert max(results[0][1], results[1][1]) >= 1
