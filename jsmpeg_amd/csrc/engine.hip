@@ -550,6 +550,8 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	 * the caches -- to see what the reads' source is worth (profiles/r04_recon_notes.md) */
 	static const int fixed_fwd = getenv("JSMPEG_HIP_T_FIXEDFWD") ? atoi(getenv("JSMPEG_HIP_T_FIXEDFWD")) : 0;
 	if (fixed_fwd && D.fwd) D.fwd = b->d_pool + (uint64_t)(p % (uint32_t)fixed_fwd) * b->g.frame_bytes;
+	static const int fixed_dst = getenv("JSMPEG_HIP_T_FIXEDDST") ? atoi(getenv("JSMPEG_HIP_T_FIXEDDST")) : 0;   /* ... and every plane store into the first n frames */
+	if (fixed_dst) D.dst = b->d_pool + (uint64_t)(p % (uint32_t)fixed_dst) * b->g.frame_bytes;
 }
 
 /* JSMPEG_HIP_TRACE=1: where the HOST's time goes in one decode call (stderr, ms since the call began) */
