@@ -239,12 +239,15 @@ int jsmpeg_hip_batch_level_timings(jsmpeg_hip_batch_t *b, float *out_ms, uint32_
  * picture before last, see part 4), [7] slice start codes found (01 .. AF; [4] counts the ones a picture owns). */
 int jsmpeg_hip_batch_counters(jsmpeg_hip_batch_t *b, uint64_t out[8]);
 /* How the last decode reconstructed (waits for the stream): [0] reconstruct launches -- 1: the ORDERED launch (one launch
- * for the whole batch: every eighth of the GPU walks its streams in lockstep and a picture's tiles wait for the picture
- * before it in its stream; batches of >= 8 streams that fill eight classes evenly), else one launch per dependency
+ * for the whole batch: every eighth of the GPU walks its streams -- or, in a narrow batch, its GOP chains -- in lockstep and
+ * a picture's tiles wait for its forward reference; batches that fill eight classes evenly), else one launch per dependency
  * level; [1] streams a class walks in lockstep (0: level by level; environment JSMPEG_HIP_RECON_ORDER = 0 / n);
  * [2] waits of the ordered launch that found their picture unfinished at the first look; [3] its status (0: clean;
- * non-zero: the launch flagged itself, the frames were reconstructed a second time level by level before
- * jsmpeg_hip_batch_sync returned, and the batch stays with per-level launches).  Frames of an ordered launch are final
+ * 1 / 2: the launch flagged itself -- a wait ran out of patience / a class ran on two XCDs --, the frames were
+ * reconstructed a second time level by level before jsmpeg_hip_batch_sync returned, and the batch stays with per-level
+ * launches; 4: a NARROW batch (fewer than eight streams: the classes walk GOP chains instead of streams, on the
+ * assumption that a chain's first two pictures write every macroblock) whose assumption did not hold for this input:
+ * done over level by level, this decode only).  Frames of an ordered launch are final
  * once jsmpeg_hip_batch_sync (or any call that reads them back) has returned. */
 int jsmpeg_hip_batch_recon_info(jsmpeg_hip_batch_t *b, uint32_t out[4]);
 /* Streams that CONTINUE other streams (part 4: the units a sharded job cuts its streams into).  prev[s] >= 0: stream s

@@ -128,6 +128,8 @@ struct jsmpeg_hip_batch_t {
 	uint32_t last_group;         /* lockstep width of the last decode's launch, 0: it went level by level */
 	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level; JM_ORDER_AUTO: by the picture size */
 	bool ordered;                /* the last decode used the ordered launch (its status is checked at the next sync) */
+	std::vector<uint32_t> chain_heads;   /* ordered by GOP chains (narrow batches): the pictures whose `stale` frame lies in ANOTHER chain -- they must
+	                                        turn out to have written every macroblock (checked at the next sync, else the frames are done over) */
 	bool stats_pending;          /* n_levels / n_uncovered of the last decode not worked out yet (needs the parse's counts) */
 	uint32_t ordered_status;     /* status of the last checked ordered launch (non-zero: it was done over) */
 	uint32_t ordered_waits;      /* polls of the last checked ordered launch that found their picture unfinished */
@@ -734,8 +736,34 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmOrderedPlan plan;
 	const uint32_t per_picture = jm_recon_tiles_per_picture(b->g);
 	const uint32_t group = b->order_group == JM_ORDER_AUTO ? 1 + (JM_ORDER_DISTANCE + per_picture - 1) / per_picture : b->order_group;
-	if (group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) && (size_t)8 * plan.rows <= b->desc_cap &&
-	    (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE)) {
+	b->chain_heads.clear();
+	static const bool force_chains = getenv("JSMPEG_HIP_RECON_CHAINS") != nullptr;     /* tests: GOP chains whatever the batch's shape */
+	bool planned = !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
+	               (size_t)8 * plan.rows <= b->desc_cap && (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
+	std::vector<uint32_t> chain_of;
+	if (!planned && group && (b->order_group == JM_ORDER_AUTO || force_chains) && b->link_prev.empty() && b->seeded.empty()) {
+		/* NARROW batches (fewer than eight streams, or streams of very different lengths: one file of many GOPs): the
+		 * classes walk GOP CHAINS instead of streams -- a chain = an intra picture and the P pictures behind it.  The one
+		 * thing that crosses chains is the `stale` frame of a chain's first two pictures (it belongs to the GOP before,
+		 * maybe another class's): the plan assumes those pictures write every macroblock -- intra pictures and a GOP's first
+		 * P picture practically always do -- and the assumption is CHECKED once the parse's counts are in
+		 * (batch_settle): a picture that did not is done over, with everything else, level by level. */
+		std::vector<JmPic> by_chain(b->h_pics, b->h_pics + b->n_pics);
+		std::vector<int32_t> cur(b->n_streams, -1);
+		chain_of.assign(b->n_pics, JM_NONE);
+		uint32_t n_chains = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) {
+			JmPic &pic = by_chain[p];
+			if (!pic.decoded || pic.stream >= b->n_streams) continue;
+			if (pic.fwd < 0 || cur[pic.stream] < 0) cur[pic.stream] = (int32_t)n_chains++;
+			chain_of[p] = (uint32_t)cur[pic.stream];
+			pic.stream = chain_of[p];
+		}
+		planned = n_chains >= 8 && jm_plan_ordered(by_chain.data(), b->n_pics, n_chains, group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap &&
+		          (force_chains || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
+		if (!planned) chain_of.clear();
+	}
+	if (planned) {
 		/* ---- 4. ONE launch: every class walks its streams in lockstep; a picture's tiles wait for its forward reference,
 		 * and a tile with a macroblock the picture never wrote for the frame that keeps showing there -- decided by the
 		 * tile itself, so nothing here needs the parse's counts: no host turn-around between parse and reconstruct ---- */
@@ -747,6 +775,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 			D.done_pic = (uint32_t)p;
 			D.wait_fwd = b->h_pics[p].fwd >= 0 ? (uint32_t)b->h_pics[p].fwd : JM_NONE;
 			D.wait_stale = stale[p] >= 0 ? (uint32_t)stale[p] : JM_NONE;
+			if (!chain_of.empty() && stale[p] >= 0 && chain_of[stale[p]] != chain_of[p]) { D.wait_stale = JM_NONE; b->chain_heads.push_back((uint32_t)p); }
 		}
 		if (const char *e = getenv("JSMPEG_HIP_RECON_BREAK")) {   /* tests: picture n of the plan never reports, its successor's wait runs out */
 			const size_t i = (size_t)atoi(e);
@@ -775,6 +804,20 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 /* What is left of a decode once its stream has drained: the ordered launch's status (a launch that gave a wait up, or
  * met a class on two XCDs, is done over level by level -- once; the batch then stays with per-level launches), and
  * the statistics that need the parse's counts. */
+static int batch_redo_by_levels(jsmpeg_hip_batch_t *b) {
+	std::vector<int32_t> stale;
+	const uint32_t n_roots = batch_plan_stale(b, stale);
+	JmReconBufs rb;
+	rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
+	HostTrace tr;
+	b->n_level_ev = 0; b->last_group = 0;
+	if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
+	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	b->stats_pending = false;
+	return 0;
+}
+
 static int batch_settle(jsmpeg_hip_batch_t *b) {
 	if (b->ordered) {
 		b->ordered = false;
@@ -783,18 +826,19 @@ static int batch_settle(jsmpeg_hip_batch_t *b) {
 		if (b->h_rstatus[0]) {
 			fprintf(stderr, "jsmpeg_hip: the ordered reconstruct flagged itself (status %u: %s); reconstructing level by level, and from now on\n",
 			        b->h_rstatus[0], (b->h_rstatus[0] & 2) ? "a class of workgroups ran on two XCDs" : "a picture's wait ran out of patience");
-			b->order_group = 0; b->last_group = 0;
-			std::vector<int32_t> stale;
-			const uint32_t n_roots = batch_plan_stale(b, stale);
-			JmReconBufs rb;
-			rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
-			HostTrace tr;
-			b->n_level_ev = 0;
-			if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
-			HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], b->stream));
-			HIP_TRY(hipStreamSynchronize(b->stream));
-			b->stats_pending = false;
+			b->order_group = 0;
+			if (batch_redo_by_levels(b) < 0) return -1;
+		} else if (!b->chain_heads.empty()) {
+			/* ordered by GOP chains: did the pictures whose `stale` frame lies in another chain write every macroblock? */
+			HIP_TRY(hipEventSynchronize(b->ev_cov));
+			bool ok = true;
+			for (uint32_t p : b->chain_heads) ok = ok && b->h_covered[p] >= (uint32_t)b->g.mb_size;
+			if (!ok) {
+				b->ordered_status = 4;          /* done over: a chain's first pictures left macroblocks unwritten */
+				if (batch_redo_by_levels(b) < 0) return -1;
+			}
 		}
+		b->chain_heads.clear();
 	}
 	if (b->stats_pending) {
 		b->stats_pending = false;

@@ -133,7 +133,12 @@ static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t 
 	for (uint32_t c = 0; c < 8; c++) {
 		std::vector<uint32_t> active, at;            /* the streams walked in lockstep, and where each one is */
 		size_t next = 0, i = 0;
-		while (active.size() < group && next < cls[c].size()) { active.push_back(cls[c][next++]); at.push_back(0); }
+		/* how many at a time: `group` -- or a few more, so that the class's LAST set is not a remainder of fewer than
+		 * `group` (five chains two at a time would end with one chain walking alone: every picture right behind its
+		 * reference; three, then two, do not) */
+		size_t width = std::min<size_t>(group, cls[c].size());
+		while (width < cls[c].size() && cls[c].size() % width != 0 && cls[c].size() % width < group) width++;
+		while (active.size() < width && next < cls[c].size()) { active.push_back(cls[c][next++]); at.push_back(0); }
 		while (!active.empty()) {
 			for (size_t a = 0; a < active.size();) {
 				const std::vector<int32_t> &l = of[active[a]];

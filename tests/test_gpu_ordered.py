@@ -162,3 +162,47 @@ print("DONE")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "flagged itself" in r.stderr
+
+
+def test_narrow_batches_walk_gop_chains(hip_lib, libs):
+    """ONE stream of many GOPs (a file): the classes of the ordered launch walk GOP chains instead of streams -- one launch,
+    every picture against the oracle"""
+    es, _ = synth.generate_config("cfg1_720p", n_frames=192, stream=2, gop=6)
+    frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+    want = [hashing.frame_hash(*f) for f in frames]
+    with jb.Batch(1280, 720, 1, 200, len(es) + 8192) as b:
+        b.upload([es])
+        for rep in range(2):
+            assert b.decode() == 192
+            info = b.recon_info()
+            assert info["launches"] == 1 and info["group"] >= 3 and info["status"] == 0, info
+            assert [int(h) for h in b.frame_hashes()] == want
+
+
+def test_a_chain_whose_first_pictures_leave_macroblocks_unwritten_is_done_over(hip_lib):
+    """the assumption of the chain plan, broken on purpose: the fixture's first P pictures leave macroblocks unwritten that show
+    the GOP before (another chain: possibly another class).  Forced onto GOP chains (JSMPEG_HIP_RECON_CHAINS), the decode
+    notices once the parse's counts are in (status 4), reconstructs level by level, and the pictures are the golden ones."""
+    code = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %r)
+from jsmpeg_amd import batch as jb, synth
+fx = json.load(open(os.path.join(%r, "tests", "golden", "frames_uncovered_first_p_118x197.json")))
+es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+n = 6
+with jb.Batch(fx["info"]["width"], fx["info"]["height"], n, n * fx["n_frames"] + 4, n * (len(es) + 64) + 8192) as b:
+    b.upload([es] * n)
+    for rep in range(2):
+        assert b.decode() == n * fx["n_frames"]
+        info = b.recon_info()
+        print("INFO", info)
+        assert info["status"] == 4 and info["launches"] > 1, info
+        for p in range(n * fx["n_frames"]):
+            h = hashlib.md5()
+            for plane in b.read_frame(p):
+                h.update(plane.tobytes())
+            assert h.hexdigest() == fx["frame_md5"][p %% fx["n_frames"]], p
+print("DONE")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JSMPEG_HIP_RECON_CHAINS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -189,7 +189,8 @@ def test_ordered_plan_properties(sim):
             if q >= 0:
                 assert pos[q] % 8 == i % 8 and pos[q] < i
                 # every picture of its stream in between the two is impossible; the distance is the streams in lockstep
-                assert (i - pos[q]) // 8 <= group
+                # (a class walks `group` at a time, or a few more where that keeps its last set from being a small remainder)
+                assert (i - pos[q]) // 8 <= 2 * group
         cls_load = [sum(1 for x in seq[c::8] if x >= 0) for c in range(8)]
         assert max(cls_load) == rows and max(cls_load) * 8 * 100 <= n_dec * 108
         assert lockstep == min(group, min(len({stream[p] for p in seq[c::8] if p >= 0}) for c in range(8)))
