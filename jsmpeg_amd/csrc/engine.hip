@@ -748,17 +748,8 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		 * maybe another class's): the plan assumes those pictures write every macroblock -- intra pictures and a GOP's first
 		 * P picture practically always do -- and the assumption is CHECKED once the parse's counts are in
 		 * (batch_settle): a picture that did not is done over, with everything else, level by level. */
-		std::vector<JmPic> by_chain(b->h_pics, b->h_pics + b->n_pics);
-		std::vector<int32_t> cur(b->n_streams, -1);
-		chain_of.assign(b->n_pics, JM_NONE);
-		uint32_t n_chains = 0;
-		for (uint32_t p = 0; p < b->n_pics; p++) {
-			JmPic &pic = by_chain[p];
-			if (!pic.decoded || pic.stream >= b->n_streams) continue;
-			if (pic.fwd < 0 || cur[pic.stream] < 0) cur[pic.stream] = (int32_t)n_chains++;
-			chain_of[p] = (uint32_t)cur[pic.stream];
-			pic.stream = chain_of[p];
-		}
+		std::vector<JmPic> by_chain;
+		const uint32_t n_chains = jm_plan_chains(b->h_pics, b->n_pics, b->n_streams, chain_of, &by_chain);
 		planned = n_chains >= 8 && jm_plan_ordered(by_chain.data(), b->n_pics, n_chains, group, 8, plan) && (size_t)8 * plan.rows <= b->desc_cap &&
 		          (force_chains || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
 		if (!planned) chain_of.clear();

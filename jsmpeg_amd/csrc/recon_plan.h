@@ -152,4 +152,24 @@ static inline bool jm_plan_ordered(const JmPic *pics, uint32_t n_pics, uint32_t 
 	return true;
 }
 
+/* GOP CHAINS of a batch (the ordered plan of NARROW batches: classes walk chains instead of streams): chain[p] = the
+ * number of the chain decoded picture p belongs to -- a new chain begins at every decoded picture without a forward
+ * reference and at a stream's first decoded picture -- JM_NONE for pictures that are not decoded.  Returns the number of
+ * chains.  by_chain (optional): a copy of the picture table with the chain number in place of the stream number, which
+ * is what jm_plan_ordered then deals to the classes. */
+static inline uint32_t jm_plan_chains(const JmPic *pics, uint32_t n_pics, uint32_t n_streams, std::vector<uint32_t> &chain, std::vector<JmPic> *by_chain) {
+	chain.assign(n_pics, JM_NONE);
+	if (by_chain) by_chain->assign(pics, pics + n_pics);
+	std::vector<int32_t> cur(n_streams, -1);
+	uint32_t n_chains = 0;
+	for (uint32_t p = 0; p < n_pics; p++) {
+		const JmPic &pic = pics[p];
+		if (!pic.decoded || pic.stream >= n_streams) continue;
+		if (pic.fwd < 0 || cur[pic.stream] < 0) cur[pic.stream] = (int32_t)n_chains++;
+		chain[p] = (uint32_t)cur[pic.stream];
+		if (by_chain) (*by_chain)[p].stream = chain[p];
+	}
+	return n_chains;
+}
+
 #endif

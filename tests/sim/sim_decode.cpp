@@ -301,4 +301,14 @@ int sim_plan_ordered(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded
 	return (int)plan.rows;
 }
 
+// GOP chains (recon_plan.h, jm_plan_chains): chain number per picture (0xffffffff: not decoded); returns the number of chains.
+int sim_plan_chains(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded, const int32_t *fwd, const uint32_t *stream, uint32_t *out_chain) {
+	std::vector<JmPic> pics(n_pics);
+	for (uint32_t p = 0; p < n_pics; p++) { pics[p] = JmPic(); pics[p].decoded = decoded[p]; pics[p].fwd = fwd[p]; pics[p].stream = stream[p]; }
+	std::vector<uint32_t> chain;
+	const uint32_t n = jm_plan_chains(pics.data(), n_pics, n_streams, chain, nullptr);
+	for (uint32_t p = 0; p < n_pics; p++) out_chain[p] = chain[p];
+	return (int)n;
+}
+
 }  // extern "C"

@@ -210,3 +210,34 @@ def test_ordered_plan_benchmark_shape(sim):
     for p in range(len(decoded)):
         if prev[p] >= 0:
             assert (pos[p] - pos[prev[p]]) // 8 == 2
+
+
+def test_gop_chains(sim):
+    """jm_plan_chains: a chain begins at every decoded picture without a forward reference and at a stream's first decoded
+    picture; pictures that are not decoded belong to none; a P picture is in its forward reference's chain"""
+    rng = np.random.default_rng(23)
+    for case in range(100):
+        n_streams = int(rng.integers(1, 5))
+        n = int(rng.integers(1, 90))
+        stream = sorted(int(x) for x in rng.integers(0, n_streams, size=n))
+        decoded = [int(rng.random() < 0.9) for _ in range(n)]
+        fwd, last = [], {}
+        for p in range(n):
+            is_p = decoded[p] and stream[p] in last and rng.random() < 0.8
+            fwd.append(last[stream[p]] if is_p else -1)
+            if decoded[p]:
+                last[stream[p]] = p
+        out = (ctypes.c_uint32 * max(1, n))()
+        k = sim.sim_plan_chains(n, n_streams, (ctypes.c_uint8 * n)(*decoded), (ctypes.c_int32 * n)(*fwd), (ctypes.c_uint32 * n)(*stream), out)
+        chain = [out[p] for p in range(n)]
+        heads = 0
+        for p in range(n):
+            if not decoded[p]:
+                assert chain[p] == 0xFFFFFFFF
+                continue
+            if fwd[p] >= 0:
+                assert chain[p] == chain[fwd[p]]
+            else:
+                heads += 1
+                assert chain[p] == heads - 1                 # numbered in picture order
+        assert k == heads
