@@ -738,10 +738,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	const uint32_t group = b->order_group == JM_ORDER_AUTO ? 1 + (JM_ORDER_DISTANCE + per_picture - 1) / per_picture : b->order_group;
 	b->chain_heads.clear();
 	static const bool force_chains = getenv("JSMPEG_HIP_RECON_CHAINS") != nullptr;     /* tests: GOP chains whatever the batch's shape */
-	bool planned = !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
+	/* (a batch without a single predicted picture has nothing to order: one plain launch) */
+	const bool any_dependency = n_roots < b->n_decoded;
+	bool planned = any_dependency && !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
 	               (size_t)8 * plan.rows <= b->desc_cap && (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
 	std::vector<uint32_t> chain_of;
-	if (!planned && group && (b->order_group == JM_ORDER_AUTO || force_chains) && b->link_prev.empty() && b->seeded.empty()) {
+	if (!planned && any_dependency && group && (b->order_group == JM_ORDER_AUTO || force_chains) && b->link_prev.empty() && b->seeded.empty()) {
 		/* NARROW batches (fewer than eight streams, or streams of very different lengths: one file of many GOPs): the
 		 * classes walk GOP CHAINS instead of streams -- a chain = an intra picture and the P pictures behind it.  The one
 		 * thing that crosses chains is the `stale` frame of a chain's first two pictures (it belongs to the GOP before,

@@ -63,7 +63,8 @@ def test_ordered_launch_matches_golden(group, hip_lib):
             for rep in range(2):          # the second pass: the counts are reset, the epoch moves on
                 assert b.decode() == n_streams * fx["n_frames"]
                 info = b.recon_info()
-                assert info["launches"] == 1 and info["group"] == min(group, 2) and info["status"] == 0, (path, info)
+                predicted = any(i.forward >= 0 for i in b.pictures())     # (a batch of intra pictures only has nothing to order: one plain launch)
+                assert info["launches"] == 1 and info["group"] == (min(group, 2) if predicted else 0) and info["status"] == 0, (path, info)
                 for p in range(n_streams * fx["n_frames"]):
                     if rep == 0 or p % 7 == 0:
                         assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], (os.path.basename(path), p)
