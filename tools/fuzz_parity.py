@@ -58,6 +58,26 @@ for c in range(cases):
         p_last, k_last = per[0][-1]
         if not np.array_equal(b.read_rgba(p_last), checkers.oracle_rgba(build.LIB_ORACLE, *want[0][k_last], ov["width"], ov["height"])):
             ok = False; why.append("rgba")
+    # the ORDERED reconstruct (one dependency-ordered launch: classes of streams in lockstep, FUZZ_ORDERED=<streams in lockstep>;
+    # with JSMPEG_HIP_RECON_CHAINS=1 in the environment: classes of GOP chains): the case's streams eight times over in one batch,
+    # every copy's pictures against the oracle
+    if os.environ.get("FUZZ_ORDERED"):
+        os.environ["JSMPEG_HIP_RECON_ORDER"] = os.environ["FUZZ_ORDERED"]
+        try:
+            b8 = jb.Batch(ov["width"], ov["height"], 8 * n_streams, 2 * 8 * n_streams * n + 4, 8 * (sum(len(s) for s in streams) + 64 * n_streams) + 4096)
+        finally:
+            del os.environ["JSMPEG_HIP_RECON_ORDER"]
+        with b8:
+            b8.upload(streams * 8)
+            b8.decode()
+            dev8 = b8.frame_hashes()
+            info8 = b8.recon_info()
+            seen8 = {}
+            for p, inf in enumerate(b8.pictures()):
+                k = seen8.get(inf.stream, 0)
+                seen8[inf.stream] = k + 1
+                if inf.decoded and int(dev8[p]) != hashing.frame_hash(*want[inf.stream % n_streams][k]):
+                    ok = False; why.append("ordered batch stream %d picture %d (%r)" % (inf.stream, k, info8)); break
     got, _, _ = cabi.decode_stream(build.LIB_HIP, streams[0], keep="planes")
     if len(got) != len(want_abi[0]) or any(not all(np.array_equal(a, bb) for a, bb in zip(x, y)) for x, y in zip(got, want_abi[0])):
         ok = False; why.append("decoder abi")
