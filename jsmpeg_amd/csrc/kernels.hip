@@ -761,7 +761,12 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* ordered launch: a tile with a macroblock its picture never wrote copies it from the `stale` frame -- complete? */
 	if (D.wait_stale != JM_NONE && __ballot(valid && !B.live) != 0) jm_recon_wait(b, D.wait_stale, lane);
 	if (valid) X = jm_recon_pixels(c, B, mine);
-	if (X.store && !later) jm_recon_store(c, B, X);
+	/* A row store is whole 128-byte lines only with ALL its lanes (half-masked it is partial sectors all the way down: measured,
+	 * profiles/r04_recon_notes.md).  A wavefront that holds a block whose transform has to wait for a later pass therefore keeps
+	 * ALL its rows until that block is through and stores them in one piece at the end (dense intra tiles: 320x240 intra -1 %,
+	 * 2160p high bitrate -0.8 % of the reconstruct). */
+	const bool wave_waits = __ballot(later) != 0;
+	if (X.store && !wave_waits) jm_recon_store(c, B, X);
 
 	/* further passes (workgroup-uniform, rare: more than JM_RECON_SLOTS blocks of the tile need the transform): the
 	 * blocks left over take the slots again, JM_RECON_PASS at a time; their lanes look at the record and the tokens
@@ -791,9 +796,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 			for (int i = 0; i < 16; i++) B2.P[i] = X.p[i];
 			B2.pred = B.pred;
 			X = jm_recon_pixels(c, B2, t);
-			if (X.store) jm_recon_store(c, B2, X);
 		}
 	}
+	if (wave_waits && X.store) jm_recon_store(c, B, X);
 	/* ORDERED launch: this tile's rows are in the L2 (every wavefront's stores acknowledged), then the picture's count
 	 * goes up -- one atomic per workgroup */
 	if (b.need != 0 && D.done_pic != JM_NONE) {
