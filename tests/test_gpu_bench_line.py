@@ -1,0 +1,44 @@
+"""bench.py's own line, on a small workload: the contract fields the driver reads, the roofline / cpu_baseline objects, the
+parity gate -- and the multi-rank path (GOP units, contiguous plan, links, RCCL calls, whole-stream gate) with the ranks
+present.  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "8", "--frames", "24", "--steps", "2", "--warmup", "1",
+                        "--no-audio", "--no-other-configs", "--no-h2d"] + list(args), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one JSON line: %r" % lines[:3]
+    return json.loads(lines[0])
+
+
+def test_one_rank_line():
+    d = run_bench("--no-cpu-baseline")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "frames/s" and d["higher_is_better"] is True and d["value"] > 0
+    assert "workload" in d["config"] and d["config"]["pictures_per_step"] == 8 * 24
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] in ("k_recon", "k_parse") and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
+    assert rf["reconstruct"]["status"] == 0 and set(rf["ceiling_frac"]) >= {"device_copy", "valu_skeleton"}
+    assert d["parity_gate"]["pool_overwritten_before_timed_region"] is True
+
+
+def test_multi_rank_path_with_the_ranks_present():
+    d = run_bench("--force-dist", "--no-cpu-baseline")
+    ex = d["exchange"]
+    assert ex["units"] == 8 * 2 and ex["pictures_differing_from_unsplit_streams"] == 0 and ex["cross_rank_units_needing_history"] == 0
+    assert ex["local_ingest"]["value"] > 0 and d["value"] > 0
+    assert "every unit of every stream" in d["parity_checked"]
