@@ -548,12 +548,15 @@ static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, i
 	                     : (jm_stale_is_seed(stale) && jm_stale_seed_slot(stale) < b->seed_frames.size() ? b->seed_frames[jm_stale_seed_slot(stale)] : nullptr);
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
 	D.done_pic = D.wait_fwd = D.wait_stale = JM_NONE; D.pad_ = 0;
-	/* measurements only (wrong pictures): every prediction read from the batch's FIRST frames -- a source that stays in
-	 * the caches -- to see what the reads' source is worth (profiles/r04_recon_notes.md) */
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
+	/* measurement builds only (-DJSMPEG_HIP_MEASUREMENT_HOOKS; WRONG pictures): every prediction read from / every plane store
+	 * into the batch's first n frames -- a source / destination that stays in the caches -- to see what the traffic's way to
+	 * DRAM is worth (profiles/r04_recon_notes.md) */
 	static const int fixed_fwd = getenv("JSMPEG_HIP_T_FIXEDFWD") ? atoi(getenv("JSMPEG_HIP_T_FIXEDFWD")) : 0;
 	if (fixed_fwd && D.fwd) D.fwd = b->d_pool + (uint64_t)(p % (uint32_t)fixed_fwd) * b->g.frame_bytes;
-	static const int fixed_dst = getenv("JSMPEG_HIP_T_FIXEDDST") ? atoi(getenv("JSMPEG_HIP_T_FIXEDDST")) : 0;   /* ... and every plane store into the first n frames */
+	static const int fixed_dst = getenv("JSMPEG_HIP_T_FIXEDDST") ? atoi(getenv("JSMPEG_HIP_T_FIXEDDST")) : 0;
 	if (fixed_dst) D.dst = b->d_pool + (uint64_t)(p % (uint32_t)fixed_dst) * b->g.frame_bytes;
+#endif
 }
 
 /* JSMPEG_HIP_TRACE=1: where the HOST's time goes in one decode call (stderr, ms since the call began) */
