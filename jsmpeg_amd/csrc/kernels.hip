@@ -657,10 +657,29 @@ static __device__ __forceinline__ void jm_recon_wait(const JmReconBufs &b, uint3
 	asm volatile("" ::: "memory");
 }
 
+#ifdef JM_T_PHASECLK
+/* TIMING BUILD (tools/variants.sh): where a tile's life goes.  Wavefront 0 of every workgroup reads the shader clock at
+ * the kernel's own synchronisation points (and, at the very end, behind an s_waitcnt vmcnt(0) the product does not have:
+ * the plane stores' acknowledgement); every 61st workgroup adds the differences up (all of them: a same-address atomic
+ * hot spot, ten times the kernel's time): jsmpeg_hip_debug_phase_clk() */
+__device__ unsigned long long jm_phase_clk[8];
+#define JM_STAMP(i) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x % 61 == 0) atomicAdd(&jm_phase_clk[i], (unsigned long long)(now_ - clk_)); clk_ = now_; } while (0)
+extern "C" int jsmpeg_hip_debug_phase_clk(unsigned long long *out) {
+	unsigned long long z[8] = { 0 };
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(jm_phase_clk), sizeof z) != hipSuccess) return -1;
+	return hipMemcpyToSymbol(HIP_SYMBOL(jm_phase_clk), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#else
+#define JM_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
+#ifdef JM_T_PHASECLK
+	uint64_t clk_ = __builtin_amdgcn_s_memtime();
+#endif
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
 	const uint32_t tile = q % (uint32_t)T.per_picture, k = (q / (uint32_t)T.per_picture) * 8 + xcd;
 	if (k >= b.n_level_pics) return;
@@ -720,7 +739,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	const uint32_t beforeB = __builtin_amdgcn_mbcnt_hi((uint32_t)(needB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needB, 0));
 	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(needA) | ((uint32_t)__popcll(needB) << 16);
 	if (threadIdx.x < 12) reinterpret_cast<uint4 *>(qm)[threadIdx.x] = tq;
+	JM_STAMP(0);      /* descriptor, record, the block's first look; token and prediction loads requested */
 	__syncthreads();
+	JM_STAMP(1);      /* ... waiting for the workgroup's other wavefronts */
 	uint32_t prior = 0, sum = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
@@ -740,7 +761,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	jm_recon_konst(c, B);
 	if (B.idct && !later) jm_recon_scatter(c, B, mine);
 	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
+	JM_STAMP(2);      /* tokens arrive, dequantise and scatter; prediction rows arrive, half-pel */
 	__syncthreads();
+	JM_STAMP(3);
 	/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the workgroup
 	 * 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past the last
 	 * packed block skip it altogether */
@@ -753,7 +776,9 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 			else jm_recon_idct_pair<false>(sl, (int)(lane >> 5));
 		}
 	}
+	JM_STAMP(4);      /* the transform */
 	__syncthreads();
+	JM_STAMP(5);
 	/* phase 3 */
 	JmPix X;
 	X.store = false;
@@ -799,6 +824,11 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 		}
 	}
 	if (wave_waits && X.store) jm_recon_store(c, B, X);
+	JM_STAMP(6);      /* add, clamp, the row stores issued */
+#ifdef JM_T_PHASECLK
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	JM_STAMP(7);      /* ... and acknowledged */
+#endif
 	/* ORDERED launch: this tile's rows are in the L2 (every wavefront's stores acknowledged), then the picture's count
 	 * goes up -- one atomic per workgroup */
 	if (b.need != 0 && D.done_pic != JM_NONE) {

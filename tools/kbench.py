@@ -23,6 +23,17 @@ if os.environ.get("JSMPEG_SYNTH_MV_JITTER"):       # coherent motion: one vector
 gen = bench.generate_streams(0, n_streams, frames)
 streams = [g[0] for g in gen]
 total = sum(len(s) for s in streams)
+def phase_clk():
+    """a JM_T_PHASECLK timing build (tools/variants.sh): the clocks wavefront 0 of every k_recon workgroup spent per phase since the last call"""
+    import ctypes
+    from jsmpeg_amd import build
+    lib = ctypes.CDLL(build.LIB_HIP)
+    if not hasattr(lib, "jsmpeg_hip_debug_phase_clk"):
+        return None
+    out = (ctypes.c_ulonglong * 8)()
+    return list(out) if lib.jsmpeg_hip_debug_phase_clk(out) == 0 else None
+
+
 def run(order):
     if order is not None:
         os.environ["JSMPEG_HIP_RECON_ORDER"] = order
@@ -30,11 +41,18 @@ def run(order):
         b.upload(streams)
         acc = None
         for r in range(reps):
+            if r == reps - 1:
+                phase_clk()      # (reset)
             b.decode()
             t = b.timings()
             if r >= warm:
                 acc = t if acc is None else {k: acc[k] + t[k] for k in t}
         lv = b.counters()["levels"]
+        pc = phase_clk()
+        if pc:
+            names = ("first look", "(barrier)", "scatter + predict", "(barrier)", "transform", "(barrier)", "pixels + stores issued", "stores acknowledged")
+            print("wavefront 0's clocks of the last pass by phase (JM_T_PHASECLK), share of the sum:",
+                  ", ".join("%s %.1f %%" % (n, 100.0 * v / max(1, sum(pc))) for n, v in zip(names, pc)), "| sum %.3e" % sum(pc))
         try:
             lt = b.level_timings()
             print("recon launches ms:", " ".join("%.3f" % x for x in lt))
