@@ -673,6 +673,9 @@ extern "C" int jsmpeg_hip_debug_phase_clk(unsigned long long *out) {
 #define JM_STAMP(i) do { } while (0)
 #endif
 
+#ifdef JM_T_WAVES_PER_EU   /* timing builds: more wavefronts per SIMD than the registers allow by themselves (with -DJM_RECON_SLOTS=184: six workgroups per CU) */
+__attribute__((amdgpu_waves_per_eu(JM_T_WAVES_PER_EU, JM_T_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
 	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
