@@ -759,6 +759,22 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		          (force_chains || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
 		if (!planned) chain_of.clear();
 	}
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
+	/* measurement builds only: JSMPEG_HIP_T_SHADOW_PARSE=n -- the slice parse a SECOND time (same input, same output: the
+	 * reconstruct reads what it rewrites with the same values), with n resident workgroups on a side stream, enqueued right
+	 * before the reconstruct: what a step would cost whose parse runs beside the reconstruct of the step before
+	 * (step - parse_ms = the pipelined step; profiles/r04_recon_notes.md) */
+	static const int shadow = getenv("JSMPEG_HIP_T_SHADOW_PARSE") ? atoi(getenv("JSMPEG_HIP_T_SHADOW_PARSE")) : 0;
+	static hipStream_t side = nullptr; static hipEvent_t side_ev[2];
+	if (shadow > 0) {
+		if (!side) { HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking)); HIP_TRY(hipEventCreate(&side_ev[0])); HIP_TRY(hipEventCreate(&side_ev[1])); }
+		HIP_TRY(hipEventRecord(side_ev[0], st));
+		HIP_TRY(hipStreamWaitEvent(side, side_ev[0], 0));
+		jm_parse_resident_once = (uint32_t)shadow;
+		HIP_TRY(jm_launch_parse(pb, side));
+		HIP_TRY(hipEventRecord(side_ev[1], side));
+	}
+#endif
 	if (planned) {
 		/* ---- 4. ONE launch: every class walks its streams in lockstep; a picture's tiles wait for its forward reference,
 		 * and a tile with a macroblock the picture never wrote for the frame that keeps showing there -- decided by the
@@ -790,6 +806,9 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		b->ordered = true; b->stats_pending = true; b->last_group = plan.lockstep;
 		tr.mark("ordered-enqueued");
 	} else if (recon_by_levels(b, rb, stale, n_roots, st, tr) < 0) return -1;
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
+	if (shadow > 0) HIP_TRY(hipStreamWaitEvent(st, side_ev[1], 0));
+#endif
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], st));
 	HIP_TRY(hipEventRecord(b->ev[4], st));
 	tr.mark("levels-enqueued");
