@@ -577,6 +577,12 @@ struct HostTrace {
  * parse has reported which pictures wrote every macroblock -- one launch per dependency level (step 4b).  The form
  * for batches that do not fill eight classes (recon_plan.h), the one-off fallback of an ordered launch that flagged
  * itself, and JSMPEG_HIP_RECON_ORDER=0. */
+/* no picture of the launch has a forward frame: the tile's form without prediction (k_recon_intra) */
+static uint32_t none_predicts(const JmReconDesc *d, size_t n) {
+	for (size_t i = 0; i < n; i++) if (d[i].fwd != nullptr) return 0;
+	return 1;
+}
+
 static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::vector<int32_t> &stale, uint32_t n_roots, hipStream_t st, HostTrace &tr) {
 	{
 		if ((size_t)b->n_decoded + n_roots > b->desc_cap) return fail("internal: descriptor table too small");
@@ -586,8 +592,10 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 	}
 	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
-		HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
+	rb.no_forward = none_predicts(b->h_desc, n_roots);      /* (a seeded stream's first P picture is a root WITH a forward frame) */
+	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 	HIP_TRY(jm_launch_recon(rb, st));
+	rb.no_forward = 0;
 
 	/* ---- 4b. the parse has told which pictures wrote every macroblock (the GPU is busy with step 4a meanwhile):
 	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
@@ -613,6 +621,7 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 			for (uint32_t l = 1; l < n_levels; l++) {
 				rb.desc = b->d_desc + n_roots + off[l];
 				rb.n_level_pics = off[l + 1] - off[l];
+				rb.no_forward = none_predicts(b->h_desc + n_roots + off[l], rb.n_level_pics);
 				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 				HIP_TRY(jm_launch_recon(rb, st));
 			}
@@ -733,7 +742,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	JmReconBufs rb;
 	rb.g = b->g; rb.luts = b->d_luts;
 	rb.epoch = b->epoch; rb.zero_uncovered = 1;
-	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = 0;
 	b->n_level_ev = 0;
 	b->ordered = false; b->stats_pending = false; b->last_group = 0; b->ordered_status = 0; b->ordered_waits = 0;
 	JmOrderedPlan plan;
@@ -823,7 +832,7 @@ static int batch_redo_by_levels(jsmpeg_hip_batch_t *b) {
 	std::vector<int32_t> stale;
 	const uint32_t n_roots = batch_plan_stale(b, stale);
 	JmReconBufs rb;
-	rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
+	rb.g = b->g; rb.luts = b->d_luts; rb.epoch = b->epoch; rb.zero_uncovered = 1; rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = 0;
 	HostTrace tr;
 	b->n_level_ev = 0; b->last_group = 0;
 	if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
@@ -1475,7 +1484,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
-	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = desc.fwd == nullptr;
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));

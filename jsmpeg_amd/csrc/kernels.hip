@@ -676,21 +676,18 @@ extern "C" int jsmpeg_hip_debug_phase_clk(unsigned long long *out) {
 #define JM_STAMP(i) do { } while (0)
 #endif
 
-#ifdef JM_T_WAVES_PER_EU   /* timing builds: more wavefronts per SIMD than the registers allow by themselves (with -DJM_RECON_SLOTS=184: six workgroups per CU) */
-__attribute__((amdgpu_waves_per_eu(JM_T_WAVES_PER_EU, JM_T_WAVES_PER_EU)))
-#endif
-__global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) {
-	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
-	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
-	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
+/* One tile.  PRED == false: the form for launches in which NO picture has a forward frame (k_recon_intra: the intra
+ * level of the per-level launches, all-intra batches, the one-picture interface's I pictures) -- no prediction addresses,
+ * no prediction loads, no half-pel pass, residuals clamped as they are: the same pixels (a zero prediction adds nothing)
+ * for ~100 VALU instructions and nine load instructions per wavefront fewer; 3-4 % of such a launch (r04_recon_notes.md 8).
+ * (Both forms in ONE kernel behind a scalar branch run out of scalar registers -- 106, spills into a vector register
+ * and from there into scratch memory -- and the predicted levels pay 4 % for it: measured, hence two kernels.) */
+template <bool PRED>
+static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const JmTiles &T, const JmReconDesc &D, const uint32_t tile, const uint32_t xcd,
+                                                     int16_t *coef, uint8_t *qm, uint32_t *wave_total) {
 #ifdef JM_T_PHASECLK
 	uint64_t clk_ = __builtin_amdgcn_s_memtime();
 #endif
-	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-	const uint32_t tile = q % (uint32_t)T.per_picture, k = (q / (uint32_t)T.per_picture) * 8 + xcd;
-	if (k >= b.n_level_pics) return;
-	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
-	if (D.dst == nullptr) return;                    /* ordered launch: a class with fewer pictures than the longest */
 	/* the wavefront's number as a scalar: what depends on (tile, wavefront) alone -- the tile's place in its plane, the
 	 * rows this wavefront takes -- is then scalar arithmetic, not 64 lanes' */
 	const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -705,7 +702,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	 * frames are padded so that no aligned load behind one frame's end reaches the next one's first line), so the L1
 	 * holds no line of it; producer and consumer are workgroups of one class = one XCD = one L2 (checked: status[8 +
 	 * class]), so the rows come out of the L2 the stores were acknowledged by. */
-	if (b.need != 0 && D.wait_fwd != JM_NONE) jm_recon_wait(b, D.wait_fwd, lane);
+	if (PRED && b.need != 0 && D.wait_fwd != JM_NONE) jm_recon_wait(b, D.wait_fwd, lane);
 	if (b.need != 0 && tile == 0 && threadIdx.x == 0) {
 		/* which XCD this class runs on (HW_REG_XCC_ID): one answer per class, or the launch is flagged */
 		uint32_t xcc;
@@ -723,7 +720,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* the descriptor's addresses are device memory: say so (JM_GLOBAL), or every access through them is a flat one */
 	c.mb = (JM_GLOBAL const JmMbRec *)D.mb;
 	c.tok = (JM_GLOBAL const uint16_t *)D.tok;
-	c.has_fwd = D.fwd != nullptr;
+	c.has_fwd = PRED && D.fwd != nullptr;
 	c.dst = (JM_GLOBAL uint8_t *)D.dst;
 	/* lanes without prediction read twelve bytes all the same (no branch around the loads): of the forward frame when
 	 * there is one, else of the stream's matrix table -- never of a frame that is not complete (ordered launches) */
@@ -736,7 +733,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	/* phase 1: every lane looks at its own block (nothing here reads LDS: the set-up barrier comes after the loads;
 	 * no branch around them, see recon_block.h -- lanes without a block look at a neighbour's and are masked after) */
 	JmBlk B;
-	jm_recon_front(c, Q, B);
+	jm_recon_front<PRED>(c, Q, B);
 	if (!valid) { B.idct = false; B.lowf = false; B.k00 = false; B.live = false; B.pred = false; B.cnt = 0; B.konst = 0; }
 	/* the blocks that need the transform, packed into the workgroup's slots: first the ones whose coefficients all
 	 * lie in the top-left 4x4 (wavefronts that hold only those run the cheap transform), then the rest */
@@ -766,7 +763,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	LdsSlot mine = { coef + (later ? 0u : rank) * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
 	if (B.idct && !later) jm_recon_scatter(c, B, mine);
-	if (valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
+	if (PRED && valid) jm_recon_predict(B);      /* the raw rows were requested in phase 1: their latency is behind us */
 	JM_STAMP(2);      /* tokens arrive, dequantise and scatter; prediction rows arrive, half-pel */
 	__syncthreads();
 	JM_STAMP(3);
@@ -791,7 +788,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	if (later) B.idct = false;           /* for now the prediction alone (an idct block's konst is 0) */
 	/* ordered launch: a tile with a macroblock its picture never wrote copies it from the `stale` frame -- complete? */
 	if (D.wait_stale != JM_NONE && __ballot(valid && !B.live) != 0) jm_recon_wait(b, D.wait_stale, lane);
-	if (valid) X = jm_recon_pixels(c, B, mine);
+	if (valid) X = jm_recon_pixels<PRED>(c, B, mine);
 	/* A row store is whole 128-byte lines only with ALL its lanes (half-masked it is partial sectors all the way down: measured,
 	 * profiles/r04_recon_notes.md).  A wavefront that holds a block whose transform has to wait for a later pass therefore keeps
 	 * ALL its rows until that block is through and stores them in one piece at the end (dense intra tiles: 320x240 intra -1 %,
@@ -826,7 +823,7 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 #pragma unroll
 			for (int i = 0; i < 16; i++) B2.P[i] = X.p[i];
 			B2.pred = B.pred;
-			X = jm_recon_pixels(c, B2, t);
+			X = jm_recon_pixels<PRED>(c, B2, t);
 		}
 	}
 	if (wave_waits && X.store) jm_recon_store(c, B, X);
@@ -844,6 +841,28 @@ __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T)
 	}
 }
 
+/* five workgroups per CU (the LDS allows exactly that: see JM_RECON_SLOTS) = five wavefronts per SIMD = 96 registers.
+ * JM_T_WAVES_PER_EU: timing builds (with -DJM_RECON_SLOTS=184: six workgroups per CU) */
+#ifdef JM_T_WAVES_PER_EU
+#define JM_RECON_ATTR __attribute__((amdgpu_waves_per_eu(JM_T_WAVES_PER_EU, JM_T_WAVES_PER_EU)))
+#else
+#define JM_RECON_ATTR
+#endif
+template <bool PRED>
+static __device__ __forceinline__ void jm_recon_body(const JmReconBufs &b, const JmTiles &T) {
+	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
+	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
+	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
+	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+	const uint32_t tile = q % (uint32_t)T.per_picture, k = (q / (uint32_t)T.per_picture) * 8 + xcd;
+	if (k >= b.n_level_pics) return;
+	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
+	if (D.dst == nullptr) return;                    /* ordered launch: a class with fewer pictures than the longest */
+	jm_recon_tile<PRED>(b, T, D, tile, xcd, coef, qm, wave_total);
+}
+JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) { jm_recon_body<true>(b, T); }
+JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon_intra(JmReconBufs b, JmTiles T) { jm_recon_body<false>(b, T); }
+
 uint32_t jm_recon_tiles_per_picture(const JmGeom &g) {
 	JmTiles T;
 	jm_tiles_init(T, g);
@@ -860,7 +879,8 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	if (a.patience == 0) a.patience = JM_RECON_PATIENCE;
 	/* JSMPEG_HIP_RECON_LDSPAD (measurements): bytes of unused dynamic LDS per workgroup -- fewer workgroups per CU */
 	static const uint32_t pad = getenv("JSMPEG_HIP_RECON_LDSPAD") ? (uint32_t)atoi(getenv("JSMPEG_HIP_RECON_LDSPAD")) : 0u;
-	hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
+	if (b.no_forward) hipLaunchKernelGGL(k_recon_intra, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
+	else hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
 	return hipGetLastError();
 }
 

@@ -584,11 +584,13 @@ JM_HD void jm_recon_predict(JmBlk &B) {
  * macroblock this picture never wrote, outside batch mode: the plane keeps its old content). */
 struct JmPix { uint32_t p[16]; bool store; };
 
-template <class Slot>
+/* PRED == false: a picture WITHOUT a forward reference (intra pictures; the tile's form is picked once per workgroup, from
+ * the descriptor): nothing is predicted, B.P is not looked at, the residual is clamped as it is (mpeg1.c:1646-1668). */
+template <bool PRED = true, class Slot>
 JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 	JmPix X;
 #pragma unroll
-	for (int i = 0; i < 16; i++) X.p[i] = B.P[i];          /* zero unless predicted (jm_recon_predict), and only live blocks are */
+	for (int i = 0; i < 16; i++) X.p[i] = PRED ? B.P[i] : 0u;   /* zero unless predicted (jm_recon_predict), and only live blocks are */
 	X.store = B.live || c.zero_uncovered != 0;
 	if (!B.live && c.zero_uncovered && c.stale) {
 		/* a macroblock this picture never wrote: the reference's plane set still holds the picture before last there */
@@ -611,10 +613,12 @@ JM_HD JmPix jm_recon_pixels(const JmReconCtx &c, const JmBlk &B, Slot &s) {
 			if (B.idct) s.get8p(r, pk);
 #pragma unroll
 			for (int h = 0; h < 2; h++) {
-				const uint32_t p = X.p[2 * r + h];
-				const uint32_t lo = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c010c00u), pk[2 * h]));
-				const uint32_t hi = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c030c02u), pk[2 * h + 1]));
-				X.p[2 * r + h] = lo | (hi << 16);
+				if (PRED) {
+					const uint32_t p = X.p[2 * r + h];
+					const uint32_t lo = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c010c00u), pk[2 * h]));
+					const uint32_t hi = jm_sat_pk_u8(jm_pk_add_sat(jm_perm(0, p, 0x0c030c02u), pk[2 * h + 1]));
+					X.p[2 * r + h] = lo | (hi << 16);
+				} else X.p[2 * r + h] = jm_sat_pk_u8(pk[2 * h]) | (jm_sat_pk_u8(pk[2 * h + 1]) << 16);
 			}
 		}
 	}
@@ -636,9 +640,9 @@ JM_HD void jm_recon_store(const JmReconCtx &c, const JmBlk &B, const JmPix &X) {
 }
 
 /* PHASE 3 as one call (the simulator; the kernel pairs lanes for wider stores where it can) */
-template <class Slot>
+template <bool PRED = true, class Slot>
 JM_HD void jm_recon_back(const JmReconCtx &c, const JmBlk &B, Slot &s) {
-	const JmPix X = jm_recon_pixels(c, B, s);
+	const JmPix X = jm_recon_pixels<PRED>(c, B, s);
 	if (X.store) jm_recon_store(c, B, X);
 }
 

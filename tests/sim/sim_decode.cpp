@@ -216,7 +216,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 					valid[l] = jm_recon_where_tile(c.g, T, tile, l >> 6, l & 63, Q);
 					if (valid[l]) {
 						Q.rw = *reinterpret_cast<const uint4_like_t *>(c.mb + Q.mbaddr);
-						jm_recon_front(c, Q, B[l]);
+						if (c.has_fwd) jm_recon_front<true>(c, Q, B[l]); else jm_recon_front<false>(c, Q, B[l]);   // the kernel's two forms of a tile (k_recon)
 						jm_recon_konst(c, B[l]);
 						g_blocks_seen++;
 					}
@@ -226,14 +226,14 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 				const int total = totalA + totalB;
 				g_idct[0] += (uint64_t)totalA; g_idct[1] += (uint64_t)totalB; g_idct[2] += (uint64_t)(totalA / 64); g_idct[3] += (uint64_t)((total + 63) / 64);
 				for (int l = 0; l < 256; l++) if (B[l].idct) jm_recon_scatter(c, B[l], slots[rank[l]]);
-				for (int l = 0; l < 256; l++) if (valid[l]) jm_recon_predict(B[l]);
+				for (int l = 0; l < 256; l++) if (valid[l] && c.has_fwd) jm_recon_predict(B[l]);
 				// the pair transform: lane j and lane j + 32 of a wavefront share a slot; a wavefront's 32 slots run the
 				// cheap transform when all of them are low-frequency blocks (same rule as the kernel)
 				for (int l = 0; l < total; l++) {
 					const bool low = (l / 32) * 32 + 32 <= totalA;
 					if (low) sim_idct_pair<true>(slots[l]); else sim_idct_pair<false>(slots[l]);
 				}
-				for (int l = 0; l < 256; l++) if (valid[l]) jm_recon_back(c, B[l], slots[rank[l]]);
+				for (int l = 0; l < 256; l++) if (valid[l]) { if (c.has_fwd) jm_recon_back<true>(c, B[l], slots[rank[l]]); else jm_recon_back<false>(c, B[l], slots[rank[l]]); }
 			}
 			if (g_blocks_seen != (uint64_t)6 * g.mb_size) return -3;   // the tiles cover every block of the picture exactly once
 			g_blocks_seen = 0;
