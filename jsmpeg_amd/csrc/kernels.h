@@ -99,7 +99,9 @@ struct JmParseBufs {
 	uint32_t *dbg;               /* diagnostics only: 4 words per start-code entry, or null */
 };
 hipError_t jm_launch_parse(const JmParseBufs &b, hipStream_t st);
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
 extern uint32_t jm_parse_resident_once;
+#endif
 
 /* One picture of a reconstruct launch: everything a workgroup needs to start, as device addresses, in two scalar
  * loads (no pointer arithmetic on picture / stream numbers in the kernel, and fewer scalar registers held). */

@@ -489,7 +489,9 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	}
 }
 
-uint32_t jm_parse_resident_once = 0;   /* measurement builds (engine.hip, JSMPEG_HIP_T_SHADOW_PARSE): the next launch's resident workgroups */
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
+uint32_t jm_parse_resident_once = 0;   /* measurement builds (engine.hip, JSMPEG_HIP_T_SHADOW_PARSE): the next launch's resident workgroups; not thread-safe, not in the product */
+#endif
 hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	JmParseBufs b = b_in;
 	if (!b.slice_sc) b.n_lanes = b.n_sc;
@@ -565,8 +567,12 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	uint32_t groups = (b.n_batches + JM_PARSE_WAVES - 1) / JM_PARSE_WAVES;
 	static const uint32_t resident = getenv("JSMPEG_HIP_PARSE_RESIDENT") ? (uint32_t)atoi(getenv("JSMPEG_HIP_PARSE_RESIDENT"))
 	                                                                      : JM_PARSE_RESIDENT_WGS;   /* tests: the ticket path on small inputs */
+#ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
 	const uint32_t resident_now = jm_parse_resident_once ? jm_parse_resident_once : resident;
 	jm_parse_resident_once = 0;
+#else
+	const uint32_t resident_now = resident;
+#endif
 	if (groups > resident_now && resident_now >= 1 && b.ticket) {
 		groups = resident_now;
 		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
