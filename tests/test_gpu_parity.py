@@ -119,6 +119,18 @@ def test_randomised_sweep(hip_lib, libs):
     assert "16 cases, 0 mismatches" in out.stdout
 
 
+def test_randomised_call_patterns_of_the_one_picture_interface(hip_lib, libs):
+    """tools/fuzz_abi_chunks.py, a short run: random chunking, EVICT stores that evict, EXPAND stores that grow, partial pulls
+    that leave pictures decoded ahead queued across writes and evictions, seeks -- the identical call sequence on the product
+    and on the oracle: every decode()'s return value, cursor and planes."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_abi_chunks.py"), "120", "5"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "120 cases, 0 mismatches" in out.stdout
+    assert int(out.stdout.rsplit(";", 1)[1].split()[0]) > 200      # ... and the decode-ahead was part of it
+
+
 def test_cfg4_2160p_batch_at_scale(hip_lib, libs):
     """SURVEY.md 8d cfg4 (3840x2160, high bitrate): 6 streams x 13 pictures in one batch, every frame hash against the
     oracle (decoded on host threads)."""
