@@ -95,6 +95,18 @@ def test_reference_under_node_matches_golden(impl, libs):
     assert out["sizes"] == [[fx["info"]["width"], fx["info"]["height"]]]
 
 
+def test_oracle_equals_the_references_c_build_on_random_call_patterns(libs):
+    """tools/fuzz_abi_chunks.py with the reference's own C build (oracle/_ref) in the product's place: random chunking, EVICT
+    stores that evict, EXPAND stores that grow, partial pulls, seeks -- every decode()'s return value, cursor and planes of the
+    restatement against the reference's (buffer.c + mpeg1.c)."""
+    import sys
+    if not os.path.exists(libs.get("ref") or ""):
+        pytest.skip("oracle/_ref/libjsmpeg_ref.so not built")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_abi_chunks.py"), "150", "8"], capture_output=True, text=True,
+                         env=dict(os.environ, FUZZ_LIB=libs["ref"]))
+    assert out.returncode == 0 and "150 cases, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not have_reference(), reason="container only: pins the test-side encoder to the streams it committed")
 def test_encoder_script_reproduces_the_committed_streams():

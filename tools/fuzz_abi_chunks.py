@@ -16,9 +16,9 @@ sys.path.insert(0, ROOT)
 from jsmpeg_amd import build, cabi, synth  # noqa: E402
 
 # FUZZ_LIB: another library with the same 15 functions in the product's place (the reference's own C build, oracle/_ref: is the
-# call pattern inside the contract? -- run on the CPU: 300 cases, 299 agree; the one that does not is the native build showing
-# malloc's leftovers in macroblocks no picture has written yet, where the JS / wasm builds -- and the oracle, checked against
-# both under Node -- show the zeros of a fresh typed array / linear memory)
+# call pattern inside the contract, and does the oracle's store behave like the reference's? -- run on the CPU,
+# tests/test_oracle_pin.py: 2300 cases, all agree.  The native build shows malloc's leftovers in macroblocks no picture has
+# written yet where the JS / wasm builds show the zeros of a fresh typed array / linear memory: oracle/ref_zeroed_malloc.c)
 TESTED = os.environ.get("FUZZ_LIB") or build.LIB_HIP
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
