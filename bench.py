@@ -168,6 +168,54 @@ OTHER_CONFIGS = (
 )
 
 
+def two_batches_in_flight(b, make_batch, give_streams, n_pictures, want, passes=6):
+    """Two batch objects, two HIP streams, two host threads, `passes` decode + sync each (after one warm-up pass each):
+    frames/s of both together, and every picture of BOTH frame pools against the oracle's hashes (`want`, per stream)."""
+    import ctypes
+    import threading
+    import torch
+    b2 = make_batch()
+    try:
+        bs, keep, ptrs = [b, b2], [torch.cuda.Stream(), torch.cuda.Stream()], []
+        for bb, st in zip(bs, keep):
+            ptrs.append(ctypes.c_void_p(st.cuda_stream))
+            give_streams(bb, ptrs[-1])
+            if bb.decode(stream=ptrs[-1]) != n_pictures:
+                raise RuntimeError("decoded a different number of pictures")
+        err = []
+
+        def loop(i):
+            try:
+                for _ in range(passes):
+                    bs[i].decode(stream=ptrs[i])
+            except Exception as e:   # noqa: BLE001 (reported below)
+                err.append(repr(e))
+        th = [threading.Thread(target=loop, args=(i,)) for i in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (2 * passes)
+        if err:
+            raise RuntimeError(err[0])
+        if want is not None:
+            for bb in bs:
+                per, dev = {}, bb.frame_hashes()
+                for p, i in enumerate(bb.pictures()):
+                    per.setdefault(i.stream, []).append(int(dev[p]))
+                for s_, w in enumerate(want):
+                    if per.get(s_, []) != w:
+                        raise RuntimeError("PARITY FAILURE against the oracle on stream %d" % s_)
+        return {"value": round(n_pictures / dt, 1), "unit": "frames/s", "ms_per_pass": round(dt * 1e3, 3), "passes": 2 * passes,
+                "parity": "every picture of both frame pools: device hash == oracle" if want is not None else "not checked (JSMPEG_BENCH_PARITY_STREAMS)",
+                "note": "two batch objects with the same streams, each decoded pass after pass on its own HIP stream by its own host thread: one batch's "
+                        "start-code index, host turn-around and slice parse beside the other's reconstruct (profiles/r04_recon_notes.md: the two kernels "
+                        "want the same things of a CU, 3-4 %); a reported extra, never `value`"}
+    finally:
+        b2.close()
+
+
 def other_configs(device, passes=5):
     """The other BASELINE.json configurations as witnessed timings (never `value`): each one generated, decoded through the
     batch interface (`passes` timed passes after two warm-up passes, host clock around decode + sync, median), and
@@ -244,6 +292,7 @@ def main():
                     help="testing: run the multi-rank code path (GOP units, RCCL scatter / all-gather) with the ranks present, even one")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra run that starts every step from host memory (value_incl_h2d)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the witnessed timings of the other BASELINE.json configurations (other_configs)")
+    ap.add_argument("--two-batches", action="store_true", help="report two_batches_in_flight even with --no-other-configs (it is part of the default line)")
     args = ap.parse_args()
     args.h2d = False
 
@@ -899,6 +948,18 @@ def main():
         line["exchange"] = exchange
     # rank 0, after the timed runs, at every N: the baseline is per host core and does not scale with the GPUs
     line["cpu_baseline"] = cpu_baseline(streams[:2], width, height) if not args.no_cpu_baseline else None
+    # a reported extra (never `value`): TWO batches in flight -- a second batch object with the same streams, each batch
+    # decoded pass after pass on its own HIP stream by its own host thread, so that one batch's start-code index, host
+    # turn-around and slice parse run beside the other's reconstruct; both batches gated against the oracle like the headline
+    if world == 1 and not multi and (args.two_batches or not args.no_other_configs):
+        try:
+            line["two_batches_in_flight"] = two_batches_in_flight(
+                b, lambda: jb.Batch(width, height, n_streams, n_pictures + 8, len(packed) + 4096, device=local_rank),
+                lambda bb, sp: bb.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sp),
+                n_pictures, [oracle_hashes(("stream", s_), streams[s_]) for s_ in range(n_streams)] if len(check) == n_streams else None)
+        except Exception as e:
+            log("two batches in flight failed: %r" % (e,))
+            line["two_batches_in_flight"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_other_configs:
         try:
             b.close()                       # the headline batch's 24 GB frame pool, before the other shapes take theirs
