@@ -25,7 +25,7 @@ def run_bench(*args):
 def test_one_rank_line():
     d = run_bench("--no-cpu-baseline", "--two-batches")
     two = d["two_batches_in_flight"]      # a reported extra: both batches' frame pools gated against the oracle
-    assert two["value"] > 0 and two["passes"] == 12 and two["parity"].startswith("every picture of both frame pools"), two
+    assert two["value"] > 0 and two["passes"] == 24 and two["parity"].startswith("every picture of both frame pools"), two
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
         assert key in d, key

@@ -19,7 +19,8 @@ gen = bench.generate_streams(0, 64, 120)
 streams = [g[0] for g in gen]
 total = sum(len(s) for s in streams)
 bs, sts = [], []
-for k in range(2):
+N_BATCHES = int(os.environ.get("JSMPEG_PROBE_BATCHES", "2"))     # batches in flight (each its own HIP stream and host thread)
+for k in range(N_BATCHES):
     b = jb.Batch(cfg["width"], cfg["height"], 64, 64 * 120 + 8, total + 64 * 64 + 4096)
     b.upload(streams)
     b.decode()
@@ -42,9 +43,9 @@ def loop(i, delay):
 
 
 for delay in (0.0, 0.004, 0.007, 0.010):
-    th = [threading.Thread(target=loop, args=(0, 0.0)), threading.Thread(target=loop, args=(1, delay))]
+    th = [threading.Thread(target=loop, args=(i, delay * i)) for i in range(N_BATCHES)]
     t0 = time.perf_counter()
     [t.start() for t in th]
     [t.join() for t in th]
-    par = (time.perf_counter() - t0) / (2 * reps)
-    print("two batches on two streams, second started %.0f ms late: %.2f ms per pass" % (delay * 1e3, par * 1e3))
+    par = (time.perf_counter() - t0) / (N_BATCHES * reps)
+    print("%d batches on %d streams, each started %.0f ms after the one before: %.2f ms per pass" % (N_BATCHES, N_BATCHES, delay * 1e3, par * 1e3))
