@@ -577,10 +577,29 @@ struct HostTrace {
  * parse has reported which pictures wrote every macroblock -- one launch per dependency level (step 4b).  The form
  * for batches that do not fill eight classes (recon_plan.h), the one-off fallback of an ordered launch that flagged
  * itself, and JSMPEG_HIP_RECON_ORDER=0. */
-/* no picture of the launch has a forward frame: the tile's form without prediction (k_recon_intra) */
-static uint32_t none_predicts(const JmReconDesc *d, size_t n) {
+/* no picture of the launch has a forward frame: the tile's form without prediction (k_recon_intra) -- and, when those pictures are
+ * DENSE (bytes of compressed data per macroblock: practically every block then has AC coefficients and a tile needs a transform
+ * slot per lane), the variant with 256 slots (2; measured: cfg0, 21 bytes per macroblock, -6 %; cfg2's intra pictures, 12.7, +11 %:
+ * profiles/r04_recon_notes.md 8).  `bytes_per_mb_x16`: of the launch's pictures, in sixteenths. */
+#define JM_DENSE_INTRA_X16 310      /* 19.4 bytes per macroblock: all-intra 1080p at 18.0 is 5 % faster with 220 slots, at 20.7 5 % faster with 256 */
+static uint32_t none_predicts(const JmReconDesc *d, size_t n, uint32_t bytes_per_mb_x16) {
 	for (size_t i = 0; i < n; i++) if (d[i].fwd != nullptr) return 0;
-	return 1;
+	static const int forced = getenv("JSMPEG_HIP_RECON_DENSE") ? atoi(getenv("JSMPEG_HIP_RECON_DENSE")) : -1;   /* measurements: 0 / 1 */
+	if (forced >= 0) return forced ? 2u : 1u;
+	return bytes_per_mb_x16 >= JM_DENSE_INTRA_X16 ? 2u : 1u;
+}
+
+/* compressed bytes per macroblock (x 16) of the batch's decoded pictures without a forward reference */
+static uint32_t batch_root_density(const jsmpeg_hip_batch_t *b) {
+	uint64_t bytes = 0, n = 0;
+	for (uint32_t p = 0; p < b->n_pics; p++) {
+		const JmPic &pic = b->h_pics[p];
+		if (!pic.decoded || pic.fwd >= 0 || pic.stream >= b->n_streams) continue;
+		const uint32_t end = p + 1 < b->n_pics && b->h_pics[p + 1].stream == pic.stream ? b->h_pics[p + 1].pos : b->h_streams[pic.stream].es_end;
+		bytes += end > pic.pos ? end - pic.pos : 0;
+		n++;
+	}
+	return n ? (uint32_t)std::min<uint64_t>(bytes * 16 / (n * (uint64_t)std::max(1, b->g.mb_size)), 0xffffffffu) : 0u;
 }
 
 static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::vector<int32_t> &stale, uint32_t n_roots, hipStream_t st, HostTrace &tr) {
@@ -592,7 +611,7 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 	}
 	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
-	rb.no_forward = none_predicts(b->h_desc, n_roots);      /* (a seeded stream's first P picture is a root WITH a forward frame) */
+	rb.no_forward = none_predicts(b->h_desc, n_roots, batch_root_density(b));      /* (a seeded stream's first P picture is a root WITH a forward frame) */
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 	HIP_TRY(jm_launch_recon(rb, st));
 	rb.no_forward = 0;
@@ -621,7 +640,7 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 			for (uint32_t l = 1; l < n_levels; l++) {
 				rb.desc = b->d_desc + n_roots + off[l];
 				rb.n_level_pics = off[l + 1] - off[l];
-				rb.no_forward = none_predicts(b->h_desc + n_roots + off[l], rb.n_level_pics);
+				rb.no_forward = none_predicts(b->h_desc + n_roots + off[l], rb.n_level_pics, 0);
 				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 				HIP_TRY(jm_launch_recon(rb, st));
 			}
@@ -1484,7 +1503,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
-	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = desc.fwd == nullptr;
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = desc.fwd == nullptr ? 2u : 0u;   /* (one picture: fewer workgroups than CUs -- the slot per lane costs no occupancy) */
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));

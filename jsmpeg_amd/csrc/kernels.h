@@ -139,7 +139,8 @@ struct JmReconBufs {
 	uint32_t patience;           /* polls (~1 us each) before a wait is given up and the launch flags itself; 0: JM_RECON_PATIENCE */
 	uint32_t *status;            /* ordered launches: [0] error flags (1: a wait ran out of patience, 2: a class met two XCDs),
 	                                [1] polls that found their picture unfinished, [8 + c] XCC id class c ran on (preset 0xffffffff) */
-	uint32_t no_forward;         /* host side: NO picture of this launch has a forward frame -> k_recon_intra (the tile's form without prediction) */
+	uint32_t no_forward;         /* host side: NO picture of this launch has a forward frame -> 1: k_recon_intra (the tile's form without prediction),
+	                                2: k_recon_intra_dense (... with a transform slot per lane: pictures of many bytes per macroblock) */
 };
 #define JM_RECON_STATUS_WORDS 16
 #define JM_DONE_STRIDE 32     /* words between two pictures' tile counts: k_recon's first look at one goes through the L1 */

@@ -616,6 +616,10 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 #endif
 #define JM_RECON_PASS (JM_RECON_SLOTS < JM_RECON_WG / 2 ? JM_RECON_SLOTS : JM_RECON_WG / 2)
 static_assert(JM_RECON_SLOTS >= 32 && JM_RECON_SLOTS <= JM_RECON_WG, "a wavefront round takes 32 slots");
+/* k_recon_intra_dense: a slot per lane (36.9 KB: four workgroups per CU, 114 registers), no later passes -- for intra pictures whose
+ * tiles hold more than JM_RECON_SLOTS blocks with AC coefficients as a rule (high bitrate: cfg0's 21 bytes per macroblock -6 %; cfg2's
+ * intra pictures, 12.7 bytes per macroblock, are 11 % SLOWER with it: the fifth workgroup per CU is worth more than the rare later pass) */
+#define JM_RECON_DENSE_SLOTS JM_RECON_WG
 
 struct LdsSlot {
 	int16_t *base;
@@ -688,9 +692,10 @@ extern "C" int jsmpeg_hip_debug_phase_clk(unsigned long long *out) {
  * for ~100 VALU instructions and nine load instructions per wavefront fewer; 3-4 % of such a launch (r04_recon_notes.md 8).
  * (Both forms in ONE kernel behind a scalar branch run out of scalar registers -- 106, spills into a vector register
  * and from there into scratch memory -- and the predicted levels pay 4 % for it: measured, hence two kernels.) */
-template <bool PRED>
+template <bool PRED, uint32_t SLOTS>
 static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const JmTiles &T, const JmReconDesc &D, const uint32_t tile, const uint32_t xcd,
                                                      int16_t *coef, uint8_t *qm, uint32_t *wave_total) {
+	constexpr uint32_t PASS = SLOTS < JM_RECON_WG / 2 ? SLOTS : JM_RECON_WG / 2;     /* blocks a later pass takes */
 #ifdef JM_T_PHASECLK
 	uint64_t clk_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -720,7 +725,7 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	uint4 tq = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < 8) tq = ((JM_GLOBAL const uint4 *)D.qm)[threadIdx.x];
 	else if (threadIdx.x < 12) tq = reinterpret_cast<const uint4 *>(b.luts->zigzag)[threadIdx.x - 8];
-	if (threadIdx.x < JM_RECON_SLOTS) { LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES }; own.zero(); }
+	if (threadIdx.x < SLOTS) { LdsSlot own = { coef + threadIdx.x * JM_SLOT_HALVES }; own.zero(); }
 	JmReconCtx c;
 	c.g = b.g;
 	/* the descriptor's addresses are device memory: say so (JM_GLOBAL), or every access through them is a flat one */
@@ -761,11 +766,11 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	uint32_t firstB = totalA;
 	{
 		const uint32_t up = (totalA + 31u) & ~31u;
-		if ((totalB + 31u) / 32u < (totalA + totalB + 31u) / 32u - totalA / 32u && up + totalB <= JM_RECON_SLOTS) firstB = up;
+		if ((totalB + 31u) / 32u < (totalA + totalB + 31u) / 32u - totalA / 32u && up + totalB <= SLOTS) firstB = up;
 	}
 	const uint32_t total = firstB + totalB;
 	const uint32_t rank = B.lowf ? (prior & 0xffffu) + beforeA : firstB + (prior >> 16) + beforeB;
-	const bool later = B.idct && rank >= JM_RECON_SLOTS;      /* no slot in the first pass: see the end of the kernel */
+	const bool later = B.idct && rank >= SLOTS;      /* no slot in the first pass: see the end of the kernel */
 	LdsSlot mine = { coef + (later ? 0u : rank) * JM_SLOT_HALVES };
 	jm_recon_konst(c, B);
 	if (B.idct && !later) jm_recon_scatter(c, B, mine);
@@ -776,7 +781,7 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the workgroup
 	 * 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past the last
 	 * packed block skip it altogether */
-	const uint32_t held = total < JM_RECON_SLOTS ? total : JM_RECON_SLOTS;
+	const uint32_t held = total < SLOTS ? total : SLOTS;
 	for (uint32_t r0 = 0; r0 < held; r0 += JM_RECON_WG / 2) {
 		const uint32_t s0 = r0 + wave * 32;
 		if (s0 + (lane & 31) < held) {                                                  /* both lanes of a pair, or neither */
@@ -802,12 +807,12 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	const bool wave_waits = __ballot(later) != 0;
 	if (X.store && !wave_waits) jm_recon_store(c, B, X);
 
-	/* further passes (workgroup-uniform, rare: more than JM_RECON_SLOTS blocks of the tile need the transform): the
-	 * blocks left over take the slots again, JM_RECON_PASS at a time; their lanes look at the record and the tokens
+	/* further passes (workgroup-uniform, rare: more than SLOTS blocks of the tile need the transform): the
+	 * blocks left over take the slots again, PASS at a time; their lanes look at the record and the tokens
 	 * a second time (nothing of the first look is kept alive for this but the predicted pixels) */
-	for (uint32_t base = JM_RECON_SLOTS; base < total; base += JM_RECON_PASS) {
+	for (uint32_t base = SLOTS; base < total; base += PASS) {
 		__syncthreads();                                   /* everybody has read their residuals */
-		const bool now = later && rank >= base && rank < base + JM_RECON_PASS;
+		const bool now = later && rank >= base && rank < base + PASS;
 		LdsSlot t = { coef + (now ? rank - base : 0u) * JM_SLOT_HALVES };
 		JmBlk B2;
 		if (now) {
@@ -819,7 +824,7 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 			jm_recon_scatter(c, B2, t);
 		}
 		__syncthreads();
-		const uint32_t n = total - base < JM_RECON_PASS ? total - base : JM_RECON_PASS, s0 = wave * 32;
+		const uint32_t n = total - base < PASS ? total - base : PASS, s0 = wave * 32;
 		if (s0 + (lane & 31) < n) {
 			LdsSlot sl = { coef + (s0 + (lane & 31)) * JM_SLOT_HALVES };
 			jm_recon_idct_pair<false>(sl, (int)(lane >> 5));
@@ -854,9 +859,9 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 #else
 #define JM_RECON_ATTR
 #endif
-template <bool PRED>
+template <bool PRED, uint32_t SLOTS>
 static __device__ __forceinline__ void jm_recon_body(const JmReconBufs &b, const JmTiles &T) {
-	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * JM_RECON_SLOTS];
+	__shared__ __attribute__((aligned(16))) int16_t coef[JM_SLOT_HALVES * SLOTS];
 	__shared__ __attribute__((aligned(16))) uint8_t qm[192];   /* intra matrix, non-intra matrix, zig-zag order */
 	__shared__ uint32_t wave_total[JM_RECON_WG / 64];
 	const uint32_t xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -864,10 +869,11 @@ static __device__ __forceinline__ void jm_recon_body(const JmReconBufs &b, const
 	if (k >= b.n_level_pics) return;
 	const JmReconDesc D = b.desc[k];                 /* uniform: scalar loads */
 	if (D.dst == nullptr) return;                    /* ordered launch: a class with fewer pictures than the longest */
-	jm_recon_tile<PRED>(b, T, D, tile, xcd, coef, qm, wave_total);
+	jm_recon_tile<PRED, SLOTS>(b, T, D, tile, xcd, coef, qm, wave_total);
 }
-JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) { jm_recon_body<true>(b, T); }
-JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon_intra(JmReconBufs b, JmTiles T) { jm_recon_body<false>(b, T); }
+JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon(JmReconBufs b, JmTiles T) { jm_recon_body<true, JM_RECON_SLOTS>(b, T); }
+JM_RECON_ATTR __global__ __launch_bounds__(JM_RECON_WG) void k_recon_intra(JmReconBufs b, JmTiles T) { jm_recon_body<false, JM_RECON_SLOTS>(b, T); }
+__global__ __launch_bounds__(JM_RECON_WG) void k_recon_intra_dense(JmReconBufs b, JmTiles T) { jm_recon_body<false, JM_RECON_DENSE_SLOTS>(b, T); }
 
 uint32_t jm_recon_tiles_per_picture(const JmGeom &g) {
 	JmTiles T;
@@ -885,7 +891,8 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
 	if (a.patience == 0) a.patience = JM_RECON_PATIENCE;
 	/* JSMPEG_HIP_RECON_LDSPAD (measurements): bytes of unused dynamic LDS per workgroup -- fewer workgroups per CU */
 	static const uint32_t pad = getenv("JSMPEG_HIP_RECON_LDSPAD") ? (uint32_t)atoi(getenv("JSMPEG_HIP_RECON_LDSPAD")) : 0u;
-	if (b.no_forward) hipLaunchKernelGGL(k_recon_intra, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
+	if (b.no_forward == 2) hipLaunchKernelGGL(k_recon_intra_dense, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
+	else if (b.no_forward) hipLaunchKernelGGL(k_recon_intra, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
 	else hipLaunchKernelGGL(k_recon, dim3(groups * 8 * (uint32_t)T.per_picture), dim3(JM_RECON_WG), pad, st, a, T);
 	return hipGetLastError();
 }
