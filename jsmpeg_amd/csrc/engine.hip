@@ -126,6 +126,7 @@ struct jsmpeg_hip_batch_t {
 	std::vector<uint8_t> seeded;
 	std::vector<const uint8_t *> seed_frames;   /* [2 * stream + which] */
 	uint32_t last_group;         /* lockstep width of the last decode's launch, 0: it went level by level */
+	int dense_mode;              /* -1: dense intra pictures by their bytes per macroblock (JM_DENSE_INTRA_X16); 0 / 1: never / always (JSMPEG_HIP_RECON_DENSE) */
 	uint32_t order_group;        /* streams a class walks in lockstep; 0: always level by level; JM_ORDER_AUTO: by the picture size */
 	bool ordered;                /* the last decode used the ordered launch (its status is checked at the next sync) */
 	std::vector<uint32_t> chain_heads;   /* ordered by GOP chains (narrow batches): the pictures whose `stale` frame lies in ANOTHER chain -- they must
@@ -232,7 +233,9 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
 	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0;
 	b->d_done = nullptr; b->d_rstatus = nullptr; b->h_rstatus = nullptr; b->ordered = false; b->stats_pending = false; b->ordered_waits = 0; b->ordered_status = 0; b->last_group = 0;
-	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_AUTO; } b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
+	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_AUTO; }
+	{ const char *e = getenv("JSMPEG_HIP_RECON_DENSE"); b->dense_mode = e ? (atoi(e) ? 1 : 0) : -1; }   /* measurements / tests: 0 never, 1 always the dense intra form; read when a batch is created */
+ b->desc_cap = 0; b->d_mb = nullptr; b->d_tokens = nullptr;
 	b->d_pool_alloc = nullptr; b->d_pool = nullptr; b->d_hashes = nullptr; b->h_counters = nullptr; b->d_dbg = nullptr; b->d_rgba = nullptr;
 	b->d_ts = nullptr; b->ts_cap = 0; b->d_ts_rec = nullptr; b->d_ts_es_off = nullptr; b->d_ts_cand = nullptr; b->d_ts_writes = nullptr; b->ts_pkt_cap = 0;
 	b->d_ts_begin = nullptr; b->d_ts_len = nullptr; b->d_ts_small = nullptr;
@@ -582,10 +585,9 @@ struct HostTrace {
  * slot per lane), the variant with 256 slots (2; measured: cfg0, 21 bytes per macroblock, -6 %; cfg2's intra pictures, 12.7, +11 %:
  * profiles/r04_recon_notes.md 8).  `bytes_per_mb_x16`: of the launch's pictures, in sixteenths. */
 #define JM_DENSE_INTRA_X16 310      /* 19.4 bytes per macroblock: all-intra 1080p at 18.0 is 5 % faster with 220 slots, at 20.7 5 % faster with 256 */
-static uint32_t none_predicts(const JmReconDesc *d, size_t n, uint32_t bytes_per_mb_x16) {
+static uint32_t none_predicts(const JmReconDesc *d, size_t n, uint32_t bytes_per_mb_x16, int dense_mode) {
 	for (size_t i = 0; i < n; i++) if (d[i].fwd != nullptr) return 0;
-	static const int forced = getenv("JSMPEG_HIP_RECON_DENSE") ? atoi(getenv("JSMPEG_HIP_RECON_DENSE")) : -1;   /* measurements: 0 / 1 */
-	if (forced >= 0) return forced ? 2u : 1u;
+	if (dense_mode >= 0) return dense_mode ? 2u : 1u;
 	return bytes_per_mb_x16 >= JM_DENSE_INTRA_X16 ? 2u : 1u;
 }
 
@@ -611,7 +613,7 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 	}
 	/* ---- 4a. reconstruct the pictures that wait for nothing ---- */
 	rb.desc = b->d_desc; rb.n_level_pics = n_roots;
-	rb.no_forward = none_predicts(b->h_desc, n_roots, batch_root_density(b));      /* (a seeded stream's first P picture is a root WITH a forward frame) */
+	rb.no_forward = none_predicts(b->h_desc, n_roots, batch_root_density(b), b->dense_mode);      /* (a seeded stream's first P picture is a root WITH a forward frame) */
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 	HIP_TRY(jm_launch_recon(rb, st));
 	rb.no_forward = 0;
@@ -640,7 +642,7 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 			for (uint32_t l = 1; l < n_levels; l++) {
 				rb.desc = b->d_desc + n_roots + off[l];
 				rb.n_level_pics = off[l + 1] - off[l];
-				rb.no_forward = none_predicts(b->h_desc + n_roots + off[l], rb.n_level_pics, 0);
+				rb.no_forward = none_predicts(b->h_desc + n_roots + off[l], rb.n_level_pics, 0, b->dense_mode);
 				if (b->n_level_ev < 64) HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev++], st));
 				HIP_TRY(jm_launch_recon(rb, st));
 			}
@@ -771,10 +773,19 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	static const bool force_chains = getenv("JSMPEG_HIP_RECON_CHAINS") != nullptr;     /* tests: GOP chains whatever the batch's shape */
 	/* (a batch without a single predicted picture has nothing to order: one plain launch) */
 	const bool any_dependency = n_roots < b->n_decoded;
-	bool planned = any_dependency && !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
+	/* DENSE intra pictures (cfg4's: 27 bytes per macroblock) are worth a launch of their own -- k_recon_intra_dense, which only a
+	 * launch without predicted pictures can take: 2160p 64 x 24: reconstruct 10.73-10.81 ms level by level against 11.05-11.18 in
+	 * one ordered launch.  So, left to itself, a batch with such pictures and a shallow dependency structure goes level by level. */
+	bool dense_roots = false;
+	if (b->order_group == JM_ORDER_AUTO && b->dense_mode != 0 && any_dependency && !force_chains && batch_root_density(b) >= JM_DENSE_INTRA_X16) {
+		int32_t deepest = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) deepest = std::max(deepest, b->h_pics[p].level);
+		dense_roots = deepest < 16;
+	}
+	bool planned = any_dependency && !dense_roots && !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
 	               (size_t)8 * plan.rows <= b->desc_cap && (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
 	std::vector<uint32_t> chain_of;
-	if (!planned && any_dependency && group && (b->order_group == JM_ORDER_AUTO || force_chains) && b->link_prev.empty() && b->seeded.empty()) {
+	if (!planned && !dense_roots && any_dependency && group && (b->order_group == JM_ORDER_AUTO || force_chains) && b->link_prev.empty() && b->seeded.empty()) {
 		/* NARROW batches (fewer than eight streams, or streams of very different lengths: one file of many GOPs): the
 		 * classes walk GOP CHAINS instead of streams -- a chain = an intra picture and the P pictures behind it.  The one
 		 * thing that crosses chains is the `stale` frame of a chain's first two pictures (it belongs to the GOP before,

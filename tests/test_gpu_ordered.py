@@ -121,13 +121,18 @@ def test_the_lockstep_width_follows_the_picture_size(hip_lib):
     launch; 176x144 x 16 -> per level"""
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_enc_static_1920x1080.json")))
     es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
-    with jb.Batch(1920, 1080, 16, 16 * fx["n_frames"] + 4, 16 * (len(es) + 64) + 8192) as b:
-        b.upload([es] * 16)
-        assert b.decode() == 16 * fx["n_frames"]
-        info = b.recon_info()
-        assert info["launches"] == 1 and info["group"] == 2 and info["status"] == 0, info
-        for p in range(16 * fx["n_frames"]):
-            assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], p
+    # (the fixture's intra picture is DENSE -- more than 19.4 bytes per macroblock: left to itself such a batch goes level by level
+    #  so that its intra pictures get k_recon_intra_dense; JSMPEG_HIP_RECON_DENSE=0, read when a batch is created, takes that rule out)
+    for dense_rule, want in ((0, dict(launches=1, group=2)), (None, dict(launches=fx["n_frames"], group=0))):
+        with order_env(**({"JSMPEG_HIP_RECON_DENSE": dense_rule} if dense_rule is not None else {})):
+            b = jb.Batch(1920, 1080, 16, 16 * fx["n_frames"] + 4, 16 * (len(es) + 64) + 8192)
+        with b:
+            b.upload([es] * 16)
+            assert b.decode() == 16 * fx["n_frames"]
+            info = b.recon_info()
+            assert info["launches"] == want["launches"] and info["group"] == want["group"] and info["status"] == 0, (dense_rule, info)
+            for p in range(16 * fx["n_frames"]):
+                assert md5_planes(b.read_frame(p)) == fx["frame_md5"][p % fx["n_frames"]], p
     es, _ = synth.generate_config("cfg1_720p", n_frames=13, stream=1, width=176, height=144)
     with jb.Batch(176, 144, 16, 16 * 13 + 4, 16 * (len(es) + 64) + 8192) as b:
         b.upload([es] * 16)
