@@ -93,11 +93,13 @@ def run(path, es, ops, mode, cap):
 bad = served = 0
 for c in range(cases):
     w, h = int(rng.integers(1, 23)) * 16 - int(rng.integers(0, 16)), int(rng.integers(1, 19)) * 16 - int(rng.integers(0, 16))
-    ov = dict(width=max(w, 2), height=max(h, 2), gop=int(rng.choice([1, 2, 5, 12, 40])), ac_max=int(rng.choice([0, 3, 24])),
-              coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 8)), syntax_quirks=int(rng.choice([0, 0, 1, 2, 5])),
-              mv_jitter=int(rng.choice([0, 2])))
+    ov = dict(width=max(w, 2), height=max(h, 2), gop=int(rng.choice([1, 2, 5, 12, 40])), ac_max=int(rng.choice([0, 3, 24, 63])),
+              coded_permille=int(rng.choice([50, 400, 950])), f_code_max=int(rng.integers(1, 8)), syntax_quirks=int(rng.choice([0, 0, 1, 2, 3, 5, 7])),
+              mv_jitter=int(rng.choice([0, 2, 6])), qscale_lo=int(rng.integers(1, 8)), qscale_hi=int(rng.integers(8, 32)),
+              escape_permille=int(rng.choice([0, 20, 300, 1000])), custom_quant=int(rng.integers(0, 2)), quirk_levels=int(rng.integers(0, 2)),
+              dc_size_max=int(rng.integers(0, 9)))
     if ov["syntax_quirks"] & 2:
-        ov["ac_max"] = max(ov["ac_max"], 1)
+        ov["ac_max"], ov["dc_size_max"] = max(ov["ac_max"], 1), max(ov["dc_size_max"], 2)
     n = int(rng.integers(3, 40))
     try:
         es, offs = synth.generate_config("cfg1_720p", n_frames=n, stream=7000 + c, **ov)
