@@ -95,6 +95,16 @@ def test_reference_under_node_matches_golden(impl, libs):
     assert out["sizes"] == [[fx["info"]["width"], fx["info"]["height"]]]
 
 
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference and node")
+def test_oracle_equals_the_reference_under_node_on_random_streams(libs):
+    """tools/fuzz_oracle_vs_node.py, a short run: random streams of the generator's whole parameter space through the unmodified
+    reference's JS and wasm decoders under Node (its own ts.js in front) and through the restatement: the same pictures."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_oracle_vs_node.py"), "30", "3"], capture_output=True, text=True)
+    assert out.returncode == 0 and "30 cases, 0 mismatches" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_oracle_equals_the_references_c_build_on_random_call_patterns(libs):
     """tools/fuzz_abi_chunks.py with the reference's own C build (oracle/_ref) in the product's place: random chunking, EVICT
     stores that evict, EXPAND stores that grow, partial pulls, seeks -- every decode()'s return value, cursor and planes of the
