@@ -204,7 +204,12 @@ int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t picture, jsmpe
  * luma_bytes + chroma_bytes; frame p at pool + p * frame_stride. */
 int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *coded_width, int32_t *coded_height,
                               uint32_t *luma_bytes, uint32_t *chroma_bytes, uint64_t *frame_stride);
-void *jsmpeg_hip_batch_frame_pool(jsmpeg_hip_batch_t *b);              /* device pointer */
+/* Device pointer of the pool.  The frames are FINAL only after jsmpeg_hip_batch_sync (or any call of this header that
+ * reads pictures back: read_frame, frame_hashes, render_rgba*, read_rgba*, uncovered, counters): the dependency-ordered
+ * reconstruct launch is provisional until its status words have been looked at -- a launch that flagged itself is done
+ * over level by level inside that call.  A consumer that reads the pool from its own kernels on the decode stream
+ * calls jsmpeg_hip_batch_sync first. */
+void *jsmpeg_hip_batch_frame_pool(jsmpeg_hip_batch_t *b);
 /* Device-to-host copy of one picture's planes (any of y/cr/cb may be NULL). */
 int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t picture, void *y, void *cr, void *cb);
 /* 64-bit content hash of every picture's planes, computed on the device
@@ -404,6 +409,12 @@ int jsmpeg_hip_dist_scatter(jsmpeg_hip_dist_t *d, int32_t src_rank, const void *
  * receives.  Enqueued on `hip_stream`.  Returns 0 or < 0. */
 int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_dev, const uint64_t *send_offset, const uint64_t *send_bytes,
                              void *dst_dev, const uint64_t *recv_offset, const uint64_t *recv_bytes, void *hip_stream);
+/* PLAN-TIME check of an exchange (call it once per plan, on every rank, before the first jsmpeg_hip_dist_exchange with
+ * these tables): the ranks' send_bytes / recv_bytes tables are all-gathered over the communicator and every pair is
+ * compared -- what rank a sends to rank r must be what r expects from a.  A plan that fails is refused ON EVERY RANK
+ * (< 0, jsmpeg_hip_last_error names the pairs): enqueued, its receive would never complete and the job would hang.
+ * Synchronises `hip_stream`.  Returns 0 or < 0. */
+int jsmpeg_hip_dist_check_exchange(jsmpeg_hip_dist_t *d, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *hip_stream);
 /* The reverse (set-up: streams that arrived on several ranks are collected where they are distributed from). */
 int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, const void *src_dev, const uint64_t *offset,
                            const uint64_t *bytes, void *dst_dev, void *hip_stream);

@@ -706,6 +706,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	pb.ticket = b->d_order_hist + 2 * JM_ORDER_BINS;
 	pb.slice_sc = b->d_slice_sc; pb.n_lanes = std::min(b->h_counters[4], b->sc_cap);   /* a lane per slice code (not per start code) */
 	pb.long_slices = 0;
+	pb.bytes_per_mb_x16 = 0; pb.t_cold = 0;
+	{   /* compressed bytes per macroblock of the decoded pictures: what the parse's header-step threshold follows */
+		uint64_t n_dec = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) n_dec += b->h_pics[p].decoded ? 1u : 0u;
+		if (n_dec) pb.bytes_per_mb_x16 = (uint32_t)std::min<uint64_t>(1u << 20, (uint64_t)b->es_bytes * 16 / (n_dec * (uint64_t)std::max(1, b->g.mb_size)));
+	}
 	if (!getenv("JSMPEG_HIP_STREAM_ORDER")) {   /* (the variable: slices in stream order, for measurements) */
 		JmOrderBufs ob;
 		ob.slice_sc = b->d_slice_sc; ob.sc_pos = b->d_sc_pos; ob.sc_owner = b->d_sc_owner;
@@ -904,6 +910,15 @@ static int batch_settle(jsmpeg_hip_batch_t *b) {
 	return 0;
 }
 
+/* Readers of the frame pool call this first: an ordered reconstruct launch is PROVISIONAL until batch_settle has looked
+ * at its status words (a launch that flagged itself, or whose GOP-chain assumption failed, is done over level by level) --
+ * so a reader waits for the decode stream and settles before it looks at a frame.  Nothing pending: no wait at all. */
+static int batch_settle_pending(jsmpeg_hip_batch_t *b) {
+	if (!b->ordered) return 0;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return batch_settle(b);
+}
+
 extern "C" int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b) {
 	g_err[0] = 0;
 	if (!b) return fail("null batch");
@@ -970,6 +985,7 @@ extern "C" int jsmpeg_hip_batch_render_rgba(jsmpeg_hip_batch_t *b, uint32_t firs
 	if (!b || !dev_rgba) return fail("null argument");
 	if ((uint64_t)first_picture + count > b->n_pics) return fail("picture range [%u, %u) outside the %u decoded pictures", first_picture, first_picture + count, b->n_pics);
 	HIP_TRY(hipSetDevice(b->device));
+	if (batch_settle_pending(b) < 0) return -1;
 	JmRgbaBufs r;
 	r.frames = b->d_pool; r.first_frame = first_picture; r.n_frames = count;
 	r.frame_stride = b->g.frame_bytes; r.luma_bytes = b->g.luma_bytes; r.chroma_bytes = b->g.chroma_bytes;
@@ -986,6 +1002,7 @@ extern "C" int jsmpeg_hip_batch_render_rgba_gl(jsmpeg_hip_batch_t *b, uint32_t f
 	if (!b || !dev_rgba) return fail("null argument");
 	if ((uint64_t)first_picture + count > b->n_pics) return fail("picture range [%u, %u) outside the %u decoded pictures", first_picture, first_picture + count, b->n_pics);
 	HIP_TRY(hipSetDevice(b->device));
+	if (batch_settle_pending(b) < 0) return -1;
 	JmRgbaBufs r;
 	r.frames = b->d_pool; r.first_frame = first_picture; r.n_frames = count;
 	r.frame_stride = b->g.frame_bytes; r.luma_bytes = b->g.luma_bytes; r.chroma_bytes = b->g.chroma_bytes;
@@ -1172,7 +1189,7 @@ struct mpeg1_decoder_t {
 	struct Ahead { unsigned index_before, index_after; uint32_t picture; };
 	jsmpeg_hip_batch_t *ahead;      /* made on first use for the stream's size */
 	std::vector<Ahead> ahead_q; size_t ahead_next;
-	std::vector<uint8_t> seq_bytes; /* the sequence header as it stood in the stream (the batch engine reads size and matrices from it) */
+	std::vector<uint8_t> seq_bytes; /* the sequence header as this decoder parsed it, written out again complete (the batch engine reads size and matrices from it) */
 	uint8_t *ahead_stage; size_t ahead_stage_cap;   /* pinned: header + the run's bytes on their way into the batch */
 	unsigned ahead_max;
 	unsigned last_after;            /* cursor the last decode() that returned a picture left behind (decode-ahead waits for a caller that PULLS) */
@@ -1368,7 +1385,8 @@ static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
 	d->height = (int)host_bits(d, bit, 12); bit += 12;
 	bit += 4;
 	static const float rates[16] = MPEG1_PICTURE_RATE_INIT;
-	d->frame_rate = rates[host_bits(d, bit, 4)]; bit += 4;
+	const uint32_t rate_code = host_bits(d, bit, 4); bit += 4;
+	d->frame_rate = rates[rate_code];
 	bit += 18 + 1 + 10 + 1;
 	static const uint8_t zz[64] = MPEG1_ZIGZAG_INIT;
 	static const uint8_t dq[64] = MPEG1_DEFAULT_INTRA_QUANT_INIT;
@@ -1393,10 +1411,25 @@ static int dec_sequence_header(mpeg1_decoder_t *d, unsigned pos) {
 	d->has_sequence_header = 1;
 	if (!getenv("JSMPEG_HIP_DECODE_AHEAD"))
 		d->ahead_max = (unsigned)std::min<uint64_t>(JM_DECODE_AHEAD, std::max<uint64_t>(8, (160ull << 20) / std::max<uint64_t>(1, d->g.frame_bytes)));
-	{   /* the header's bytes, up to the next start code (decode-ahead hands them to the batch engine) */
-		size_t k = first_code_from(d, pos + 4);
-		const unsigned end = k < d->codes.size() ? d->codes[k].pos : d->length;
-		d->seq_bytes.assign(d->bytes + pos, d->bytes + std::max(end, pos));
+	{   /* Decode-ahead hands the batch engine a sequence header to read size and matrices from.  Not the header's bytes as
+		 * they stood in the store when it was first seen (the write may have ended inside it: truncated bytes, or trailing
+		 * ones that are not part of it) but what THIS parse read, written out again as a complete header -- 12 + 12 + 4 + 4 +
+		 * 18 + 1 + 10 + 1 bits, then both matrices explicitly, in zig-zag order -- so that jm_index_stream arrives at
+		 * exactly d->h_stream's values whatever the store held (round 4 advisor). */
+		std::vector<uint8_t> &o = d->seq_bytes;
+		o.clear();
+		uint64_t acc = 0; int nacc = 0;
+		auto put = [&](uint32_t v, int n) {
+			acc = (acc << n) | (v & ((1ull << n) - 1)); nacc += n;
+			while (nacc >= 8) { o.push_back((uint8_t)(acc >> (nacc - 8))); nacc -= 8; }
+		};
+		put(0x000001B3u, 32);
+		put((uint32_t)d->width, 12); put((uint32_t)d->height, 12);
+		put(1, 4); put(rate_code, 4);
+		put(0x3ffff, 18); put(1, 1); put(0, 10); put(0, 1);
+		put(1, 1); for (int i = 0; i < 64; i++) put(s.intra_q[zz[i]], 8);
+		put(1, 1); for (int i = 0; i < 64; i++) put(s.nonintra_q[zz[i]], 8);
+		if (nacc) put(0, 8 - nacc);
 	}
 	return 0;
 }
@@ -1508,13 +1541,16 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	JmParseBufs pb;
 	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
 	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
-	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.long_slices = 0; pb.ticket = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
+	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.long_slices = 0; pb.bytes_per_mb_x16 = 0; pb.t_cold = 0; pb.ticket = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;
 	rb.luts = d->d_luts;
 	rb.epoch = d->epoch; rb.zero_uncovered = 0;     /* unwritten macroblocks keep the plane's old content */
-	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = desc.fwd == nullptr ? 2u : 0u;   /* (one picture: fewer workgroups than CUs -- the slot per lane costs no occupancy) */
+	rb.need = 0; rb.patience = 0; rb.status = nullptr; rb.done = nullptr; rb.no_forward = 0;
+	/* (the one-picture interface always takes the predicted form: desc.fwd is the other rotating frame for EVERY picture
+	 * type, because the reference predicts the skipped macroblocks even of an I picture from planes_forward,
+	 * mpeg1.c:1072-1082 -- the forms without prediction are the batch engine's, whose index knows its roots) */
 	HIP_TRY(jm_launch_recon(rb, st));
 	HIP_TRY(hipMemcpyAsync(d->h_frame, d->d_pool + (uint64_t)d->cur * d->g.frame_bytes,
 	                       (size_t)d->g.luma_bytes + 2 * d->g.chroma_bytes, hipMemcpyDeviceToHost, st));
@@ -1564,8 +1600,8 @@ static PicScan dec_scan_picture(const mpeg1_decoder_t *d, unsigned from_index) {
 }
 
 /* DECODE-AHEAD (mpeg1_decoder_t::ahead): the batch engine over the run of pictures `run` -- complete (the start code that
- * ends each one is buffered), of a decoded type, with slices.  The batch gets one stream: the sequence header as it
- * stood in the stream + the bytes from the first picture's start code to the code that ends the last one, seeded with
+ * ends each one is buffered), of a decoded type, with slices.  The batch gets one stream: the sequence header as this
+ * decoder parsed it (dec_sequence_header) + the bytes from the first picture's start code to the code that ends the last one, seeded with
  * the two rotating frames (the run's first P picture predicts from the frame decoded last; macroblocks its first two
  * pictures never write show the frames before).  0: the queue is filled; -1: not this time (the caller decodes one
  * picture the plain way; g_err says why if it was a HIP failure). */
@@ -1596,6 +1632,13 @@ static int dec_ahead_build(mpeg1_decoder_t *d, const std::vector<PicScan> &run) 
 	if (n < 0 || jsmpeg_hip_batch_sync(d->ahead) < 0) return -1;
 	/* the engine must have found exactly the pictures the scan found, every one of them decoded, where the scan saw them */
 	if ((size_t)n != run.size()) return -1;
+	/* ... and have read this decoder's picture size and matrices out of the header it was handed */
+	{
+		JmStream a;
+		const JmStream &m = d->h_stream;
+		if (hipMemcpy(&a, d->ahead->d_streams, sizeof(a), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+		if (a.width != m.width || a.height != m.height || memcmp(a.intra_q, m.intra_q, 64) != 0 || memcmp(a.nonintra_q, m.nonintra_q, 64) != 0) return -1;
+	}
 	for (size_t i = 0; i < run.size(); i++) {
 		const JmPic &pic = d->ahead->h_pics[i];
 		if (!pic.decoded || pic.pos - d->ahead->h_streams[0].es_begin != d->seq_bytes.size() + (d->codes[run[i].k].pos - begin)) return -1;

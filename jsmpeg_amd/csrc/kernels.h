@@ -91,6 +91,10 @@ struct JmParseBufs {
 	uint8_t epoch;
 	uint32_t lanes_per_wave;     /* set by jm_launch_parse: slices a wavefront takes (64, fewer for small batches) */
 	int cold_threshold;          /* ... and the lanes that must queue for the header step before it runs */
+	uint32_t bytes_per_mb_x16;   /* caller's figure: compressed bytes per macroblock of the pass, x 16 (0: unknown) -- the header step's queue
+	                                threshold follows it (jm_launch_parse: sparse content queues longer) */
+	uint32_t t_cold;             /* set by jm_launch_parse: the threshold for a full wavefront (of 64) */
+	uint32_t prio_batches;       /* set by jm_launch_parse: the first so many batches (the longest slices) run at raised wavefront priority */
 	uint32_t long_slices;        /* caller's estimate of how many slices are much longer than the mean (those of the intra pictures), 0: none
 	                                -- with the slices in longest-first order, jm_launch_parse gives the first ones fewer lanes per wavefront */
 	uint32_t head_batches[2], head_lanes[2], head_first[3];   /* set by jm_launch_parse: batches [0, hb0) take hl0 slices each from slice 0,

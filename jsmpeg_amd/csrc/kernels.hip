@@ -13,6 +13,14 @@
 
 #include <stdlib.h>
 
+/* These kernels are written for ONE target: the ordered reconstruct launch leans on gfx950's workgroup -> XCD mapping
+ * (checked at run time through HW_REG_XCC_ID), on stores being acknowledged by the XCD's L2 (s_waitcnt vmcnt) and on
+ * the vector L1 being write-through; the parse and the transform on its LDS size and instruction set.  Any other
+ * offload architecture is a build error, not a silently different program. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "jsmpeg_amd kernels are gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 #include "index_tables.h"
 #include "recon_block.h"
 #include "slice_parse.h"
@@ -381,7 +389,8 @@ hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
 __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
 	__shared__ uint32_t es_ring[JM_PARSE_WAVES][JM_ES_RING_ROWS][JM_RING_STRIDE];
-	__shared__ uint32_t tk_ring[JM_PARSE_WAVES][JM_TK_RING / 2][JM_RING_STRIDE];
+	__shared__ __attribute__((aligned(4096))) uint16_t tk_ring[JM_PARSE_WAVES][JM_TK_RING][JM_RING_STRIDE];   /* a wavefront's tile: 4096 bytes at a multiple of 4096 (slice_parse.h jm_tk_put) */
+	static_assert(sizeof(tk_ring[0]) == 4096, "a token slot's address is (cursor & 0xf80) | the lane's column");
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(b.luts);
 		uint4 *dst = reinterpret_cast<uint4 *>(&lut);
@@ -401,14 +410,17 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	uint32_t lanes = b.lanes_per_wave, first = b.head_first[2] + (batch - b.head_batches[0] - b.head_batches[1]) * b.lanes_per_wave;
 	if (batch < b.head_batches[0]) { lanes = b.head_lanes[0]; first = batch * lanes; }
 	else if (batch < b.head_batches[0] + b.head_batches[1]) { lanes = b.head_lanes[1]; first = b.head_first[1] + (batch - b.head_batches[0]) * lanes; }
-	const int cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+	const int cold_threshold = (int)((b.t_cold * lanes + 63) / 64);
+	/* the wavefronts with the longest slices ahead of the others in their SIMD's issue arbitration: the pass cannot be
+	 * shorter than their walk (s_setprio takes an immediate: batch is wave-uniform, the branch is scalar) */
+	if (batch < b.prio_batches) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 	const uint32_t j = (uint32_t)lane < lanes ? first + (uint32_t)lane : 0xffffffffu;
 	uint32_t i = 0xffffffffu;
 	if (b.slice_sc) { if (j < b.n_lanes) i = b.slice_sc[j]; }
 	else i = j;
 	JmLane L;
-	L.es_ring = &es_ring[wave][0][lane];
-	L.tk_ring = &tk_ring[wave][0][lane];
+	L.es_ring = (jm_es_ring_t)reinterpret_cast<uintptr_t>(&es_ring[wave][0][lane]);     /* LDS byte addresses (the low half of the generic address) */
+	L.tk_ring = (jm_tk_ring_t)reinterpret_cast<uintptr_t>(&tk_ring[wave][0][lane]);
 	L.state = JM_ST_DONE;
 	JmSliceCtx c;
 	c.lut = &lut;
@@ -452,9 +464,12 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
 		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, its token slots) */
 		const bool live = L.state != JM_ST_DONE;
-		const int n_cold = __builtin_popcountll(__ballot(live && ready && L.state == JM_ST_COLD));
-		const uint64_t blocked = __ballot(live && !ready);
-		const bool others = __ballot(live && L.state != JM_ST_COLD) != 0 || blocked != 0;
+		/* the wavefront's view as three lane masks and scalar logic on them (as booleans combined per lane the compiler
+		 * materialised every && in a vector register: 26 vector instructions per turn, now 9) */
+		const uint64_t m_ready = __ballot(ready), m_live = __ballot(live), m_cold = __ballot(L.state == JM_ST_COLD);
+		const int n_cold = __builtin_popcountll(m_cold & m_ready);
+		const uint64_t blocked = m_live & ~m_ready;
+		const bool others = ((m_live & ~m_cold) | blocked) != 0;
 		if (n_cold == 0 && !others) break;
 		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_service(L)) }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
@@ -514,7 +529,16 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	{ static const int forced = getenv("JSMPEG_HIP_PARSE_LANES") ? atoi(getenv("JSMPEG_HIP_PARSE_LANES")) : 0;   /* tuning only */
 	  if (forced >= 1 && forced <= 64) { lanes = (uint32_t)forced; lanes_forced = true; } }
 	b.lanes_per_wave = lanes;
-	b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+	/* The header step's queue threshold (slice_parse.h jm_run_cold).  The step is the longest of the turn; the denser the
+	 * content, the smaller the share of a lane's steps that are header steps and the less it pays to let them queue:
+	 * measured on the box (profiles/r05_parse_notes.md) -- 2160p at 46 bytes per macroblock, 64 x 24: 6.40 / 6.14 ms at
+	 * 24 / 12, 16 x 24: 4.80 / 4.73; 320x240 intra at 26 bytes: 0.887 / 0.861; cfg2 and cfg1 (8 bytes per macroblock)
+	 * are fastest at 24 (cfg2: 2.97 / 2.83 / 2.85 / 2.99 at 12 / 24 / 32 / 40). */
+	b.t_cold = JM_T_COLD;
+	if (b.bytes_per_mb_x16 >= JM_T_COLD_DENSE_X16) b.t_cold = JM_T_COLD_DENSE;
+	{ static const int forced = getenv("JSMPEG_HIP_T_COLD") ? atoi(getenv("JSMPEG_HIP_T_COLD")) : 0;   /* tuning only */
+	  if (forced >= 1 && forced <= 64) b.t_cold = (uint32_t)forced; }
+	b.cold_threshold = (int)((b.t_cold * lanes + 63) / 64);
 	/* Mid-size passes with a few LONG slices (16 x 24 pictures of 4K: the 8 % of the slices that belong to intra pictures
 	 * are three times the others): the pass lasts as long as the wavefront that holds the longest slices walks, and a
 	 * wavefront with one or two slices walks about twice as fast as one with 16+ (its turns run only the step kinds those
@@ -552,7 +576,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 			b.head_lanes[0] = b.head_lanes[1] = lh;
 			lanes = lt;
 			b.lanes_per_wave = lanes;
-			b.cold_threshold = (int)((JM_T_COLD * lanes + 63) / 64);
+			b.cold_threshold = (int)((b.t_cold * lanes + 63) / 64);
 		} else H = 0;
 	}
 	if (H) {
@@ -562,6 +586,10 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 		b.head_first[2] = std::min<uint32_t>(seg_a + b.head_batches[1] * b.head_lanes[1], b.n_lanes);
 	}
 	b.n_batches = b.head_batches[0] + b.head_batches[1] + (b.n_lanes - b.head_first[2] + lanes - 1) / lanes;
+	b.prio_batches = 0;
+	{ static const int prio = getenv("JSMPEG_HIP_PARSE_PRIO") ? atoi(getenv("JSMPEG_HIP_PARSE_PRIO")) : -1;   /* tuning: < 0 the rule, else that many batches */
+	  if (prio >= 0) b.prio_batches = (uint32_t)prio;
+	  else if (b.long_slices) b.prio_batches = b.head_batches[0] + b.head_batches[1] ? b.head_batches[0] + b.head_batches[1] : (b.long_slices + lanes - 1) / lanes; }
 	/* as many workgroups as there are batches -- or, for large passes, as the GPU holds at a time (2 per CU: 80 KB of
 	 * LDS each), their wavefronts drawing further batches by ticket */
 	uint32_t groups = (b.n_batches + JM_PARSE_WAVES - 1) / JM_PARSE_WAVES;
@@ -667,7 +695,14 @@ static __device__ __forceinline__ void jm_recon_wait(const JmReconBufs &b, uint3
 		}
 		if (++spins > b.patience) { if (lane == 0) atomicOr(b.status, 1u); break; }
 	}
+#ifdef JM_ORDERED_FENCES
+	/* the memory model's way of saying it (round 4 advisor): an agent-scope acquire = buffer_inv sc1, this CU's WHOLE vector
+	 * L1 dropped at every tile's wait.  Measured (profiles/r05_recon_notes.md) against the design's own argument -- no CU
+	 * holds a line of a frame before the frame is complete, producer and consumer share one L2 -- which needs no invalidate. */
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
 	asm volatile("" ::: "memory");
+#endif
 }
 
 #ifdef JM_T_PHASECLK
@@ -687,7 +722,7 @@ extern "C" int jsmpeg_hip_debug_phase_clk(unsigned long long *out) {
 #endif
 
 /* One tile.  PRED == false: the form for launches in which NO picture has a forward frame (k_recon_intra: the intra
- * level of the per-level launches, all-intra batches, the one-picture interface's I pictures) -- no prediction addresses,
+ * level of the per-level launches, all-intra batches; NOT the one-picture interface, see engine.hip dec_picture_gpu) -- no prediction addresses,
  * no prediction loads, no half-pel pass, residuals clamped as they are: the same pixels (a zero prediction adds nothing)
  * for ~100 VALU instructions and nine load instructions per wavefront fewer; 3-4 % of such a launch (r04_recon_notes.md 8).
  * (Both forms in ONE kernel behind a scalar branch run out of scalar registers -- 106, spills into a vector register
@@ -848,7 +883,11 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	if (b.need != 0 && D.done_pic != JM_NONE) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
+#ifdef JM_ORDERED_FENCES
+		if (threadIdx.x == 0) __hip_atomic_fetch_add((JM_GLOBAL uint32_t *)b.done + (size_t)JM_DONE_STRIDE * D.done_pic, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
 		if (threadIdx.x == 0) __hip_atomic_fetch_add((JM_GLOBAL uint32_t *)b.done + (size_t)JM_DONE_STRIDE * D.done_pic, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 	}
 }
 

@@ -363,6 +363,42 @@ extern "C" int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_de
 	return 0;
 }
 
+/* Plan-time check of an exchange: every rank's two tables to every rank (one all-gather of 2 x world x 8 bytes per
+ * rank), then the whole matrix on the host -- so every rank reaches the same verdict and all refuse together. */
+extern "C" int jsmpeg_hip_dist_check_exchange(jsmpeg_hip_dist_t *d, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *hip_stream) {
+	jm_clear_error();
+	if (!d || !send_bytes || !recv_bytes) return sfail("bad exchange check arguments");
+	SHIP_TRY(hipSetDevice(d->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	const size_t w = (size_t)d->world, row = 2 * w;
+	std::vector<uint64_t> mine(row), all(row * w);
+	for (size_t r = 0; r < w; r++) { mine[r] = send_bytes[r]; mine[w + r] = recv_bytes[r]; }
+	uint64_t *dev = nullptr;
+	SHIP_TRY(hipMalloc((void **)&dev, (row + row * w) * sizeof(uint64_t)));
+	int rc = 0;
+	do {
+		if (hipMemcpyAsync(dev, mine.data(), row * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) { rc = sfail("exchange check: copy in failed"); break; }
+		const ncclResult_t r = g_rccl.AllGather(dev, dev + row, row * sizeof(uint64_t), ncclUint8, d->comm, st);
+		if (r != ncclSuccess) { rc = sfail("ncclAllGather: %s", g_rccl.GetErrorString(r)); break; }
+		if (hipMemcpyAsync(all.data(), dev + row, row * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess) { rc = sfail("exchange check: copy out failed"); break; }
+	} while (0);
+	(void)hipFree(dev);
+	if (rc) return rc;
+	char msg[220];
+	size_t used = 0, bad = 0;
+	msg[0] = 0;
+	for (size_t a = 0; a < w; a++)
+		for (size_t r = 0; r < w; r++) {
+			const uint64_t sent = all[a * row + r], expected = all[r * row + w + a];
+			if (sent == expected) continue;
+			if (bad++ < 2) used += (size_t)snprintf(msg + used, sizeof msg - used, "%srank %zu sends %llu bytes to rank %zu, which expects %llu",
+			                                         bad > 1 ? "; " : "", a, (unsigned long long)sent, r, (unsigned long long)expected);
+		}
+	if (bad) return sfail("exchange plan refused (%zu pair%s): %s", bad, bad == 1 ? "" : "s", msg);
+	return 0;
+}
+
 /* `bytes_per_rank` bytes from every rank to every rank (reporting: 8 bytes per picture of plane hashes):
  * dst_dev[r * bytes_per_rank ...] = rank r's src_dev. */
 extern "C" int jsmpeg_hip_dist_allgather(jsmpeg_hip_dist_t *d, const void *src_dev, void *dst_dev, uint64_t bytes_per_rank,

@@ -24,7 +24,16 @@
  *     sizes are what lets 16 wavefronts share a CU's 160 KB of LDS.)
  *   - No bit window is carried: the next 32 bits at any bit position are one
  *     LDS read of two ring rows (ds_read2st64_b32) and one 64-bit shift.  The
- *     ring holds the stream as big-endian dwords so that is all it takes.
+ *     ring holds the stream as big-endian dwords so that is all it takes
+ *     (jm_bits32: four vector instructions and the read).
+ *   - The pass is bound by VECTOR INSTRUCTION ISSUE (round 5 counters: 1.58 G
+ *     wavefront instructions x 4 clocks / 1024 SIMDs = 91 % of its time, 26 of
+ *     64 lanes active per instruction), so the lane state is kept in the form
+ *     the steps use it in: the token cursor and the scan position pre-shifted
+ *     (tw7 = slot x 128 = the ring's byte offset, n10 = position << 10 = the
+ *     token's upper bits), the token ring one 16-bit column per lane whose
+ *     address is one v_and_or of the cursor, the DC predictors in three
+ *     registers (selects, no 64-bit field arithmetic).
  *   - The walk is cut into steps -- COLD (macroblock header, and the record of
  *     the macroblock before it), DC (intra DC), COEF (one run/level symbol of
  *     at most 8 bits + sign: ONE table lookup; or end_of_block and the choice
@@ -64,7 +73,9 @@
 #endif
 #define JM_STEP_BITS (116 + JM_PAIR_BITS * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
 #define JM_COEF_SLOTS 3    /* token slots a COEF step may use: two tokens and the alignment slot of an odd run */
-#define JM_RING_STRIDE 64  /* rings are [row][lane] tiles of one wavefront: conflict-free for any per-lane row */
+#define JM_RING_STRIDE 64  /* the ES ring is a [row][lane] tile of dwords of one wavefront: conflict-free for any per-lane row */
+#define JM_TW_UNIT 128u    /* the token ring is a [slot][lane] tile of 16-bit tokens: a slot is 128 bytes on; cursors count in these (tw7, tf7) */
+#define JM_TW_SHIFT 7
 
 enum { JM_ST_COLD = 0, JM_ST_DC = 1, JM_ST_COEF = 2, JM_ST_SLOW = 3, JM_ST_WAIT = 4, JM_ST_DONE = 5, JM_ST_KINDS = 6 };
 
@@ -75,30 +86,42 @@ struct JmSliceCtx {
 	uint8_t epoch;
 };
 
-#define JM_DC_RESET 0x008000800080ull /* 128, 128, 128 */
+#define JM_DC_RESET 128
+
+/* A lane's two rings.  On the device they are LDS byte addresses (the lane's column of its wavefront's tile): the
+ * accesses below are then exactly the instructions meant -- a generic pointer costs an address computation the
+ * compiler cannot fold (it does not know the tile's alignment).  The test-only simulator (tests/sim) has plain arrays. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JM_LDS __attribute__((address_space(3)))
+typedef uint32_t jm_es_ring_t;   /* byte address of row 0 of the lane's dword column; row r at + 256 r */
+typedef uint32_t jm_tk_ring_t;   /* byte address of slot 0 of the lane's 16-bit column; slot k at + 128 k.  The tile is 4096-byte aligned */
+#else
+typedef uint32_t *jm_es_ring_t;  /* row r at [r * JM_RING_STRIDE] */
+typedef uint16_t *jm_tk_ring_t;  /* slot k at [k * JM_RING_STRIDE] */
+#endif
 
 /* Everything a lane carries between steps. */
 struct JmLane {
 	/* compressed data: es16[] is the slice's bytes as 16-byte chunks from a 16-byte aligned address;
 	 * bit positions count from the first bit of es16[0] */
 	const uint4_like_t *es16;
-	uint32_t *es_ring;      /* this lane's column of the LDS ring: dword d at es_ring[(d & 31) * JM_RING_STRIDE] */
-	uint32_t *tk_ring;      /* token ring, two tokens per dword, same indexing */
-	uint32_t fillc;         /* chunks [0, fillc) have been loaded; the ring holds the last 8 */
+	jm_es_ring_t es_ring;   /* dword d of the slice at row (d & 15); row 16 repeats row 0 */
+	jm_tk_ring_t tk_ring;   /* token slot k at ring slot (k & 31) */
+	uint32_t fillc;         /* chunks [0, fillc) have been loaded; the ring holds the last 4 */
 	uint32_t bp;            /* bit position of the next unread bit */
 	uint32_t bp0, bp_end;   /* first payload bit; first bit past the payload */
 	uint32_t limit_bytes;
 	/* output */
 	uint4_like_t *tokens;   /* batch token buffer, from the picture's 32-byte aligned base, as 8-token units */
-	uint32_t tw;            /* next token slot */
-	uint32_t tflushed;      /* slots below this are in HBM; multiple of JM_TK_GROUP */
+	uint32_t tw7;           /* next token slot x JM_TW_UNIT */
+	uint32_t tf7;           /* slots below this (x JM_TW_UNIT) are in HBM; a multiple of JM_TK_GROUP slots */
 	uint32_t tok_rel;       /* the picture's first slot: JmMbRec.tok = slot - tok_rel */
 	JmMbRec *mb;            /* the picture's records */
 	uint32_t stored;        /* records written by this lane (the picture is fully covered when they add up to mb_size) */
 	/* parser state (mpeg1.c:694-751) */
 	int state;
 	int qscale;
-	uint64_t dc;            /* three 16-bit DC predictors: luma, block 4, block 5 (mpeg1.c:739-741) */
+	int dcy, dc4, dc5;      /* DC predictors: luma, block 4, block 5 (mpeg1.c:739-741) */
 	int mvh, mvv, pmh, pmv; /* motion_fw_{h,v} and their _prev (mpeg1.c:734-737) */
 	int addr, inc;          /* macroblock_address; pending escape increments */
 	int slice_begin;
@@ -108,16 +131,63 @@ struct JmLane {
 	int rec_mvh, rec_mvv;
 	uint64_t cnts;
 	/* current block */
-	int n, cnt;
+	uint32_t n10;           /* scan position << 10 (a token's upper bits) */
+	int cnt;
 	uint32_t tsel;          /* 512 while the next coefficient is the first of a non-intra block, else 0 (the pair table's context) */
 };
 
 /* ---- bits: MSB-first like bit_buffer_peek/read (buffer.c:113-135) ---- */
+#if defined(__HIP_DEVICE_COMPILE__)
+JM_D uint32_t jm_bits32(const JmLane &L, uint32_t bp) {
+	/* rows d and d + 1 of the lane's column in ONE read whose second half lands in the LOW register of the pair (offset0:1):
+	 * the pair is the 64-bit window as v_lshlrev_b64 wants it -- written in C++ the compiler reads the rows in address
+	 * order and swaps them with two moves, and forms the row address (row (bp >> 5) & 15, 256 bytes a row) with three
+	 * instructions instead of two (and, shift-add); nine vector instructions per look became four.  The wait is in the statement: the compiler's
+	 * own counters do not see an asm's LDS access. */
+#ifdef JM_BITS32_CXX   /* timing variant: the compiler's own form (profiles/r05_parse_notes.md) */
+	JM_LDS const uint32_t *r = reinterpret_cast<JM_LDS const uint32_t *>(((bp & 0x1e0u) << 3) + L.es_ring);
+	const uint32_t hi = r[0], lo = r[JM_RING_STRIDE];
+	return (uint32_t)(((((uint64_t)hi << 32) | lo) << (bp & 31)) >> 32);
+#endif
+	uint64_t v;
+	uint32_t a;
+	asm volatile("v_and_b32_e32 %1, 0x1e0, %2\n\tv_lshl_add_u32 %1, %1, 3, %3\n\tds_read2st64_b32 %0, %1 offset0:1\n\ts_waitcnt lgkmcnt(0)"
+	             : "=v"(v), "=&v"(a) : "v"(bp), "v"(L.es_ring));
+	return (uint32_t)((v << (bp & 31u)) >> 32);
+}
+JM_D void jm_es_put(const JmLane &L, uint32_t row, uint32_t v) { *reinterpret_cast<JM_LDS uint32_t *>(L.es_ring + row * (4u * JM_RING_STRIDE)) = v; }
+/* token slot k x JM_TW_UNIT (any lap of the ring): ONE instruction forms the address, the tile being 4096-byte aligned */
+JM_D void jm_tk_put(const JmLane &L, uint32_t k7, uint32_t t) { *reinterpret_cast<JM_LDS uint16_t *>((k7 & ((JM_TK_RING - 1u) << JM_TW_SHIFT)) | L.tk_ring) = (uint16_t)t; }
+/* ring slots s and s + 1 (s even, below JM_TK_RING) as one dword, the first token low */
+JM_D uint32_t jm_tk_get2(const JmLane &L, uint32_t s) {
+	JM_LDS const uint16_t *p = reinterpret_cast<JM_LDS const uint16_t *>(L.tk_ring + s * JM_TW_UNIT);
+	return (uint32_t)p[0] | ((uint32_t)p[JM_RING_STRIDE] << 16);
+}
+#else
 JM_HD uint32_t jm_bits32(const JmLane &L, uint32_t bp) {
 	const uint32_t d = (bp >> 5) & (JM_ES_RING_DW - 1);
 	const uint32_t hi = L.es_ring[d * JM_RING_STRIDE], lo = L.es_ring[(d + 1) * JM_RING_STRIDE];
 	return (uint32_t)(((((uint64_t)hi << 32) | lo) << (bp & 31)) >> 32);
 }
+JM_HD void jm_es_put(const JmLane &L, uint32_t row, uint32_t v) { L.es_ring[row * JM_RING_STRIDE] = v; }
+JM_HD void jm_tk_put(const JmLane &L, uint32_t k7, uint32_t t) { L.tk_ring[((k7 >> JM_TW_SHIFT) & (JM_TK_RING - 1u)) * JM_RING_STRIDE] = (uint16_t)t; }
+JM_HD uint32_t jm_tk_get2(const JmLane &L, uint32_t s) { return (uint32_t)L.tk_ring[s * JM_RING_STRIDE] | ((uint32_t)L.tk_ring[(s + 1) * JM_RING_STRIDE] << 16); }
+#endif
+/* (x & mask) << sh, plus add: two instructions (v_and, v_lshl_add); left to itself the compiler shifts first, masks, adds */
+#if defined(__HIP_DEVICE_COMPILE__)
+JM_D uint32_t jm_and_shl_add(uint32_t x, uint32_t mask, int sh, uint32_t add) {
+	uint32_t t = x & mask;
+	asm("" : "+v"(t));
+	return (t << sh) + add;
+}
+#else
+JM_HD uint32_t jm_and_shl_add(uint32_t x, uint32_t mask, int sh, uint32_t add) { return ((x & mask) << sh) + add; }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+JM_D int jm_opaque(int x) { asm("" : "+v"(x)); return x; }   /* the value, with its origin hidden from the optimiser */
+#else
+JM_HD int jm_opaque(int x) { return x; }
+#endif
 JM_HD uint32_t jm_get(JmLane &L, int n) {           /* 1..32 */
 	const uint32_t v = jm_bits32(L, L.bp) >> (32 - n);
 	L.bp += (uint32_t)n;
@@ -128,52 +198,62 @@ JM_HD uint32_t jm_consumed(const JmLane &L) { return L.bp - L.bp0; }
 JM_HD bool jm_slice_ended(const JmLane &L) { return ((jm_consumed(L) + 7) >> 3) >= L.limit_bytes; }
 
 /* ---- service: top up the compressed-data ring, drain whole token groups ---- */
-JM_HD void jm_lane_refill(JmLane &L) {
-	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;   /* the chunk being read + the rest of the ring ahead */
-	/* all loads first, then the LDS writes: one memory latency per refill, not one per chunk */
-	uint4_like_t v[JM_ES_RING_DW / 4];
-#pragma unroll
-	for (int i = 0; i < JM_ES_RING_DW / 4; i++) {
-		const uint32_t ch = L.fillc + (uint32_t)i;
-		/* only the chunks the lane has room for (a lane takes one or two per service, the service runs every ~7th turn).
-		 * Round 1 loaded four unconditionally -- a chunk not needed re-read the last one -- to have no branch between
-		 * the loads; each of those is a request to the L2 all the same: 6.0 -> 4.0 GB fetched per pass, 3.68 -> 3.45 ms */
-		v[i].x = v[i].y = v[i].z = v[i].w = 0;
-		if (ch < target) v[i] = L.es16[ch];
-	}
 #if defined(__HIP_DEVICE_COMPILE__)
-	/* every loaded register is "used" here, on every path: the compiler places its wait for the loads HERE.  Without
-	 * it the waits sit inside the conditional ring writes below, the loads count as possibly pending ever after, and
-	 * every step of the turn loop starts with s_waitcnt vmcnt(0) -- which, loads and stores sharing one in-order
-	 * counter, also waits for every token / record store still on its way (measured in round 2: the wavefronts spent
-	 * 45 % of their time in waits) */
-#pragma unroll
-	for (int i = 0; i < JM_ES_RING_DW / 4; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
-#endif
-#pragma unroll
-	for (int i = 0; i < JM_ES_RING_DW / 4; i++) {
-		const uint32_t ch = L.fillc + (uint32_t)i;
-		if (ch < target) {
-			const uint32_t row = (ch & (JM_ES_RING_DW / 4 - 1)) * 4;
-			uint32_t *r = L.es_ring + row * JM_RING_STRIDE;
-			const uint32_t x = __builtin_bswap32(v[i].x);
-			r[0] = x; r[JM_RING_STRIDE] = __builtin_bswap32(v[i].y);
-			r[2 * JM_RING_STRIDE] = __builtin_bswap32(v[i].z); r[3 * JM_RING_STRIDE] = __builtin_bswap32(v[i].w);
-			if (row == 0) L.es_ring[JM_ES_RING_DW * JM_RING_STRIDE] = x;
-		}
+typedef uint32_t jm_u32x4 __attribute__((ext_vector_type(4)));
+JM_D void jm_lane_refill(JmLane &L) {
+	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;   /* the chunk being read + the rest of the ring ahead */
+	/* Only the chunks the lane has room for (a lane takes one or two per service, the service runs every ~5th turn:
+	 * round 1 loaded four unconditionally, a chunk not needed re-read the last one, 6.0 GB fetched per pass instead of
+	 * 4.0) -- ALL requested before the first is awaited: one memory latency per refill.  The loads are written out
+	 * (asm) because the compiler's form of "load under a condition into a register that is otherwise zero" is load,
+	 * wait, move -- four latencies one after the other; here a register that was not loaded is simply not looked at.
+	 * The one wait names every loaded register, so nothing that uses them is scheduled ahead of it; and it is HERE on
+	 * every path -- loads left "possibly pending" made every step of the turn loop start with s_waitcnt vmcnt(0), which
+	 * (loads and stores share one in-order counter) also waits for every token / record store still on its way
+	 * (round 2: the wavefronts spent 45 % of their time in waits). */
+	jm_u32x4 v0, v1, v2, v3;
+	const uint32_t f = L.fillc;
+	const uint4_like_t *src = L.es16 + f;
+	if (f < target) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src));
+	if (f + 1 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v1) : "v"(src));
+	if (f + 2 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(v2) : "v"(src));
+	if (f + 3 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(v3) : "v"(src));
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+#define JM_REFILL_PUT(i, v)                                                                          \
+	if (f + i < target) {                                                                            \
+		const uint32_t row = ((f + i) & (JM_ES_RING_DW / 4 - 1)) * 4;                                \
+		const uint32_t x = __builtin_bswap32(v.x);                                                   \
+		jm_es_put(L, row, x); jm_es_put(L, row + 1, __builtin_bswap32(v.y));                         \
+		jm_es_put(L, row + 2, __builtin_bswap32(v.z)); jm_es_put(L, row + 3, __builtin_bswap32(v.w)); \
+		if (row == 0) jm_es_put(L, JM_ES_RING_DW, x);                                                \
+	}
+	JM_REFILL_PUT(0, v0) JM_REFILL_PUT(1, v1) JM_REFILL_PUT(2, v2) JM_REFILL_PUT(3, v3)
+#undef JM_REFILL_PUT
+	if (L.fillc < target) L.fillc = target;
+}
+#else
+JM_HD void jm_lane_refill(JmLane &L) {       /* the simulator's: the same chunks into the same rows */
+	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;
+	for (uint32_t ch = L.fillc; ch < target && ch < L.fillc + JM_ES_RING_DW / 4; ch++) {
+		const uint4_like_t v = L.es16[ch];
+		const uint32_t row = (ch & (JM_ES_RING_DW / 4 - 1)) * 4;
+		const uint32_t x = __builtin_bswap32(v.x);
+		jm_es_put(L, row, x); jm_es_put(L, row + 1, __builtin_bswap32(v.y));
+		jm_es_put(L, row + 2, __builtin_bswap32(v.z)); jm_es_put(L, row + 3, __builtin_bswap32(v.w));
+		if (row == 0) jm_es_put(L, JM_ES_RING_DW, x);
 	}
 	if (L.fillc < target) L.fillc = target;
 }
+#endif
 JM_HD void jm_lane_drain(JmLane &L) {
-	while (L.tw - L.tflushed >= JM_TK_GROUP) {
-		const uint32_t d0 = (L.tflushed & (JM_TK_RING - 1)) >> 1;
+	while (L.tw7 - L.tf7 >= JM_TK_GROUP * JM_TW_UNIT) {
+		const uint32_t s0 = (L.tf7 >> JM_TW_SHIFT) & (JM_TK_RING - 1);    /* 0 or 16: groups never straddle the ring's end */
 		uint4_like_t a, b;
-		const uint32_t *r = L.tk_ring + d0 * JM_RING_STRIDE;
-		a.x = r[0]; a.y = r[JM_RING_STRIDE]; a.z = r[2 * JM_RING_STRIDE]; a.w = r[3 * JM_RING_STRIDE];
-		b.x = r[4 * JM_RING_STRIDE]; b.y = r[5 * JM_RING_STRIDE]; b.z = r[6 * JM_RING_STRIDE]; b.w = r[7 * JM_RING_STRIDE];
-		uint4_like_t *dst = L.tokens + (L.tflushed >> 3);                 /* 32-byte aligned: two dwordx4 stores */
+		a.x = jm_tk_get2(L, s0); a.y = jm_tk_get2(L, s0 + 2); a.z = jm_tk_get2(L, s0 + 4); a.w = jm_tk_get2(L, s0 + 6);
+		b.x = jm_tk_get2(L, s0 + 8); b.y = jm_tk_get2(L, s0 + 10); b.z = jm_tk_get2(L, s0 + 12); b.w = jm_tk_get2(L, s0 + 14);
+		uint4_like_t *dst = L.tokens + (L.tf7 >> (JM_TW_SHIFT + 3));      /* 32-byte aligned: two dwordx4 stores */
 		dst[0] = a; dst[1] = b;
-		L.tflushed += JM_TK_GROUP;
+		L.tf7 += JM_TK_GROUP * JM_TW_UNIT;
 	}
 }
 JM_HD void jm_lane_service(JmLane &L) {
@@ -182,25 +262,21 @@ JM_HD void jm_lane_service(JmLane &L) {
 }
 /* a turn needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for its tokens (DC 1, SLOW 1, per COEF step JM_COEF_SLOTS) */
 JM_HD bool jm_lane_blocked(const JmLane &L) {
-	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw - L.tflushed > JM_TK_RING - 2 - JM_COEF_SLOTS * JM_COEF_REPEAT;
+	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw7 - L.tf7 > (JM_TK_RING - 2 - JM_COEF_SLOTS * JM_COEF_REPEAT) * JM_TW_UNIT;
 }
-JM_HD void jm_emit_at(JmLane &L, uint32_t tw, uint16_t t) {
-	const uint32_t slot = tw & (JM_TK_RING - 1);
-	reinterpret_cast<uint16_t *>(L.tk_ring + (slot >> 1) * JM_RING_STRIDE)[slot & 1] = t;
-}
-JM_HD void jm_emit(JmLane &L, uint16_t t) {
-	jm_emit_at(L, L.tw, t);
-	L.tw++;
+JM_HD void jm_emit(JmLane &L, uint32_t t) {        /* the low 16 bits of t */
+	jm_tk_put(L, L.tw7, t);
+	L.tw7 += JM_TW_UNIT;
 }
 /* end of the slice: the tokens still in the ring, dword by dword (never past the last token's dword) */
 JM_HD void jm_lane_finish(JmLane &L) {
 	jm_lane_drain(L);
-	const uint32_t d0 = (L.tflushed & (JM_TK_RING - 1)) >> 1;
-	uint32_t *dst = reinterpret_cast<uint32_t *>(L.tokens + (L.tflushed >> 3));
+	const uint32_t s0 = (L.tf7 >> JM_TW_SHIFT) & (JM_TK_RING - 1);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(L.tokens + (L.tf7 >> (JM_TW_SHIFT + 3)));
 #pragma unroll
 	for (uint32_t j = 0; j < JM_TK_GROUP / 2; j++)
-		if (L.tflushed + 2 * j < L.tw) dst[j] = L.tk_ring[(d0 + j) * JM_RING_STRIDE];
-	L.tflushed = L.tw;
+		if (L.tf7 + 2 * j * JM_TW_UNIT < L.tw7) dst[j] = jm_tk_get2(L, s0 + 2 * j);
+	L.tf7 = L.tw7;
 }
 
 /* One JmMbRec as four dwords built in registers (no addressable local: keeps
@@ -228,13 +304,13 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	L.bp = L.bp0;
 	L.limit_bytes = limit_bytes; L.bp_end = L.bp0 + limit_bytes * 8u;
 	L.fillc = 0;
-	L.tokens = tokens; L.tw = L.tflushed = tok_slot; L.tok_rel = tok_rel; L.mb = mb; L.stored = 0;
+	L.tokens = tokens; L.tw7 = L.tf7 = tok_slot * JM_TW_UNIT; L.tok_rel = tok_rel; L.mb = mb; L.stored = 0;
 	jm_lane_refill(L);
-	L.dc = JM_DC_RESET;
+	L.dcy = L.dc4 = L.dc5 = JM_DC_RESET;
 	L.mvh = L.mvv = L.pmh = L.pmv = 0;
 	L.inc = 0; L.slice_begin = 1;
 	L.intra = 0; L.cbp = 0; L.cur = -1; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
-	L.n = 0; L.cnt = 0; L.tsel = 0;
+	L.n10 = 0; L.cnt = 0; L.tsel = 0;
 	/* decode_slice header (mpeg1.c:1011-1016) */
 	L.qscale = (int)jm_get(L, 5);
 	int st = JM_ST_COLD;
@@ -263,9 +339,10 @@ JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &ba
 	}
 	L.bp += (uint32_t)used;
 	prev += d;
-	if (prev > (f << 4) - 1) prev -= f << 5;
-	else if (prev < -(f << 4)) prev += f << 5;
-	return prev;
+	/* the reference's wrap into [-16 f, 16 f - 1] by -+ 32 f (mpeg1.c:1163-1168): prev was inside, |d| <= 16 f, so one
+	 * wrap always lands inside -- i.e. the sum's low 5 + r_size bits, sign-extended (one v_bfe_i32) */
+	const int bits = 5 + r_size;                                    /* 5 .. 11 */
+	return (int)((uint32_t)prev << (32 - bits)) >> (32 - bits);
 }
 
 /* The first coded block of blocks `rem` (pattern bits, block b = bit 0x20 >> b; rem != 0) becomes the
@@ -273,7 +350,7 @@ JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &ba
  * the "first coefficient" table. */
 JM_HD int jm_open_block(JmLane &L, int rem) {
 	L.cur = __builtin_clz((unsigned)rem) - 26;
-	L.n = 0; L.cnt = 0;
+	L.n10 = 0; L.cnt = 0;
 	L.tsel = 512u;
 	return L.intra ? JM_ST_DC : JM_ST_COEF;
 }
@@ -285,16 +362,23 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
 	const uint32_t w = jm_bits32(L, L.bp);
 	const uint32_t e = b < 4 ? c.lut->dcl[w >> 25] : c.lut->dcc[w >> 24];
 	const int len = (int)(e >> 8), size = (int)(e & 15);
-	const int dsh = b < 4 ? 0 : (b - 3) * 16;
-	int dcv = (int)(int16_t)(L.dc >> dsh);
+	const bool is4 = b == 4, is5 = b == 5;
+	/* (the values made opaque first: a select between two loads of the lane's fields is turned into ONE load through a
+	 * select of their ADDRESSES -- which makes the lane addressable and puts all of it into scratch memory) */
+	int dcv = jm_opaque(L.dcy);
+	const int p4 = jm_opaque(L.dc4), p5 = jm_opaque(L.dc5);
+	dcv = is5 ? p5 : (is4 ? p4 : dcv);
 	if (size > 0) {
 		const int diff = (int)((w << len) >> (32 - size));   /* len + size <= 16 bits */
 		dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
 	}
 	L.bp += (uint32_t)(len + size);
-	L.dc = (L.dc & ~(0xffffull << dsh)) | ((uint64_t)(uint16_t)dcv << dsh);
-	jm_emit(L, (uint16_t)(int16_t)dcv);
-	L.n = 1; L.cnt = 1;
+	/* the reference's predictors are ints that only ever hold what a 16-bit token holds on valid streams; kept as the
+	 * token's value (sign-extended 16 bits), like the packed form before */
+	dcv = (int)(int16_t)dcv;
+	L.dc4 = is4 ? dcv : L.dc4; L.dc5 = is5 ? dcv : L.dc5; L.dcy = (is4 || is5) ? L.dcy : dcv;
+	jm_emit(L, (uint32_t)dcv);
+	L.n10 = 1u << 10; L.cnt = 1;
 	L.tsel = 0;
 	L.state = len ? JM_ST_COEF : JM_ST_DONE;
 }
@@ -306,30 +390,32 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
  * of 10+ bits) hands the lane to the SLOW step without consuming a bit. */
 JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 	const uint32_t w = jm_bits32(L, L.bp);
-	/* the first coefficient of a non-intra block reads "1s" as (0, +-1): its own entries, 512 further on */
-	const uint32_t idx = (w >> (32 - JM_PAIR_BITS)) + (L.tsel & (uint32_t)((int32_t)w >> 31));
+	/* the first coefficient of a non-intra block reads "1s" as (0, +-1): its own entries, 512 further on (tsel is 512
+	 * there, and bit 9 of the index is the window's first bit) */
+	const uint32_t i10 = w >> (32 - JM_PAIR_BITS);
+	const uint32_t idx = i10 + (i10 & L.tsel);
 	const uint32_t s = c.lut->pair_s[idx], d = c.lut->pair_d[idx];
-	const int len = (int)(s & 15u);
+	const uint32_t len = s & 15u;
 	if (len == 0) { L.state = JM_ST_SLOW; return; }
-	const int n_new = L.n + (int)(s >> 8);
+	const uint32_t n10_new = jm_and_shl_add(s, 0xff00u, 2, L.n10);
 	/* a position past 63: the reference indexes ZIG_ZAG out of range there.  The lane stops; the macroblock is never
 	 * recorded, so it does not matter that a first symbol that still fitted is not emitted */
-	if (n_new > 64 || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
+	if (n10_new > (64u << 10) || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
 	const uint32_t nc = (s >> 4) & 3u;
-	const uint32_t base = (uint32_t)L.n << 10;
 	/* both slots are written whatever nc says: a slot at or past tw is not part of the stream until tw passes it
-	 * (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free) */
-	jm_emit_at(L, L.tw, (uint16_t)(base + (d & 0xffffu)));
-	jm_emit_at(L, L.tw + 1, (uint16_t)(base + (d >> 16)));
-	L.tw += nc;
+	 * (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free).  A token is its scan position
+	 * << 10 plus the table's (run << 10 | level): two adds on the entry's halves, the store takes the low 16 bits */
+	jm_tk_put(L, L.tw7, d + L.n10);
+	jm_tk_put(L, L.tw7 + JM_TW_UNIT, (d >> 16) + L.n10);
+	L.tw7 += nc << JM_TW_SHIFT;
 	L.cnt += (int)nc;
-	L.n = n_new;
+	L.n10 = n10_new;
 	L.tsel = 0;
-	L.bp += (uint32_t)len;
+	L.bp += len;
 	if (s & 64u) {
 		/* end_of_block.  Runs are dword aligned for the reconstruct loads: an odd run leaves one slot
 		 * unused (never read: the record carries the count). */
-		L.tw += (uint32_t)(L.cnt & 1);
+		L.tw7 = (L.tw7 + JM_TW_UNIT) & ~(2u * JM_TW_UNIT - 1u);      /* blocks begin on even slots, so an odd count is an odd cursor: round it up */
 		L.cnts |= (uint64_t)(uint32_t)L.cnt << (8 * L.cur);
 		const int rem = L.cbp & (0x1f >> L.cur);         /* pattern bits of the blocks after this one */
 		L.state = rem ? jm_open_block(L, rem) : JM_ST_COLD;
@@ -356,16 +442,16 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	const int f_level = ((w >> ((31 - flen) & 31)) & 1) ? -f_mag : f_mag;
 	const bool f_bad = !flen || lz < 6 || lz > 11;
 
-	const int run = esc ? (int)((w >> 20) & 63) : (int)((f >> 6) & 31);
+	const uint32_t run = esc ? (w >> 20) & 63u : (f >> 6) & 31u;
 	const int level = esc ? e_level : f_level;
 	const int used = esc ? (e_long ? 28 : 20) : flen + 1;
-	const int n = L.n + run;
-	const bool bad = L.bp >= L.bp_end || n > 63 || (!esc && f_bad);
+	const uint32_t n10 = L.n10 + (run << 10);
+	const bool bad = L.bp >= L.bp_end || n10 > (63u << 10) || (!esc && f_bad);
 	int st = JM_ST_DONE;
 	if (!bad) {
 		L.bp += (uint32_t)used;
-		jm_emit(L, jm_token(n, level));
-		L.n = n + 1;
+		jm_emit(L, n10 | ((uint32_t)level & 1023u));
+		L.n10 = n10 + (1u << 10);
 		L.cnt++;
 		L.tsel = 0;
 		st = JM_ST_COEF;
@@ -417,14 +503,14 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 			go = false;
 		} else {
 			if (inc > 1) {
-				L.dc = JM_DC_RESET;
+				L.dcy = L.dc4 = L.dc5 = JM_DC_RESET;
 				if (is_p) L.mvh = L.mvv = L.pmh = L.pmv = 0;
 			}
 			while (inc > 1) {
 				/* skipped macroblock: prediction only (mpeg1.c:1072-1082) */
 				L.addr++;
 				if (L.addr >= 0)
-					{ jm_store_mbrec(L.mb + L.addr, L.tw - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch); L.stored++; }
+					{ jm_store_mbrec(L.mb + L.addr, (L.tw7 >> JM_TW_SHIFT) - L.tok_rel, L.mvh, L.mvv, 0, (uint32_t)(L.qscale | JM_MB_PRED), c.epoch); L.stored++; }
 				inc--;
 			}
 			L.addr++;
@@ -456,10 +542,10 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 		L.pmh = zero ? 0 : ph; L.pmv = zero ? 0 : pv;
 		const int fh = c.full_pel ? ph << 1 : ph, fv = c.full_pel ? pv << 1 : pv;
 		L.mvh = zero ? 0 : (has_mv ? fh : L.mvh); L.mvv = zero ? 0 : (has_mv ? fv : L.mvv);
-		L.dc = intra ? L.dc : JM_DC_RESET;                 /* mpeg1.c:1116-1119 */
+		if (!intra) L.dcy = L.dc4 = L.dc5 = JM_DC_RESET;   /* mpeg1.c:1116-1119 */
 		L.intra = intra ? 1 : 0;
 		L.qf = (uint32_t)(L.qscale | (intra ? JM_MB_INTRA : JM_MB_PRED));
-		L.tok_first = L.tw - L.tok_rel;
+		L.tok_first = (L.tw7 >> JM_TW_SHIFT) - L.tok_rel;
 		L.rec_mvh = L.mvh; L.rec_mvv = L.mvv;
 		if (bad) { st = JM_ST_DONE; go = false; }
 	}
@@ -496,6 +582,8 @@ JM_HD int jm_lane_wants(const JmLane &L) {
 #ifndef JM_T_COLD
 #define JM_T_COLD 24
 #endif
+#define JM_T_COLD_DENSE 12          /* passes from JM_T_COLD_DENSE_X16 / 16 compressed bytes per macroblock up */
+#define JM_T_COLD_DENSE_X16 (20 * 16)
 JM_HD bool jm_run_cold(int n_cold, int n_other, int threshold) { return n_cold >= threshold || (n_cold > 0 && n_other == 0); }
 
 #endif

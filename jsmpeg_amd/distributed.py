@@ -22,7 +22,8 @@ class GopUnit(ctypes.Structure):
 DIST_ID_BYTES = 128
 SHARD_SYMBOLS = ("jsmpeg_hip_split_gops", "jsmpeg_hip_plan_shards", "jsmpeg_hip_plan_contiguous", "jsmpeg_hip_plan_rebalance", "jsmpeg_hip_dist_unique_id",
                  "jsmpeg_hip_dist_create", "jsmpeg_hip_dist_destroy", "jsmpeg_hip_dist_rank", "jsmpeg_hip_dist_world",
-                 "jsmpeg_hip_dist_scatter", "jsmpeg_hip_dist_exchange", "jsmpeg_hip_dist_gather", "jsmpeg_hip_dist_allgather")
+                 "jsmpeg_hip_dist_scatter", "jsmpeg_hip_dist_exchange", "jsmpeg_hip_dist_check_exchange", "jsmpeg_hip_dist_gather",
+                 "jsmpeg_hip_dist_allgather")
 _bound = False
 
 
@@ -41,6 +42,8 @@ def _lib():
         L.jsmpeg_hip_plan_rebalance.argtypes = [u64p, u32p, ctypes.c_uint32, ctypes.c_uint32, u32p]
         L.jsmpeg_hip_dist_exchange.restype = ctypes.c_int
         L.jsmpeg_hip_dist_exchange.argtypes = [vp, vp, u64p, u64p, vp, u64p, u64p, vp]
+        L.jsmpeg_hip_dist_check_exchange.restype = ctypes.c_int
+        L.jsmpeg_hip_dist_check_exchange.argtypes = [vp, u64p, u64p, vp]
         L.jsmpeg_hip_dist_unique_id.restype = ctypes.c_int
         L.jsmpeg_hip_dist_unique_id.argtypes = [vp]
         L.jsmpeg_hip_dist_create.restype = vp
@@ -152,6 +155,12 @@ class Dist:
                                            self._arr(recv_offsets), self._arr(recv_sizes), stream) != 0:
             raise RuntimeError(_batch.last_error())
 
+    def check_exchange(self, send_sizes, recv_sizes, stream=None):
+        """plan time, every rank: the tables of all ranks compared through the communicator itself; raises on every rank
+        when a pair disagrees (the library's own check, for hosts without another control plane)"""
+        if self.L.jsmpeg_hip_dist_check_exchange(self.h, self._arr(send_sizes), self._arr(recv_sizes), stream) != 0:
+            raise RuntimeError(_batch.last_error())
+
     def gather(self, dst_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
         if self.L.jsmpeg_hip_dist_gather(self.h, dst_rank, src_ptr, self._arr(offsets), self._arr(sizes), dst_ptr, stream) != 0:
             raise RuntimeError(_batch.last_error())
@@ -159,6 +168,41 @@ class Dist:
     def allgather(self, src_ptr, dst_ptr, bytes_per_rank, stream=None):
         if self.L.jsmpeg_hip_dist_allgather(self.h, src_ptr, dst_ptr, int(bytes_per_rank), stream) != 0:
             raise RuntimeError(_batch.last_error())
+
+
+# ---- an exchange plan is checked BEFORE anything is enqueued (a mismatch between what rank a sends to r and what r
+# expects from a is a ncclRecv that never completes: the job hangs) ----
+
+def exchange_mismatches(send_tables, recv_tables):
+    """send_tables[a][r] = bytes rank a sends to rank r, recv_tables[r][a] = bytes rank r expects from rank a (every rank's
+    tables, in rank order).  Returns [(a, r, sent, expected)] for every pair that disagrees -- the same list on every rank
+    that holds the same tables, so all of them refuse together."""
+    world = len(send_tables)
+    bad = []
+    for a in range(world):
+        if len(send_tables[a]) != world or len(recv_tables[a]) != world:
+            bad.append((a, a, len(send_tables[a]), len(recv_tables[a])))
+            continue
+    if bad:
+        return bad
+    for a in range(world):
+        for r in range(world):
+            if int(send_tables[a][r]) != int(recv_tables[r][a]):
+                bad.append((a, r, int(send_tables[a][r]), int(recv_tables[r][a])))
+    return bad
+
+
+def verify_exchange_plan(allgather, send_bytes, recv_bytes, what="exchange"):
+    """Plan-time check of one rank's tables against everybody's: allgather(obj) -> [obj of rank 0, ...] over the job's
+    control plane (torch.distributed all_gather_object, any backend).  Raises RuntimeError ON EVERY RANK, with the
+    offending pairs, when a rank's send table does not mirror its peers' receive tables."""
+    tables = allgather(([int(x) for x in send_bytes], [int(x) for x in recv_bytes]))
+    bad = exchange_mismatches([t[0] for t in tables], [t[1] for t in tables])
+    if bad:
+        raise RuntimeError("%s plan refused: " % what + "; ".join(
+            "rank %d sends %d bytes to rank %d, which expects %d" % (a, n, r, m) for a, r, n, m in bad[:8])
+            + (" (+ %d more)" % (len(bad) - 8) if len(bad) > 8 else "") + " -- enqueued, the receive would never complete")
+    return tables
 
 
 # ---- numpy restatements (what tests/test_distributed.py holds the C code against) ----
@@ -544,6 +588,7 @@ def resolve_history_dist(b, hist, hists, owner, rank, world, comm, redecode, fra
                 if f is not None:
                     copy_frame(send_addr + cur[r], f)
                 cur[r] += frame_bytes
+        verify_exchange_plan(comm.allgather, send_n, recv_n, "history exchange (round %d)" % rounds)
         comm.exchange(send_addr, send_off, send_n, recv_addr, recv_off, recv_n)
         del send_keep
         cur = list(recv_off)

@@ -112,7 +112,8 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 
 	// k_parse, one emulated 64-lane wavefront at a time: same lane functions, same scheduling rule
 	// (results do not depend on the rule; the counters do)
-	static uint32_t es_ring[JM_ES_RING_ROWS][JM_RING_STRIDE], tk_ring[JM_TK_RING / 2][JM_RING_STRIDE];
+	static uint32_t es_ring[JM_ES_RING_ROWS][JM_RING_STRIDE];
+	static uint16_t tk_ring[JM_TK_RING][JM_RING_STRIDE];
 	for (uint32_t w0 = 0; w0 < n_sc; w0 += 64) {
 		JmLane L[64];
 		JmSliceCtx C[64];
@@ -120,7 +121,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 		for (int l = 0; l < 64; l++) {
 			const uint32_t i = w0 + (uint32_t)l;
 			L[l].es_ring = &es_ring[0][l]; L[l].tk_ring = &tk_ring[0][l];
-			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].tw = L[l].tflushed = 0;
+			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].tw7 = L[l].tf7 = 0;
 			mine[l] = false;
 			C[l].lut = &luts; C[l].epoch = epoch;
 			if (i >= n_sc || owner[i] == JM_NONE) continue;

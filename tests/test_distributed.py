@@ -148,6 +148,12 @@ def _worker_local(rank, port, oracle_path, q):
         for u, b, e in zip(lay["units"], lay["begin"], lay["end"]):
             if u in my_bytes and owner[u] == rank:
                 work[int(b):int(e)] = my_bytes[u]
+        def allgather(obj):
+            out = [None] * WORLD
+            dist.all_gather_object(out, obj)
+            return out
+
+        jd.verify_exchange_plan(allgather, lay["send_bytes"], lay["recv_bytes"])      # plan time: before anything is enqueued
         reqs = []
         for r in range(WORLD):
             if r == rank:
@@ -203,6 +209,56 @@ def test_two_ranks_ingest_their_own_streams_and_move_only_the_imbalance(libs, hi
         # 3 + 1 streams of 3 units each: 9 + 3 -> 6 + 6, three units leave rank 0 and nothing leaves rank 1
         assert counts == [6, 6] and moved > 0
         assert (sent > 0) == (rank == 0)
+
+
+def _worker_asymmetric(rank, port, q):
+    """rank 0 plans to send rank 1 4096 bytes, rank 1 expects 1024: the receive would never complete.  Both ranks must
+    refuse at plan time, with the same message, and nothing may hang."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from jsmpeg_amd import distributed as jd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        def allgather(obj):
+            out = [None] * WORLD
+            dist.all_gather_object(out, obj)
+            return out
+
+        send = [0, 4096] if rank == 0 else [512, 0]
+        recv = [0, 512] if rank == 0 else [1024, 0]
+        try:
+            jd.verify_exchange_plan(allgather, send, recv, "test exchange")
+            q.put((rank, None))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        # a symmetric plan passes on both ranks
+        jd.verify_exchange_plan(allgather, [0, 4096] if rank == 0 else [512, 0], [0, 512] if rank == 0 else [4096, 0])
+        q.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_asymmetric_exchange_plan_is_refused_on_every_rank_before_anything_is_enqueued():
+    import torch.multiprocessing as mp
+    from jsmpeg_amd import distributed as jd
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_asymmetric, args=(r, port, q)) for r in range(WORLD)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=120) for _ in range(2 * WORLD)]
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    refusals = {r: m for r, m in got if m != "ok"}
+    assert set(refusals) == {0, 1} and refusals[0] == refusals[1]
+    assert "rank 0 sends 4096 bytes to rank 1, which expects 1024" in refusals[0]
+    assert sorted(r for r, m in got if m == "ok") == [0, 1]
+    # the table check itself: every disagreeing pair, nothing else
+    assert jd.exchange_mismatches([[0, 5], [7, 0]], [[0, 7], [5, 0]]) == []
+    assert jd.exchange_mismatches([[0, 5], [7, 0]], [[0, 7], [6, 0]]) == [(0, 1, 5, 6)]
+    assert jd.exchange_mismatches([[1, 5], [7, 0]], [[2, 7], [5, 0]]) == [(0, 0, 1, 2)]
 
 
 def test_rebalance_plan_equals_its_restatement_and_moves_nothing_when_balanced(hip_lib):
