@@ -94,11 +94,45 @@ def pack(streams):
     return buf, np.array(begin, np.uint32), np.array(end, np.uint32)
 
 
+def host_cores():
+    """The cores this process may really use: its affinity mask, capped by the cgroup's CPU quota (cpu.max; v1:
+    cpu.cfs_quota_us / cpu.cfs_period_us).  os.cpu_count() says what the machine has, not what the container gets."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    info = {"affinity": n, "os_cpu_count": os.cpu_count()}
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        info["cgroup_quota"] = round(quota, 2)
+        n = max(1, min(n, int(quota + 0.999)))
+    try:     # hardware threads per physical core (SMT): two decoders on one core's two threads do not each get a core
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        info["threads_per_core"] = len([x for part in sib.split(",") for x in (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1))])
+    except (OSError, ValueError):
+        pass
+    return n, info
+
+
 def cpu_baseline(sample_streams, width, height):
     """The reference's own decoder on the host cores, on a bounded sample of the same workload.
     value = the reference's shipped wasm build under Node (what BASELINE.json names), single core;
-    also the reference's C compiled natively (oracle/_ref/libjsmpeg_ref.so)."""
-    from jsmpeg_amd import build, cabi
+    also the reference's C compiled natively (oracle/_ref/libjsmpeg_ref.so); the same on every core this process may
+    use (all_cores); and BASELINE.json's configs[0] as it is written (cfg0: 320x240 I-only .ts through the reference's
+    demuxer and JS / wasm decoders)."""
+    from jsmpeg_amd import build, cabi, synth
     res = {"value": None, "unit": "frames/s", "cores": 1, "kind": "reference",
            "sample": "%d of the step's streams (1920x1080, %d pictures each), decoded one after another on one core"
                      % (len(sample_streams), FRAMES_PER_STREAM)}
@@ -140,18 +174,49 @@ def cpu_baseline(sample_streams, width, height):
                                           "1 core, median of 3" % rj.get("node", "?"))
                     except Exception as e:
                         res["js_error"] = repr(e)[:200]
-                nproc = os.cpu_count() or 1
-                par = nproc              # all cores = what nproc says on this box
+                # every core this process may use: one Node process per core, each decoding one of the sample streams over
+                # and over for >= 3 s of DECODE time after one warm-up pass (start-up, file reads, wasm compile and JIT tier-up
+                # are outside what it reports)
+                par, core_info = host_cores()
+                loop_s = 3.0
                 t0 = time.perf_counter()
-                procs = [subprocess.Popen(["node", host, wasm, "--once", paths[i % len(paths)]],
+                procs = [subprocess.Popen(["node", host, wasm, "--loop", str(loop_s), paths[i % len(paths)]],
                                           stdout=subprocess.PIPE) for i in range(par)]
                 outs = [json.loads(p.communicate()[0]) for p in procs]
                 wall = time.perf_counter() - t0
-                res["all_cores"] = {"value": round(sum(o["frames"] for o in outs) / max(o["seconds"] for o in outs), 2),
-                                    "cores": par, "host_cores": nproc, "wall_s": round(wall, 2),
-                                    "note": "%d independent Node processes, one stream each" % par}
+                agg = sum(o["frames"] / o["seconds"] for o in outs)
+                per_core = agg / par
+                allc = {"value": round(agg, 2), "cores": par, "per_core": round(per_core, 2),
+                        "per_core_over_single_core": round(per_core / r["fps"], 3), "wall_s": round(wall, 2), "host": core_info,
+                        "note": "%d independent Node processes (one per core of the affinity mask, capped by the cgroup quota), each looping one "
+                                "stream for >= %.0f s of decode time after a warm-up pass; value = sum of their frames / decode seconds" % (par, loop_s)}
+                if not 0.7 <= allc["per_core_over_single_core"] <= 1.3:
+                    allc["why_not_linear"] = ("%d hardware threads per physical core share its execution units (the single-core figure had a core to itself), "
+                                              "and %d decoders stream %d MB of planes each through the shared caches and memory; all-core clocks are lower than one busy core's"
+                                              % (core_info.get("threads_per_core", 1), par, width * height * 3 // 2 * 2 // 1000000 + 1))
+                res["all_cores"] = allc
             except Exception as e:  # the baseline is reported, never fatal
                 res["wasm_error"] = repr(e)[:200]
+            # BASELINE.json configs[0] AS WRITTEN: 320x240 I-frame-only .ts via the reference's JS / wasm decoder under Node, CPU only
+            try:
+                ts_host, js_bundle = os.path.join(ROOT, "oracle", "ts_baseline.js"), build.JS_REF
+                if os.path.exists(ts_host) and os.path.exists(js_bundle):
+                    es0, offs0 = synth.generate_config("cfg0_240p_intra", n_frames=300)[:2]
+                    ts0 = np.asarray(synth.mux_ts(es0, offs0), dtype=np.uint8)
+                    p0 = os.path.join(td, "cfg0.ts")
+                    ts0.tofile(p0)
+                    c0 = {"unit": "frames/s", "cores": 1, "kind": "reference",
+                          "sample": "configs[0]: one 320x240 I-frame-only stream, 300 pictures, as a %d-byte MPEG-TS file" % len(ts0),
+                          "via": "the reference's own Demuxer.TS -> Decoder.MPEG1Video / MPEG1VideoWASM (+ its WASMModule loader and inlined wasm binary), "
+                                 "all from the shipped jsmpeg.min.js, under Node; timed: demux + write + decode, median of 3 passes after a warm-up pass"}
+                    for impl in ("wasm", "js"):
+                        rr = json.loads(subprocess.check_output(["node", ts_host, js_bundle, impl, p0], timeout=300))
+                        assert rr["frames"] == 300, rr
+                        c0["value" if impl == "wasm" else "js_fps"] = round(rr["fps"], 2)
+                        c0["node"] = rr.get("node")
+                    res["cfg0"] = c0
+            except Exception as e:
+                res["cfg0_error"] = repr(e)[:200]
     if res["value"] is None and "native_c_fps" in res:
         res["value"] = res["native_c_fps"]
         res["sample"] += " (wasm baseline unavailable: value is the native C build)"
@@ -160,11 +225,11 @@ def cpu_baseline(sample_streams, width, height):
 
 OTHER_CONFIGS = (
     # (BASELINE.json config it stands for, generator config, streams, pictures per stream, streams checked against the oracle)
-    ("configs[0] shape: 320x240 I-frame-only", "cfg0_240p_intra", 64, 300, 2),
+    ("configs[0] shape: 320x240 I-frame-only", "cfg0_240p_intra", 64, 300, 4),
     ("configs[1]: 1280x720 I+P, single stream", "cfg1_720p", 1, 360, 1),
-    ("configs[1] content, 64 streams batched", "cfg1_720p", 64, 120, 2),
-    ("configs[4] content (3840x2160 high bitrate), 16 streams", "cfg4_2160p", 16, 24, 1),
-    ("configs[4] content (3840x2160 high bitrate), 64 streams", "cfg4_2160p", 64, 24, 1),
+    ("configs[1] content, 64 streams batched", "cfg1_720p", 64, 120, 4),
+    ("configs[4] content (3840x2160 high bitrate), 16 streams", "cfg4_2160p", 16, 24, 4),
+    ("configs[4] content (3840x2160 high bitrate), 64 streams", "cfg4_2160p", 64, 24, 4),
 )
 
 
@@ -263,15 +328,23 @@ def other_configs(device, passes=5):
                 per = {}
                 for p, i in enumerate(b.pictures()):
                     per.setdefault(i.stream, []).append(int(dev[p]))
-                checked = sorted(set([0, n_streams - 1][:n_check]))
-                for s_ in checked:
+                # the first, the last and two from the middle (all of them when the batch has fewer), each on its own host thread
+                checked = sorted(set([0, n_streams - 1, n_streams // 3, (2 * n_streams) // 3][:max(1, n_check)])) if n_streams > 1 else [0]
+                bad = []
+
+                def gate(s_):
                     want = []
                     with cabi.Mpeg1Decoder(lib_oracle, len(streams[s_]) + 1024, cabi.MODE_EXPAND) as dec:
                         dec.write(streams[s_])
                         while dec.decode():
                             want.append(hashing.frame_hash(*dec.planes()))
                     if per.get(s_, []) != want:
-                        raise RuntimeError("PARITY FAILURE against the oracle on stream %d" % s_)
+                        bad.append(s_)
+                gts = [threading.Thread(target=gate, args=(s_,)) for s_ in checked]
+                [t.start() for t in gts]
+                [t.join() for t in gts]
+                if bad:
+                    raise RuntimeError("PARITY FAILURE against the oracle on streams %r" % sorted(bad))
                 info = b.recon_info()
             med = statistics.median(ms)
             alg = es_bytes + 384 * stats["macroblocks"] + 384 * stats["predicted"]
@@ -291,6 +364,70 @@ def other_configs(device, passes=5):
     return out
 
 
+def via_napi(streams, want_hashes, width, height, frames, steps, warmup, device):
+    """The same batch driven from the host north_star names -- Node.js over the N-API addon (tools/bench_node.js,
+    JSMpeg.HIPBatch): inputs uploaded once, `warmup` untimed and `steps` timed decode() calls, every picture's device hash
+    against what the oracle said (want_hashes: {stream: [int]}).  A reported extra, never `value`."""
+    import tempfile
+    addon = os.path.join(ROOT, "jsmpeg_amd", "js", "jsmpeg_hip.node")
+    if not os.path.exists(addon):
+        return {"error": "jsmpeg_amd/js/jsmpeg_hip.node is not built"}
+    with tempfile.TemporaryDirectory() as td:
+        for i, es in enumerate(streams):
+            es.tofile(os.path.join(td, "s%d.m1v" % i))
+        hp = os.path.join(td, "hashes.json")
+        json.dump({str(k): ["%016x" % h for h in v] for k, v in want_hashes.items()}, open(hp, "w"))
+        cmd = ["node", os.path.join(ROOT, "tools", "bench_node.js"), "--dir", td, "--streams", str(len(streams)), "--width", str(width),
+               "--height", str(height), "--frames", str(frames), "--steps", str(steps), "--warmup", str(warmup), "--hashes", hp,
+               "--device", str(device)]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"error": "no result (rc %d): %s" % (p.returncode, p.stderr.decode()[-300:])}
+        return json.loads(lines[-1])
+
+
+def counters_in_this_run(args, n_streams, frames):
+    """HBM traffic and instruction counts of the kernels, measured BY this run: two steps of this very program again under
+    rocprofv3, one --pmc pass per counter (counters only + the kernel trace; FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU are not
+    collectable together).  Returns {"fetch_bytes": {kernel: bytes}, "write_bytes": ..., "valu": ..., "source": ...} with
+    the guide's corrections applied (KiB -> bytes; gfx950's FETCH_SIZE counts half of streamed reads: x 2), or {"error": ...}."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {"error": "rocprofv3 is not on PATH"}
+    out = {"fetch_bytes": {}, "write_bytes": {}, "valu": {}, "dispatches": {}}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--streams", str(n_streams), "--frames", str(frames),
+             "--no-cpu-baseline", "--no-other-configs", "--no-h2d", "--no-audio", "--no-napi", "--no-counters"]
+    env = dict(os.environ, TMPDIR="/tmp", JSMPEG_BENCH_PARITY_STREAMS="0")     # the child's gate: one stream (the parent gated them all)
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counters, key in ((("FETCH_SIZE",), "fetch_bytes"), (("WRITE_SIZE",), "write_bytes"), (("SQ_INSTS_VALU",), "valu")):
+            d = os.path.join(td, key)
+            try:
+                p = subprocess.run([exe, "--kernel-trace", "--pmc"] + list(counters) + ["-d", d, "--"] + child, cwd="/tmp", env=env,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            except subprocess.TimeoutExpired:
+                return {"error": "rocprofv3 --pmc %s timed out" % counters[0]}
+            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+            if p.returncode != 0 or not dbs:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %s" % (counters[0], p.returncode, p.stderr.decode()[-200:])}
+            db = sqlite3.connect(dbs[-1])
+            for name, cnt, avg in db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                                             "group by kernel_name", (counters[0],)):
+                k = name.split("(")[0]
+                if not k.startswith("k_"):
+                    continue
+                out["dispatches"][k] = cnt
+                out[key][k] = int(avg * 1024 * 2) if key == "fetch_bytes" else (int(avg * 1024) if key == "write_bytes" else int(avg))
+    out["source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (one pass each) over "
+                     "`bench.py --steps 2 --warmup 1` of the same workload, per-dispatch averages; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes "
+                     "(MI355X_MICROARCH.md: gfx950's FETCH_SIZE counts half of streamed reads)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,6 +442,8 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra run that starts every step from host memory (value_incl_h2d)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the witnessed timings of the other BASELINE.json configurations (other_configs)")
     ap.add_argument("--two-batches", action="store_true", help="report two_batches_in_flight even with --no-other-configs (it is part of the default line)")
+    ap.add_argument("--no-napi", action="store_true", help="skip the Node-hosted run of the same batch (value_via_napi)")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc passes over two steps of this same program (roofline.traffic measured in this run)")
     args = ap.parse_args()
     args.h2d = False
 
@@ -341,7 +480,8 @@ def main():
         from jsmpeg_amd import distributed as jd
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("JSMPEG_BENCH_CONTROL_TIMEOUT", "600"))))
         box = [jd.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         D = jd.Dist(rank, world, box[0], device=local_rank)
@@ -435,6 +575,15 @@ def main():
         d_work = [torch.from_numpy(h_work).to(dev) for _ in range(2)]   # what arrives lands behind the kept units, double-buffered
         del h_send, h_work, my_bytes
         sent_by_rank = [int(sum(ly["send_bytes"])) for ly in lays]
+        # plan time, every rank: what a sends to r is what r expects from a -- a disagreement is refused HERE, on all ranks,
+        # not discovered as a receive that never completes (control plane, and the library's own check over RCCL)
+
+        def _allgather(obj):
+            out_ = [None] * world
+            dist.all_gather_object(out_, obj)
+            return out_
+        jd.verify_exchange_plan(_allgather, lay["send_bytes"], lay["recv_bytes"], "local-ingest exchange")
+        D.check_exchange(lay["send_bytes"], lay["recv_bytes"], sptr)
         modes = {
             "single_source": dict(begin=mine["begin"], end=mine["end"], shard_len=shard_len, bufs=d_piece, units_of_rank=[p["units"] for p in pieces],
                                   owner=owner, hists=[jd.HistoryRank(table, p["units"]) for p in pieces],
@@ -463,7 +612,32 @@ def main():
         b.upload_device(ctypes.c_void_p(d_es.data_ptr()), shard_len, begin, end, sptr)
 
     overlap = multi and not os.environ.get("JSMPEG_BENCH_NO_OVERLAP")
-    state = {"cur": 0, "pending": None}
+    state = {"cur": 0, "pending": None, "n": 0}
+
+    # N > 1: nothing waits for the device for ever.  A step that hangs (a peer that never sends, a receive posted for
+    # bytes that are not coming) costs STEP_LIMIT seconds, names its rank and its call on stderr and ends the rank with
+    # status 3 (torchrun then ends the others) -- not the driver's whole lease.
+    STEP_LIMIT = float(os.environ.get("JSMPEG_BENCH_STEP_TIMEOUT", "180"))
+
+    def bounded_wait(events, what):
+        t_w = time.perf_counter()
+        while not all(e.query() for e in events):
+            if time.perf_counter() - t_w > STEP_LIMIT:
+                sys.stderr.write("bench.py: rank %d of %d: %s did not complete within %.0f s -- giving up (JSMPEG_BENCH_STEP_TIMEOUT)\n"
+                                 % (rank, world, what, STEP_LIMIT))
+                sys.stderr.flush()
+                os._exit(3)
+            time.sleep(0.0002)
+
+    def bounded_sync(what):
+        if not multi:
+            return
+        evs = []
+        for st_ in (stream, xfer):
+            e_ = torch.cuda.Event()
+            e_.record(st_)
+            evs.append(e_)
+        bounded_wait(evs, what)
 
     def start_scatter(i):
         # the path's one exchange step: the compressed units, grouped RCCL send / recv over xGMI -- rank 0 -> owners
@@ -503,6 +677,7 @@ def main():
             if state["pending"] is None:
                 state["pending"] = start_scatter(state["cur"])
             e0, e1 = state["pending"]
+            bounded_wait([e1], "step %d: the %s of this step's units (RCCL)" % (state["n"], "scatter from rank 0" if X is modes["single_source"] else "rank-to-rank exchange"))
             stream.wait_event(e1)
             # the piece is decoded where it arrived (no placement pass); its buffer is next written by the scatter two steps on,
             # which waits for this stream (start_scatter)
@@ -534,7 +709,9 @@ def main():
         n = b.decode(stream=sptr, sync=False)
         if n != n_pictures:
             raise SystemExit("rank %d: decoded %d pictures, expected %d" % (rank, n, n_pictures))
+        state["n"] = state.get("n", 0) + 1
         if collect:
+            bounded_sync("step %d: the decode kernels" % state["n"])
             t = b.timings()           # waits for the step's last event
             for k in phase:
                 phase[k] += t[k]
@@ -559,9 +736,10 @@ def main():
     def timed_run(steps, warmup):
         pool_pictures = n_pictures
         pool = torch.as_tensor(_DevMem(b.frame_pool_ptr, pool_pictures * frame_stride), device=dev).view(pool_pictures, frame_stride)
-        state["cur"], state["pending"] = 0, None
+        state["cur"], state["pending"], state["n"] = 0, None, 0
         for i in range(warmup):
             step(False, i + 1 < warmup)      # nothing is prefetched across the warm-up / timed boundary
+        bounded_sync("the warm-up steps")
         torch.cuda.synchronize()
         pool.fill_(0xA5)
         torch.cuda.synchronize()
@@ -578,6 +756,7 @@ def main():
                 scrub["events"] = (e0, e1)
                 scrub["frames"] = len(range(steps % SCRUB_EVERY, pool_pictures, SCRUB_EVERY))
             step(True, i + 1 < steps)
+        bounded_sync("the last timed step")
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -752,6 +931,8 @@ def main():
         parity_gate(X["units_of_rank"], "every rank its own streams")
         tot = torch.tensor([float(n_pictures)], dtype=torch.float64)
         dist.all_reduce(tot)
+        local_run = {"elapsed": dt, "phase": dict(phase), "level_ms": list(level_ms), "recon_how": dict(recon_how), "n_pictures": n_pictures,
+                     "uncovered": b.counters()["uncovered_pictures"]}
         local_ingest = {"value": round(float(tot.item()) * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
                         "bytes_leaving_busiest_rank_per_step": max(sent_by_rank), "bytes_leaving_each_rank_per_step": sent_by_rank,
                         "units_this_rank": X["n_units"], "exchange_ms_avg_rank0": round(sum(X["ms"]) / max(1, len(X["ms"])), 3),
@@ -781,7 +962,7 @@ def main():
 
     if multi:
         totals = [None] * world
-        dist.all_gather_object(totals, (es_bytes, stats["macroblocks"], stats["predicted"], deviating, uncovered))
+        dist.all_gather_object(totals, (es_bytes, stats["macroblocks"], stats["predicted"], deviating, uncovered, phase["total_ms"] / max(1, args.steps)))
     if rank != 0:
         if multi:
             D.close()
@@ -821,6 +1002,26 @@ def main():
         alg_bytes_rank = es_bytes + 384 * stats["macroblocks"] + 384 * stats["predicted"]
         job_alg_bytes = alg_bytes_rank
         pred_rank = stats["predicted"]
+    # ---- N > 1: which ingest mode is the headline.  north_star words the single source ("RCCL ... of stream slices"): it
+    # stays the headline as long as its scatter is fully hidden -- the step takes what the slowest rank's kernels take.
+    # Where it is not (rank 0's links carry every other rank's units every step), the mode in which every rank ingests its
+    # own streams and only the imbalance travels is the job as it would be deployed, and it becomes `value`; the other
+    # mode's figures stay beside it in `exchange`.
+    headline_mode, single_source_run = "single_source", None
+    if multi and local_ingest:
+        kernels_ms = max(t[5] for t in totals)                      # the slowest rank's decode kernels per step, single-source run
+        single_ms = elapsed / args.steps * 1e3
+        hidden = single_ms <= 1.03 * kernels_ms
+        single_source_run = {"value": round(sum(unit_pics) * args.steps / elapsed, 1), "unit": "frames/s", "ms_per_step": round(single_ms, 3),
+                             "slowest_rank_kernels_ms": round(kernels_ms, 3), "scatter_fully_hidden": bool(hidden)}
+        if not hidden and local_ingest["value"] > single_source_run["value"]:
+            headline_mode = "local_ingest"
+            elapsed = local_run["elapsed"]
+            phase.update(local_run["phase"])
+            level_ms[:] = local_run["level_ms"]
+            recon_how.clear()
+            recon_how.update(local_run["recon_how"])
+            n_pictures = local_run["n_pictures"]
     ms_per_step = elapsed / args.steps * 1e3
     fps = g_pictures * args.steps / elapsed
     k = args.steps
@@ -927,8 +1128,10 @@ def main():
                    "content": "uniform-random synthetic syntax elements (SURVEY.md 8d): every macroblock its own random motion "
                               "vector (+-8 / 16 / 32 pixels by f_code), random levels -- no spatial or temporal coherence, the worst "
                               "case for the prediction reads' cache lines; says nothing about coherent-motion content",
-                   "parallelism": ("(stream, GOP) units sharded over %d rank(s): grouped RCCL send / recv from rank 0 every step, "
-                                   "overlapped with the previous step's kernels" % world) if multi else "one rank, whole streams"},
+                   "parallelism": (("(stream, GOP) units sharded over %d rank(s): grouped RCCL send / recv from rank 0 every step, "
+                                    "overlapped with the previous step's kernels" % world) if headline_mode == "single_source" else
+                                   ("(stream, GOP) units sharded over %d rank(s): every rank ingests its own streams, the rebalancing plan's units "
+                                    "travel rank to rank (one RCCL group per step) beside the previous step's kernels" % world)) if multi else "one rank, whole streams"},
         "mpixel_per_s": round(fps * width * height / 1e6, 1),
         "parity_checked": ("every unit of every stream of every rank against the oracle fed the same unit (%d streams x %d pictures per rank)"
                            if multi else "every stream of every rank (%d x %d pictures per rank), device hash == oracle") % (len(check), frames),
@@ -944,6 +1147,18 @@ def main():
     if multi:
         sm = modes["single_source"]["ms"]
         exchange["scatter_ms_avg_rank0"] = round(sum(sm) / max(1, len(sm)), 3)
+        exchange["headline_mode"] = headline_mode
+        exchange["single_source"] = single_source_run
+        # what rank 0's links have to carry per step in the single-source mode: one piece per peer, each over its own xGMI
+        # link (7 links x ~153 GB/s per GPU: point to point, MI355X_MICROARCH.md) -- the floor of the scatter, beside its
+        # measured time and the step's
+        XGMI_LINK_GBS = 153.0
+        per_link = max([int(x) for x in psizes[1:]] or [0])
+        exchange["bytes_per_link_max_rank0"] = per_link
+        exchange["bytes_leaving_rank0_over_7_links"] = int(sum(psizes[1:]) / 7)
+        exchange["xgmi_link_GBps_assumed"] = XGMI_LINK_GBS
+        exchange["scatter_floor_ms"] = round(max(per_link, sum(psizes[1:]) / 7) / (XGMI_LINK_GBS * 1e9) * 1e3, 3)
+        exchange["scatter_over_step"] = round(exchange["scatter_ms_avg_rank0"] / max(1e-9, single_source_run["ms_per_step"] if single_source_run else ms_per_step), 3)
         exchange["local_ingest"] = local_ingest
         exchange["note"] = ("scatter of step k+1 runs on its own HIP stream beside the kernels of step k; its time is inside "
                             "ms_per_step only where it is not hidden")
@@ -972,6 +1187,21 @@ def main():
         except Exception as e:
             log("two batches in flight failed: %r" % (e,))
             line["two_batches_in_flight"] = {"error": repr(e)[:300]}
+    # the same batch from the host north_star names: Node.js over the N-API addon (never `value`)
+    if world == 1 and not multi and not args.no_napi:
+        try:
+            hs = {s_: oracle_hashes(("stream", s_), streams[s_]) for s_ in check}
+            r_n = via_napi(streams, hs, width, height, frames, args.steps, args.warmup, local_rank)
+            if "value" in r_n:
+                r_n["value"] = round(r_n["value"], 1)
+                r_n["ms_per_step"] = round(r_n["ms_per_step"], 3)
+                r_n["over_value"] = round(r_n["value"] / fps, 4)
+                r_n["note"] = ("tools/bench_node.js: JSMpeg.HIPBatch (jsmpeg_amd/js/batch-hip.js) over jsmpeg_hip.node, the same %d streams uploaded once, "
+                               "%d warm-up and %d timed decode() calls on the host clock, every picture's device hash against the oracle's" % (n_streams, args.warmup, args.steps))
+            line["value_via_napi"] = r_n
+        except Exception as e:
+            log("Node-hosted run failed: %r" % (e,))
+            line["value_via_napi"] = {"error": repr(e)[:300]}
     if world == 1 and not args.no_other_configs:
         try:
             b.close()                       # the headline batch's 24 GB frame pool, before the other shapes take theirs
@@ -990,6 +1220,46 @@ def main():
         except Exception as e:
             log("audio stage figure failed: %r" % (e,))
             line["audio_stage"] = {"error": repr(e)}
+    # the counters that price the kernels' waste, measured by THIS run (N = 1, rank 0, everything else done and its memory
+    # released): two steps of this program again under rocprofv3, one --pmc pass per counter; the static figures of the last
+    # committed profile stay only where rocprofv3 is missing or a pass fails (and say so)
+    if world == 1 and not multi and not args.no_counters and not os.environ.get("JSMPEG_BENCH_COUNTERS_CHILD"):
+        try:
+            b.close()
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        t_c = time.perf_counter()
+        os.environ["JSMPEG_BENCH_COUNTERS_CHILD"] = "1"
+        cn = counters_in_this_run(args, n_streams, frames)
+        log("counter passes: %s in %.1fs" % ("ok" if "error" not in cn else cn["error"], time.perf_counter() - t_c))
+        if "error" not in cn:
+            k = roofline["kernel"]
+            if k in cn["fetch_bytes"] and k in cn["write_bytes"]:
+                t_b = cn["fetch_bytes"][k] + cn["write_bytes"][k]
+                roofline["traffic"] = int(t_b)
+                roofline["traffic_source"] = cn["source"]
+                roofline["traffic_rate"] = round(t_b / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                roofline["traffic_over_algorithmic"] = round(t_b / max(1, roofline["algorithmic_bytes_per_launch"]), 3)
+                roofline["traffic_split"] = {"fetch_bytes": cn["fetch_bytes"][k], "write_bytes": cn["write_bytes"][k]}
+            if parse_roof and "k_parse" in cn["valu"]:
+                n_inst = cn["valu"]["k_parse"]
+                parse_roof["instructions_per_pass"] = int(n_inst)
+                parse_roof["instructions_source"] = "measured in this run (SQ_INSTS_VALU pass; see roofline.traffic_source)"
+                parse_roof["achieved"] = round(n_inst / (parse_roof["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                parse_roof["frac"] = round(parse_roof["achieved"] / parse_roof["peak"], 4)
+                parse_roof["frac_at_slow_class_rate"] = round(parse_roof["achieved"] / (1024 / 1.8), 4)
+                parse_roof["simd_issue_busy"] = round(n_inst * 4 / 1024 / (parse_roof["avg_launch_ms"] * 1e-3) / 2.29e9, 3)
+                parse_roof["simd_issue_busy_note"] = ("instructions x 4 clocks / 1024 SIMDs / the pass's time at the 2.29 GHz the pass runs at (GRBM_GUI_ACTIVE, "
+                                                      "profiles/r05_parse_notes.md): the share of the SIMDs' issue slots the pass fills -- the rest is the pass's tail")
+                if "k_parse" in cn["fetch_bytes"] and "k_parse" in cn["write_bytes"]:
+                    parse_roof["hbm_fetch_over_es"] = round(cn["fetch_bytes"]["k_parse"] / max(1, es_bytes), 2)
+                    parse_roof["hbm_traffic_over_es"] = round((cn["fetch_bytes"]["k_parse"] + cn["write_bytes"]["k_parse"]) / max(1, es_bytes), 2)
+                    parse_roof["write_bytes"] = cn["write_bytes"]["k_parse"]
+            if "k_recon" in cn["valu"]:
+                roofline["valu_instructions_per_launch"] = cn["valu"]["k_recon"]
+        else:
+            roofline["counters_error"] = cn["error"]
     json_out.write(json.dumps(line) + "\n")
     json_out.flush()
     if multi:

@@ -420,7 +420,10 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	else i = j;
 	JmLane L;
 	L.es_ring = (jm_es_ring_t)reinterpret_cast<uintptr_t>(&es_ring[wave][0][lane]);     /* LDS byte addresses (the low half of the generic address) */
-	L.tk_ring = (jm_tk_ring_t)reinterpret_cast<uintptr_t>(&tk_ring[wave][0][lane]);
+	/* the token column of lane l sits at 16-bit position 2 (l & 31) + (l >> 5) of a slot's row: lanes l and l + 32 share a
+	 * dword, the 32 lanes of one LDS pass touch 32 different banks whatever slots they are at (with lane l at position l,
+	 * neighbours shared a bank: twice the bank-conflict cycles of the round-4 dword rows, profiles/r05_parse_notes.md) */
+	L.tk_ring = (jm_tk_ring_t)reinterpret_cast<uintptr_t>(&tk_ring[wave][0][2 * (lane & 31) + (lane >> 5)]);
 	L.state = JM_ST_DONE;
 	JmSliceCtx c;
 	c.lut = &lut;

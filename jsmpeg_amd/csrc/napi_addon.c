@@ -35,6 +35,7 @@
  *   batchReadRGBA(handle, p, Uint8ClampedArray)                      jsmpeg_hip_batch_read_rgba
  *   batchGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
  *   batchTimings(handle) -> {indexMs, hostMs, parseMs, reconMs, totalMs}
+ *   batchFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures    jsmpeg_hip_batch_frame_hashes (device-side 64-bit plane hashes)
  *
  * MP2 audio (include/jsmpeg_hip.h part 3; what module.instance.exports._mp2_decoder_* is for the reference's
  * src/mp2-wasm.js:21-104), used by jsmpeg_amd/js/mp2-hip.js:
@@ -535,6 +536,24 @@ static napi_value fn_batch_read_rgba(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* batchFrameHashes(handle, Uint8Array(8 * pictures)): the device-computed 64-bit content hash of every picture's planes
+ * (jsmpeg_hip_batch_frame_hashes), little-endian, picture after picture -- 8 bytes per picture instead of the planes */
+static napi_value fn_batch_frame_hashes(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b || argc < 2) return NULL;
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (napi_get_typedarray_info(env, argv[1], &t, &len, &data, &ab, &off) != napi_ok || t != napi_uint8_array ||
+	    len < 8u * (size_t)jsmpeg_hip_batch_picture_count(b) || ((uintptr_t)data & 7u)) {
+		napi_throw_type_error(env, NULL, "jsmpeg_hip: the hash target must be an 8-byte aligned Uint8Array of 8 bytes per picture"); return NULL;
+	}
+	if (jsmpeg_hip_batch_frame_hashes(b, (uint64_t *)data) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_uint32(env, jsmpeg_hip_batch_picture_count(b), &out));
+	return out;
+}
+
 static napi_value fn_batch_geometry(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1], out;
@@ -909,7 +928,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
 		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },
-		{ "batchGeometry", fn_batch_geometry }, { "batchTimings", fn_batch_timings },
+		{ "batchGeometry", fn_batch_geometry }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },
 		{ "mp2GetIndex", fn_mp2_get_index }, { "mp2SetIndex", fn_mp2_set_index }, { "mp2GetSampleRate", fn_mp2_get_sample_rate },
 		{ "mp2Decode", fn_mp2_decode }, { "mp2GetChannels", fn_mp2_get_channels },

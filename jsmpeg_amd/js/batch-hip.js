@@ -121,6 +121,19 @@ function install(JSMpeg, options) {
   };
   HIPBatch.prototype.pictureInfo = function (p) { return this.native.batchPictureInfo(this.handle, p); };
   HIPBatch.prototype.timings = function () { return this.native.batchTimings(this.handle); };
+  // the device-computed 64-bit content hash of every picture of the last decode (Y | Cr | Cb planes), as 16 hex digits
+  // each, picture after picture: what a host compares instead of reading 3 MB of planes per picture back
+  HIPBatch.prototype.frameHashes = function () {
+    const raw = new Uint8Array(new ArrayBuffer(8 * Math.max(1, this.pictures)));
+    this.native.batchFrameHashes(this.handle, raw);
+    const out = new Array(this.pictures);
+    for (let p = 0; p < this.pictures; p++) {
+      let h = '';
+      for (let k = 7; k >= 0; k--) h += (raw[8 * p + k] + 256).toString(16).slice(1);      // little-endian u64 -> hex
+      out[p] = h;
+    }
+    return out;
+  };
 
   HIPBatch.prototype.readPlanes = function (p, target) {
     target = target || { y: new Uint8Array(this.lumaBytes), cr: new Uint8Array(this.chromaBytes), cb: new Uint8Array(this.chromaBytes) };

@@ -5,7 +5,7 @@
 // it travels to the GPU box where /root/reference does not exist.  The bundle is loaded into a `vm` context with the few
 // browser globals it touches at load time; the decoder is driven the way the player drives it: write() everything,
 // decode() until false, a sink that takes resize() / render() and does nothing.
-//   node js_baseline.js <jsmpeg.min.js> [--once] [--hash] <stream.m1v>...
+//   node js_baseline.js <jsmpeg.min.js> [--once | --loop seconds] [--hash] <stream.m1v>...
 'use strict';
 const fs = require('fs');
 const vm = require('vm');
@@ -14,8 +14,10 @@ const crypto = require('crypto');
 const args = process.argv.slice(2);
 const bundle = args.shift();
 const once = args.includes('--once');
+const loopAt = args.indexOf('--loop');
+const loop = loopAt >= 0 ? parseFloat(args[loopAt + 1]) : 0;   // --loop s: one warm-up pass, then passes until s seconds of decode time
 const hash = args.includes('--hash');
-const files = args.filter((a) => !a.startsWith('--'));
+const files = args.filter((a, i) => !a.startsWith('--') && !(loopAt >= 0 && i === loopAt + 1));
 
 const sandbox = {
   console, setTimeout, clearTimeout, WebAssembly,
@@ -49,6 +51,13 @@ function decodeAll(hashes) {
   return frames;
 }
 if (hash) { const h = []; decodeAll(h); process.stdout.write(JSON.stringify({ hashes: h }) + '\n'); process.exit(0); }
+if (loop > 0) {
+  decodeAll(null);                    // warm-up: wasm compile / JIT tiers
+  let total = 0, n = 0, passes = 0;
+  while (total < loop) { const t0 = process.hrtime.bigint(); n += decodeAll(null); total += Number(process.hrtime.bigint() - t0) / 1e9; passes++; }
+  process.stdout.write(JSON.stringify({ frames: n, seconds: total, fps: n / total, passes, node: process.version }) + '\n');
+  process.exit(0);
+}
 const times = [];
 let frames = 0;
 const reps = once ? 1 : 4;           // 1 warm-up + 3 timed

@@ -5,7 +5,7 @@
 // GPU box -- doing what that loader does: provide env.memory / _sbrk /
 // ___assert_fail / __memory_base, then drive the exported mpeg1_decoder_* ABI
 // the way src/mpeg1-wasm.js does (write all bytes, decode until false).
-//   node wasm_baseline.js <module.wasm> [--once] [--hash] <stream.m1v>...
+//   node wasm_baseline.js <module.wasm> [--once | --loop seconds] [--hash] <stream.m1v>...
 'use strict';
 const fs = require('fs');
 const crypto = require('crypto');
@@ -13,8 +13,10 @@ const crypto = require('crypto');
 const args = process.argv.slice(2);
 const wasmPath = args.shift();
 const once = args.includes('--once');
+const loopAt = args.indexOf('--loop');
+const loop = loopAt >= 0 ? parseFloat(args[loopAt + 1]) : 0;   // --loop s: one warm-up pass, then passes until s seconds of decode time
 const hash = args.includes('--hash');
-const files = args.filter((a) => !a.startsWith('--'));
+const files = args.filter((a, i) => !a.startsWith('--') && !(loopAt >= 0 && i === loopAt + 1));
 
 function leb(buf, pos) {
   let v = 0, shift = 0, b;
@@ -82,6 +84,13 @@ WebAssembly.instantiate(wasm, { env }).then(({ instance }) => {
     return frames;
   }
   if (hash) { const h = []; decodeAll(h); process.stdout.write(JSON.stringify({ hashes: h }) + '\n'); return; }
+  if (loop > 0) {
+    decodeAll(null);                    // warm-up: wasm compile / JIT tiers
+    let total = 0, n = 0, passes = 0;
+    while (total < loop) { const t0 = process.hrtime.bigint(); n += decodeAll(null); total += Number(process.hrtime.bigint() - t0) / 1e9; passes++; }
+    process.stdout.write(JSON.stringify({ frames: n, seconds: total, fps: n / total, passes, node: process.version }) + '\n');
+    return;
+  }
   const times = [];
   let frames = 0;
   const reps = once ? 1 : 4;           // 1 warm-up + 3 timed

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def run_bench(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "8", "--frames", "24", "--steps", "2", "--warmup", "1",
-                        "--no-audio", "--no-other-configs", "--no-h2d"] + list(args), capture_output=True, text=True, timeout=600)
+                        "--no-audio", "--no-other-configs", "--no-h2d"] + list(args), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "stdout must carry exactly one JSON line: %r" % lines[:3]
@@ -23,7 +23,7 @@ def run_bench(*args):
 
 
 def test_one_rank_line():
-    d = run_bench("--no-cpu-baseline", "--two-batches")
+    d = run_bench("--no-cpu-baseline", "--two-batches", "--no-napi", "--no-counters")
     two = d["two_batches_in_flight"]      # a reported extra: both batches' frame pools gated against the oracle
     assert two["value"] > 0 and two["passes"] == 24 and two["parity"].startswith("every picture of both frame pools"), two
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
@@ -39,8 +39,42 @@ def test_one_rank_line():
 
 
 def test_multi_rank_path_with_the_ranks_present():
-    d = run_bench("--force-dist", "--no-cpu-baseline")
+    d = run_bench("--force-dist", "--no-cpu-baseline", "--no-napi", "--no-counters")
     ex = d["exchange"]
     assert ex["units"] == 8 * 2 and ex["pictures_differing_from_unsplit_streams"] == 0 and ex["cross_rank_units_needing_history"] == 0
     assert ex["local_ingest"]["value"] > 0 and d["value"] > 0
+    assert "every unit of every stream" in d["parity_checked"]
+
+    assert ex["headline_mode"] in ("single_source", "local_ingest") and ex["single_source"]["value"] > 0
+    assert ex["scatter_floor_ms"] >= 0 and "scatter_over_step" in ex
+
+
+def test_line_carries_the_node_hosted_value_and_counters_measured_in_the_run():
+    """value_via_napi: the same batch through Node + the N-API addon, parity-gated, close to `value`;
+    roofline.traffic: measured by rocprofv3 passes this very run started (skipped where rocprofv3 is missing)."""
+    import shutil
+    d = run_bench("--no-cpu-baseline")
+    vn = d["value_via_napi"]
+    assert "error" not in vn, vn
+    assert vn["value"] > 0 and vn["parity"].startswith("device hash == oracle") and 0.5 < vn["over_value"] < 1.5, vn
+    rf = d["roofline"]
+    if shutil.which("rocprofv3"):
+        assert "counters_error" not in rf, rf.get("counters_error")
+        assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+        assert rf["traffic"] > 0 and rf["traffic_over_algorithmic"] > 0, rf
+        assert d["roofline_parse"]["instructions_source"].startswith("measured in this run")
+
+
+def test_two_ranks_on_two_gpus_when_the_box_has_them():
+    """First contact with more than one device must not be the driver's 8-GPU run: where >= 2 GPUs are visible, the real thing
+    -- two processes, two devices, RCCL between them, both ingest modes parity-gated against the UNSPLIT streams."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank run needs two (world-size-2 logic runs on CPU in tests/test_distributed.py)")
+    d = run_bench("--gpus", "2", "--no-cpu-baseline", "--no-napi", "--no-counters")
+    ex = d["exchange"]
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert ex["pictures_differing_from_unsplit_streams"] == 0
+    assert ex["single_source"]["value"] > 0 and ex["local_ingest"]["value"] > 0
+    assert ex["headline_mode"] in ("single_source", "local_ingest")
     assert "every unit of every stream" in d["parity_checked"]
