@@ -831,11 +831,12 @@ def main():
             # this rank's units whose predecessor was decoded elsewhere and that need it (first two decoded pictures with
             # unwritten macroblocks); every rank learns all of them
             hist = X["hists"][rank]
-            needy = jd.needy_streams([(i.stream, i.decoded) for i in b.pictures()], b.uncovered(), len(hist.units))
-            mine_needy = [hist.units[i] for i in hist.remote if needy[i]]
-            all_needy = [None] * world
-            dist.all_gather_object(all_needy, mine_needy)
-            needing[0] = sorted(u for lst in all_needy for u in lst)
+            pics_ = [(i.stream, i.decoded) for i in b.pictures()]
+            needy = jd.needy_streams(pics_, b.uncovered(), len(hist.units))
+            all_sets = [None] * world
+            dist.all_gather_object(all_sets, (sorted(i for i in range(len(hist.units)) if needy[i]), sorted(jd.short_streams(pics_, len(hist.units)))))
+            unres = jd.unresolved_streams(X["hists"], X["owner"], [set(x[0]) for x in all_sets], [set(x[1]) for x in all_sets], [set() for _ in range(world)])
+            needing[0] = sorted(X["hists"][r].units[i] for r in range(world) for i in unres[r])
             if needing[0]:
                 # ... and resolved: two frames per such cut travel rank to rank (the library's RCCL exchange), the ranks
                 # that received some decode again (jsmpeg_amd/distributed.py; tests/test_gpu_shards.py runs it with two

@@ -405,7 +405,13 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * from a ticket counter (large passes are launched with as many workgroups as the GPU holds, jm_launch_parse) --
 	 * a wavefront that is through starts on the next slices at once instead of waiting for the seven others of its
 	 * workgroup, and the pass has no rounds of workgroups to fall between. */
-	for (uint32_t batch = blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave; batch < b.n_batches;) {
+	/* (first batch.  A pass WITHOUT tickets -- every batch resident at once: 2160p 16 x 24 -- gives wavefront w of workgroup g
+	 * batch w * workgroups + g: the batches come longest first, and the longest, whose walk is the pass, then sit one to a
+	 * workgroup beside short ones that leave them the SIMD early, instead of eight to a workgroup sharing its SIMDs with each
+	 * other to the end: 4.81 -> 4.63 ms.  A pass with tickets keeps them together: its SIMDs stay full either way, and a round
+	 * of four intra wavefronts (289 instructions a turn) is shorter than one of an intra and three predicted ones (316): cfg2
+	 * 2.73 against 2.83 ms the other way round -- profiles/r05_parse_notes.md) */
+	for (uint32_t batch = b.ticket ? blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave : (uint32_t)wave * gridDim.x + blockIdx.x; batch < b.n_batches;) {
 	/* (mid-size passes: the batches of the longest slices take fewer of them, jm_launch_parse) */
 	uint32_t lanes = b.lanes_per_wave, first = b.head_first[2] + (batch - b.head_batches[0] - b.head_batches[1]) * b.lanes_per_wave;
 	if (batch < b.head_batches[0]) { lanes = b.head_lanes[0]; first = batch * lanes; }

@@ -380,7 +380,11 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 	 * rows stay in flight across the set-up barrier and are only awaited where they are used
 	 * (measured against the branchy form in round 1: 13.3 against 13.6 ms of reconstruct) */
 	{
+#ifdef JM_T_TOK_CACHED   /* TIMING BUILD (wrong pictures; profiles/r05_recon_notes.md): every block's tokens from the picture's first 2 KB -- what the token reads' way to HBM is worth at most */
+		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? (B.tkw & 0x3f8u) : 0u));
+#else
 		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? B.tkw : 0u));
+#endif
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
 	}
 
@@ -404,11 +408,39 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		const uint32_t wstride = B.pred ? (uint32_t)stride : 0u;
 		if (!B.pred) { B.oh = B.ov = 0; }
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
+#ifdef JM_T_PAIR_LOADS   /* TIMING BUILD (wrong pictures; profiles/r05_recon_notes.md, review item 6a): the left block of every luma pair loads the
+		 * pair's 20 bytes per row (16 + 4), the right block loads NOTHING (it would be handed its 12 bytes by DPP, 27 moves that are
+		 * not here): what halving the lanes in the nine gathers is worth at most */
+		const bool right = bnum < 4 && (bnum & 1);
+#pragma unroll
+		for (int r = 0; r < 9; r++) B.R[3 * r] = B.R[3 * r + 1] = B.R[3 * r + 2] = 0;
+#if JM_T_PAIR_LOADS == 1   /* the right blocks' lanes masked off: a branch around the loads (the kernel's counted waits become waits for everything) */
+		if (!right) {
+#pragma unroll
+			for (int r = 0; r < 9; r++) {
+				JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
+				B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
+				if (bnum < 4) { B.R[3 * r + 1] ^= wr[3]; B.R[3 * r + 2] ^= wr[4]; }
+			}
+		}
+#else                       /* no branch: the right blocks' lanes all read ONE address (like the lanes without prediction), the left ones 16 + 4 bytes */
+		{
+			const uint32_t woff2 = right ? 0u : woff, wstride2 = right ? 0u : wstride;
+#pragma unroll
+			for (int r = 0; r < 9; r++) {
+				JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff2 + (uint32_t)(r < 8 ? r : last) * wstride2));
+				B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
+				B.R[3 * r + 1] ^= wr[3]; B.R[3 * r + 2] ^= wr[4];
+			}
+		}
+#endif
+#else
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
 			JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
 		}
+#endif
 	}
 
 	/* ---- does the block need the transform?  Blocks that hold nothing but the (0,0) term do not:

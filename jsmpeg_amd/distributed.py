@@ -487,6 +487,59 @@ def final_states(pictures, n_streams, prev_local, seeds, frame_of):
     return state
 
 
+def short_streams(pictures, n_streams):
+    """the batch streams with fewer than two DECODED pictures (a one-picture GOP, all-intra content cut picture by picture): what such a
+    unit hands its successor as 'the picture before last' is not its own but its predecessor's last one"""
+    seen = [0] * n_streams
+    for s, dec in pictures:
+        if dec and s < n_streams:
+            seen[s] += 1
+    return {s for s in range(n_streams) if seen[s] < 2}
+
+
+def unresolved_streams(hists, owner, needy, short, seeded):
+    """Which batch streams must be seeded with their cross-rank predecessor's last two frames before their rank's pictures are
+    right -- per rank a set, computed alike by every rank from everybody's needy / short / seeded sets (sets of batch streams).
+      - a NEEDY stream (one of its first two decoded pictures leaves macroblocks unwritten) whose predecessor sits on another
+        rank, and that has not been seeded yet;
+      - and, behind any such dependency, every SHORT unit (fewer than two decoded pictures) on the way: what a short unit
+        hands on as 'the picture before last' is its own predecessor's last picture, which it only knows if it is linked to
+        that unit inside its batch or has been seeded -- so a short unit whose predecessor is on another rank is unresolved
+        too, whether or not its own pictures need anything (the round-4 advisor's case: a one-picture GOP, all-intra content).
+    The walk goes back through batch links while the units are short, and across ranks through `remote`."""
+    world = len(hists)
+    unresolved = [set() for _ in range(world)]
+
+    def provider(r, k):
+        """stream k of rank r hands its final state to a successor that needs it: make sure that state can be right"""
+        added = False
+        while k in short[r]:
+            if hists[r].prev_local[k] >= 0:
+                k = hists[r].prev_local[k]          # linked inside the batch: the state flows through the link
+                continue
+            if k in hists[r].remote and k not in seeded[r] and k not in unresolved[r]:
+                unresolved[r].add(k)
+                added = True
+            break
+        return added
+
+    for r, hist in enumerate(hists):
+        for i in sorted(needy[r]):
+            if hist.prev_local[i] >= 0:
+                provider(r, hist.prev_local[i])
+            elif i in hist.remote and i not in seeded[r]:
+                unresolved[r].add(i)
+    changed = True
+    while changed:
+        changed = False
+        for r, hist in enumerate(hists):
+            for i in sorted(unresolved[r]):
+                pred = hist.remote[i]
+                pr = owner[pred]
+                changed = provider(pr, hists[pr].index[pred]) or changed
+    return unresolved
+
+
 def history_transfers(hists, owner, unresolved):
     """One round of the resolution, computed alike by every rank: `unresolved[r]` = the batch streams of rank r that need
     their remote predecessor's frames and do not have them yet.  A predecessor can hand its frames over once nothing it
@@ -527,10 +580,12 @@ def resolve_history_emulated(ranks, table, owner, max_rounds=64):
         needy = needy_streams(pics, b.uncovered(), n)
         stride, pool = b.frame_stride, b.frame_pool_ptr
         rk["states"] = final_states(pics, n, rk["hist"].prev_local, rk["seeds"], lambda p: pool + p * stride)
-        return {i for i in rk["hist"].remote if needy[i] and i not in rk["seeds"]}
+        rk["short"] = short_streams(pics, n)
+        return {i for i in range(n) if needy[i]}
 
     for _ in range(max_rounds):
-        unresolved = [look(rk) for rk in ranks]
+        needy_sets = [look(rk) for rk in ranks]
+        unresolved = unresolved_streams(hists, owner, needy_sets, [rk["short"] for rk in ranks], [set(rk["seeds"]) for rk in ranks])
         if not any(unresolved):
             return again
         moves = history_transfers(hists, owner, unresolved)
@@ -560,8 +615,8 @@ def resolve_history_dist(b, hist, hists, owner, rank, world, comm, redecode, fra
     for rounds in range(max_rounds):
         pics = [(i.stream, i.decoded) for i in b.pictures()]
         needy = needy_streams(pics, b.uncovered(), n)
-        mine = sorted(i for i in hist.remote if needy[i] and i not in seeds)
-        unresolved = [set(x) for x in comm.allgather(mine)]
+        everybody = comm.allgather((sorted(i for i in range(n) if needy[i]), sorted(short_streams(pics, n)), sorted(seeds)))
+        unresolved = unresolved_streams(hists, owner, [set(x[0]) for x in everybody], [set(x[1]) for x in everybody], [set(x[2]) for x in everybody])
         if not any(unresolved):
             return rounds, seeds, keep
         moves = history_transfers(hists, owner, unresolved)

@@ -123,7 +123,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			L[l].es_ring = &es_ring[0][l]; L[l].tk_ring = &tk_ring[0][l];
 			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].tw7 = L[l].tf7 = 0;
 			mine[l] = false;
-			C[l].lut = &luts; C[l].epoch = epoch;
+			C[l].lut = &luts; C[l].epoch = epoch; C[l].pic_type = 0;
 			if (i >= n_sc || owner[i] == JM_NONE) continue;
 			const uint32_t p = owner[i];
 			const JmPic &pic = pics[p];

@@ -345,13 +345,17 @@ def test_contiguous_plan_equals_its_restatement_and_keeps_streams_together(hip_l
 
 
 def test_history_resolution_converges_to_the_unsplit_result():
-    """A model of the procedure without a decoder: a unit's pictures are 'right' iff it does not need its predecessor, or
-    started from its predecessor's RIGHT final state.  Random placements and needs; every rank links what it holds,
-    needy units with a remote predecessor are seeded round by round (history_transfers); in the end every unit is right,
-    and a unit is only ever seeded from a predecessor that was right at that moment."""
+    """A model of the procedure without a decoder.  A unit's PICTURES are right iff it does not need its predecessor, or
+    started from its predecessor's right final state; its FINAL STATE (last, before last) is right iff its pictures are and --
+    for a unit with a single decoded picture, whose 'before last' is its predecessor's last picture -- it started from a
+    right state too (or has no predecessor).  Random placements, needs and one-picture units; every rank links what it
+    holds, units are seeded round by round (history_transfers), a one-picture unit in front of a needy one is pulled in
+    (unresolved_streams: the round-4 advisor's case); in the end every unit's pictures are right, and a unit is
+    only ever seeded from a predecessor whose STATE was right at that moment."""
     from jsmpeg_amd import distributed as jd
     rng = np.random.default_rng(11)
-    for case in range(300):
+    pulled_in = 0
+    for case in range(400):
         n_streams = int(rng.integers(1, 6))
         table = jd.unit_table([[1000] * int(rng.integers(1, 9)) for _ in range(n_streams)])
         world = int(rng.integers(1, 5))
@@ -363,29 +367,38 @@ def test_history_resolution_converges_to_the_unsplit_result():
         else:
             owner = jd.plan_contiguous([n for _, _, n in table], world)
         needs = [bool(table[u][1] > 0 and rng.random() < 0.5) for u in range(len(table))]
+        one_picture = [bool(rng.random() < 0.3) for _ in table]
         hists = [jd.HistoryRank(table, [u for u in range(len(table)) if owner[u] == r]) for r in range(world)]
         seeded = [dict() for _ in range(world)]             # stream -> was the state it was seeded with right?
+        short = [{i for i, u in enumerate(h.units) if one_picture[u]} for h in hists]
 
         def evaluate():
-            right = {}
+            pictures, state = {}, {}
             for r, h in enumerate(hists):
                 for i, u in enumerate(h.units):            # batch order = job order inside a rank: a link's target comes first
-                    if not needs[u]:
-                        right[u] = True
+                    if table[u][1] == 0:
+                        start = True                        # a stream's first unit starts from nothing, like the unsplit stream
                     elif h.prev_local[i] >= 0:
-                        right[u] = right[h.units[h.prev_local[i]]]
+                        start = state[h.units[h.prev_local[i]]]
                     else:
-                        right[u] = seeded[r].get(i, False)
-            return right
+                        start = seeded[r].get(i, False)
+                    pictures[u] = (not needs[u]) or start
+                    state[u] = pictures[u] and (start or not one_picture[u])
+            return pictures, state
 
-        for _ in range(len(table) + 2):
-            right = evaluate()
-            unresolved = [{i for i in h.remote if needs[h.units[i]] and i not in seeded[r]} for r, h in enumerate(hists)]
+        for _ in range(2 * len(table) + 2):
+            pictures, state = evaluate()
+            plain = [{i for i in h.remote if needs[h.units[i]] and i not in seeded[r]} for r, h in enumerate(hists)]
+            unresolved = jd.unresolved_streams(hists, owner, [{i for i, u in enumerate(h.units) if needs[u]} for h in hists], short,
+                                               [set(x) for x in seeded])
+            assert all(p_ <= u_ for p_, u_ in zip(plain, unresolved))
             if not any(unresolved):
                 break
+            pulled_in += sum(len(x) for x in unresolved) - sum(len(x) for x in plain)
             moves = jd.history_transfers(hists, owner, unresolved)
             assert moves, "stuck"
             for pr, j, r, i in moves:
-                assert right[hists[pr].units[j]], "seeded from a predecessor that was not final"
+                assert state[hists[pr].units[j]], "seeded from a predecessor whose final state was not right"
                 seeded[r][i] = True
-        assert all(evaluate().values())
+        assert all(evaluate()[0].values())
+    assert pulled_in > 0, "no case exercised a one-picture unit in front of a needy one"
