@@ -385,7 +385,11 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 #else
 		JM_GLOBAL const uint32_t *tk = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.tok + (B.cnt > 0 ? B.tkw : 0u));
 #endif
+#if defined(JM_T_TOK_NT) && defined(__HIP_DEVICE_COMPILE__)    /* variant (same pictures): the tokens are read once -- stream them past the caches */
+		B.tw[0] = __builtin_nontemporal_load(tk); B.tw[1] = __builtin_nontemporal_load(tk + 1); B.tw[2] = __builtin_nontemporal_load(tk + 2); B.tw[3] = __builtin_nontemporal_load(tk + 3);
+#else
 		B.tw[0] = tk[0]; B.tw[1] = tk[1]; B.tw[2] = tk[2]; B.tw[3] = tk[3];
+#endif
 	}
 
 	/* ---- forward prediction, raw rows: 9 rows x 12 bytes from a dword-aligned address ---- */
@@ -403,8 +407,14 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 		if (sx + 8 + (int)B.oh > stride) sx = stride - 8 - (int)B.oh;
 		if (sy + 8 + (int)B.ov > ph) sy = ph - 8 - (int)B.ov;
 		const uint32_t off = (uint32_t)(sy * stride + sx);
+#ifdef JM_T_PRED_UNALIGNED   /* variant (same pictures): the rows loaded from their own byte address -- no alignment step in the half-pel pass (27 vector
+                              * instructions per wavefront), the address unit splits what straddles */
+		const uint32_t woff = B.pred ? plane_off + off : 0u;
+		B.m = 0u;
+#else
 		const uint32_t woff = B.pred ? plane_off + (off & ~3u) : 0u;
 		B.m = B.pred ? off & 3u : 0u;
+#endif
 		const uint32_t wstride = B.pred ? (uint32_t)stride : 0u;
 		if (!B.pred) { B.oh = B.ov = 0; }
 		const int last = (sy + 8 < ph) ? 8 : 7;            /* row 8 is only used when ov == 1 (then it is inside) */
@@ -438,7 +448,11 @@ JM_HD void jm_recon_front(const JmReconCtx &c, const JmLoc &Q, JmBlk &B) {
 #pragma unroll
 		for (int r = 0; r < 9; r++) {
 			JM_GLOBAL const uint32_t *wr = reinterpret_cast<JM_GLOBAL const uint32_t *>(c.fwd + (woff + (uint32_t)(r < 8 ? r : last) * wstride));
+#if defined(JM_T_PRED_NT) && defined(__HIP_DEVICE_COMPILE__)   /* variant (same pictures): the prediction rows loaded with the non-temporal hint */
+			B.R[3 * r] = __builtin_nontemporal_load(wr); B.R[3 * r + 1] = __builtin_nontemporal_load(wr + 1); B.R[3 * r + 2] = __builtin_nontemporal_load(wr + 2);
+#else
 			B.R[3 * r] = wr[0]; B.R[3 * r + 1] = wr[1]; B.R[3 * r + 2] = wr[2];
+#endif
 		}
 #endif
 	}
