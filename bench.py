@@ -364,6 +364,104 @@ def other_configs(device, passes=5):
     return out
 
 
+class RehearsalPlane:
+    """TEST stand-in for the library's RCCL communicator (jsmpeg_amd.distributed.Dist), `--rehearse-on-one-gpu` only: the same
+    calls with the same arguments (device addresses, per-rank byte tables), the bytes travelling as host tensors over the
+    control plane (torch.distributed, gloo).  What it is for: every line of bench.py's N > 1 program -- the cut, the plans,
+    both ingest modes, the links, the cross-rank history, the gates, the bounded waits -- running with N REAL ranks on a box
+    that has one GPU, so that the first run on N devices is not the first run of the program.  RCCL itself is exercised by the
+    `--force-dist` runs and tests/test_gpu_shards.py with the ranks present.  Synchronous: a call returns when the bytes are there."""
+
+    def __init__(self, rank, world, dev, dist, jd):
+        self.rank, self.world, self.dev, self.dist, self.jd = rank, world, dev, dist, jd
+
+    class _Mem:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+    def _view(self, ptr, n):
+        import torch
+        addr = ptr.value if hasattr(ptr, "value") else int(ptr)
+        return torch.as_tensor(self._Mem(addr, int(n)), device=self.dev)
+
+    def _at(self, ptr, off):
+        return (ptr.value if hasattr(ptr, "value") else int(ptr)) + int(off)
+
+    def scatter(self, src_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
+        import torch
+        torch.cuda.synchronize()
+        if self.rank == src_rank:
+            for r in range(self.world):
+                if not sizes[r]:
+                    continue
+                piece = self._view(self._at(src_ptr, offsets[r]), sizes[r])
+                if r == self.rank:
+                    if dst_ptr:
+                        self._view(dst_ptr, sizes[r]).copy_(piece)
+                else:
+                    self.dist.send(piece.cpu(), dst=r)
+        elif sizes[self.rank]:
+            buf = torch.empty(int(sizes[self.rank]), dtype=torch.uint8)
+            self.dist.recv(buf, src=src_rank)
+            self._view(dst_ptr, sizes[self.rank]).copy_(buf)
+        torch.cuda.synchronize()
+
+    def gather(self, dst_rank, src_ptr, offsets, sizes, dst_ptr, stream=None):
+        import torch
+        torch.cuda.synchronize()
+        if self.rank == dst_rank:
+            for r in range(self.world):
+                if not sizes[r]:
+                    continue
+                if r == self.rank:
+                    self._view(self._at(dst_ptr, offsets[r]), sizes[r]).copy_(self._view(src_ptr, sizes[r]))
+                else:
+                    buf = torch.empty(int(sizes[r]), dtype=torch.uint8)
+                    self.dist.recv(buf, src=r)
+                    self._view(self._at(dst_ptr, offsets[r]), sizes[r]).copy_(buf)
+        elif sizes[self.rank]:
+            self.dist.send(self._view(src_ptr, sizes[self.rank]).cpu(), dst=dst_rank)
+        torch.cuda.synchronize()
+
+    def exchange(self, src_ptr, send_offsets, send_sizes, dst_ptr, recv_offsets, recv_sizes, stream=None):
+        import torch
+        torch.cuda.synchronize()
+        if send_sizes[self.rank]:
+            self._view(self._at(dst_ptr, recv_offsets[self.rank]), send_sizes[self.rank]).copy_(self._view(self._at(src_ptr, send_offsets[self.rank]), send_sizes[self.rank]))
+        reqs, keep = [], []
+        for r in range(self.world):
+            if r != self.rank and send_sizes[r]:
+                keep.append(self._view(self._at(src_ptr, send_offsets[r]), send_sizes[r]).cpu())
+                reqs.append(self.dist.isend(keep[-1], dst=r))
+        for r in range(self.world):
+            if r != self.rank and recv_sizes[r]:
+                buf = torch.empty(int(recv_sizes[r]), dtype=torch.uint8)
+                self.dist.recv(buf, src=r)
+                self._view(self._at(dst_ptr, recv_offsets[r]), recv_sizes[r]).copy_(buf)
+        [q.wait() for q in reqs]
+        torch.cuda.synchronize()
+
+    def allgather(self, src_ptr, dst_ptr, bytes_per_rank, stream=None):
+        import torch
+        torch.cuda.synchronize()
+        mine = self._view(src_ptr, bytes_per_rank).cpu()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        for r, part in enumerate(parts):
+            self._view(self._at(dst_ptr, r * int(bytes_per_rank)), bytes_per_rank).copy_(part)
+        torch.cuda.synchronize()
+
+    def check_exchange(self, send_sizes, recv_sizes, stream=None):
+        def allgather(obj):
+            out = [None] * self.world
+            self.dist.all_gather_object(out, obj)
+            return out
+        self.jd.verify_exchange_plan(allgather, send_sizes, recv_sizes, "exchange (rehearsal plane)")
+
+    def close(self):
+        pass
+
+
 def via_napi(streams, want_hashes, width, height, frames, steps, warmup, device):
     """The same batch driven from the host north_star names -- Node.js over the N-API addon (tools/bench_node.js,
     JSMpeg.HIPBatch): inputs uploaded once, `warmup` untimed and `steps` timed decode() calls, every picture's device hash
@@ -442,6 +540,9 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra run that starts every step from host memory (value_incl_h2d)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the witnessed timings of the other BASELINE.json configurations (other_configs)")
     ap.add_argument("--two-batches", action="store_true", help="report two_batches_in_flight even with --no-other-configs (it is part of the default line)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="TEST MODE, never a measurement: the N ranks of --gpus N share the visible device(s) and the compressed units travel "
+                         "over the control plane (gloo) instead of RCCL -- every line of the N > 1 program runs, on a box with one GPU")
     ap.add_argument("--no-napi", action="store_true", help="skip the Node-hosted run of the same batch (value_via_napi)")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc passes over two steps of this same program (roofline.traffic measured in this run)")
     args = ap.parse_args()
@@ -452,11 +553,13 @@ def main():
     import torch                     # FIRST: the decode library must bind to the HIP runtime torch loads, not bring its own
     from jsmpeg_amd import batch as jb, launch
     visible = int(torch.cuda.device_count())
-    how = launch.plan(args.gpus, os.environ, visible, os.path.abspath(__file__), sys.argv[1:])
+    how = launch.plan(args.gpus, os.environ, visible, os.path.abspath(__file__), sys.argv[1:], rehearse=args.rehearse_on_one_gpu)
     if how["mode"] == "spawn":
         log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(how["cmd"])))
         raise SystemExit(subprocess.call(how["cmd"], env=how["env"]))
     rank, local_rank, world = how["rank"], how["local_rank"], how["world"]
+    if args.rehearse_on_one_gpu:
+        local_rank = local_rank % max(1, visible)          # the ranks share what is there
 
     # stdout carries exactly one JSON line: anything native libraries print there (RCCL's version banner, ...) is sent to
     # stderr instead -- file descriptor 1 becomes stderr, the JSON goes to a duplicate of the original stdout
@@ -482,11 +585,22 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         import datetime
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("JSMPEG_BENCH_CONTROL_TIMEOUT", "600"))))
-        box = [jd.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        D = jd.Dist(rank, world, box[0], device=local_rank)
+        if args.rehearse_on_one_gpu:
+            D = RehearsalPlane(rank, world, dev, dist, jd)
+        else:
+            box = [jd.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            D = jd.Dist(rank, world, box[0], device=local_rank)
 
     cfg = synth.CONFIGS[CONFIG]
+    # rehearsals and --force-dist tests only: other generator parameters for the same picture size (e.g. short GOPs with
+    # coherent motion and few coded macroblocks: content whose cross-rank cuts NEED their predecessor's frames) -- never the headline's
+    synth_overrides = os.environ.get("JSMPEG_BENCH_SYNTH_OVERRIDES", "") if (args.rehearse_on_one_gpu or args.force_dist) else ""
+    for kv in filter(None, synth_overrides.split(",")):
+        key, val = kv.split("=")
+        if key in ("width", "height"):
+            raise SystemExit("JSMPEG_BENCH_SYNTH_OVERRIDES: the picture size is the workload's")
+        cfg[key] = int(val)
     width, height = cfg["width"], cfg["height"]
     n_streams, frames = args.streams, args.frames
 
@@ -521,6 +635,8 @@ def main():
         unit_pics = [n for r in info_all for pics in r[1] for n in pics]
         # contiguous ranges of the job's unit list: a stream's units stay on one rank except at <= world - 1 range boundaries
         owner = jd.plan_contiguous_c([n for _, _, n in table], world)
+        if os.environ.get("JSMPEG_BENCH_PLAN") == "alternate" and (args.rehearse_on_one_gpu or args.force_dist):
+            owner = [u % world for u in range(len(table))]          # tests only: EVERY cut of every stream crosses ranks (the history procedure's worst case)
         pieces = jd.layout_pieces(table, owner, world)
         offsets, psizes, src_total = jd.piece_offsets(pieces)
         flat_len = [sum(n for units in r[0] for n in units) for r in info_all]
@@ -837,6 +953,7 @@ def main():
             dist.all_gather_object(all_sets, (sorted(i for i in range(len(hist.units)) if needy[i]), sorted(jd.short_streams(pics_, len(hist.units)))))
             unres = jd.unresolved_streams(X["hists"], X["owner"], [set(x[0]) for x in all_sets], [set(x[1]) for x in all_sets], [set() for _ in range(world)])
             needing[0] = sorted(X["hists"][r].units[i] for r in range(world) for i in unres[r])
+            X["needing"], X["history"] = len(needing[0]), None          # per ingest mode (each has its own plan, hence its own cuts)
             if needing[0]:
                 # ... and resolved: two frames per such cut travel rank to rank (the library's RCCL exchange), the ranks
                 # that received some decode again (jsmpeg_amd/distributed.py; tests/test_gpu_shards.py runs it with two
@@ -870,6 +987,7 @@ def main():
                 rounds, _, history_keep = jd.resolve_history_dist(b, hist, X["hists"], X["owner"], rank, world, _Comm(), _redecode, frame_stride, _alloc,
                                                                   lambda dst, src: _view(dst, frame_stride).copy_(_view(src, frame_stride)))
                 history_info.update(rounds=int(rounds), ms=round((time.perf_counter() - t_h) * 1e3, 2))
+                X["history"] = dict(history_info)
                 got_of = device_hashes_by_unit(units_of_rank)
         else:
             dev_hashes = b.frame_hashes()
@@ -1118,10 +1236,12 @@ def main():
                                          "note": "read + write traffic of a 2 GiB torch device-to-device copy on this GPU, same run: "
                                                  "what HBM gives a plain kernel with the dominant kernel's half-read half-write mix"}}
     line = {
-        "metric": "1080p MPEG-1 decode throughput", "value": round(fps, 1), "unit": "frames/s",
+        "metric": "1080p MPEG-1 decode throughput" if not args.rehearse_on_one_gpu else
+                  "REHEARSAL (not a measurement): %d ranks sharing %d device(s), units over gloo" % (world, visible),
+        "value": round(fps, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic",
+        "dtype": "int32", "data": "synthetic" if not synth_overrides else "synthetic (test overrides: %s)" % synth_overrides,
         "config": {"workload": "%s: %d streams x %d pictures 1920x1080 I+P (GOP 12) per GPU, batched; cfg3 sharding at N>1"
                                % (CONFIG, n_streams, frames),
                    "streams": g_streams, "pictures_per_step": g_pictures, "es_bytes_per_gpu": es_bytes,
@@ -1164,8 +1284,10 @@ def main():
         exchange["note"] = ("scatter of step k+1 runs on its own HIP stream beside the kernels of step k; its time is inside "
                             "ms_per_step only where it is not hidden")
         exchange["pictures_differing_from_unsplit_streams"] = int(deviating)
-        exchange["cross_rank_units_needing_history"] = len(needing[0])
-        exchange["history_resolution"] = dict(history_info) or None
+        hm = modes[headline_mode]
+        exchange["cross_rank_units_needing_history"] = hm.get("needing", 0)
+        exchange["history_resolution"] = hm.get("history")
+        exchange["history_by_mode"] = {k: {"cross_rank_units_needing_history": m.get("needing", 0), "history_resolution": m.get("history")} for k, m in modes.items()}
         exchange["history_note"] = ("units are planned as contiguous ranges of the job's unit list (jsmpeg_hip_plan_contiguous) and linked inside a "
                                     "rank's batch (jsmpeg_hip_batch_link_streams): the parity gate holds every unit against the UNSPLIT stream's "
                                     "pictures.  A unit behind one of the <= n_gpus - 1 cross-rank cuts needs its predecessor's last two frames only "

@@ -22,12 +22,18 @@ def free_port():
     return p
 
 
-def plan(gpus, env, visible, script, argv, port=None):
+def plan(gpus, env, visible, script, argv, port=None, rehearse=False):
     """What to do with `python <script> <argv>` asking for `gpus` GPUs when `visible` devices are present.
     Returns {"mode": "rank", "rank", "local_rank", "world"} or {"mode": "spawn", "cmd": [...], "env": {...}};
-    raises SystemExit with the reason when the request cannot be met."""
+    raises SystemExit with the reason when the request cannot be met.
+    rehearse: the explicit test mode of bench.py (`--rehearse-on-one-gpu`): the N ranks may SHARE the visible devices (rank r
+    on device r % visible) -- a rehearsal of the N > 1 program on a smaller box, never a measurement; needs at least one device."""
     if gpus < 1:
         raise SystemExit("--gpus %d: at least one GPU" % gpus)
+    if rehearse:
+        if visible < 1:
+            raise SystemExit("%d GPUs requested for a rehearsal, 0 visible" % gpus)
+        visible = max(visible, gpus)
     ws = (env.get("WORLD_SIZE") or "").strip()
     if ws:
         world = int(ws)

@@ -78,3 +78,36 @@ def test_two_ranks_on_two_gpus_when_the_box_has_them():
     assert ex["single_source"]["value"] > 0 and ex["local_ingest"]["value"] > 0
     assert ex["headline_mode"] in ("single_source", "local_ingest")
     assert "every unit of every stream" in d["parity_checked"]
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_rehearsal_of_the_n_rank_program_on_one_gpu(ranks):
+    """Every line of bench.py's N > 1 program with N REAL ranks (torch.distributed.run, gloo control plane, the cut, both plans,
+    both ingest modes, links, cross-rank history, gates against the UNSPLIT streams, bounded waits, the headline rule) on a box
+    with one GPU: the ranks share the device and the units travel over gloo instead of RCCL (`--rehearse-on-one-gpu`, a test
+    mode that says so in its metric).  The first run on N devices must not be the first run of the program."""
+    d = run_bench("--gpus", str(ranks), "--rehearse-on-one-gpu", "--no-cpu-baseline", "--no-napi", "--no-counters", "--streams", "3")
+    assert d["metric"].startswith("REHEARSAL") and d["n_gpus"] == ranks and d["value"] > 0
+    ex = d["exchange"]
+    assert ex["units"] == 3 * ranks * 2 and ex["pictures_differing_from_unsplit_streams"] == 0
+    assert ex["single_source"]["value"] > 0 and ex["local_ingest"]["value"] > 0
+    assert ex["headline_mode"] in ("single_source", "local_ingest")
+    assert "every unit of every stream" in d["parity_checked"]
+    assert d["config"]["streams"] == 3 * ranks and d["config"]["pictures_per_step"] == 3 * ranks * 24
+
+
+def test_rehearsal_with_every_cut_crossing_ranks_resolves_the_history_across_real_ranks():
+    """content whose units need their predecessor's frames (short GOPs, coherent motion, few coded macroblocks), every cut of
+    every stream across ranks: the cross-rank history procedure (all-gather who needs what, two frames per cut through the
+    exchange, decode again) with four real ranks -- and every picture still equals the UNSPLIT stream's"""
+    env = dict(os.environ, JSMPEG_BENCH_PLAN="alternate", JSMPEG_BENCH_SYNTH_OVERRIDES="gop=3,mv_jitter=1,coded_permille=60,ac_max=1,f_code_max=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse-on-one-gpu", "--streams", "3", "--frames", "24", "--steps", "2",
+                        "--warmup", "1", "--no-audio", "--no-other-configs", "--no-h2d", "--no-cpu-baseline", "--no-napi", "--no-counters"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    ex = d["exchange"]
+    assert ex["pictures_differing_from_unsplit_streams"] == 0 and ex["pictures_with_unwritten_macroblocks"] > 0
+    single = ex["history_by_mode"]["single_source"]
+    assert single["cross_rank_units_needing_history"] > 0 and single["history_resolution"]["rounds"] >= 1
+    assert "test overrides" in d["data"]

@@ -41,6 +41,19 @@ def test_more_gpus_than_visible_is_an_error_not_a_smaller_run():
         _plan(0, {}, 1)
 
 
+def test_rehearsal_shares_the_visible_devices_and_says_so_only_when_asked():
+    """`--rehearse-on-one-gpu`: N ranks on fewer devices is allowed ONLY in the explicit test mode (and never without a device)"""
+    from jsmpeg_amd import launch
+    p = launch.plan(4, {"PATH": "/bin"}, 1, "/x/bench.py", ["--gpus", "4", "--rehearse-on-one-gpu"], port=1, rehearse=True)
+    assert p["mode"] == "spawn" and p["cmd"][p["cmd"].index("--nproc-per-node") + 1] == "4"
+    env = {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3", "LOCAL_WORLD_SIZE": "4"}
+    assert launch.plan(4, env, 1, "/x/bench.py", [], rehearse=True) == {"mode": "rank", "rank": 3, "local_rank": 3, "world": 4}
+    with pytest.raises(SystemExit):
+        launch.plan(4, env, 1, "/x/bench.py", [])                    # the same request without the flag: refused as ever
+    with pytest.raises(SystemExit):
+        launch.plan(2, {}, 0, "/x/bench.py", [], rehearse=True)      # a rehearsal still needs a device
+
+
 def test_a_rank_under_the_drivers_launcher():
     env = {"WORLD_SIZE": "4", "RANK": "2", "LOCAL_RANK": "2", "LOCAL_WORLD_SIZE": "4"}
     assert _plan(4, env, 8) == {"mode": "rank", "rank": 2, "local_rank": 2, "world": 4}
