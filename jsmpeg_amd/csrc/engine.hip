@@ -188,7 +188,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_pic_sc, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(jm_malloc(&b->d_slice_sc, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_slice_order, sizeof(uint32_t) * b->sc_cap));
-	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * (2 * JM_ORDER_BINS + 16)));   /* + the parse pass's ticket counter */
+	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * (2 * JM_ORDER_BINS + 16 + JM_PARSE_CU_KEYS)));   /* + the parse pass's ticket counter + its per-CU arrival counters */
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
 	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
 	b->desc_cap = 2 * std::max(1u, c.max_pictures) + 64;   /* every picture once, the ones without a forward reference twice (steps 4a, 4b); ordered: padding of up to 8 % */
@@ -704,6 +704,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	pb.pics = b->d_pics; pb.streams = b->d_streams; pb.luts = b->d_luts; pb.mb = b->d_mb; pb.tokens = b->d_tokens;
 	pb.n_sc = b->n_sc; pb.mb_size = b->g.mb_size; pb.epoch = b->epoch; pb.covered = b->d_covered;
 	pb.ticket = b->d_order_hist + 2 * JM_ORDER_BINS;
+	pb.cu_order = b->d_order_hist + 2 * JM_ORDER_BINS + 16;
 	pb.slice_sc = b->d_slice_sc; pb.n_lanes = std::min(b->h_counters[4], b->sc_cap);   /* a lane per slice code (not per start code) */
 	pb.long_slices = 0;
 	pb.bytes_per_mb_x16 = 0; pb.t_cold = 0;
@@ -1541,7 +1542,7 @@ static int dec_picture_gpu(mpeg1_decoder_t *d, size_t pic_k, size_t first, size_
 	JmParseBufs pb;
 	pb.es = d->d_es; pb.sc_pos = d->d_sc_pos; pb.sc_code = d->d_sc_code; pb.sc_owner = d->d_sc_owner;
 	pb.pics = d->d_pic; pb.streams = d->d_stream; pb.luts = d->d_luts; pb.mb = d->d_mb; pb.tokens = d->d_tokens;
-	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.long_slices = 0; pb.bytes_per_mb_x16 = 0; pb.t_cold = 0; pb.ticket = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
+	pb.n_sc = (uint32_t)n_entries; pb.slice_sc = nullptr; pb.n_lanes = 0; pb.long_slices = 0; pb.bytes_per_mb_x16 = 0; pb.t_cold = 0; pb.ticket = nullptr; pb.cu_order = nullptr; pb.mb_size = d->g.mb_size; pb.epoch = d->epoch; pb.debug_flags = 0; pb.dbg = nullptr; pb.covered = nullptr;
 	HIP_TRY(jm_launch_parse(pb, st));
 	JmReconBufs rb;
 	rb.g = d->g; rb.desc = d->d_desc; rb.n_level_pics = 1;

@@ -71,6 +71,7 @@ struct JmOrderBufs {
 };
 hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st);
 
+#define JM_PARSE_CU_KEYS 4096u   /* (XCC id << 8) | HW_ID's se / sh / cu bits */
 struct JmParseBufs {
 	const uint8_t *es;
 	const uint32_t *sc_pos;
@@ -85,6 +86,8 @@ struct JmParseBufs {
 	const uint32_t *slice_sc;    /* the start-code entries that take a lane (the scan's list of slice codes), or null: all n_sc */
 	uint32_t n_lanes;            /* entries of slice_sc */
 	uint32_t *ticket;            /* one word of device memory for large passes (zeroed by the launch), or null */
+	uint32_t *cu_order;          /* JM_PARSE_CU_KEYS words (zeroed by the launch when used), or null: passes WITHOUT tickets count the workgroups that
+	                                arrive on a CU, so that the CU's second workgroup starts its longest batches on other SIMDs than the first */
 	uint32_t n_batches;          /* set by jm_launch_parse: wavefront-sized batches of slices */
 	int mb_size;
 	uint32_t *covered;           /* [n_pics] += records written, per picture (zeroed by the caller), or null */

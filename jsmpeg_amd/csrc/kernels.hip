@@ -396,6 +396,20 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		uint4 *dst = reinterpret_cast<uint4 *>(&lut);
 		for (uint32_t i = threadIdx.x; i < sizeof(JmVlcLuts) / 16; i += blockDim.x) dst[i] = src[i];
 	}
+	/* a pass without tickets: which workgroup of its CU is this one -- the first to arrive, or the second?  (HW_REG_HW_ID's
+	 * shader engine / array / CU bits under the XCC's number: one counter per CU, one atomic per workgroup) */
+	__shared__ uint32_t wg_order, slot_taken;
+	if (threadIdx.x == 0) {
+		slot_taken = 0;
+		uint32_t o = 0;
+		if (!b.ticket && b.cu_order) {
+			uint32_t hw, xcc;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+			o = atomicAdd(&b.cu_order[((xcc & 15u) << 8) | ((hw >> 8) & 0xffu)], 1u);
+		}
+		wg_order = o;
+	}
 	__syncthreads();   /* the only workgroup barrier: from here on the wavefronts run on their own */
 	/* lanes_per_wave < 64 (small batches, jm_launch_parse): a wavefront takes only that many slices -- fewer lanes are at
 	 * fewer different syntax elements, a turn issues fewer of the step kinds, and the one wavefront whose walk is the
@@ -411,7 +425,27 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * other to the end: 4.81 -> 4.63 ms.  A pass with tickets keeps them together: its SIMDs stay full either way, and a round
 	 * of four intra wavefronts (289 instructions a turn) is shorter than one of an intra and three predicted ones (316): cfg2
 	 * 2.73 against 2.83 ms the other way round -- profiles/r05_parse_notes.md) */
-	for (uint32_t batch = b.ticket ? blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave : (uint32_t)wave * gridDim.x + blockIdx.x; batch < b.n_batches;) {
+	/* (... by SIMD: the hardware puts a workgroup's wavefronts w and w + 4 on one SIMD and 0 .. 3 on four different ones, starting
+	 * anywhere (tools/hwid_probe.hip) -- so the wavefront on SIMD s takes slot s of its half, and in the CU's SECOND workgroup (by
+	 * arrival, counted above) slot (s + 2) % 4: the CU's four longest batches then sit on its four SIMDs, where two on one SIMD
+	 * walk at half speed once the short ones beside them are through.  A wavefront claims its slot in a bitmap and takes the
+	 * next free one if the hardware did otherwise: every batch is walked exactly once whatever the placement.) */
+	uint32_t slot = (uint32_t)wave;
+	if (!b.ticket) {
+		if (lane == 0) {
+			uint32_t hw;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+			uint32_t want = ((((hw >> 4) & 3u) + 2u * wg_order) & 3u) + ((uint32_t)wave & 4u);
+			for (;;) {
+				const uint32_t old = atomicOr(&slot_taken, 1u << want);
+				if (!(old & (1u << want))) break;
+				want = (want + 1u) & (JM_PARSE_WAVES - 1);
+			}
+			slot = want;
+		}
+		slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+	}
+	for (uint32_t batch = b.ticket ? blockIdx.x * JM_PARSE_WAVES + (uint32_t)wave : slot * gridDim.x + blockIdx.x; batch < b.n_batches;) {
 	/* (mid-size passes: the batches of the longest slices take fewer of them, jm_launch_parse) */
 	uint32_t lanes = b.lanes_per_wave, first = b.head_first[2] + (batch - b.head_batches[0] - b.head_batches[1]) * b.lanes_per_wave;
 	if (batch < b.head_batches[0]) { lanes = b.head_lanes[0]; first = batch * lanes; }
@@ -614,7 +648,13 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 		groups = resident_now;
 		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
 		if (e != hipSuccess) return e;
-	} else b.ticket = nullptr;
+	} else {
+		b.ticket = nullptr;
+		if (b.cu_order && groups > 1) {
+			hipError_t e = hipMemsetAsync(b.cu_order, 0, sizeof(uint32_t) * JM_PARSE_CU_KEYS, st);
+			if (e != hipSuccess) return e;
+		} else b.cu_order = nullptr;
+	}
 	hipLaunchKernelGGL(k_parse, dim3(groups), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }

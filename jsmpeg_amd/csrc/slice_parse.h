@@ -351,7 +351,7 @@ JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &ba
 JM_HD int jm_open_block(JmLane &L, int rem) {
 	L.cur = __builtin_clz((unsigned)rem) - 26;
 	L.n10 = 0; L.cnt = 0;
-	L.tsel = 512u;
+	L.tsel = JM_PAIR_HALF;
 	return L.intra ? JM_ST_DC : JM_ST_COEF;
 }
 

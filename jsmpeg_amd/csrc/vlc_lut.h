@@ -15,7 +15,8 @@
  *                                non-intra block when the next bit is 1 ("1s" is (0, +-1), mpeg1.js:763-790; with a
  *                                leading 0 the two contexts read alike) -- index (next10) + 512 there.  A symbol is a
  *                                run/level code INCLUDING its sign bit, or end_of_block; the second symbol is always
- *                                read in the "later" context and only taken when it lies completely inside the 10 bits.
+ *                                read in the "later" context and only taken when it lies completely inside the 10 bits;
+ *                                behind two run/level symbols an end_of_block that still fits is taken too.
  *                                  pair_s: bits consumed (0 = the first symbol is not here: escape or a code of
  *                                          10+ bits, the SLOW step's) | tokens << 4 (0..2) | end_of_block << 6 |
  *                                          scan positions consumed << 8 (run + 1 per token)
@@ -36,10 +37,14 @@
 #include "mpeg1_dev.h"
 #include "mpeg1_vlc_codes.h"
 
+#ifndef JM_PAIR_BITS
 #define JM_PAIR_BITS 10
+#endif
+#define JM_PAIR_HALF (1u << (JM_PAIR_BITS - 1))   /* the first-coefficient context's entries: the windows with a leading 1, JM_PAIR_HALF further on */
+#define JM_PAIR_N (3u * JM_PAIR_HALF)
 struct JmVlcLuts {
-	uint32_t pair_d[1536];  /* token deltas of up to two DCT symbols */
-	uint16_t pair_s[1536];  /* bits | tokens << 4 | end_of_block << 6 | positions << 8 */
+	uint32_t pair_d[JM_PAIR_N];  /* token deltas of up to two DCT symbols */
+	uint16_t pair_s[JM_PAIR_N];  /* bits | tokens << 4 | end_of_block << 6 | positions << 8 */
 	uint16_t cbp[512];
 	uint16_t dcc[256];
 	uint16_t dcl[128];
@@ -125,9 +130,9 @@ static inline int jm_lut_symbol(uint32_t v, int avail, int first, int *run, int 
 	return 0;
 }
 static inline void jm_lut_pairs(JmVlcLuts *L) {
-	for (uint32_t idx = 0; idx < 1536; idx++) {
-		const int first = idx >= 1024;
-		const uint32_t p = first ? idx - 512 : idx;              /* the next 10 bits; first context: only those with a leading 1 */
+	for (uint32_t idx = 0; idx < JM_PAIR_N; idx++) {
+		const int first = idx >= 2 * JM_PAIR_HALF;
+		const uint32_t p = first ? idx - JM_PAIR_HALF : idx;     /* the next JM_PAIR_BITS bits; first context: only those with a leading 1 */
 		const uint32_t v = p << (32 - JM_PAIR_BITS);
 		int r1, l1, e1, r2, l2, e2;
 		const int n1 = jm_lut_symbol(v, JM_PAIR_BITS, first, &r1, &l1, &e1);
@@ -140,6 +145,11 @@ static inline void jm_lut_pairs(JmVlcLuts *L) {
 			else if (n2) {
 				s = (uint32_t)(n1 + n2) | (2u << 4) | ((uint32_t)(r1 + 1 + r2 + 1) << 8);
 				d = d1 | ((((uint32_t)(r1 + 1 + r2) << 10) | ((uint32_t)l2 & 1023u)) << 16);
+				/* ... and an end_of_block right behind the two, when it is still inside the window ("11s 11s 10" is 8 bits): a
+				 * block of two short symbols then ends in the look that reads them (round 5) */
+				int r3, l3, e3;
+				const int n3 = jm_lut_symbol(v << (n1 + n2), JM_PAIR_BITS - n1 - n2, 0, &r3, &l3, &e3);
+				if (n3 && e3) s = (s & ~15u) | (uint32_t)(n1 + n2 + n3) | (1u << 6);
 			} else { s = (uint32_t)n1 | (1u << 4) | ((uint32_t)(r1 + 1) << 8); d = d1; }
 		}
 		L->pair_s[idx] = (uint16_t)s; L->pair_d[idx] = d;

@@ -250,7 +250,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 static const JmVlcLuts &sim_luts() { static JmVlcLuts L; static bool ready = false; if (!ready) { jm_build_luts(&L); ready = true; } return L; }
 void sim_lut_pair(uint32_t w, int first, uint32_t *s, uint32_t *d) {
 	const JmVlcLuts &L = sim_luts();
-	const uint32_t idx = (w >> (32 - JM_PAIR_BITS)) + ((first ? 512u : 0u) & (uint32_t)((int32_t)w >> 31));
+	const uint32_t idx = (w >> (32 - JM_PAIR_BITS)) + ((first ? JM_PAIR_HALF : 0u) & (uint32_t)((int32_t)w >> 31));
 	*s = L.pair_s[idx]; *d = L.pair_d[idx];
 }
 uint32_t sim_lut_mba(uint32_t w) { const JmVlcLuts &L = sim_luts(); return jm_lut2(L.mba1, L.mba2, w); }

@@ -136,9 +136,10 @@ def _dct_symbol(bits, first):
 
 
 def test_pair_table_decodes_every_10_bit_window_like_a_symbol_by_symbol_walk(lut):
-    """every window of both contexts: the first symbol, and the second when it lies completely inside the 10 bits"""
+    """every window of both contexts: the first symbol, the second when it lies completely inside the 10 bits, and the
+    end_of_block behind two run/level symbols when that does too"""
     import ctypes
-    pairs = singles = 0
+    pairs = singles = triples = 0
     for first in (0, 1):
         for p in range(1 << 10):
             bits = format(p, "010b")
@@ -164,10 +165,16 @@ def test_pair_table_decodes_every_10_bit_window_like_a_symbol_by_symbol_walk(lut
                 pairs += 1
             else:
                 _, n2, r2, l2 = b
-                assert (length, nc, eob, adv) == (n1 + n2, 2, 0, r1 + 1 + r2 + 1), (first, bits)
+                # ... and an end_of_block right behind the two symbols, when it still lies inside the window, is taken with them
+                c = _dct_symbol(bits[n1 + n2:], False)
+                if c is not None and c[0] == "eob":
+                    assert (length, nc, eob, adv) == (n1 + n2 + 2, 2, 1, r1 + 1 + r2 + 1), (first, bits)
+                    triples += 1
+                else:
+                    assert (length, nc, eob, adv) == (n1 + n2, 2, 0, r1 + 1 + r2 + 1), (first, bits)
                 assert d >> 16 == ((r1 + 1 + r2) << 10) | (l2 & 1023), (first, bits)
                 pairs += 1
-    assert pairs > 500 and singles > 100
+    assert pairs > 500 and singles > 100 and triples > 20
 
 
 def test_every_ordered_pair_of_dct_symbols_through_the_tables(lut):
