@@ -465,6 +465,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * neighbours shared a bank: twice the bank-conflict cycles of the round-4 dword rows, profiles/r05_parse_notes.md) */
 	L.tk_ring = (jm_tk_ring_t)reinterpret_cast<uintptr_t>(&tk_ring[wave][0][2 * (lane & 31) + (lane >> 5)]);
 	L.state = JM_ST_DONE;
+	L.win = 0; L.bp = 0;
 	JmSliceCtx c;
 	c.lut = &lut;
 	c.pic_type = 0; c.full_pel = 0; c.f_code = 0; c.mb_width = 0; c.mb_size = 0; c.epoch = b.epoch;
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 			JM_STAT(st_coef2 += __popcll(__ballot(ready && L.state == JM_ST_COEF));) JM_CK(ck_coef2, if (ready && L.state == JM_ST_COEF) jm_step_coef(L, c))
 		}
 	}
+	jm_win_settle(L);
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {
 		uint32_t *o = b.dbg + (size_t)batch * 16;

@@ -109,6 +109,8 @@ struct JmLane {
 	jm_tk_ring_t tk_ring;   /* token slot k at ring slot (k & 31) */
 	uint32_t fillc;         /* chunks [0, fillc) have been loaded; the ring holds the last 4 */
 	uint32_t bp;            /* bit position of the next unread bit */
+	uint64_t win;           /* the ring's dwords d (high half) and d + 1 around bp, d = bp >> 5: requested as soon as a step knows its
+	                           new bp (jm_win_fetch), awaited where the next step looks at its bits (jm_win) */
 	uint32_t bp0, bp_end;   /* first payload bit; first bit past the payload */
 	uint32_t limit_bytes;
 	/* output */
@@ -187,6 +189,39 @@ JM_HD uint32_t jm_and_shl_add(uint32_t x, uint32_t mask, int sh, uint32_t add) {
 JM_D int jm_opaque(int x) { asm("" : "+v"(x)); return x; }   /* the value, with its origin hidden from the optimiser */
 #else
 JM_HD int jm_opaque(int x) { return x; }
+#endif
+/* The CARRIED window.  A step's first look at its bits used to be an LDS round trip in front of the table look-up (which is
+ * a second one): a wavefront alone on its SIMD -- the walk of the longest slices, which is what passes of a few long slices
+ * last -- sits both out.  Now the dwords around bp are REQUESTED the moment a step knows its new bp (jm_win_fetch: the same
+ * three instructions, no wait), the rest of the step (tokens, counts, the next block) runs while they travel, and the next
+ * step of the lane finds them in L.win (jm_win: the wait, usually over, and the 64-bit shift).  Same instructions, one
+ * exposed round trip less per step.  The 32 bits at bp are valid whenever a lane may step (jm_lane_blocked) and a ring
+ * service never touches the chunk bp is in, so a window fetched before a service is the window after it.
+ * (device: the register is tied in and out of the asm, so the masked-off lanes keep theirs and the compiler has no copy to
+ * make between the request and the wait -- tools/check_parse_isa.py looks at the ISA for one.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+JM_D void jm_win_fetch(JmLane &L) {
+	uint32_t a;
+	asm volatile("v_and_b32_e32 %1, 0x1e0, %2\n\tv_lshl_add_u32 %1, %1, 3, %3\n\tds_read2st64_b32 %0, %1 offset0:1"
+	             : "+v"(L.win), "=&v"(a) : "v"(L.bp), "v"(L.es_ring));
+}
+JM_D uint32_t jm_win(JmLane &L) {
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L.win));
+	return (uint32_t)((L.win << (L.bp & 31u)) >> 32);
+}
+JM_D void jm_win_settle(JmLane &L) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L.win)); }   /* end of a walk: no request is left in flight when the registers go to other uses */
+#else
+extern "C" { extern unsigned long long jm_sim_stale_windows; }   /* tests/sim: looks whose carried window was not the ring's */
+JM_HD void jm_win_fetch(JmLane &L) {
+	const uint32_t d = (L.bp >> 5) & (JM_ES_RING_DW - 1);
+	L.win = ((uint64_t)L.es_ring[d * JM_RING_STRIDE] << 32) | L.es_ring[(d + 1) * JM_RING_STRIDE];
+}
+JM_HD uint32_t jm_win(JmLane &L) {
+	const uint32_t w = (uint32_t)((L.win << (L.bp & 31u)) >> 32);
+	if (w != jm_bits32(L, L.bp)) jm_sim_stale_windows++;
+	return w;
+}
+JM_HD void jm_win_settle(JmLane &) {}
 #endif
 JM_HD uint32_t jm_get(JmLane &L, int n) {           /* 1..32 */
 	const uint32_t v = jm_bits32(L, L.bp) >> (32 - n);
@@ -320,12 +355,12 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	}
 	L.state = st;
 	L.addr = (slice_code - 1) * c.mb_width - 1;
+	jm_win_fetch(L);
 }
 
 /* decode_motion_vectors, one component (mpeg1.c:1149-1172): the new predictor value, by value
  * (a reference into the lane state would make the state addressable: scratch memory) */
-JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &bad) {
-	const uint32_t w = jm_bits32(L, L.bp);
+JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &bad, uint32_t w) {   /* w: the 32 bits at L.bp */
 	const uint32_t e = jm_lut2(c.lut->mot1, c.lut->mot2, w);
 	const int len = (int)(e >> 8);
 	if (!len) bad = true;
@@ -359,9 +394,11 @@ JM_HD int jm_open_block(JmLane &L, int rem) {
  * block's first token. */
 JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
 	const int b = L.cur;
-	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t w = jm_win(L);
 	const uint32_t e = b < 4 ? c.lut->dcl[w >> 25] : c.lut->dcc[w >> 24];
 	const int len = (int)(e >> 8), size = (int)(e & 15);
+	L.bp += (uint32_t)(len + size);
+	jm_win_fetch(L);
 	const bool is4 = b == 4, is5 = b == 5;
 	/* (the values made opaque first: a select between two loads of the lane's fields is turned into ONE load through a
 	 * select of their ADDRESSES -- which makes the lane addressable and puts all of it into scratch memory) */
@@ -372,7 +409,6 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
 		const int diff = (int)((w << len) >> (32 - size));   /* len + size <= 16 bits */
 		dcv += (diff & (1 << (size - 1))) ? diff : (int)((0xffffffffu << size) | (uint32_t)(diff + 1));
 	}
-	L.bp += (uint32_t)(len + size);
 	/* the reference's predictors are ints that only ever hold what a 16-bit token holds on valid streams; kept as the
 	 * token's value (sign-extended 16 bits), like the packed form before */
 	dcv = (int)(int16_t)dcv;
@@ -389,18 +425,24 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
  * stores its record).  In cfg2 a coded block is 2.7 symbols, 1.5 looks.  Anything else at the head (escape, a code
  * of 10+ bits) hands the lane to the SLOW step without consuming a bit. */
 JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
-	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t w = jm_win(L);
 	/* the first coefficient of a non-intra block reads "1s" as (0, +-1): its own entries, 512 further on (tsel is 512
 	 * there, and bit 9 of the index is the window's first bit) */
 	const uint32_t i10 = w >> (32 - JM_PAIR_BITS);
 	const uint32_t idx = i10 + (i10 & L.tsel);
-	const uint32_t s = c.lut->pair_s[idx], d = c.lut->pair_d[idx];
+	uint32_t s = c.lut->pair_s[idx], d = c.lut->pair_d[idx];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JM_T_PAIR_SPLIT)   /* (timing variant: the compiler's order) */
+	/* both halves of the entry in ONE round trip: left alone the compiler sinks the second read behind the test on the first */
+	asm volatile("" : "+v"(s), "+v"(d));
+#endif
 	const uint32_t len = s & 15u;
 	if (len == 0) { L.state = JM_ST_SLOW; return; }
 	const uint32_t n10_new = jm_and_shl_add(s, 0xff00u, 2, L.n10);
 	/* a position past 63: the reference indexes ZIG_ZAG out of range there.  The lane stops; the macroblock is never
 	 * recorded, so it does not matter that a first symbol that still fitted is not emitted */
 	if (n10_new > (64u << 10) || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
+	L.bp += len;
+	jm_win_fetch(L);
 	const uint32_t nc = (s >> 4) & 3u;
 	/* both slots are written whatever nc says: a slot at or past tw is not part of the stream until tw passes it
 	 * (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free).  A token is its scan position
@@ -411,7 +453,6 @@ JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 	L.cnt += (int)nc;
 	L.n10 = n10_new;
 	L.tsel = 0;
-	L.bp += len;
 	if (s & 64u) {
 		/* end_of_block.  Runs are dword aligned for the reconstruct loads: an odd run leaves one slot
 		 * unused (never read: the record carries the count). */
@@ -427,7 +468,7 @@ JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	/* both forms are worked out for every lane and selected at the end: the lanes of a wave that are here hold a mix of
 	 * escapes and long codes, and a branch would run both sides anyway, plus its bookkeeping */
-	const uint32_t w = jm_bits32(L, L.bp);
+	const uint32_t w = jm_win(L);
 	const bool esc = (w >> 26) == 1;
 	/* escape: 6 + 6-bit run, 8- or 16-bit level */
 	const int e_lv8 = (int)((w >> 12) & 255), e_low = (int)((w >> 4) & 255);
@@ -450,6 +491,7 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	int st = JM_ST_DONE;
 	if (!bad) {
 		L.bp += (uint32_t)used;
+		jm_win_fetch(L);
 		jm_emit(L, n10 | ((uint32_t)level & 1023u));
 		L.n10 = n10 + (1u << 10);
 		L.cnt++;
@@ -470,6 +512,11 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	const bool is_p = c.pic_type == JM_PIC_PREDICTIVE;
 	int st = JM_ST_COLD;
 	bool go = true;
+	/* The header's looks: increment + type + quantizer_scale are at most 11 + 6 + 5 bits -- ONE window, the carried one;
+	 * each motion component (at most 17 bits) takes its own; the pattern (9 bits) is still inside whichever came last
+	 * (22 + 9 or 17 + 9 bits).  wc = that window, wbase = the bit position it was read at: five looks became one (no
+	 * vector) or three -- an LDS round trip and its four instructions each. */
+	uint32_t wc = 0, wbase = L.bp;
 	/* ---- the macroblock whose last block just ended: its record, and the end of the slice
 	 * (mpeg1.c:1018-1020) ---- */
 	if (L.cur >= 0) {
@@ -480,7 +527,8 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	}
 	/* ---- macroblock_address_increment (mpeg1.c:1028-1043) ---- */
 	if (go) {
-		const uint32_t e = jm_lut2(T->mba1, T->mba2, jm_bits32(L, L.bp));
+		wc = jm_win(L);                                                /* the step's first look: bp is where the last step left it */
+		const uint32_t e = jm_lut2(T->mba1, T->mba2, wc);
 		if (!(e >> 8) || L.bp >= L.bp_end) { st = JM_ST_DONE; go = false; }
 		else {
 			L.bp += e >> 8;
@@ -520,7 +568,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	/* ---- macroblock_type, quantizer_scale (mpeg1.c:1092-1108): at most 6 + 5 bits, one look ---- */
 	int type = 0;
 	if (go) {
-		const uint32_t w = jm_bits32(L, L.bp);
+		const uint32_t w = wc << (L.bp - wbase);                       /* the increment's code was at most 11 bits */
 		const uint32_t e = is_p ? T->type_p[w >> 26] : T->type_i[w >> 30];
 		const int len = (int)(e >> 8);
 		type = (int)(e & 31);
@@ -535,8 +583,9 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 		int ph = L.pmh, pv = L.pmv;
 		bool bad = false;
 		if (has_mv) {
-			ph = jm_motion_component(L, c, ph, bad);
-			pv = jm_motion_component(L, c, pv, bad);
+			ph = jm_motion_component(L, c, ph, bad, jm_bits32(L, L.bp));
+			wbase = L.bp; wc = jm_bits32(L, L.bp);
+			pv = jm_motion_component(L, c, pv, bad, wc);
 		}
 		const bool zero = intra || (!has_mv && is_p);      /* intra: mpeg1.c:1110-1114; no vector in a P picture: 1200-1204 */
 		L.pmh = zero ? 0 : ph; L.pmv = zero ? 0 : pv;
@@ -553,7 +602,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 	if (go) {
 		int cbp = L.intra ? 0x3f : 0;
 		if (type & 0x02) {
-			const uint32_t e = T->cbp[jm_bits32(L, L.bp) >> 23];
+			const uint32_t e = T->cbp[(wc << (L.bp - wbase)) >> 23];
 			L.bp += e >> 8;
 			cbp = (e >> 8) ? (int)(e & 0xff) : -1;
 		}
@@ -566,6 +615,7 @@ JM_HD void jm_step_cold(JmLane &L, const JmSliceCtx &c) {
 		}
 	}
 	L.state = st;
+	jm_win_fetch(L);
 }
 
 /* What the lane is waiting for. */

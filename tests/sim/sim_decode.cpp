@@ -275,6 +275,8 @@ const uint64_t *sim_idct_counts(void) { return g_idct; }
 uint64_t sim_cost(void) { return g_cost; }
 void sim_kcost(const int *t) { for (int k = 0; k <= JM_ST_KINDS; k++) g_kcost[k] = t[k]; }
 const uint64_t *sim_served(void) { return g_served; }
+unsigned long long jm_sim_stale_windows;   /* slice_parse.h jm_win (host form): looks whose carried window differed from the ring's bits */
+unsigned long long sim_stale_windows(void) { return jm_sim_stale_windows; }
 void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; g_cost = 0; }
 
 // The engine's reconstruct plan (recon_plan.h) on plain arrays: stale[] and level[] out, returns the number of levels.

@@ -30,6 +30,7 @@ def sim():
                                "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.sim_decode_stream.restype = ctypes.c_int
+    lib.sim_stale_windows.restype = ctypes.c_ulonglong
     lib.sim_decode_stream.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int]
     return lib
@@ -46,6 +47,8 @@ def test_device_functions_match_golden(path, sim):
     assert n == fx["n_frames"]
     got = [hashlib.md5(out[i * fb:(i + 1) * fb].tobytes()).hexdigest() for i in range(n)]
     assert got == fx["frame_md5"]
+    # the parse's carried bit window (slice_parse.h jm_win): every look found the bits the ring holds at its position
+    assert sim.sim_stale_windows() == 0
 
 
 def plan_reference(decoded, fwd, stream, covered, mb_size):
