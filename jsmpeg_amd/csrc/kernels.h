@@ -97,6 +97,7 @@ struct JmParseBufs {
 	uint32_t bytes_per_mb_x16;   /* caller's figure: compressed bytes per macroblock of the pass, x 16 (0: unknown) -- the header step's queue
 	                                threshold follows it (jm_launch_parse: sparse content queues longer) */
 	uint32_t t_cold;             /* set by jm_launch_parse: the threshold for a full wavefront (of 64) */
+	uint32_t split_service;      /* set by jm_launch_parse: the ring service in two halves a turn apart (slice_parse.h jm_lane_request / jm_lane_land) */
 	uint32_t prio_batches;       /* set by jm_launch_parse: the first so many batches (the longest slices) run at raised wavefront priority */
 	uint32_t long_slices;        /* caller's estimate of how many slices are much longer than the mean (those of the intra pictures), 0: none
 	                                -- with the slices in longest-first order, jm_launch_parse gives the first ones fewer lanes per wavefront */

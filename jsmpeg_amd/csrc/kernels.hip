@@ -386,7 +386,11 @@ hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
 #define JM_PARSE_FILL_WAVES 4096u   /* wavefronts that fill the GPU for this kernel: 256 CUs x 16 */
 #define JM_PARSE_RESIDENT_WGS (JM_PARSE_FILL_WAVES / JM_PARSE_WAVES)
 
-__global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
+/* SPLIT: the ring service in two halves a turn apart (slice_parse.h jm_lane_request / jm_lane_land).  Two kernels, not a
+ * run-time switch: with both forms in one body the compiler keeps the requested chunks in one set of registers and copies
+ * them to another right behind the loads -- reading registers whose data has not landed (tools/check_parse_isa.py found it). */
+template <bool SPLIT>
+static __device__ __forceinline__ void jm_parse_body(const JmParseBufs &b) {
 	__shared__ __attribute__((aligned(16))) JmVlcLuts lut;
 	__shared__ uint32_t es_ring[JM_PARSE_WAVES][JM_ES_RING_ROWS][JM_RING_STRIDE];
 	__shared__ __attribute__((aligned(4096))) uint16_t tk_ring[JM_PARSE_WAVES][JM_TK_RING][JM_RING_STRIDE];   /* a wavefront's tile: 4096 bytes at a multiple of 4096 (slice_parse.h jm_tk_put) */
@@ -465,7 +469,10 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	 * neighbours shared a bank: twice the bank-conflict cycles of the round-4 dword rows, profiles/r05_parse_notes.md) */
 	L.tk_ring = (jm_tk_ring_t)reinterpret_cast<uintptr_t>(&tk_ring[wave][0][2 * (lane & 31) + (lane >> 5)]);
 	L.state = JM_ST_DONE;
-	L.win = 0; L.bp = 0;
+	L.win = 0; L.bp = 0; L.pend_t = 0; L.fillc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	L.pv0 = L.pv1 = L.pv2 = L.pv3 = jm_u32x4{0, 0, 0, 0};
+#endif
 	JmSliceCtx c;
 	c.lut = &lut;
 	c.pic_type = 0; c.full_pel = 0; c.f_code = 0; c.mb_width = 0; c.mb_size = 0; c.epoch = b.epoch;
@@ -505,7 +512,9 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 #define JM_STAT(x)
 #define JM_CK(acc, body) { body; }
 #endif
+	bool landing = false;                            /* (wave-uniform) the last turn requested chunks: they land at the top of this one */
 	for (uint32_t turn = 0; turn < (1u << 24); turn++) {
+		if (SPLIT && landing) { JM_CK(ck_service, jm_lane_land(L); if (L.state != JM_ST_DONE) jm_lane_drain(L)) landing = false; }
 		const bool ready = !jm_lane_blocked(L);      /* for every step of this turn (JM_STEP_BITS, its token slots) */
 		const bool live = L.state != JM_ST_DONE;
 		/* the wavefront's view as three lane masks and scalar logic on them (as booleans combined per lane the compiler
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		const uint64_t blocked = m_live & ~m_ready;
 		const bool others = ((m_live & ~m_cold) | blocked) != 0;
 		if (n_cold == 0 && !others) break;
-		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_service(L)) }
+		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) { if (SPLIT) jm_lane_request(L); else jm_lane_service(L); }) landing = SPLIT; }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
 		if (jm_run_cold(n_cold, others ? 1 : 0, cold_threshold)) { JM_STAT(st_cold++;) JM_CK(ck_cold, if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c)) }
 		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
@@ -530,6 +539,7 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 		}
 	}
 	jm_win_settle(L);
+	if (SPLIT) jm_lane_settle(L);
 #ifdef JM_PARSE_STATS
 	if (b.dbg && lane == 0) {
 		uint32_t *o = b.dbg + (size_t)batch * 16;
@@ -548,6 +558,8 @@ __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) {
 	batch = gridDim.x * JM_PARSE_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 	}
 }
+__global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) { jm_parse_body<false>(b); }
+__global__ __launch_bounds__(JM_PARSE_WG) void k_parse_split(JmParseBufs b) { jm_parse_body<true>(b); }
 
 #ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
 uint32_t jm_parse_resident_once = 0;   /* measurement builds (engine.hip, JSMPEG_HIP_T_SHADOW_PARSE): the next launch's resident workgroups; not thread-safe, not in the product */
@@ -575,15 +587,25 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	  if (forced >= 1 && forced <= 64) { lanes = (uint32_t)forced; lanes_forced = true; } }
 	b.lanes_per_wave = lanes;
 	/* The header step's queue threshold (slice_parse.h jm_run_cold).  The step is the longest of the turn; the denser the
-	 * content, the smaller the share of a lane's steps that are header steps and the less it pays to let them queue:
-	 * measured on the box (profiles/r05_parse_notes.md) -- 2160p at 46 bytes per macroblock, 64 x 24: 6.40 / 6.14 ms at
-	 * 24 / 12, 16 x 24: 4.80 / 4.73; 320x240 intra at 26 bytes: 0.887 / 0.861; cfg2 and cfg1 (8 bytes per macroblock)
-	 * are fastest at 24 (cfg2: 2.97 / 2.83 / 2.85 / 2.99 at 12 / 24 / 32 / 40). */
+	 * content, the smaller the share of a lane's steps that are header steps and the less it pays to let them queue.
+	 * Measured on the box (profiles/r05_parse_notes.md; late round 5, the carried-window kernel): the 2160p configuration
+	 * (17 bytes per macroblock over its I and P pictures) 64 x 24 at 24 / 16 / 12 / 8: 5.20 / 5.08 / 5.11 / 5.26 ms, 16 x 24 at
+	 * 24 / 12: 4.15 / 4.08; 320x240 intra (21 bytes) at 16 / 12 / 8: 0.69 / 0.69 / 0.71; cfg2 and cfg1 (8 bytes per macroblock)
+	 * are fastest at 24 (cfg2: 2.97 / 2.83 / 2.85 / 2.99 at 12 / 24 / 32 / 40).  So: 14 from 12 bytes per macroblock up.
+	 * (until late in round 5 the cut was at 20 bytes, which the 2160p configuration as generated never reached) */
 	b.t_cold = JM_T_COLD;
 	if (b.bytes_per_mb_x16 >= JM_T_COLD_DENSE_X16) b.t_cold = JM_T_COLD_DENSE;
 	{ static const int forced = getenv("JSMPEG_HIP_T_COLD") ? atoi(getenv("JSMPEG_HIP_T_COLD")) : 0;   /* tuning only */
 	  if (forced >= 1 && forced <= 64) b.t_cold = (uint32_t)forced; }
 	b.cold_threshold = (int)((b.t_cold * lanes + 63) / 64);
+	/* The ring service in two halves (slice_parse.h jm_lane_request / jm_lane_land: a refill's memory latency behind a turn of
+	 * work) where the wavefronts with the longest slices walk alone for much of the pass -- dense content, by the same
+	 * figure: 2160p 64 x 24 5.66 -> 5.20 ms, 320x240 intra 64 x 300 0.755 -> 0.70, 2160p 16 x 24 and one 720p stream
+	 * unchanged; cfg2 (sparse, the issue port full to the end) measured 2-3 % slower with it (2.55 -> 2.62, four
+	 * alternating pairs: profiles/r05z_parse_split_service.txt) and keeps the one-piece service */
+	b.split_service = b.bytes_per_mb_x16 >= JM_T_COLD_DENSE_X16 ? 1u : 0u;
+	{ static const int forced = getenv("JSMPEG_HIP_PARSE_SPLIT") ? atoi(getenv("JSMPEG_HIP_PARSE_SPLIT")) : -1;   /* tuning / tests: 0 / 1 */
+	  if (forced >= 0) b.split_service = forced ? 1u : 0u; }
 	/* Mid-size passes with a few LONG slices (16 x 24 pictures of 4K: the 8 % of the slices that belong to intra pictures
 	 * are three times the others): the pass lasts as long as the wavefront that holds the longest slices walks, and a
 	 * wavefront with one or two slices walks about twice as fast as one with 16+ (its turns run only the step kinds those
@@ -657,7 +679,11 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 			if (e != hipSuccess) return e;
 		} else b.cu_order = nullptr;
 	}
-	hipLaunchKernelGGL(k_parse, dim3(groups), dim3(JM_PARSE_WG), 0, st, b);
+	{ static const bool say = getenv("JSMPEG_HIP_PARSE_SAY") != nullptr;   /* tuning: what the launch decided */
+	  if (say) fprintf(stderr, "k_parse%s: %u slices, %u per wavefront, %u batches in %u workgroups%s, header threshold %u, %u/16 bytes per macroblock\n",
+	                   b.split_service ? "_split" : "", b.n_lanes, b.lanes_per_wave, b.n_batches, groups, b.ticket ? " + tickets" : "", b.t_cold, b.bytes_per_mb_x16); }
+	if (b.split_service) hipLaunchKernelGGL(k_parse_split, dim3(groups), dim3(JM_PARSE_WG), 0, st, b);
+	else hipLaunchKernelGGL(k_parse, dim3(groups), dim3(JM_PARSE_WG), 0, st, b);
 	return hipGetLastError();
 }
 

@@ -93,6 +93,7 @@ struct JmSliceCtx {
  * compiler cannot fold (it does not know the tile's alignment).  The test-only simulator (tests/sim) has plain arrays. */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define JM_LDS __attribute__((address_space(3)))
+typedef uint32_t jm_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t jm_es_ring_t;   /* byte address of row 0 of the lane's dword column; row r at + 256 r */
 typedef uint32_t jm_tk_ring_t;   /* byte address of slot 0 of the lane's 16-bit column; slot k at + 128 k.  The tile is 4096-byte aligned */
 #else
@@ -109,6 +110,10 @@ struct JmLane {
 	jm_tk_ring_t tk_ring;   /* token slot k at ring slot (k & 31) */
 	uint32_t fillc;         /* chunks [0, fillc) have been loaded; the ring holds the last 4 */
 	uint32_t bp;            /* bit position of the next unread bit */
+	uint32_t pend_t;        /* chunks [fillc, pend_t) are on their way (jm_lane_request) and land at the top of the next turn (jm_lane_land); 0: none */
+#if defined(__HIP_DEVICE_COMPILE__)
+	jm_u32x4 pv0, pv1, pv2, pv3;   /* ... in these registers */
+#endif
 	uint64_t win;           /* the ring's dwords d (high half) and d + 1 around bp, d = bp >> 5: requested as soon as a step knows its
 	                           new bp (jm_win_fetch), awaited where the next step looks at its bits (jm_win) */
 	uint32_t bp0, bp_end;   /* first payload bit; first bit past the payload */
@@ -234,7 +239,6 @@ JM_HD bool jm_slice_ended(const JmLane &L) { return ((jm_consumed(L) + 7) >> 3) 
 
 /* ---- service: top up the compressed-data ring, drain whole token groups ---- */
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef uint32_t jm_u32x4 __attribute__((ext_vector_type(4)));
 JM_D void jm_lane_refill(JmLane &L) {
 	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;   /* the chunk being read + the rest of the ring ahead */
 	/* Only the chunks the lane has room for (a lane takes one or two per service, the service runs every ~5th turn:
@@ -279,6 +283,58 @@ JM_HD void jm_lane_refill(JmLane &L) {       /* the simulator's: the same chunks
 	}
 	if (L.fillc < target) L.fillc = target;
 }
+#endif
+/* The service of the turn loop, in two halves a turn apart.  A lane that is blocked at the top of turn N does not step in
+ * turn N whatever happens (the turn's `ready` is taken before the service), so its chunks need not be there before the top
+ * of turn N + 1: turn N only REQUESTS them (jm_lane_request: the loads, no wait) and the wavefront goes on stepping its
+ * other lanes; the top of turn N + 1 LANDS them (jm_lane_land: the wait -- a turn old by then -- and the ring writes) before
+ * it looks who is ready.  The memory latency of a refill, which a wavefront alone on its SIMD sat out 0.2 times per turn,
+ * is behind a turn of work.  Same chunks into the same rows at the same point of every lane's walk as the one-piece service.
+ * (the loaded registers are tied in and out of the asm statements like the carried window: tools/check_parse_isa.py) */
+#if defined(__HIP_DEVICE_COMPILE__)
+JM_D void jm_lane_request(JmLane &L) {
+	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;
+	const uint32_t f = L.fillc;
+	const uint4_like_t *src = L.es16 + f;
+	if (f < target) asm volatile("global_load_dwordx4 %0, %1, off ; jm_req" : "+v"(L.pv0) : "v"(src));
+	if (f + 1 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:16 ; jm_req" : "+v"(L.pv1) : "v"(src));
+	if (f + 2 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:32 ; jm_req" : "+v"(L.pv2) : "v"(src));
+	if (f + 3 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:48 ; jm_req" : "+v"(L.pv3) : "v"(src));
+	L.pend_t = target;
+}
+JM_D void jm_lane_land(JmLane &L) {
+	asm volatile("s_waitcnt vmcnt(0) ; jm_land" : "+v"(L.pv0), "+v"(L.pv1), "+v"(L.pv2), "+v"(L.pv3));
+	const uint32_t f = L.fillc, target = L.pend_t;
+#define JM_REFILL_PUT(i, v)                                                                          \
+	if (f + i < target) {                                                                            \
+		const uint32_t row = ((f + i) & (JM_ES_RING_DW / 4 - 1)) * 4;                                \
+		const uint32_t x = __builtin_bswap32(v.x);                                                   \
+		jm_es_put(L, row, x); jm_es_put(L, row + 1, __builtin_bswap32(v.y));                         \
+		jm_es_put(L, row + 2, __builtin_bswap32(v.z)); jm_es_put(L, row + 3, __builtin_bswap32(v.w)); \
+		if (row == 0) jm_es_put(L, JM_ES_RING_DW, x);                                                \
+	}
+	JM_REFILL_PUT(0, L.pv0) JM_REFILL_PUT(1, L.pv1) JM_REFILL_PUT(2, L.pv2) JM_REFILL_PUT(3, L.pv3)
+#undef JM_REFILL_PUT
+	if (L.fillc < target) L.fillc = target;
+	L.pend_t = 0;
+}
+JM_D void jm_lane_settle(JmLane &L) { asm volatile("s_waitcnt vmcnt(0) ; jm_land" : "+v"(L.pv0), "+v"(L.pv1), "+v"(L.pv2), "+v"(L.pv3)); }
+#else
+JM_HD void jm_lane_request(JmLane &L) { L.pend_t = (L.bp >> 7) + JM_ES_RING_DW / 4; }
+JM_HD void jm_lane_land(JmLane &L) {
+	const uint32_t target = L.pend_t;
+	for (uint32_t ch = L.fillc; ch < target && ch < L.fillc + JM_ES_RING_DW / 4; ch++) {
+		const uint4_like_t v = L.es16[ch];
+		const uint32_t row = (ch & (JM_ES_RING_DW / 4 - 1)) * 4;
+		const uint32_t x = __builtin_bswap32(v.x);
+		jm_es_put(L, row, x); jm_es_put(L, row + 1, __builtin_bswap32(v.y));
+		jm_es_put(L, row + 2, __builtin_bswap32(v.z)); jm_es_put(L, row + 3, __builtin_bswap32(v.w));
+		if (row == 0) jm_es_put(L, JM_ES_RING_DW, x);
+	}
+	if (L.fillc < target) L.fillc = target;
+	L.pend_t = 0;
+}
+JM_HD void jm_lane_settle(JmLane &) {}
 #endif
 JM_HD void jm_lane_drain(JmLane &L) {
 	while (L.tw7 - L.tf7 >= JM_TK_GROUP * JM_TW_UNIT) {
@@ -338,7 +394,7 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	L.bp0 = (payload_off & 15u) * 8u;
 	L.bp = L.bp0;
 	L.limit_bytes = limit_bytes; L.bp_end = L.bp0 + limit_bytes * 8u;
-	L.fillc = 0;
+	L.fillc = 0; L.pend_t = 0;
 	L.tokens = tokens; L.tw7 = L.tf7 = tok_slot * JM_TW_UNIT; L.tok_rel = tok_rel; L.mb = mb; L.stored = 0;
 	jm_lane_refill(L);
 	L.dcy = L.dc4 = L.dc5 = JM_DC_RESET;
@@ -479,19 +535,22 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	const uint32_t i2 = (uint32_t)((lz - 6) & 7) * 16u + ((w >> ((27 - lz) & 31)) & 15u);
 	const uint32_t f = c.lut->far_[i2 < 96 ? i2 : 0];
 	const int flen = (int)(f >> 11);
+	/* the symbol's length is all the next look needs: its window is requested here, the symbol is worked out while it
+	 * travels (a lane whose symbol turns out bad stops; nobody looks at its bp again) */
+	const bool past = L.bp >= L.bp_end;
+	const int used = esc ? (e_long ? 28 : 20) : flen + 1;
+	L.bp += (uint32_t)used;
+	jm_win_fetch(L);
 	const int f_mag = (int)(f & 63);
 	const int f_level = ((w >> ((31 - flen) & 31)) & 1) ? -f_mag : f_mag;
 	const bool f_bad = !flen || lz < 6 || lz > 11;
 
 	const uint32_t run = esc ? (w >> 20) & 63u : (f >> 6) & 31u;
 	const int level = esc ? e_level : f_level;
-	const int used = esc ? (e_long ? 28 : 20) : flen + 1;
 	const uint32_t n10 = L.n10 + (run << 10);
-	const bool bad = L.bp >= L.bp_end || n10 > (63u << 10) || (!esc && f_bad);
+	const bool bad = past || n10 > (63u << 10) || (!esc && f_bad);
 	int st = JM_ST_DONE;
 	if (!bad) {
-		L.bp += (uint32_t)used;
-		jm_win_fetch(L);
 		jm_emit(L, n10 | ((uint32_t)level & 1023u));
 		L.n10 = n10 + (1u << 10);
 		L.cnt++;
@@ -632,8 +691,8 @@ JM_HD int jm_lane_wants(const JmLane &L) {
 #ifndef JM_T_COLD
 #define JM_T_COLD 24
 #endif
-#define JM_T_COLD_DENSE 12          /* passes from JM_T_COLD_DENSE_X16 / 16 compressed bytes per macroblock up */
-#define JM_T_COLD_DENSE_X16 (20 * 16)
+#define JM_T_COLD_DENSE 14          /* passes from JM_T_COLD_DENSE_X16 / 16 compressed bytes per macroblock up */
+#define JM_T_COLD_DENSE_X16 (12 * 16)
 JM_HD bool jm_run_cold(int n_cold, int n_other, int threshold) { return n_cold >= threshold || (n_cold > 0 && n_other == 0); }
 
 #endif

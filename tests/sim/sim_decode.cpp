@@ -43,6 +43,7 @@ static void sim_idct_pair(HostSlot &s) {
 static int g_thr[JM_ST_KINDS] = { JM_T_COLD, 1, 1, 1, 1, 0 };   // experiments: the scheduler's COLD threshold
 static uint64_t g_idct[4];         // reconstruct: low-frequency / other blocks through the transform, wavefronts that run the cheap / any transform
 static uint64_t g_blocks_seen;
+static int g_split_service = 1;    // the ring service in two halves a turn apart (jm_launch_parse picks per pass), or in one piece
 static uint64_t g_picks;           // turns (scheduling decisions)
 static uint64_t g_cost;            // cost model: instructions issued by the wavefronts
 static int g_kcost[JM_ST_KINDS + 1] = { 430, 60, 95, 110, 270, 0, 50 };   // per handler; [KINDS] = per turn
@@ -121,7 +122,7 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 		for (int l = 0; l < 64; l++) {
 			const uint32_t i = w0 + (uint32_t)l;
 			L[l].es_ring = &es_ring[0][l]; L[l].tk_ring = &tk_ring[0][l];
-			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].tw7 = L[l].tf7 = 0;
+			L[l].state = JM_ST_DONE; L[l].fillc = L[l].bp = 0; L[l].pend_t = 0; L[l].tw7 = L[l].tf7 = 0;
 			mine[l] = false;
 			C[l].lut = &luts; C[l].epoch = epoch; C[l].pic_type = 0;
 			if (i >= n_sc || owner[i] == JM_NONE) continue;
@@ -140,7 +141,9 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			             reinterpret_cast<uint4_like_t *>(tokens.data()) + ((pic.tok_off - rel) >> 3), slot, rel);
 			mine[l] = true;
 		}
+		bool landing = false;
 		for (;;) {
+			if (landing) { for (int l = 0; l < 64; l++) { jm_lane_land(L[l]); if (L[l].state != JM_ST_DONE) jm_lane_drain(L[l]); } landing = false; }
 			bool ready[64];
 			int n_cold = 0, n_other = 0, n_blocked = 0;
 			for (int l = 0; l < 64; l++) {
@@ -154,7 +157,8 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			g_picks++; g_cost += (uint64_t)g_kcost[JM_ST_KINDS];
 			if (n_blocked) {
 				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n_blocked; g_cost += (uint64_t)g_kcost[JM_ST_WAIT];
-				for (int l = 0; l < 64; l++) if (L[l].state != JM_ST_DONE) jm_lane_service(L[l]);
+				for (int l = 0; l < 64; l++) if (L[l].state != JM_ST_DONE) { if (g_split_service) jm_lane_request(L[l]); else jm_lane_service(L[l]); }
+				landing = g_split_service != 0;
 			}
 			const bool cold = jm_run_cold(n_cold, n_other, g_thr[JM_ST_COLD]);
 			static const int order[4 + 4] = { JM_ST_COLD, JM_ST_DC, JM_ST_COEF, JM_ST_SLOW, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF };
@@ -277,6 +281,7 @@ void sim_kcost(const int *t) { for (int k = 0; k <= JM_ST_KINDS; k++) g_kcost[k]
 const uint64_t *sim_served(void) { return g_served; }
 unsigned long long jm_sim_stale_windows;   /* slice_parse.h jm_win (host form): looks whose carried window differed from the ring's bits */
 unsigned long long sim_stale_windows(void) { return jm_sim_stale_windows; }
+void sim_split_service(int on) { g_split_service = on; }
 void sim_reset_counters(void) { memset(g_turns, 0, sizeof(g_turns)); memset(g_served, 0, sizeof(g_served)); memset(g_states, 0, sizeof(g_states)); g_picks = 0; g_cost = 0; }
 
 // The engine's reconstruct plan (recon_plan.h) on plain arrays: stale[] and level[] out, returns the number of levels.

@@ -36,8 +36,10 @@ def sim():
     return lib
 
 
+@pytest.mark.parametrize("split", [1, 0], ids=["service_in_two_halves", "service_in_one_piece"])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-5] for p in FIXTURES])
-def test_device_functions_match_golden(path, sim):
+def test_device_functions_match_golden(path, split, sim):
+    sim.sim_split_service(split)       # jm_launch_parse picks the form per pass (kernels.hip): both are the product
     fx = json.load(open(path))
     es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
     fb = fx["info"]["coded_size"] * 3 // 2

@@ -21,9 +21,12 @@ def kernel_isa(defs=()):
                                "-I", os.path.join(ROOT, "jsmpeg_amd", "csrc"), "-S", "--cuda-device-only", "-o", out,
                                *defs, os.path.join(ROOT, "jsmpeg_amd", "csrc", "kernels.hip")], stderr=subprocess.DEVNULL)
         text = open(out).read()
-    m = re.search(r"^_Z7k_parse11JmParseBufs:.*?^\s*\.size\s+_Z7k_parse11JmParseBufs", text, re.S | re.M)
-    assert m, "k_parse not found in the assembly"
-    return m.group(0).splitlines()
+    out = {}
+    for sym in ("_Z7k_parse11JmParseBufs", "_Z13k_parse_split11JmParseBufs"):
+        m = re.search(r"^%s:.*?^\s*\.size\s+%s" % (sym, sym), text, re.S | re.M)
+        assert m, sym + " not found in the assembly"
+        out[sym] = m.group(0).splitlines()
+    return out
 
 
 def regs_of(line):
@@ -71,6 +74,39 @@ def check_uses(lines):
     return carried, bad
 
 
+def check_chunks(lines):
+    """the third rule, for the refill's two halves (jm_lane_request / jm_lane_land, tagged `jm_req` / `jm_land` in the asm): from a
+    request to the next landing wait nothing names the requested registers -- in program order to the end of the turn loop,
+    and from the loop's head (the target of the backward branch that closes the loop around the requests) to the first wait"""
+    req = [n for n, l in enumerate(lines) if "jm_req" in l]
+    land = [n for n, l in enumerate(lines) if "jm_land" in l]
+    if not req:
+        return set(), []
+    R = set()
+    for n in req:
+        R |= regs_of(lines[n].split(";")[0].split(",")[0])
+    labels = {l.split(":")[0].strip(): n for n, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
+    first_land = min(land)
+    head = None
+    for n in range(max(req) + 1, len(lines)):
+        m = re.match(r"\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", lines[n])
+        if m and labels.get(m.group(1), len(lines)) < first_land:
+            head = labels[m.group(1)]            # (the innermost such loop is closed first)
+            break
+    assert head is not None, "no loop around the requests"
+    bad, flying = [], False
+    order = list(range(min(req), len(lines))) + list(range(head, first_land + 1))
+    for n in order:
+        l = lines[n]
+        if "jm_req" in l:
+            flying = True
+        elif "jm_land" in l:
+            flying = False
+        elif flying and regs_of(l) & R and not l.split(";")[0].strip().endswith(":"):
+            bad.append((min(req), n, l.strip()))
+    return R, bad
+
+
 def check(lines):
     bad, pending, requests = [], None, 0
     for n, line in enumerate(lines):
@@ -89,12 +125,18 @@ def check(lines):
 
 
 if __name__ == "__main__":
-    lines = kernel_isa(sys.argv[1:])
-    requests, bad = check(lines)
-    carried, bad2 = check_uses(lines)
-    print("k_parse: %d window requests, %d instructions touch a window register before its wait" % (requests, len(bad)))
-    print("carried window registers: %s; %d readers without a wait behind the request" % (sorted(carried), len(bad2)))
-    bad += bad2
-    for r, n, l in bad:
-        print("  request at line %d: line %d: %s" % (r, n, l))
-    sys.exit(1 if bad or not requests else 0)
+    rc = 0
+    for sym, lines in kernel_isa(sys.argv[1:]).items():
+        requests, bad = check(lines)
+        carried, bad2 = check_uses(lines)
+        print("%s: %d window requests, %d instructions touch a window register before its wait" % (sym, requests, len(bad)))
+        print("  carried window registers: %s; %d readers without a wait behind the request" % (sorted(carried), len(bad2)))
+        bad += bad2
+        R, bad3 = check_chunks(lines)
+        print("  requested chunk registers: v%d..v%d; %d instructions name one between request and landing" % (min(R), max(R), len(bad3)) if R else "  (the refill in one piece)")
+        bad += bad3
+        for r, n, l in bad[:40]:
+            print("  request at line %d: line %d: %s" % (r, n, l))
+        if bad or not requests or (("split" in sym) != bool(R)):
+            rc = 1
+    sys.exit(rc)

@@ -44,6 +44,7 @@ for c in range(cases):
     cw, ch = (ov["width"] + 15) // 16 * 16, (ov["height"] + 15) // 16 * 16
     fb = cw * ch * 3 // 2
     out = np.zeros((n + 2) * fb, dtype=np.uint8)
+    sim.sim_split_service(c & 1)         # the ring service in two halves / in one piece (jm_launch_parse picks per pass)
     got = sim.sim_decode_stream(es.ctypes.data, len(es), ov["width"], ov["height"], out.ctypes.data, n + 2)
     ok = got == len(frames)
     if ok:
