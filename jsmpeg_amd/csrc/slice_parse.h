@@ -139,7 +139,7 @@ struct JmLane {
 	uint64_t cnts;
 	/* current block */
 	uint32_t n10;           /* scan position << 10 (a token's upper bits) */
-	int cnt;
+	uint32_t tb7;           /* the cursor (tw7) at the block's first token: the block's token count is the difference when it ends */
 	uint32_t tsel;          /* 512 while the next coefficient is the first of a non-intra block, else 0 (the pair table's context) */
 };
 
@@ -401,7 +401,7 @@ JM_HD void jm_lane_init(JmLane &L, const uint4_like_t *es_base16, uint32_t paylo
 	L.mvh = L.mvv = L.pmh = L.pmv = 0;
 	L.inc = 0; L.slice_begin = 1;
 	L.intra = 0; L.cbp = 0; L.cur = -1; L.qf = 0; L.tok_first = 0; L.rec_mvh = L.rec_mvv = 0; L.cnts = 0;
-	L.n10 = 0; L.cnt = 0; L.tsel = 0;
+	L.n10 = 0; L.tb7 = 0; L.tsel = 0;
 	/* decode_slice header (mpeg1.c:1011-1016) */
 	L.qscale = (int)jm_get(L, 5);
 	int st = JM_ST_COLD;
@@ -441,7 +441,7 @@ JM_HD int jm_motion_component(JmLane &L, const JmSliceCtx &c, int prev, bool &ba
  * the "first coefficient" table. */
 JM_HD int jm_open_block(JmLane &L, int rem) {
 	L.cur = __builtin_clz((unsigned)rem) - 26;
-	L.n10 = 0; L.cnt = 0;
+	L.n10 = 0; L.tb7 = L.tw7;
 	L.tsel = JM_PAIR_HALF;
 	return L.intra ? JM_ST_DC : JM_ST_COEF;
 }
@@ -470,7 +470,7 @@ JM_HD void jm_step_dc(JmLane &L, const JmSliceCtx &c) {
 	dcv = (int)(int16_t)dcv;
 	L.dc4 = is4 ? dcv : L.dc4; L.dc5 = is5 ? dcv : L.dc5; L.dcy = (is4 || is5) ? L.dcy : dcv;
 	jm_emit(L, (uint32_t)dcv);
-	L.n10 = 1u << 10; L.cnt = 1;
+	L.n10 = 1u << 10;
 	L.tsel = 0;
 	L.state = len ? JM_ST_COEF : JM_ST_DONE;
 }
@@ -493,27 +493,29 @@ JM_HD void jm_step_coef(JmLane &L, const JmSliceCtx &c) {
 #endif
 	const uint32_t len = s & 15u;
 	if (len == 0) { L.state = JM_ST_SLOW; return; }
-	const uint32_t n10_new = jm_and_shl_add(s, 0xff00u, 2, L.n10);
-	/* a position past 63: the reference indexes ZIG_ZAG out of range there.  The lane stops; the macroblock is never
-	 * recorded, so it does not matter that a first symbol that still fitted is not emitted */
-	if (n10_new > (64u << 10) || L.bp >= L.bp_end) { L.state = JM_ST_DONE; return; }
+	/* the next look's window as soon as the length is known (a lane that stops below is never looked at again) */
+	const bool past = L.bp >= L.bp_end;
 	L.bp += len;
 	jm_win_fetch(L);
-	const uint32_t nc = (s >> 4) & 3u;
-	/* both slots are written whatever nc says: a slot at or past tw is not part of the stream until tw passes it
-	 * (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free).  A token is its scan position
-	 * << 10 plus the table's (run << 10 | level): two adds on the entry's halves, the store takes the low 16 bits */
+	/* both slots are written whatever nc says, and whether or not the lane stops below: a slot at or past tw is not part
+	 * of the stream until tw passes it (the drain takes whole groups below tw; jm_lane_blocked keeps JM_COEF_SLOTS free).
+	 * A token is its scan position << 10 plus the table's (run << 10 | level): two adds on the entry's halves, the store
+	 * takes the low 16 bits */
 	jm_tk_put(L, L.tw7, d + L.n10);
 	jm_tk_put(L, L.tw7 + JM_TW_UNIT, (d >> 16) + L.n10);
+	L.n10 = jm_and_shl_add(s, 0xff00u, 2, L.n10);
+	/* a position past 63: the reference indexes ZIG_ZAG out of range there.  The lane stops; the macroblock is never
+	 * recorded, so it does not matter that a first symbol that still fitted is not counted */
+	if (L.n10 > (64u << 10) || past) { L.state = JM_ST_DONE; return; }
+	const uint32_t nc = (s >> 4) & 3u;
 	L.tw7 += nc << JM_TW_SHIFT;
-	L.cnt += (int)nc;
-	L.n10 = n10_new;
 	L.tsel = 0;
 	if (s & 64u) {
 		/* end_of_block.  Runs are dword aligned for the reconstruct loads: an odd run leaves one slot
 		 * unused (never read: the record carries the count). */
+		const uint32_t cnt = (L.tw7 - L.tb7) >> JM_TW_SHIFT;         /* DC, escapes and long codes included: every token moved the cursor */
 		L.tw7 = (L.tw7 + JM_TW_UNIT) & ~(2u * JM_TW_UNIT - 1u);      /* blocks begin on even slots, so an odd count is an odd cursor: round it up */
-		L.cnts |= (uint64_t)(uint32_t)L.cnt << (8 * L.cur);
+		L.cnts |= (uint64_t)cnt << (8 * L.cur);
 		const int rem = L.cbp & (0x1f >> L.cur);         /* pattern bits of the blocks after this one */
 		L.state = rem ? jm_open_block(L, rem) : JM_ST_COLD;
 	}
@@ -553,7 +555,6 @@ JM_HD void jm_step_slow(JmLane &L, const JmSliceCtx &c) {
 	if (!bad) {
 		jm_emit(L, n10 | ((uint32_t)level & 1023u));
 		L.n10 = n10 + (1u << 10);
-		L.cnt++;
 		L.tsel = 0;
 		st = JM_ST_COEF;
 	}
