@@ -247,11 +247,17 @@ def two_batches_in_flight(b, make_batch, give_streams, n_pictures, want, passes=
             give_streams(bb, ptrs[-1])
             if bb.decode(stream=ptrs[-1]) != n_pictures:
                 raise RuntimeError("decoded a different number of pictures")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()             # one more pass of the first batch, alone: what "half a pass" is on this workload
+        bs[0].decode(stream=ptrs[0])
+        torch.cuda.synchronize()
+        half_pass = 0.5 * (time.perf_counter() - t0)
         err, ends = [], [[], []]
 
         def loop(i):
             try:
-                time.sleep(0.007 * i)        # half a pass apart: started together the two run in step (tools/pipeline_probe.py)
+                time.sleep(half_pass * i)    # half a pass apart: started together the two run in step (tools/pipeline_probe.py); (a fixed
+                                             # 7 ms -- half a pass of cfg2 -- let the first thread finish a small workload before the second began)
                 for _ in range(passes + 1):
                     bs[i].decode(stream=ptrs[i])
                     ends[i].append(time.perf_counter())
