@@ -604,8 +604,7 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 	 * unchanged; cfg2 (sparse, the issue port full to the end) measured 2-3 % slower with it (2.55 -> 2.62, four
 	 * alternating pairs: profiles/r05z_parse_split_service.txt) and keeps the one-piece service */
 	b.split_service = b.bytes_per_mb_x16 >= JM_T_COLD_DENSE_X16 ? 1u : 0u;
-	{ static const int forced = getenv("JSMPEG_HIP_PARSE_SPLIT") ? atoi(getenv("JSMPEG_HIP_PARSE_SPLIT")) : -1;   /* tuning / tests: 0 / 1 */
-	  if (forced >= 0) b.split_service = forced ? 1u : 0u; }
+	if (const char *e = getenv("JSMPEG_HIP_PARSE_SPLIT")) b.split_service = atoi(e) ? 1u : 0u;   /* tuning / tests (looked up per launch: tests switch it inside a process) */
 	/* Mid-size passes with a few LONG slices (16 x 24 pictures of 4K: the 8 % of the slices that belong to intra pictures
 	 * are three times the others): the pass lasts as long as the wavefront that holds the longest slices walks, and a
 	 * wavefront with one or two slices walks about twice as fast as one with 16+ (its turns run only the step kinds those

@@ -52,6 +52,21 @@ def test_batch_matches_golden(path, hip_lib):
             assert int(dev[p]) == hashing.frame_hash(*b.read_frame(p))
 
 
+@pytest.mark.parametrize("split", ["0", "1"], ids=["k_parse", "k_parse_split"])
+def test_both_forms_of_the_parse_match_golden(split, hip_lib, monkeypatch):
+    """jm_launch_parse picks the kernel per pass by the content's bytes per macroblock (kernels.hip): the ring service in one
+    piece (k_parse) or in two halves a turn apart (k_parse_split).  Here every fixture goes through each, forced."""
+    monkeypatch.setenv("JSMPEG_HIP_PARSE_SPLIT", split)
+    for path in FIXTURES:
+        fx, es, _ = load_case(path)
+        with jb.Batch(fx["info"]["width"], fx["info"]["height"], 1, len(fx.get("abi_frame_md5", fx["frame_md5"])) + 2, len(es) + 1024) as b:
+            b.upload([es])
+            n = b.decode()
+            pics = b.pictures()
+            got = [md5_planes(b.read_frame(p)) for p in range(n) if pics[p].decoded]
+            assert got == fx["frame_md5"], os.path.basename(path)
+
+
 @pytest.mark.parametrize("path", FIXTURES, ids=IDS)
 def test_decoder_abi_matches_golden(path, hip_lib):
     """The reference's 15-function ABI, one write, pull every picture."""
