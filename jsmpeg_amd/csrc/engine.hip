@@ -118,6 +118,7 @@ struct jsmpeg_hip_batch_t {
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
 	uint32_t desc_cap, n_uncovered;
 	hipEvent_t ev_cov;
+	hipEvent_t ev_idx;           /* the index's counters and picture table have arrived on the host (the slice order runs on beside the host's turn-around) */
 	/* ordered reconstruct (one launch per batch, recon_plan.h jm_plan_ordered): per-picture tile counts, the launch's
 	 * status words (kernels.h JM_RECON_STATUS_WORDS; h_: pinned), and how the last decode went */
 	uint32_t *d_done, *d_rstatus, *h_rstatus;
@@ -167,6 +168,7 @@ static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (b->h_pics) hipHostFree(b->h_pics);
 	if (b->h_desc) hipHostFree(b->h_desc);
 	if (b->ev_cov) hipEventDestroy(b->ev_cov);
+	if (b->ev_idx) hipEventDestroy(b->ev_idx);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	for (auto &e : b->ev_level) if (e) hipEventDestroy(e);
 	delete b;
@@ -201,6 +203,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(hipHostMalloc(&b->h_pics, sizeof(JmPic) * std::max(1u, c.max_pictures), hipHostMallocDefault));
 	HIP_TRY(hipHostMalloc(&b->h_desc, sizeof(JmReconDesc) * b->desc_cap, hipHostMallocDefault));
 	HIP_TRY(hipEventCreate(&b->ev_cov));
+	HIP_TRY(hipEventCreateWithFlags(&b->ev_idx, hipEventDisableTiming));
 	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
 	HIP_TRY(jm_malloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
@@ -231,7 +234,7 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->cfg = *config;
 	b->d_es = nullptr; b->d_streams = nullptr; b->d_scan_state = nullptr; b->d_sc_pos = nullptr;
 	b->d_sc_code = nullptr; b->d_sc_owner = nullptr; b->d_pic_sc = nullptr; b->d_slice_sc = nullptr; b->d_slice_order = nullptr; b->d_order_hist = nullptr; b->d_counters = nullptr;
-	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->n_uncovered = 0;
+	b->d_pics = nullptr; b->d_desc = nullptr; b->d_covered = nullptr; b->h_covered = nullptr; b->h_pics = nullptr; b->h_desc = nullptr; b->ev_cov = nullptr; b->ev_idx = nullptr; b->n_uncovered = 0;
 	b->d_done = nullptr; b->d_rstatus = nullptr; b->h_rstatus = nullptr; b->ordered = false; b->stats_pending = false; b->ordered_waits = 0; b->ordered_status = 0; b->last_group = 0;
 	{ const char *e = getenv("JSMPEG_HIP_RECON_ORDER"); b->order_group = e ? (uint32_t)atoi(e) : JM_ORDER_AUTO; }
 	{ const char *e = getenv("JSMPEG_HIP_RECON_DENSE"); b->dense_mode = e ? (atoi(e) ? 1 : 0) : -1; }   /* measurements / tests: 0 never, 1 always the dense intra form; read when a batch is created */
@@ -681,8 +684,20 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
 	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * std::max(1u, b->cfg.max_pictures), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(b->ev_idx, st));
+	/* the slice order (longest first: kernels.hip) goes in behind the copies and runs WHILE the host reads them and lays out
+	 * the parse: its kernels take their sizes from the device's counters, so nothing of it waits for the host -- 0.08 ms of
+	 * cfg2's step that used to stand between the host's turn-around and the parse */
+	const bool stream_order = getenv("JSMPEG_HIP_STREAM_ORDER") != nullptr;   /* (the variable: slices in stream order, for measurements) */
+	if (!stream_order) {
+		JmOrderBufs ob;
+		ob.slice_sc = b->d_slice_sc; ob.sc_pos = b->d_sc_pos; ob.sc_owner = b->d_sc_owner;
+		ob.counters = b->d_counters; ob.sc_cap = b->sc_cap; ob.es_bytes = b->es_bytes;
+		ob.hist = b->d_order_hist; ob.order = b->d_slice_order;
+		HIP_TRY(jm_launch_order(ob, st));
+	}
 	tr.mark("index-enqueued");
-	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipEventSynchronize(b->ev_idx));
 	tr.mark("index-done");
 	if (b->h_counters[2]) return fail("start-code / picture table overflow: %u start codes, %u pictures (max_pictures %u)",
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
@@ -713,16 +728,8 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		for (uint32_t p = 0; p < b->n_pics; p++) n_dec += b->h_pics[p].decoded ? 1u : 0u;
 		if (n_dec) pb.bytes_per_mb_x16 = (uint32_t)std::min<uint64_t>(1u << 20, (uint64_t)b->es_bytes * 16 / (n_dec * (uint64_t)std::max(1, b->g.mb_size)));
 	}
-	if (!getenv("JSMPEG_HIP_STREAM_ORDER")) {   /* (the variable: slices in stream order, for measurements) */
-		JmOrderBufs ob;
-		ob.slice_sc = b->d_slice_sc; ob.sc_pos = b->d_sc_pos; ob.sc_owner = b->d_sc_owner;
-		ob.n_slices = pb.n_lanes; ob.n_sc = b->n_sc; ob.es_bytes = b->es_bytes;
-		const uint32_t mean = b->es_bytes / std::max(1u, pb.n_lanes);
-		ob.shift = 0;
-		while ((mean >> ob.shift) >= 512u) ob.shift++;          /* the mean length lands in bins 256 .. 511 of 1024 */
-		ob.hist = b->d_order_hist; ob.order = b->d_slice_order;
-		HIP_TRY(jm_launch_order(ob, st));
-		pb.slice_sc = b->d_slice_order;
+	if (!stream_order) {
+		pb.slice_sc = b->d_slice_order;             /* (ordered above, beside the host's turn-around) */
 		/* how many slices are much longer than the mean (the intra pictures' in an I + P batch), from the picture table:
 		 * a picture's bytes / its slices against the batch's.  The slices come longest first; jm_launch_parse gives that
 		 * many fewer lanes per wavefront when the pass is of a size where it pays. */

@@ -64,8 +64,11 @@ struct JmOrderBufs {
 	const uint32_t *slice_sc;    /* [n_slices] the scan's list, stream order */
 	const uint32_t *sc_pos;
 	const uint32_t *sc_owner;
-	uint32_t n_slices, n_sc, es_bytes;
-	uint32_t shift;              /* bin = 1 + (bytes >> shift), capped; 0: slices no picture owns (last) */
+	const uint32_t *counters;    /* the index's counters ON THE DEVICE: [0] start codes, [4] slice codes -- the launch does not wait for the
+	                                host to have read them (it is enqueued behind the index, beside the host's turn-around); the kernels
+	                                work out the sizes and the bin width (bin = 1 + (bytes >> shift), capped: the mean length lands in bins
+	                                256 .. 511 of 1024; bin 0: slices no picture owns, last) themselves */
+	uint32_t sc_cap, es_bytes;
 	uint32_t *hist;              /* [2 * JM_ORDER_BINS]: counts, cursors -- zeroed by the launch */
 	uint32_t *order;             /* out [n_slices] */
 };

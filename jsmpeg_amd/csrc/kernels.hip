@@ -311,21 +311,36 @@ hipError_t jm_launch_index(const JmIndexBufs &b, hipStream_t st) {
  * the CU stands idle behind them.  Sorted (1024 bins of mean / 256 bytes), the
  * long slices share wavefronts and start first: 5.3 -> 4.1 ms for cfg2.
  * ---------------------------------------------------------------------- */
-static __device__ __forceinline__ uint32_t order_bin(const JmOrderBufs &b, uint32_t j, uint32_t &i) {
+struct JmOrderDims { uint32_t n_slices, n_sc, shift; };
+static __device__ __forceinline__ JmOrderDims order_dims(const JmOrderBufs &b) {
+	JmOrderDims d;
+	d.n_sc = b.counters[0] < b.sc_cap ? b.counters[0] : b.sc_cap;
+	d.n_slices = b.counters[4] < b.sc_cap ? b.counters[4] : b.sc_cap;
+	const uint32_t mean = b.es_bytes / (d.n_slices ? d.n_slices : 1u);
+	d.shift = 0;
+	while ((mean >> d.shift) >= 512u) d.shift++;
+	return d;
+}
+static __device__ __forceinline__ uint32_t order_bin(const JmOrderBufs &b, const JmOrderDims &d, uint32_t j, uint32_t &i) {
 	i = b.slice_sc[j];
 	if (b.sc_owner[i] == JM_NONE) return 0;
-	const uint32_t len = (i + 1 < b.n_sc ? b.sc_pos[i + 1] : b.es_bytes) - b.sc_pos[i];
-	const uint32_t bin = 1u + (len >> b.shift);
+	const uint32_t len = (i + 1 < d.n_sc ? b.sc_pos[i + 1] : b.es_bytes) - b.sc_pos[i];
+	const uint32_t bin = 1u + (len >> d.shift);
 	return bin < JM_ORDER_BINS ? bin : JM_ORDER_BINS - 1;
 }
 
+/* (both kernels walk the slices with a grid stride: the launch is sized from the ES bytes, not from the slice count the
+ * host has not read yet -- jm_launch_order) */
 __global__ __launch_bounds__(JM_WG) void k_order_count(JmOrderBufs b) {
 	__shared__ uint32_t lh[JM_ORDER_BINS];
+	const JmOrderDims d = order_dims(b);
+	if (blockIdx.x * JM_WG >= d.n_slices) return;
 	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) lh[k] = 0;
 	__syncthreads();
-	const uint32_t j = blockIdx.x * JM_WG + threadIdx.x;
-	uint32_t i;
-	if (j < b.n_slices) atomicAdd(&lh[order_bin(b, j, i)], 1u);
+	for (uint32_t j = blockIdx.x * JM_WG + threadIdx.x; j < d.n_slices; j += gridDim.x * JM_WG) {
+		uint32_t i;
+		atomicAdd(&lh[order_bin(b, d, j, i)], 1u);
+	}
 	__syncthreads();
 	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) if (lh[k]) atomicAdd(&b.hist[k], lh[k]);
 }
@@ -335,15 +350,16 @@ __global__ __launch_bounds__(JM_WG) void k_order_place(JmOrderBufs b) {
 	__shared__ uint32_t first[JM_ORDER_BINS];
 	__shared__ uint32_t lh[JM_ORDER_BINS];       /* this workgroup's slices per bin, then where its run of the bin starts */
 	__shared__ uint32_t wave_tot[JM_WG / 64];
+	const JmOrderDims d = order_dims(b);
+	if (blockIdx.x * JM_WG >= d.n_slices) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	constexpr uint32_t PER = JM_ORDER_BINS / JM_WG;
 	uint32_t v[PER], sum = 0;
 #pragma unroll
 	for (uint32_t k = 0; k < PER; k++) { v[k] = b.hist[JM_ORDER_BINS - 1 - (threadIdx.x * PER + k)]; sum += v[k]; }   /* longest bin first */
-	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) lh[k] = 0;
 	uint32_t x = sum;
 #pragma unroll
-	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(x, d, 64); if (lane >= d) x += t; }
+	for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(x, dd, 64); if (lane >= dd) x += t; }
 	if (lane == 63) wave_tot[wave] = x;
 	__syncthreads();
 	uint32_t run = x - sum;
@@ -353,20 +369,29 @@ __global__ __launch_bounds__(JM_WG) void k_order_place(JmOrderBufs b) {
 	/* a place in the bin: rank among the workgroup's slices of the bin (LDS), the workgroup's run of the bin by ONE
 	 * global atomic per bin it holds -- the lengths crowd into a few dozen bins, and an atomic per slice on those few
 	 * addresses takes 0.45 ms for cfg2's 522 k slices */
-	const uint32_t j = blockIdx.x * JM_WG + threadIdx.x;
-	uint32_t i = 0, bin = 0, rank = 0;
-	if (j < b.n_slices) { bin = order_bin(b, j, i); rank = atomicAdd(&lh[bin], 1u); }
-	__syncthreads();
-	for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) { const uint32_t n = lh[k]; if (n) lh[k] = atomicAdd(&b.hist[JM_ORDER_BINS + k], n); }
-	__syncthreads();
-	if (j < b.n_slices) b.order[first[bin] + lh[bin] + rank] = i;
+	for (uint32_t base = blockIdx.x * JM_WG; base < d.n_slices; base += gridDim.x * JM_WG) {   /* (uniform per workgroup) */
+		for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) lh[k] = 0;
+		__syncthreads();
+		const uint32_t j = base + threadIdx.x;
+		uint32_t i = 0, bin = 0, rank = 0;
+		if (j < d.n_slices) { bin = order_bin(b, d, j, i); rank = atomicAdd(&lh[bin], 1u); }
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < JM_ORDER_BINS; k += JM_WG) { const uint32_t n = lh[k]; if (n) lh[k] = atomicAdd(&b.hist[JM_ORDER_BINS + k], n); }
+		__syncthreads();
+		if (j < d.n_slices) b.order[first[bin] + lh[bin] + rank] = i;
+		__syncthreads();
+	}
 }
 
 hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
-	if (b.n_slices == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(b.hist, 0, 2 * JM_ORDER_BINS * sizeof(uint32_t), st);
 	if (e != hipSuccess) return e;
-	const uint32_t groups = (b.n_slices + JM_WG - 1) / JM_WG;
+	/* a workgroup per 64 KB of compressed data (slices of 256 bytes: one stride), at most what the slice codes' table holds
+	 * and 2048 (cfg2: 522 k slices in 2040 workgroups' worth) -- shorter slices make the kernels stride */
+	uint32_t groups = b.es_bytes / (JM_WG * 256u) + 16u;
+	const uint32_t cap_groups = (b.sc_cap + JM_WG - 1) / JM_WG;
+	if (groups > cap_groups) groups = cap_groups;
+	if (groups > 2048u) groups = 2048u;
 	hipLaunchKernelGGL(k_order_count, dim3(groups), dim3(JM_WG), 0, st, b);
 	hipLaunchKernelGGL(k_order_place, dim3(groups), dim3(JM_WG), 0, st, b);
 	return hipGetLastError();
