@@ -838,6 +838,9 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	/* the wavefront's number as a scalar: what depends on (tile, wavefront) alone -- the tile's place in its plane, the
 	 * rows this wavefront takes -- is then scalar arithmetic, not 64 lanes' */
 	const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef JM_T_PRIO_FRONT   /* timing variant (same pictures): a tile's first look -- addresses, the loads going out -- ahead of its CU's other wavefronts */
+	__builtin_amdgcn_s_setprio(JM_T_PRIO_FRONT);
+#endif
 	/* the record of this lane's macroblock: requested first, the block's token and prediction loads hang on it */
 	JmLoc Q;
 	const bool valid = jm_recon_where_tile(b.g, T, (int)tile, (int)wave, (int)lane, Q);
@@ -890,8 +893,14 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	if (lane == 0) wave_total[wave] = (uint32_t)__popcll(needA) | ((uint32_t)__popcll(needB) << 16);
 	if (threadIdx.x < 12) reinterpret_cast<uint4 *>(qm)[threadIdx.x] = tq;
 	JM_STAMP(0);      /* descriptor, record, the block's first look; token and prediction loads requested */
+#ifdef JM_T_PRIO_FRONT
+	__builtin_amdgcn_s_setprio(0);
+#endif
 	__syncthreads();
 	JM_STAMP(1);      /* ... waiting for the workgroup's other wavefronts */
+#ifdef JM_T_PRIO_MID     /* timing variant (same pictures): everything behind a tile's first look ahead of other tiles' first looks */
+	__builtin_amdgcn_s_setprio(JM_T_PRIO_MID);
+#endif
 	uint32_t prior = 0, sum = 0;
 #pragma unroll
 	for (uint32_t i = 0; i < JM_RECON_WG / 64; i++) { const uint32_t t = wave_total[i]; if (i < wave) prior += t; sum += t; }
@@ -914,6 +923,9 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	JM_STAMP(2);      /* tokens arrive, dequantise and scatter; prediction rows arrive, half-pel */
 	__syncthreads();
 	JM_STAMP(3);
+#ifdef JM_T_PRIO_IDCT
+	__builtin_amdgcn_s_setprio(JM_T_PRIO_IDCT);
+#endif
 	/* phase 2: two lanes per block (lane j, lane j + 32), a wavefront takes 32 packed slots per round, the workgroup
 	 * 128: one round, or two when more than half the tile's blocks need the transform; wavefronts past the last
 	 * packed block skip it altogether */
@@ -930,6 +942,9 @@ static __device__ __forceinline__ void jm_recon_tile(const JmReconBufs &b, const
 	__syncthreads();
 	JM_STAMP(5);
 	/* phase 3 */
+#ifdef JM_T_PRIO_BACK    /* timing variant (same pictures): a tile's last phase -- pixels, the row stores going out -- ahead: it frees its slots sooner */
+	__builtin_amdgcn_s_setprio(JM_T_PRIO_BACK);
+#endif
 	JmPix X;
 	X.store = false;
 	if (later) B.idct = false;           /* for now the prediction alone (an idct block's konst is 0) */
