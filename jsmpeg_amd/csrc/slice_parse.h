@@ -22,10 +22,20 @@
  *     32-byte stores to 32-byte aligned addresses (whole HBM sectors).  Both
  *     happen in a "service" step that the whole wave takes together.  (Ring
  *     sizes are what lets 16 wavefronts share a CU's 160 KB of LDS.)
- *   - No bit window is carried: the next 32 bits at any bit position are one
- *     LDS read of two ring rows (ds_read2st64_b32) and one 64-bit shift.  The
- *     ring holds the stream as big-endian dwords so that is all it takes
- *     (jm_bits32: four vector instructions and the read).
+ *   - The next 32 bits at any bit position are one LDS read of two ring rows
+ *     (ds_read2st64_b32) and one 64-bit shift: the ring holds the stream as
+ *     big-endian dwords so that is all it takes (jm_bits32: four vector
+ *     instructions and the read).  No SHIFTED window is kept up to date in
+ *     registers (round 3: the top-ups cost more instructions than the reads);
+ *     but the two raw dwords around a lane's position are CARRIED from step to
+ *     step (late round 5: jm_win_fetch / jm_win): requested the moment a step
+ *     knows its new position, awaited where the lane's next step looks -- the
+ *     same instructions, the round trip out of the dependent chain that a
+ *     wavefront alone on its SIMD (the longest slices' walk) sits out.
+ *   - The ring service is one piece (k_parse: requested and awaited on the
+ *     spot; sparse content, whose SIMDs' issue ports are full to the end) or
+ *     two halves a turn apart (k_parse_split: jm_lane_request / jm_lane_land;
+ *     dense content) -- jm_launch_parse picks per pass.
  *   - The pass is bound by VECTOR INSTRUCTION ISSUE (round 5 counters: 1.58 G
  *     wavefront instructions x 4 clocks / 1024 SIMDs = 91 % of its time, 26 of
  *     64 lanes active per instruction), so the lane state is kept in the form
@@ -35,9 +45,10 @@
  *     address is one v_and_or of the cursor, the DC predictors in three
  *     registers (selects, no 64-bit field arithmetic).
  *   - The walk is cut into steps -- COLD (macroblock header, and the record of
- *     the macroblock before it), DC (intra DC), COEF (one run/level symbol of
- *     at most 8 bits + sign: ONE table lookup; or end_of_block and the choice
- *     of the next coded block), SLOW (escapes and the long codes) -- and at
+ *     the macroblock before it), DC (intra DC), COEF (up to two run/level
+ *     symbols of at most 8 bits + sign and the end_of_block behind them: ONE
+ *     look, one table entry; and the choice of the next coded block), SLOW
+ *     (escapes and the long codes) -- and at
  *     every turn the wave runs each kind that enough of its lanes are waiting
  *     for (jm_turn_mask).  Everything rare per lane but certain per 64 lanes
  *     (escapes, ring service, headers) is thereby out of the coefficient step
