@@ -82,7 +82,10 @@
 #ifndef JM_COEF_REPEAT
 #define JM_COEF_REPEAT 2   /* COEF steps per turn                                                         */
 #endif
-#define JM_STEP_BITS (116 + JM_PAIR_BITS * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
+#ifndef JM_EXTRA_DC
+#define JM_EXTRA_DC 0      /* (turn-structure experiments on the CPU simulator: further DC steps per turn) */
+#endif
+#define JM_STEP_BITS (116 + 16 * JM_EXTRA_DC + JM_PAIR_BITS * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
 #define JM_COEF_SLOTS 3    /* token slots a COEF step may use: two tokens and the alignment slot of an odd run */
 #define JM_RING_STRIDE 64  /* the ES ring is a [row][lane] tile of dwords of one wavefront: conflict-free for any per-lane row */
 #define JM_TW_UNIT 128u    /* the token ring is a [slot][lane] tile of 16-bit tokens: a slot is 128 bytes on; cursors count in these (tw7, tf7) */
@@ -364,7 +367,7 @@ JM_HD void jm_lane_service(JmLane &L) {
 }
 /* a turn needs JM_STEP_BITS + a 32-bit look-ahead in the ring and room for its tokens (DC 1, SLOW 1, per COEF step JM_COEF_SLOTS) */
 JM_HD bool jm_lane_blocked(const JmLane &L) {
-	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw7 - L.tf7 > (JM_TK_RING - 2 - JM_COEF_SLOTS * JM_COEF_REPEAT) * JM_TW_UNIT;
+	return L.fillc * 128u - L.bp < JM_STEP_BITS + 32 || L.tw7 - L.tf7 > (JM_TK_RING - 2 - JM_EXTRA_DC - JM_COEF_SLOTS * JM_COEF_REPEAT) * JM_TW_UNIT;
 }
 JM_HD void jm_emit(JmLane &L, uint32_t t) {        /* the low 16 bits of t */
 	jm_tk_put(L, L.tw7, t);

@@ -161,8 +161,13 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 				landing = g_split_service != 0;
 			}
 			const bool cold = jm_run_cold(n_cold, n_other, g_thr[JM_ST_COLD]);
+#ifdef JM_SIM_ORDER      /* turn-structure experiments (tools/sim_turn_orders.py): the steps of a turn, in order */
+			static const int order[] = { JM_SIM_ORDER };
+			for (int oi = 0; oi < (int)(sizeof(order) / sizeof(order[0])); oi++) {
+#else
 			static const int order[4 + 4] = { JM_ST_COLD, JM_ST_DC, JM_ST_COEF, JM_ST_SLOW, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF, JM_ST_COEF };
 			for (int oi = 0; oi < 3 + JM_COEF_REPEAT; oi++) {
+#endif
 				const int k = order[oi];
 				if (k == JM_ST_COLD && !cold) continue;
 				int served = 0;
