@@ -170,6 +170,15 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 #endif
 				const int k = order[oi];
 				if (k == JM_ST_COLD && !cold) continue;
+				if (k != JM_ST_COLD && g_thr[k] > 1) {
+					/* experiments (tools/sim_turn_orders.py thresholds): a step kind runs when that many lanes wait for it --
+					 * or when no kind of this turn reaches its own mark (the wavefront must move) */
+					int cnt[JM_ST_KINDS] = { 0 };
+					for (int l = 0; l < 64; l++) if (ready[l] && L[l].state < JM_ST_WAIT) cnt[L[l].state]++;
+					bool any = cold && cnt[JM_ST_COLD] > 0;
+					for (int j = JM_ST_DC; j <= JM_ST_SLOW; j++) any = any || (cnt[j] >= g_thr[j] && cnt[j] > 0);
+					if (cnt[k] < g_thr[k] && any) continue;
+				}
 				int served = 0;
 				for (int l = 0; l < 64; l++) if (ready[l] && L[l].state == k) {
 					served++;
