@@ -549,9 +549,15 @@ static __device__ __forceinline__ void jm_parse_body(const JmParseBufs &b) {
 		const uint64_t blocked = m_live & ~m_ready;
 		const bool others = ((m_live & ~m_cold) | blocked) != 0;
 		if (n_cold == 0 && !others) break;
-		if (blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) { if (SPLIT) jm_lane_request(L); else jm_lane_service(L); }) landing = SPLIT; }
+		if (!SPLIT && blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_service(L)) }
 		JM_STAT(st_turns++; st_blocked += __popcll(blocked); st_live += __popcll(__ballot(live));)
 		if (jm_run_cold(n_cold, others ? 1 : 0, cold_threshold)) { JM_STAT(st_cold++;) JM_CK(ck_cold, if (ready && L.state == JM_ST_COLD) jm_step_cold(L, c)) }
+		/* the two-halves form requests BEHIND the header step: loads and stores share one in-order counter, and the landing's
+		 * wait (the top of the next turn) then has nothing between the loads and itself -- the header step's record stores of
+		 * THIS turn are older than the loads, those of the next turn come after the landing.  (Requested in front of the header
+		 * step, the landing waited for record stores a fraction of a turn old: what cfg2, a header step in every second turn,
+		 * lost 2-3 % to.) */
+		if (SPLIT && blocked) { JM_STAT(st_service++;) JM_CK(ck_service, if (live) jm_lane_request(L)) landing = true; }
 		JM_STAT(st_dc += __popcll(__ballot(ready && L.state == JM_ST_DC));)
 		JM_CK(ck_dc, if (ready && L.state == JM_ST_DC) jm_step_dc(L, c))
 		JM_STAT(st_coef1 += __popcll(__ballot(ready && L.state == JM_ST_COEF));)

@@ -157,9 +157,10 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			g_picks++; g_cost += (uint64_t)g_kcost[JM_ST_KINDS];
 			if (n_blocked) {
 				g_turns[JM_ST_WAIT]++; g_served[JM_ST_WAIT] += n_blocked; g_cost += (uint64_t)g_kcost[JM_ST_WAIT];
-				for (int l = 0; l < 64; l++) if (L[l].state != JM_ST_DONE) { if (g_split_service) jm_lane_request(L[l]); else jm_lane_service(L[l]); }
-				landing = g_split_service != 0;
+				if (!g_split_service) for (int l = 0; l < 64; l++) if (L[l].state != JM_ST_DONE) jm_lane_service(L[l]);
 			}
+			bool live_top[64];                               /* (the two-halves form requests behind the header step: kernels.hip) */
+			for (int l = 0; l < 64; l++) live_top[l] = L[l].state != JM_ST_DONE;
 			const bool cold = jm_run_cold(n_cold, n_other, g_thr[JM_ST_COLD]);
 #ifdef JM_SIM_ORDER      /* turn-structure experiments (tools/sim_turn_orders.py): the steps of a turn, in order */
 			static const int order[] = { JM_SIM_ORDER };
@@ -169,6 +170,10 @@ int sim_decode_stream(const uint8_t *es_in, uint32_t n, int width, int height, u
 			for (int oi = 0; oi < 3 + JM_COEF_REPEAT; oi++) {
 #endif
 				const int k = order[oi];
+				if (oi == 1 && n_blocked && g_split_service) {   /* behind the header step's place in the turn, whether or not it ran */
+					for (int l = 0; l < 64; l++) if (live_top[l]) jm_lane_request(L[l]);
+					landing = true;
+				}
 				if (k == JM_ST_COLD && !cold) continue;
 				if (k != JM_ST_COLD && g_thr[k] > 1) {
 					/* experiments (tools/sim_turn_orders.py thresholds): a step kind runs when that many lanes wait for it --
