@@ -704,6 +704,20 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 		if (e != hipSuccess) return e;
 	} else {
 		b.ticket = nullptr;
+		/* A pass without tickets of MORE than one workgroup per CU but fewer than two: the dispatcher gives every CU one
+		 * workgroup and some a second -- sixteen wavefronts there, eight elsewhere, and the pass lasts as long as the CUs with
+		 * sixteen.  Launched as TWO workgroups per CU (batch = slot x workgroups + workgroup: the wavefronts without a batch
+		 * leave at once) every CU holds the same 2 x n_batches / 512 wavefronts: 320x240 intra 40 x 300 0.49 -> 0.425 ms, 2160p
+		 * 48 x 24 4.55 -> 4.24, 64 x 24 (3240 batches: 405 workgroups -> 512 of 6.3 wavefronts) 5.02 -> 4.93, 720p 32 x 120 the
+		 * same.  And the smallest passes -- at most a batch per CU: one picture's 68 slices, a wavefront each -- take a
+		 * WORKGROUP per batch: the wavefront has its CU's LDS and issue ports to itself (a decode() of one 1080p picture 0.530 ->
+		 * 0.495 ms, 720p 0.355 -> 0.341).  Between the two (fewer than one workgroup per CU, several batches each) spreading
+		 * changes nothing (2160p 8 / 16 / 32 x 24, one 720p stream: +-0.5 %).  JSMPEG_HIP_PARSE_EVEN=0: the packed grid, =2:
+		 * everything spread (measurements, profiles/r05ae_parse_grids.txt) */
+		static const int even = getenv("JSMPEG_HIP_PARSE_EVEN") ? atoi(getenv("JSMPEG_HIP_PARSE_EVEN")) : 1;
+		if (even && groups > resident_now / 2 && groups < resident_now) groups = resident_now;
+		else if (even && b.n_batches <= resident_now / 2) groups = b.n_batches;
+		else if (even >= 2 && groups < resident_now / 2) groups = resident_now / 2;
 		if (b.cu_order && groups > 1) {
 			hipError_t e = hipMemsetAsync(b.cu_order, 0, sizeof(uint32_t) * JM_PARSE_CU_KEYS, st);
 			if (e != hipSuccess) return e;
