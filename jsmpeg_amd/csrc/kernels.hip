@@ -592,13 +592,15 @@ static __device__ __forceinline__ void jm_parse_body(const JmParseBufs &b) {
 __global__ __launch_bounds__(JM_PARSE_WG) void k_parse(JmParseBufs b) { jm_parse_body<false>(b); }
 __global__ __launch_bounds__(JM_PARSE_WG) void k_parse_split(JmParseBufs b) { jm_parse_body<true>(b); }
 
+extern "C" int jsmpeg_hip_debug_parse_plan(uint32_t n_slices, uint32_t long_slices, uint32_t bytes_per_mb_x16, int with_tickets, uint32_t out[12]);
 #ifdef JSMPEG_HIP_MEASUREMENT_HOOKS
 uint32_t jm_parse_resident_once = 0;   /* measurement builds (engine.hip, JSMPEG_HIP_T_SHADOW_PARSE): the next launch's resident workgroups; not thread-safe, not in the product */
 #endif
-hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
-	JmParseBufs b = b_in;
-	if (!b.slice_sc) b.n_lanes = b.n_sc;
-	if (b.n_lanes == 0) return hipSuccess;
+/* What a pass's launch is: everything jm_launch_parse decides, as host arithmetic without a HIP call (jm_launch_parse is this
+ * + the fills + the launch; tests/test_parse_plan.py reads the rules through jsmpeg_hip_debug_parse_plan on a machine without
+ * a GPU).  b.n_lanes != 0; `have_ticket`: the caller gave a ticket counter.  Returns the workgroups; *use_ticket: the
+ * wavefronts draw further batches by ticket. */
+uint32_t jm_plan_parse(JmParseBufs &b, bool have_ticket, bool *use_ticket) {
 	/* slices per wavefront: 64, except for small batches (fewer than 512 full wavefronts: half the SIMDs would stand
 	 * idle while a few wavefronts walk 64 slices each) -- there the smallest power of two that still keeps the pass
 	 * within 4096 wavefronts, down to ONE slice per wavefront for a single picture (measured, MI355X: one 1080p
@@ -698,12 +700,9 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 #else
 	const uint32_t resident_now = resident;
 #endif
-	if (groups > resident_now && resident_now >= 1 && b.ticket) {
-		groups = resident_now;
-		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
-		if (e != hipSuccess) return e;
-	} else {
-		b.ticket = nullptr;
+	*use_ticket = groups > resident_now && resident_now >= 1 && have_ticket;
+	if (*use_ticket) groups = resident_now;
+	else {
 		/* A pass without tickets of MORE than one workgroup per CU but fewer than two: the dispatcher gives every CU one
 		 * workgroup and some a second -- sixteen wavefronts there, eight elsewhere, and the pass lasts as long as the CUs with
 		 * sixteen.  Launched as TWO workgroups per CU (batch = slot x workgroups + workgroup: the wavefronts without a batch
@@ -718,6 +717,36 @@ hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
 		if (even && groups > resident_now / 2 && groups < resident_now) groups = resident_now;
 		else if (even && b.n_batches <= resident_now / 2) groups = b.n_batches;
 		else if (even >= 2 && groups < resident_now / 2) groups = resident_now / 2;
+	}
+	return groups;
+}
+
+/* diagnostics / tests (no GPU needed): the launch a pass of `n_slices` slices would get -- out[0] kernel (0 k_parse, 1
+ * k_parse_split), [1] slices per wavefront, [2] batches, [3] workgroups, [4] tickets, [5] header threshold, [6] / [7] slices
+ * per wavefront and batches of the head (the longest slices), [8] first slice behind the head, [9] wavefronts of a workgroup */
+extern "C" int jsmpeg_hip_debug_parse_plan(uint32_t n_slices, uint32_t long_slices, uint32_t bytes_per_mb_x16, int with_tickets, uint32_t out[12]) {
+	if (!out || n_slices == 0) return -1;
+	JmParseBufs b;
+	memset(&b, 0, sizeof b);
+	b.n_lanes = n_slices; b.long_slices = long_slices; b.bytes_per_mb_x16 = bytes_per_mb_x16;
+	bool use_ticket = false;
+	const uint32_t groups = jm_plan_parse(b, with_tickets != 0, &use_ticket);
+	out[0] = b.split_service; out[1] = b.lanes_per_wave; out[2] = b.n_batches; out[3] = groups; out[4] = use_ticket ? 1u : 0u; out[5] = b.t_cold;
+	out[6] = b.head_lanes[0]; out[7] = b.head_batches[0] + b.head_batches[1]; out[8] = b.head_first[2]; out[9] = JM_PARSE_WAVES; out[10] = out[11] = 0;
+	return 0;
+}
+
+hipError_t jm_launch_parse(const JmParseBufs &b_in, hipStream_t st) {
+	JmParseBufs b = b_in;
+	if (!b.slice_sc) b.n_lanes = b.n_sc;
+	if (b.n_lanes == 0) return hipSuccess;
+	bool use_ticket = false;
+	const uint32_t groups = jm_plan_parse(b, b.ticket != nullptr, &use_ticket);
+	if (use_ticket) {
+		hipError_t e = hipMemsetAsync(b.ticket, 0, sizeof(uint32_t), st);
+		if (e != hipSuccess) return e;
+	} else {
+		b.ticket = nullptr;
 		if (b.cu_order && groups > 1) {
 			hipError_t e = hipMemsetAsync(b.cu_order, 0, sizeof(uint32_t) * JM_PARSE_CU_KEYS, st);
 			if (e != hipSuccess) return e;
