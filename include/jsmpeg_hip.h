@@ -1,6 +1,6 @@
 /*
- * jsmpeg_hip -- C ABI of the MI355X (gfx950) MPEG-1 video decode path (parts 1, 2) and of its MP2 audio
- * sibling (part 3).
+ * jsmpeg_hip -- C ABI of the MI355X (gfx950) MPEG-1 video decode path (parts 1, 2, 5) and of its MP2 audio
+ * sibling (part 3); part 4: shards across the GPUs of a node.
  *
  * Drop-in boundary.  Part 1 is, symbol for symbol, the C ABI the reference
  * already defines for this path and that its JS wrapper binds through
@@ -421,6 +421,96 @@ int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, const void *s
 /* `bytes_per_rank` bytes from every rank to every rank (reporting: the 8-byte plane hashes). */
 int jsmpeg_hip_dist_allgather(jsmpeg_hip_dist_t *d, const void *src_dev, void *dst_dev, uint64_t bytes_per_rank,
                               void *hip_stream);
+
+/* ------------------------------------------------------------------ part 5
+ * LIVE streams: N streams that GO ON (jsmpeg's main use: MPEG-TS over a WebSocket, reference src/player.js:222-228
+ * updateForStreaming -- "decode what has arrived", every tick; src/ts.js:205-210 hands a decoder one PES = one picture
+ * per write(pts, buffers); src/buffer.js:64-104 the EVICT store; src/wasm/mpeg1.c:986-994 the two plane sets that carry
+ * from picture to picture).  Part 2 decodes whole streams from nothing; here a stream persists across calls: its
+ * undecoded bytes, its FIRST sequence header (only the first one counts, mpeg1.c:812-819) and the frames of its last two
+ * decoded pictures stay in HBM, and one jsmpeg_hip_live_tick decodes the pending pictures of EVERY stream in ONE pass
+ * of the batch engine (all their slices parsed at once, one reconstruct launch) -- per stream exactly the pictures the
+ * reference's decoder gives for the same write() calls.  Nothing is copied on the way: a write() lands in a pinned
+ * staging buffer, one transfer per tick takes all of them to the device, a picture is reconstructed into its stream's
+ * ring of frames, and the next tick predicts from those frames where they lie.
+ *
+ *     id = jsmpeg_hip_live_open(l);                                   a stream joins (any time)
+ *     jsmpeg_hip_live_write(l, id, pts, bytes, n);                    == video.write(pts, [bytes])   (ts.js:205-210)
+ *     n = jsmpeg_hip_live_tick(l, JSMPEG_HIP_LIVE_FLUSH, NULL);       == for every stream: while (video.decode()) ;
+ *     for (i < n) jsmpeg_hip_live_picture(l, i, &pic);                pic.device_frame: Y | Cr | Cb in HBM
+ */
+
+typedef struct jsmpeg_hip_live_t jsmpeg_hip_live_t;
+
+typedef struct jsmpeg_hip_live_config_t {
+	int32_t width, height;            /* display size every stream's sequence header must carry */
+	uint32_t max_streams;             /* streams open at a time */
+	uint32_t max_pictures_per_tick;   /* per stream: a tick decodes at most this many picture start codes of a stream, the rest
+	                                     wait for the next tick (0: 4).  A stream's ring holds this many frames + 2. */
+	uint32_t store_bytes;             /* capacity of a stream's compressed-data store = the reference's videoBufferSize
+	                                     (0: 512 KiB, mpeg1-wasm.js:9), with its EVICT rule: see jsmpeg_hip_live_write */
+	int32_t device;                   /* HIP device ordinal, -1 = current */
+} jsmpeg_hip_live_config_t;
+
+typedef struct jsmpeg_hip_live_picture_t {
+	uint32_t stream;                  /* id from jsmpeg_hip_live_open */
+	int32_t type;                     /* picture_coding_type: 1 = I, 2 = P */
+	double pts;                       /* of the write() in which the picture's start code arrived */
+	uint64_t stream_offset;           /* byte offset of that start code in everything ever written to the stream */
+	void *device_frame;               /* DEVICE pointer: Y | Cr | Cb (jsmpeg_hip_live_geometry's sizes); valid until the next tick */
+} jsmpeg_hip_live_picture_t;
+
+typedef struct jsmpeg_hip_live_stream_info_t {
+	int32_t has_sequence_header;      /* mpeg1_decoder_has_sequence_header */
+	int32_t width, height;            /* of that header (0 before it) */
+	float frame_rate;                 /* mpeg1_decoder_get_frame_rate */
+	int32_t status;                   /* 0: fine; 1: the header's size is not the batch's -- nothing of this stream is decoded */
+	uint32_t pending_bytes;           /* written and not decoded yet */
+	uint64_t bytes_written, pictures; /* totals */
+	uint64_t evictions;               /* writes that found the store full of UNDECODED bytes and threw them away (buffer.js:48-56) */
+} jsmpeg_hip_live_stream_info_t;
+
+jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_config_t *config);
+void jsmpeg_hip_live_destroy(jsmpeg_hip_live_t *l);
+/* A stream joins: returns its id (0 .. max_streams - 1) or < 0.  It starts like a fresh decoder: no header, zeroed planes. */
+int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l);
+/* ... and leaves (its id is handed out again by a later open). */
+int jsmpeg_hip_live_close(jsmpeg_hip_live_t *l, uint32_t stream);
+/* One write(pts, buffers) of the reference's decoder (decoder.js:36-47): `n` bytes of the stream's elementary stream are
+ * appended to its store (copied during the call).  The store is the reference's EVICT store (buffer.js:30-62): decoded
+ * bytes make room; when the UNDECODED bytes + n exceed store_bytes, the undecoded bytes are thrown away first (the
+ * reference's "emergency evac") and the write starts an empty store.  n > store_bytes is refused (the reference's typed
+ * array throws a RangeError there).  Returns 0 or < 0. */
+int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n);
+/* The tick: ONE pass of the batch engine over what has been written.  Per stream, in stream order, it decodes
+ *   JSMPEG_HIP_LIVE_FLUSH: every buffered picture, the last one included -- it ends where the data ends, exactly like the
+ *       reference's decode() (mpeg1.c:853-864, 947-995), so per stream this is `while (decoder.decode());` after the same
+ *       writes.  The form for writes that carry whole pictures (ts.js completes a PES before it writes it);
+ *   0: every picture that is COMPLETE -- a start code that is not a slice's follows it in the store; the last picture waits
+ *       for the write that brings that code (or for a FLUSH tick).  The form for bytes that arrive in arbitrary pieces:
+ *       per stream the pictures are those of the whole stream decoded in one piece, whatever the pieces were.
+ * At most max_pictures_per_tick picture start codes per stream and tick; the rest wait.  Work is enqueued on
+ * `hip_stream` (void* hipStream_t, NULL = the default stream) and has FINISHED when the call returns.
+ * Returns the number of pictures decoded in this tick (all streams) or < 0. */
+#define JSMPEG_HIP_LIVE_FLUSH 1u
+int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream);
+/* The pictures of the last tick: stream by stream (ascending id), in decode order inside a stream. */
+uint32_t jsmpeg_hip_live_picture_count(jsmpeg_hip_live_t *l);
+int jsmpeg_hip_live_picture(jsmpeg_hip_live_t *l, uint32_t i, jsmpeg_hip_live_picture_t *out);
+/* Plane sizes of a frame: Y at 0, Cr at luma_bytes, Cb at luma_bytes + chroma_bytes. */
+int jsmpeg_hip_live_geometry(jsmpeg_hip_live_t *l, int32_t *coded_width, int32_t *coded_height, uint32_t *luma_bytes,
+                             uint32_t *chroma_bytes);
+/* Device-to-host copy of picture i of the last tick (any of y / cr / cb may be NULL). */
+int jsmpeg_hip_live_read_frame(jsmpeg_hip_live_t *l, uint32_t i, void *y, void *cr, void *cb);
+/* The same as Canvas2D-identical RGBA (width * height * 4 bytes; jsmpeg_hip_batch_read_rgba). */
+int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void *host_rgba);
+/* 64-bit content hashes of the last tick's pictures (jsmpeg_hip_batch_frame_hashes' function). out[picture_count]. */
+int jsmpeg_hip_live_frame_hashes(jsmpeg_hip_live_t *l, uint64_t *out);
+int jsmpeg_hip_live_stream_info(jsmpeg_hip_live_t *l, uint32_t stream, jsmpeg_hip_live_stream_info_t *out);
+/* Host clock of the last tick, milliseconds: [0] staging -> device + placement enqueued, [1] the batch engine's decode call
+ * (enqueue + its two turn-arounds), [2] waiting for the device to finish, [3] book-keeping, [4] total; and the device's
+ * own hipEvent timings of that pass: [5] index, [6] host turn-around, [7] slice parse, [8] reconstruct. */
+int jsmpeg_hip_live_timings(jsmpeg_hip_live_t *l, float out_ms[9]);
 
 /* Last error of the calling thread ("" if none). */
 const char *jsmpeg_hip_last_error(void);

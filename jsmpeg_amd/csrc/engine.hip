@@ -152,7 +152,21 @@ struct jsmpeg_hip_batch_t {
 	uint32_t n_level_ev;
 	bool timed;
 	uint32_t *h_counters; /* pinned */
+	/* LIVE (jsmpeg_hip_live_t below: a batch pass over what has arrived of streams that go on): the pool holds
+	 * `pool_frames` frames (>= max_pictures), and picture p of a pass is written to pool slot slot[p] -- a live stream
+	 * owns a ring of slots, so that the frames of its last two decoded pictures are still there, untouched, when the next
+	 * pass predicts from them.  slot empty: picture p = slot p (every other batch). */
+	uint32_t pool_frames;
+	uint32_t mb_pictures;        /* pictures the macroblock records are allocated for (max_pictures; live: what a pass can DECODE, JmPic::mb_index) */
+	uint32_t pics_first_copy;    /* picture-table entries that come to the host with the index's counters (all of them; live: a pass's usual
+	                                number -- the table is sized for the start codes a pass can SEE --, the rest in a second copy when there are more) */
+	std::vector<uint32_t> slot;
+	struct jsmpeg_hip_live_t *live;
 };
+static int live_assign_slots(jsmpeg_hip_live_t *l);    /* the live front end's turn inside a decode: once the picture table is on the host */
+static inline uint8_t *frame_of(const jsmpeg_hip_batch_t *b, uint32_t p) {
+	return b->d_pool + (uint64_t)(b->slot.empty() ? p : b->slot[p]) * b->g.frame_bytes;
+}
 
 static void batch_free(jsmpeg_hip_batch_t *b) {
 	if (!b) return;
@@ -204,12 +218,14 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(hipHostMalloc(&b->h_desc, sizeof(JmReconDesc) * b->desc_cap, hipHostMallocDefault));
 	HIP_TRY(hipEventCreate(&b->ev_cov));
 	HIP_TRY(hipEventCreateWithFlags(&b->ev_idx, hipEventDisableTiming));
-	size_t mb_bytes = sizeof(JmMbRec) * (size_t)std::max(1u, c.max_pictures) * b->g.mb_size;
+	if (!b->mb_pictures) b->mb_pictures = std::max(1u, c.max_pictures);
+	size_t mb_bytes = sizeof(JmMbRec) * (size_t)b->mb_pictures * b->g.mb_size;
 	HIP_TRY(jm_malloc(&b->d_mb, mb_bytes));
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
 	HIP_TRY(hipDeviceSynchronize());   /* the memsets ran on the null stream; decode may use a stream that is not ordered against it */
 	HIP_TRY(jm_malloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
-	size_t pool_bytes = (size_t)b->g.frame_bytes * std::max(1u, c.max_pictures) + 2 * POOL_GUARD;
+	b->pool_frames = std::max(b->pool_frames, std::max(1u, c.max_pictures));
+	size_t pool_bytes = (size_t)b->g.frame_bytes * b->pool_frames + 2 * POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_pool_alloc, pool_bytes));
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
@@ -219,7 +235,11 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	return 0;
 }
 
-extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_config_t *config) {
+static jsmpeg_hip_batch_t *batch_create(const jsmpeg_hip_batch_config_t *config, uint32_t pool_frames, uint32_t mb_pictures);
+extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_config_t *config) { return batch_create(config, 0, 0); }
+/* the live front end's form: pool_frames frames in the pool (rings of slots), macroblock records for mb_pictures pictures
+ * (0 / 0: max_pictures of each) */
+static jsmpeg_hip_batch_t *batch_create(const jsmpeg_hip_batch_config_t *config, uint32_t pool_frames, uint32_t mb_pictures) {
 	g_err[0] = 0;
 	if (!config || config->width <= 0 || config->height <= 0 || config->width > 4095 || config->height > 4095) {
 		fail("bad batch config");
@@ -247,6 +267,8 @@ extern "C" jsmpeg_hip_batch_t *jsmpeg_hip_batch_create(const jsmpeg_hip_batch_co
 	b->n_level_ev = 0;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = b->n_slice_codes = 0;
 	b->timed = false; b->stream = nullptr;
+	b->pool_frames = pool_frames; b->mb_pictures = mb_pictures; b->live = nullptr;
+	b->pics_first_copy = mb_pictures ? std::min(std::max(1u, config->max_pictures), 4 * mb_pictures + 64) : std::max(1u, config->max_pictures);
 	if (config->device >= 0) {
 		if (hipSetDevice(config->device) != hipSuccess) { fail("hipSetDevice(%d) failed", config->device); delete b; return nullptr; }
 	}
@@ -281,7 +303,7 @@ static int batch_layout(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint64_
 	b->es_bytes = (uint32_t)off;
 	b->n_streams = n_streams;
 	b->es_view = b->d_es;
-	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear();
+	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear(); b->slot.clear();
 	return 0;
 }
 
@@ -528,7 +550,7 @@ extern "C" int jsmpeg_hip_batch_attach_device(jsmpeg_hip_batch_t *b, const void 
 	b->es_bytes = (uint32_t)total_bytes;
 	b->n_streams = n_streams;
 	b->es_view = (const uint8_t *)dev_es;
-	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear();
+	b->link_prev.clear(); b->seeded.clear(); b->seed_frames.clear(); b->slot.clear();
 	/* (pageable source: the runtime has taken its copy when the call returns) */
 	if (n_streams) HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice, st));
 	return 0;
@@ -542,15 +564,15 @@ static uint32_t batch_plan_stale(const jsmpeg_hip_batch_t *b, std::vector<int32_
 static void fill_desc(const jsmpeg_hip_batch_t *b, JmReconDesc &D, uint32_t p, int32_t stale) {
 	const JmPic &pic = b->h_pics[p];
 	D.tok = b->d_tokens + pic.tok_off;
-	D.mb = b->d_mb + (size_t)p * b->g.mb_size;
-	D.dst = b->d_pool + (uint64_t)p * b->g.frame_bytes;
-	D.fwd = pic.fwd >= 0 ? b->d_pool + (uint64_t)pic.fwd * b->g.frame_bytes : nullptr;
+	D.mb = b->d_mb + (size_t)pic.mb_index * b->g.mb_size;
+	D.dst = frame_of(b, p);
+	D.fwd = pic.fwd >= 0 ? frame_of(b, (uint32_t)pic.fwd) : nullptr;
 	/* a P picture in front of which the stream has no decoded picture of its own, in a stream seeded with the frame that
 	 * was decoded last before it (jsmpeg_hip_batch_seed_stream): that frame is its forward reference */
 	if (pic.fwd < 0 && pic.type == JM_PIC_PREDICTIVE && pic.stream < b->seeded.size() && (b->seeded[pic.stream] & 1) &&
 	    (pic.stream >= b->link_prev.size() || b->link_prev[pic.stream] < 0))
 		D.fwd = b->seed_frames[2 * (size_t)pic.stream];
-	D.stale = stale >= 0 ? b->d_pool + (uint64_t)stale * b->g.frame_bytes
+	D.stale = stale >= 0 ? frame_of(b, (uint32_t)stale)
 	                     : (jm_stale_is_seed(stale) && jm_stale_seed_slot(stale) < b->seed_frames.size() ? b->seed_frames[jm_stale_seed_slot(stale)] : nullptr);
 	D.qm = reinterpret_cast<const uint8_t *>(b->d_streams + pic.stream) + offsetof(JmStream, intra_q);
 	D.done_pic = D.wait_fwd = D.wait_stale = JM_NONE; D.pad_ = 0;
@@ -683,7 +705,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
 	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * std::max(1u, b->cfg.max_pictures), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * b->pics_first_copy, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(b->ev_idx, st));
 	/* the slice order (longest first: kernels.hip) goes in behind the copies and runs WHILE the host reads them and lays out
 	 * the parse: its kernels take their sizes from the device's counters, so nothing of it waits for the host -- 0.08 ms of
@@ -703,12 +725,18 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	                                  b->h_counters[0], b->h_counters[1], b->cfg.max_pictures);
 	b->n_sc = b->h_counters[0]; b->n_pics = b->h_counters[1]; b->n_levels = b->h_counters[3];
 	b->n_slice_codes = std::min(b->h_counters[4], b->sc_cap);
-	/* (the picture table came over with the counters: one copy of the whole table, one turn-around) */
+	/* (the picture table came over with the counters: one copy of the whole table, one turn-around -- but for a pass over
+	 * live streams that saw more picture start codes than such a pass usually does) */
+	if (b->n_pics > b->pics_first_copy) {
+		HIP_TRY(hipMemcpyAsync(b->h_pics + b->pics_first_copy, b->d_pics + b->pics_first_copy, sizeof(JmPic) * (b->n_pics - b->pics_first_copy), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
 	tr.mark("pics-copied");
 	for (uint32_t i = 0; i < b->n_pics; i++) if (b->h_pics[i].decoded) { b->n_decoded++; b->n_slices += b->h_pics[i].n_slices; }
+	if (b->live && live_assign_slots(b->live) < 0) return -1;      /* live streams: which pool slot each picture of this pass is written to */
 	if (b->n_pics) HIP_TRY(hipMemsetAsync(b->d_covered, 0, sizeof(uint32_t) * b->n_pics, st));
 	if (++b->epoch == 0) {
-		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->cfg.max_pictures * b->g.mb_size, st));
+		HIP_TRY(hipMemsetAsync(b->d_mb, 0, sizeof(JmMbRec) * (size_t)b->mb_pictures * b->g.mb_size, st));
 		b->epoch = 1;
 	}
 	HIP_TRY(hipEventRecord(b->ev[2], st));
@@ -965,7 +993,7 @@ extern "C" int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t pictu
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	if (batch_settle(b) < 0) return -1;
-	const uint8_t *f = b->d_pool + (uint64_t)picture * b->g.frame_bytes;
+	const uint8_t *f = frame_of(b, picture);
 	if (y) HIP_TRY(hipMemcpy(y, f, b->g.luma_bytes, hipMemcpyDeviceToHost));
 	if (cr) HIP_TRY(hipMemcpy(cr, f + b->g.luma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
 	if (cb) HIP_TRY(hipMemcpy(cb, f + b->g.luma_bytes + b->g.chroma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
@@ -1144,6 +1172,443 @@ extern "C" int jsmpeg_hip_batch_debug_read(jsmpeg_hip_batch_t *b, int what, void
 	default: return fail("bad debug selector");
 	}
 	HIP_TRY(hipMemcpy(dst, src + offset, bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+/* =========================================================================
+ * Live streams (include/jsmpeg_hip.h part 5): streams that persist across
+ * calls, every pending picture of every stream in ONE pass of the batch engine
+ * per tick.  What replaces, for N streams at once, the reference's per-stream
+ * loop "write(pts, buffers) ... decode()" (src/ts.js:205-210, player.js:222-228,
+ * decoder.js:36-47, buffer.js:30-104, mpeg1.c:853-864, 986-994).
+ *
+ * Where things live:
+ *   h_stage (pinned)      the bytes written since the last tick, write after write (a write() is ONE memcpy, to here)
+ *   d_arena               [ staging copy | ES buffer 0 | ES buffer 1 ]: a tick sends the staging bytes over in one
+ *                         transfer and k_place lays out the pass's ES buffer -- per stream: the undecoded tail the last
+ *                         tick left (it is still in the OTHER ES buffer) + the new writes -- which the batch engine then
+ *                         reads in place (the attach form of part 2)
+ *   the batch's pool      max_streams rings of (pictures per tick + 2) frames: a stream's pictures are written to its
+ *                         ring's next slots (jsmpeg_hip_batch_t::slot), so the frames of its last two decoded pictures --
+ *                         the reference's two plane sets, mpeg1.c:986-994 -- are still there for the next tick's first
+ *                         P picture (forward reference) and unwritten macroblocks (the picture before last)
+ *   LiveStream            per stream on the host: the sequence header as the device parsed it (first pass that saw it),
+ *                         the pending byte counts, the ring position, the write() time stamps
+ * The host never looks at a byte of the streams: which pictures are complete, where the cursor rests and what the
+ * sequence header says all come back from the index kernel (JmPic::end_pos, JmStream).
+ * ========================================================================= */
+#include <deque>
+
+struct LiveSeg { uint32_t stream, stage_off, bytes; };
+struct LiveStamp { uint64_t at; double pts; };
+struct LiveStream {
+	bool open, has_header;
+	int status;
+	JmStream hdr;                       /* the index kernel's record of the stream's first sequence header */
+	uint32_t tail_off, tail_bytes;      /* undecoded bytes the last tick left: arena offset, length */
+	uint32_t new_bytes;                 /* written since (in the staging buffer) */
+	uint64_t written, consumed;         /* bytes ever written; stream offset of the first pending byte */
+	uint32_t head, have;                /* ring slot of the picture decoded last; pictures decoded so far (saturates at 2) */
+	std::deque<LiveStamp> stamps;       /* write(): stream offset, pts */
+	uint64_t pictures, evictions;
+};
+struct LivePicture { uint32_t stream, slot; int32_t type; double pts; uint64_t at; };
+
+struct jsmpeg_hip_live_t {
+	jsmpeg_hip_live_config_t cfg;
+	jsmpeg_hip_batch_t *b;
+	uint32_t ring;                      /* frames per stream */
+	uint8_t *h_stage; uint32_t stage_cap, stage_used;
+	uint8_t *d_arena; uint32_t es_off[2], es_cap; int cur;
+	uint32_t *h_tab, *d_tab; uint32_t tab_cap;   /* placement tables of a pass: source offsets | destination offsets | lengths */
+	std::vector<LiveSeg> segs;
+	std::vector<LiveStream> streams;
+	std::vector<uint32_t> pass_stream, pass_decoded;   /* of the pass under way: batch stream i = live stream pass_stream[i] */
+	JmStream *h_back;                   /* pinned: the stream table as the pass left it (the headers it found) */
+	std::vector<LivePicture> out;
+	uint32_t *d_slots; uint64_t *d_hashes; uint8_t *d_rgba;
+	float ms[9];
+};
+
+static void live_free(jsmpeg_hip_live_t *l) {
+	if (!l) return;
+	if (l->b) { hipSetDevice(l->b->device); hipDeviceSynchronize(); l->b->live = nullptr; batch_free(l->b); }
+	if (l->h_stage) hipHostFree(l->h_stage);
+	if (l->h_tab) hipHostFree(l->h_tab);
+	if (l->h_back) hipHostFree(l->h_back);
+	hipFree(l->d_arena); hipFree(l->d_tab); hipFree(l->d_slots); hipFree(l->d_hashes); hipFree(l->d_rgba);
+	delete l;
+}
+
+static int live_alloc(jsmpeg_hip_live_t *l) {
+	const uint32_t ms = l->cfg.max_streams;
+	HIP_TRY(hipHostMalloc(&l->h_stage, l->stage_cap, hipHostMallocDefault));
+	HIP_TRY(jm_malloc(&l->d_arena, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
+	HIP_TRY(hipMemset(l->d_arena, 0xff, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
+	l->tab_cap = 4 * ms + 64;
+	HIP_TRY(hipHostMalloc(&l->h_tab, sizeof(uint32_t) * 3 * (size_t)l->tab_cap, hipHostMallocDefault));
+	HIP_TRY(jm_malloc(&l->d_tab, sizeof(uint32_t) * 3 * (size_t)l->tab_cap));
+	HIP_TRY(hipHostMalloc(&l->h_back, sizeof(JmStream) * (size_t)ms, hipHostMallocDefault));
+	HIP_TRY(jm_malloc(&l->d_slots, sizeof(uint32_t) * (size_t)ms * (l->ring - 2)));
+	HIP_TRY(jm_malloc(&l->d_hashes, sizeof(uint64_t) * (size_t)ms * (l->ring - 2)));
+	HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
+extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_config_t *config) {
+	g_err[0] = 0;
+	if (!config || config->width <= 0 || config->height <= 0 || config->width > 4095 || config->height > 4095 || config->max_streams == 0) {
+		fail("bad live config");
+		return nullptr;
+	}
+	jsmpeg_hip_live_t *l = new jsmpeg_hip_live_t();
+	l->cfg = *config;
+	if (!l->cfg.max_pictures_per_tick) l->cfg.max_pictures_per_tick = 4;
+	if (!l->cfg.store_bytes) l->cfg.store_bytes = 512 * 1024;          /* mpeg1-wasm.js:9 */
+	l->b = nullptr; l->h_stage = nullptr; l->d_arena = nullptr; l->h_tab = nullptr; l->d_tab = nullptr; l->h_back = nullptr;
+	l->d_slots = nullptr; l->d_hashes = nullptr; l->d_rgba = nullptr; l->stage_used = 0; l->cur = 0; l->tab_cap = 0;
+	for (float &m : l->ms) m = 0.f;
+	const uint64_t all_stores = (uint64_t)l->cfg.max_streams * l->cfg.store_bytes;
+	const uint64_t per_tick = (uint64_t)l->cfg.max_streams * l->cfg.max_pictures_per_tick;
+	if (all_stores >= (1ull << 30) || per_tick > (1u << 20) || l->cfg.max_pictures_per_tick > 4096) {
+		fail("live config too large: max_streams x store_bytes must stay below 1 GiB, max_streams x max_pictures_per_tick below 2^20");
+		delete l;
+		return nullptr;
+	}
+	l->ring = l->cfg.max_pictures_per_tick + 2;
+	jsmpeg_hip_batch_config_t bc;
+	bc.width = l->cfg.width; bc.height = l->cfg.height; bc.max_streams = l->cfg.max_streams;
+	/* the picture TABLE is sized for the start codes a pass may see (a store full of tiny pictures), the macroblock records
+	 * and the frames for what it may decode */
+	bc.max_pictures = (uint32_t)std::min<uint64_t>(1u << 20, per_tick + all_stores / 512);
+	bc.max_es_bytes = all_stores; bc.device = l->cfg.device;
+	l->b = batch_create(&bc, (uint32_t)((uint64_t)l->cfg.max_streams * l->ring), (uint32_t)per_tick);
+	if (!l->b) { delete l; return nullptr; }
+	l->b->live = l;
+	l->es_cap = (uint32_t)(((uint64_t)l->b->es_cap + 255) & ~255ull);
+	l->stage_cap = (uint32_t)((all_stores + 16ull * 1024 + 255) & ~255ull);
+	l->es_off[0] = l->stage_cap; l->es_off[1] = l->stage_cap + l->es_cap;
+	l->streams.assign(l->cfg.max_streams, LiveStream());
+	for (LiveStream &S : l->streams) { S.open = false; S.has_header = false; S.status = 0; }
+	if (live_alloc(l) != 0) { live_free(l); return nullptr; }
+	return l;
+}
+
+extern "C" void jsmpeg_hip_live_destroy(jsmpeg_hip_live_t *l) { live_free(l); }
+
+static void live_drop_staged(jsmpeg_hip_live_t *l, uint32_t stream) {
+	for (LiveSeg &g : l->segs) if (g.stream == stream) g.bytes = 0;
+}
+
+extern "C" int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	for (uint32_t s = 0; s < l->streams.size(); s++) {
+		LiveStream &S = l->streams[s];
+		if (S.open) continue;
+		S = LiveStream();
+		S.open = true; S.has_header = false; S.status = 0; memset(&S.hdr, 0, sizeof(S.hdr));
+		S.tail_off = S.tail_bytes = S.new_bytes = 0; S.written = S.consumed = 0; S.head = 0; S.have = 0; S.pictures = S.evictions = 0;
+		return (int)s;
+	}
+	return fail("all %u streams are open", (unsigned)l->streams.size());
+}
+
+extern "C" int jsmpeg_hip_live_close(jsmpeg_hip_live_t *l, uint32_t stream) {
+	g_err[0] = 0;
+	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("close: stream %u is not open", stream);
+	l->streams[stream].open = false;
+	live_drop_staged(l, stream);
+	return 0;
+}
+
+/* the staging buffer is full of writes that were thrown away again (evictions, closed streams): move the live ones down */
+static void live_compact_stage(jsmpeg_hip_live_t *l) {
+	uint32_t at = 0;
+	size_t k = 0;
+	for (const LiveSeg &g : l->segs) {
+		if (!g.bytes) continue;
+		const uint32_t to = at + ((g.stage_off - at) & 15u);          /* same residue modulo 16: the placement's aligned form */
+		if (to != g.stage_off) memmove(l->h_stage + to, l->h_stage + g.stage_off, g.bytes);
+		l->segs[k++] = LiveSeg{ g.stream, to, g.bytes };
+		at = to + g.bytes;
+	}
+	l->segs.resize(k);
+	l->stage_used = at;
+}
+
+/* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict */
+extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n) {
+	g_err[0] = 0;
+	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("write: stream %u is not open", stream);
+	if (n == 0) return 0;
+	if (!bytes) return fail("write: null buffer");
+	LiveStream &S = l->streams[stream];
+	if (n > l->cfg.store_bytes) return fail("write of %u bytes > the stream's store of %u bytes (the reference's store throws a RangeError there)", n, l->cfg.store_bytes);
+	if ((uint64_t)S.tail_bytes + S.new_bytes + n > l->cfg.store_bytes) {
+		/* buffer.js:37-56: decoded bytes never stand in the way here (a tick drops them), so a write that does not fit finds
+		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store */
+		S.tail_bytes = 0; S.new_bytes = 0;
+		live_drop_staged(l, stream);
+		S.consumed = S.written;
+		S.stamps.clear();
+		S.evictions++;
+	}
+	const uint32_t residue = (S.tail_bytes + S.new_bytes) & 15u;      /* where the bytes will lie in the pass's ES buffer, modulo 16 */
+	uint32_t off = l->stage_used + ((residue - l->stage_used) & 15u);
+	if ((uint64_t)off + n > l->stage_cap) {
+		live_compact_stage(l);
+		off = l->stage_used + ((residue - l->stage_used) & 15u);
+		if ((uint64_t)off + n > l->stage_cap) return fail("write: the staging buffer is full (%u bytes written since the last tick): call jsmpeg_hip_live_tick", l->stage_used);
+	}
+	memcpy(l->h_stage + off, bytes, n);
+	if (!l->segs.empty() && l->segs.back().stream == stream && l->segs.back().bytes && l->segs.back().stage_off + l->segs.back().bytes == off) l->segs.back().bytes += n;
+	else l->segs.push_back(LiveSeg{ stream, off, n });
+	l->stage_used = off + n;
+	S.stamps.push_back(LiveStamp{ S.written, pts });
+	S.written += n; S.new_bytes += n;
+	return 0;
+}
+
+/* Inside jsmpeg_hip_batch_decode, once the pass's picture table is on the host: picture p of the pass is written to the
+ * next free slot of its stream's ring. */
+static int live_assign_slots(jsmpeg_hip_live_t *l) {
+	jsmpeg_hip_batch_t *b = l->b;
+	b->slot.assign(b->n_pics, 0);
+	l->pass_decoded.assign(l->pass_stream.size(), 0);
+	for (uint32_t p = 0; p < b->n_pics; p++) {
+		const JmPic &pic = b->h_pics[p];
+		if (!pic.decoded) continue;
+		if (pic.stream >= l->pass_stream.size()) return fail("internal: live pass: picture %u names stream %u of %u", p, pic.stream, (unsigned)l->pass_stream.size());
+		const uint32_t s = l->pass_stream[pic.stream], k = l->pass_decoded[pic.stream]++;
+		if (k >= l->ring - 2 || pic.mb_index >= b->mb_pictures) return fail("internal: live pass: stream %u decodes more than %u pictures in one tick", s, l->ring - 2);
+		b->slot[p] = s * l->ring + (l->streams[s].head + 1 + k) % l->ring;
+	}
+	return 0;
+}
+
+static inline double live_ms_since(std::chrono::steady_clock::time_point t0) {
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	jsmpeg_hip_batch_t *b = l->b;
+	const auto t_begin = std::chrono::steady_clock::now();
+	HIP_TRY(hipSetDevice(b->device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	const bool flush = (flags & JSMPEG_HIP_LIVE_FLUSH) != 0;
+	l->out.clear();
+	for (float &m : l->ms) m = 0.f;
+
+	/* ---- 1. the streams of this pass: the open ones with bytes pending ---- */
+	l->pass_stream.clear();
+	for (uint32_t s = 0; s < l->streams.size(); s++) {
+		LiveStream &S = l->streams[s];
+		if (!S.open) continue;
+		if (S.status) {                                              /* a stream of another size: nothing of it is ever decoded */
+			S.consumed += (uint64_t)S.tail_bytes + S.new_bytes; S.tail_bytes = S.new_bytes = 0; S.stamps.clear();
+			live_drop_staged(l, s);
+			continue;
+		}
+		if (S.tail_bytes + S.new_bytes) l->pass_stream.push_back(s);
+	}
+	const uint32_t n = (uint32_t)l->pass_stream.size();
+	if (n == 0) { l->segs.clear(); l->stage_used = 0; return 0; }
+
+	/* ---- 2. the pass's ES buffer: per stream the tail the last tick left, then the new writes in order ---- */
+	const int cur = l->cur;
+	if (l->tab_cap < n + l->segs.size()) {
+		const uint32_t cap = (uint32_t)(2 * (n + l->segs.size()) + 64);
+		uint32_t *h = nullptr, *d = nullptr;
+		HIP_TRY(hipHostMalloc(&h, sizeof(uint32_t) * 3 * (size_t)cap, hipHostMallocDefault));
+		if (jm_malloc(&d, sizeof(uint32_t) * 3 * (size_t)cap) != hipSuccess) { hipHostFree(h); return fail("live tick: cannot grow the placement tables"); }
+		HIP_TRY(hipStreamSynchronize(st));
+		hipHostFree(l->h_tab); hipFree(l->d_tab);
+		l->h_tab = h; l->d_tab = d; l->tab_cap = cap;
+	}
+	uint32_t *t_src = l->h_tab, *t_dst = l->h_tab + l->tab_cap, *t_len = l->h_tab + 2 * (size_t)l->tab_cap;
+	uint32_t n_tab = 0, max_len = 0;
+	std::vector<uint32_t> dst_at(l->streams.size(), JM_NONE);
+	b->h_streams.assign(n, JmStream());
+	uint64_t off = 16;
+	bool need_back = false;
+	for (uint32_t i = 0; i < n; i++) {
+		const LiveStream &S = l->streams[l->pass_stream[i]];
+		off = (off + 15) & ~15ull;
+		JmStream &T = b->h_streams[i];
+		if (S.has_header) T = S.hdr; else { memset(&T, 0, sizeof(T)); need_back = true; }
+		T.es_begin = (uint32_t)off; T.es_end = (uint32_t)(off + S.tail_bytes + S.new_bytes);
+		T.seq_sc = JM_NONE; T.sc_lo = T.sc_hi = T.pic_lo = T.pic_hi = 0;
+		T.live_flags = (flush ? 0 : JM_LIVE_HOLD) | (S.has_header ? JM_LIVE_HEADER : 0);
+		T.live_limit = (int32_t)l->cfg.max_pictures_per_tick;
+		if (S.tail_bytes) {
+			t_src[n_tab] = S.tail_off; t_dst[n_tab] = T.es_begin; t_len[n_tab] = S.tail_bytes;    /* (sources: arena offsets; destinations: offsets in this pass's ES buffer) */
+			max_len = std::max(max_len, S.tail_bytes); n_tab++;
+		}
+		dst_at[l->pass_stream[i]] = T.es_begin + S.tail_bytes;
+		off = (uint64_t)T.es_end + JM_STREAM_GAP;
+	}
+	const uint64_t total = off;
+	if (total + JM_ES_PAD > l->es_cap) return fail("internal: live pass of %llu bytes exceeds the ES buffer", (unsigned long long)total);
+	for (const LiveSeg &g : l->segs) {
+		if (!g.bytes || dst_at[g.stream] == JM_NONE) continue;
+		t_src[n_tab] = g.stage_off; t_dst[n_tab] = dst_at[g.stream]; t_len[n_tab] = g.bytes;
+		dst_at[g.stream] += g.bytes;
+		max_len = std::max(max_len, g.bytes); n_tab++;
+	}
+	uint8_t *es = l->d_arena + l->es_off[cur];
+	if (l->stage_used) HIP_TRY(hipMemcpyAsync(l->d_arena, l->h_stage, l->stage_used, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(l->d_tab, l->h_tab, sizeof(uint32_t) * 3 * (size_t)l->tab_cap, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(es, 0xff, (size_t)total + JM_ES_PAD, st));
+	HIP_TRY(jm_launch_place(l->d_arena, es, l->d_tab, l->d_tab + l->tab_cap, l->d_tab + 2 * (size_t)l->tab_cap, n_tab, max_len, st));
+
+	/* ---- 3. the batch reads that buffer in place; every stream is seeded with its ring's last two frames ---- */
+	b->es_bytes = (uint32_t)total; b->n_streams = n; b->es_view = es;
+	b->link_prev.clear(); b->slot.clear();
+	b->seeded.assign(n, 0); b->seed_frames.assign(2 * (size_t)n, nullptr);
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t s = l->pass_stream[i];
+		const LiveStream &S = l->streams[s];
+		if (S.have >= 1) { b->seeded[i] |= 1; b->seed_frames[2 * (size_t)i] = b->d_pool + (uint64_t)(s * l->ring + S.head) * b->g.frame_bytes; }
+		if (S.have >= 2) { b->seeded[i] |= 2; b->seed_frames[2 * (size_t)i + 1] = b->d_pool + (uint64_t)(s * l->ring + (S.head + l->ring - 1) % l->ring) * b->g.frame_bytes; }
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n, hipMemcpyHostToDevice, st));
+	l->ms[0] = (float)live_ms_since(t_begin);
+
+	/* ---- 4. one pass of the batch engine ---- */
+	const auto t_decode = std::chrono::steady_clock::now();
+	const int n_pics = jsmpeg_hip_batch_decode(b, st);
+	if (n_pics < 0) return -1;                                       /* nothing has been consumed: the writes are still staged, the tails where they were */
+	if (need_back) HIP_TRY(hipMemcpyAsync(l->h_back, b->d_streams, sizeof(JmStream) * n, hipMemcpyDeviceToHost, st));
+	l->ms[1] = (float)live_ms_since(t_decode);
+	const auto t_wait = std::chrono::steady_clock::now();
+	if (jsmpeg_hip_batch_sync(b) < 0) return -1;
+	l->ms[2] = (float)live_ms_since(t_wait);
+	const auto t_book = std::chrono::steady_clock::now();
+
+	/* ---- 5. what the pass decoded, and where each stream's cursor rests ---- */
+	uint32_t p = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t s = l->pass_stream[i];
+		LiveStream &S = l->streams[s];
+		const JmStream &T = b->h_streams[i];
+		if (!S.has_header && l->h_back[i].seq_sc != JM_NONE) {          /* mpeg1.c:812-819: the stream's FIRST sequence header, as the index kernel read it */
+			S.has_header = true; S.hdr = l->h_back[i];
+			S.status = S.hdr.valid ? 0 : 1;
+		}
+		uint32_t cursor = T.es_begin, n_dec = 0;
+		bool held = false;
+		while (p < (uint32_t)n_pics && b->h_pics[p].stream < i) p++;
+		for (; p < (uint32_t)n_pics && b->h_pics[p].stream == i; p++) {
+			const JmPic &pic = b->h_pics[p];
+			if (held) continue;
+			if (pic.end_pos == JM_NONE) { held = true; cursor = pic.pos; continue; }   /* waits for more data (or for the next tick): the cursor stays on it */
+			cursor = pic.end_pos;                                    /* where the reference's decode() leaves the cursor (mpeg1.c:980-984) */
+			if (!pic.decoded) continue;
+			const uint64_t at = S.consumed + (pic.pos - T.es_begin);
+			while (S.stamps.size() > 1 && S.stamps[1].at <= at) S.stamps.pop_front();
+			l->out.push_back(LivePicture{ s, b->slot[p], pic.type, S.stamps.empty() ? 0.0 : S.stamps.front().pts, at });
+			n_dec++;
+		}
+		/* without a header the reference's write() leaves its cursor at the end of the data (mpeg1.c:812-819); a FLUSH tick is
+		 * `while (decode());`, whose last call does the same (mpeg1.c:853-864).  A tick that only takes what is complete keeps
+		 * a header that has begun (JmStream::valid -1) and the last three bytes -- a start code may be cut there */
+		if (S.status) cursor = T.es_end;
+		else if (!S.has_header) cursor = flush ? T.es_end : l->h_back[i].valid == -1 ? (uint32_t)l->h_back[i].width : T.es_end - std::min(3u, T.es_end - T.es_begin);
+		else if (flush && !held) cursor = T.es_end;
+		S.consumed += cursor - T.es_begin;
+		S.tail_off = l->es_off[cur] + cursor; S.tail_bytes = T.es_end - cursor; S.new_bytes = 0;
+		while (S.stamps.size() > 1 && S.stamps[1].at <= S.consumed) S.stamps.pop_front();
+		S.head = (S.head + n_dec) % l->ring; S.have = std::min(2u, S.have + n_dec); S.pictures += n_dec;
+	}
+	l->segs.clear(); l->stage_used = 0; l->cur = cur ^ 1;
+	l->ms[3] = (float)live_ms_since(t_book);
+	l->ms[4] = (float)live_ms_since(t_begin);
+	float bt[5];
+	if (jsmpeg_hip_batch_timings(b, bt) == 0) { l->ms[5] = bt[0]; l->ms[6] = bt[1]; l->ms[7] = bt[2]; l->ms[8] = bt[3]; }
+	g_err[0] = 0;
+	return (int)l->out.size();
+}
+
+extern "C" uint32_t jsmpeg_hip_live_picture_count(jsmpeg_hip_live_t *l) { return l ? (uint32_t)l->out.size() : 0; }
+
+extern "C" int jsmpeg_hip_live_picture(jsmpeg_hip_live_t *l, uint32_t i, jsmpeg_hip_live_picture_t *out) {
+	if (!l || !out || i >= l->out.size()) return fail("bad picture index");
+	const LivePicture &P = l->out[i];
+	out->stream = P.stream; out->type = P.type; out->pts = P.pts; out->stream_offset = P.at;
+	out->device_frame = l->b->d_pool + (uint64_t)P.slot * l->b->g.frame_bytes;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_geometry(jsmpeg_hip_live_t *l, int32_t *cw, int32_t *ch, uint32_t *luma, uint32_t *chroma) {
+	if (!l) return fail("null live handle");
+	return jsmpeg_hip_batch_geometry(l->b, cw, ch, luma, chroma, nullptr);
+}
+
+extern "C" int jsmpeg_hip_live_read_frame(jsmpeg_hip_live_t *l, uint32_t i, void *y, void *cr, void *cb) {
+	g_err[0] = 0;
+	if (!l || i >= l->out.size()) return fail("bad picture index");
+	const jsmpeg_hip_batch_t *b = l->b;
+	HIP_TRY(hipSetDevice(b->device));
+	const uint8_t *f = b->d_pool + (uint64_t)l->out[i].slot * b->g.frame_bytes;
+	if (y) HIP_TRY(hipMemcpy(y, f, b->g.luma_bytes, hipMemcpyDeviceToHost));
+	if (cr) HIP_TRY(hipMemcpy(cr, f + b->g.luma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
+	if (cb) HIP_TRY(hipMemcpy(cb, f + b->g.luma_bytes + b->g.chroma_bytes, b->g.chroma_bytes, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void *host_rgba) {
+	g_err[0] = 0;
+	if (!l || !host_rgba || i >= l->out.size()) return fail("bad picture index");
+	jsmpeg_hip_batch_t *b = l->b;
+	HIP_TRY(hipSetDevice(b->device));
+	const size_t bytes = (size_t)b->cfg.width * b->cfg.height * 4;
+	if (!l->d_rgba) HIP_TRY(jm_malloc(&l->d_rgba, bytes));
+	JmRgbaBufs r;
+	r.frames = b->d_pool; r.first_frame = l->out[i].slot; r.n_frames = 1;
+	r.frame_stride = b->g.frame_bytes; r.luma_bytes = b->g.luma_bytes; r.chroma_bytes = b->g.chroma_bytes;
+	r.coded_width = b->g.coded_width; r.coded_height = b->g.coded_height; r.width = b->cfg.width; r.height = b->cfg.height;
+	r.rgba = l->d_rgba; r.rgba_stride = bytes;
+	HIP_TRY(jm_launch_rgba(r, b->stream));
+	HIP_TRY(hipMemcpyAsync(host_rgba, l->d_rgba, bytes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_frame_hashes(jsmpeg_hip_live_t *l, uint64_t *out) {
+	g_err[0] = 0;
+	if (!l || !out) return fail("null argument");
+	jsmpeg_hip_batch_t *b = l->b;
+	const uint32_t n = (uint32_t)l->out.size();
+	if (!n) return 0;
+	HIP_TRY(hipSetDevice(b->device));
+	std::vector<uint32_t> slots(n);
+	for (uint32_t i = 0; i < n; i++) slots[i] = l->out[i].slot;
+	HIP_TRY(hipMemcpyAsync(l->d_slots, slots.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, b->stream));
+	HIP_TRY(jm_launch_hash(b->d_pool, b->g.frame_bytes, b->g.luma_bytes + 2 * b->g.chroma_bytes, n, l->d_hashes, b->stream, l->d_slots));
+	HIP_TRY(hipMemcpyAsync(out, l->d_hashes, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_stream_info(jsmpeg_hip_live_t *l, uint32_t stream, jsmpeg_hip_live_stream_info_t *out) {
+	if (!l || !out || stream >= l->streams.size() || !l->streams[stream].open) return fail("stream %u is not open", stream);
+	const LiveStream &S = l->streams[stream];
+	static const float rates[16] = MPEG1_PICTURE_RATE_INIT;
+	out->has_sequence_header = S.has_header ? 1 : 0;
+	out->width = S.has_header ? S.hdr.width : 0; out->height = S.has_header ? S.hdr.height : 0;
+	out->frame_rate = S.has_header ? rates[S.hdr.rate_code & 15] : 0.f;
+	out->status = S.status;
+	out->pending_bytes = S.tail_bytes + S.new_bytes;
+	out->bytes_written = S.written; out->pictures = S.pictures; out->evictions = S.evictions;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_timings(jsmpeg_hip_live_t *l, float out_ms[9]) {
+	if (!l || !out_ms) return fail("null argument");
+	for (int i = 0; i < 9; i++) out_ms[i] = l->ms[i];
 	return 0;
 }
 

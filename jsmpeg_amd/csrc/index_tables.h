@@ -34,14 +34,23 @@ JM_HD uint32_t jm_lower_bound(const uint32_t *a, uint32_t n, uint32_t key) { /* 
 JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
                            uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h) {
 	st.sc_lo = jm_lower_bound(sc_pos, n_sc, st.es_begin);
-	st.sc_hi = jm_lower_bound(sc_pos, n_sc, st.es_end);
+	/* (a live stream whose last bytes are "00 00 01": the scan lists a start code there whose code byte is the gap's -- in a
+	 * pass that takes only what is complete, a start code whose fourth byte has not arrived is not one yet) */
+	st.sc_hi = jm_lower_bound(sc_pos, n_sc, (st.live_flags & JM_LIVE_HOLD) && st.es_end - st.es_begin >= 3 ? st.es_end - 3 : st.es_end);
 	st.pic_lo = jm_lower_bound(pic_sc, n_pics, st.sc_lo);
 	st.pic_hi = jm_lower_bound(pic_sc, n_pics, st.sc_hi);
 	st.seq_sc = JM_NONE;
+	if (st.live_flags & JM_LIVE_HEADER) return;      /* a live stream whose first header an earlier pass parsed: the record holds it (valid included) */
 	st.valid = 0;
 	for (uint32_t i = st.sc_lo; i < st.sc_hi; i++)
 		if (sc_code[i] == JM_CODE_SEQUENCE) { st.seq_sc = i; break; }
 	if (st.seq_sc == JM_NONE) return;
+	if ((st.live_flags & JM_LIVE_HOLD) && st.seq_sc + 1 >= st.sc_hi) {
+		/* a live stream's header that no start code ends yet may not be all there: it waits like a picture would --
+		 * valid = -1, width = where it begins (the host leaves its cursor there) */
+		st.valid = -1; st.width = (int32_t)sc_pos[st.seq_sc]; st.seq_sc = JM_NONE;
+		return;
+	}
 	uint64_t bit = ((uint64_t)sc_pos[st.seq_sc] + 4) * 8;
 	st.width = (int32_t)jm_bits_at(es, st.es_end, bit, 12); bit += 12;
 	st.height = (int32_t)jm_bits_at(es, st.es_end, bit, 12); bit += 12;
@@ -71,10 +80,12 @@ JM_HD void jm_index_picture(JmPic &pic, uint32_t p, uint32_t stream_idx, const J
 	pic.stream = stream_idx;
 	pic.pos = sc_pos[sc];
 	pic.tok_off = tokens_relative ? 0 : (uint64_t)(pic.pos - es_origin) * JM_TOKENS_PER_BYTE;
+	pic.mb_index = st.live_limit > 0 ? stream_idx * (uint32_t)st.live_limit + (p - st.pic_lo) : p;   /* (a held picture's is never used) */
+	pic.pad_ = 0;
 	uint64_t bit = ((uint64_t)pic.pos + 4) * 8 + 10;                    /* temporal_reference */
 	pic.type = (uint8_t)jm_bits_at(es, st.es_end, bit, 3); bit += 3 + 16;  /* + vbv_delay */
 	pic.full_pel = 0; pic.f_code = 0;
-	bool ok = st.valid && st.seq_sc != JM_NONE && sc > st.seq_sc &&
+	bool ok = st.valid && ((st.live_flags & JM_LIVE_HEADER) || (st.seq_sc != JM_NONE && sc > st.seq_sc)) &&
 	          (pic.type == JM_PIC_INTRA || pic.type == JM_PIC_PREDICTIVE);
 	if (pic.type == JM_PIC_PREDICTIVE) {
 		pic.full_pel = (uint8_t)jm_bits_at(es, st.es_end, bit, 1);
@@ -84,15 +95,23 @@ JM_HD void jm_index_picture(JmPic &pic, uint32_t p, uint32_t stream_idx, const J
 	pic.decoded = ok ? 1 : 0;
 	pic.first_slice_sc = JM_NONE; pic.n_slices = 0; pic.end_sc = sc + 1;
 	pic.level = 0; pic.fwd = -1;
-	if (!ok) return;
-	uint32_t j = sc + 1;
-	while (j < st.sc_hi && (sc_code[j] == JM_CODE_EXTENSION || sc_code[j] == JM_CODE_USER_DATA)) j++;
-	pic.first_slice_sc = j;
-	while (j < st.sc_hi && sc_code[j] >= JM_CODE_SLICE_FIRST && sc_code[j] <= JM_CODE_SLICE_LAST) {
-		sc_owner[j] = p;
-		j++;
+	uint32_t first = sc + 1, j = sc + 1;
+	if (ok) {
+		while (j < st.sc_hi && (sc_code[j] == JM_CODE_EXTENSION || sc_code[j] == JM_CODE_USER_DATA)) j++;
+		first = j;
+		while (j < st.sc_hi && sc_code[j] >= JM_CODE_SLICE_FIRST && sc_code[j] <= JM_CODE_SLICE_LAST) j++;
 	}
-	pic.n_slices = j - pic.first_slice_sc;
+	/* live streams: a picture that nothing ends yet waits for more data, and so does everything beyond the pass's
+	 * picture limit (held pictures are the LAST ones of their stream's range: the host leaves its cursor on the first) */
+	if (((st.live_flags & JM_LIVE_HOLD) && j >= st.sc_hi) || (st.live_limit > 0 && p - st.pic_lo >= (uint32_t)st.live_limit)) {
+		pic.decoded = 0; pic.end_pos = JM_NONE;
+		return;
+	}
+	pic.end_pos = j < st.sc_hi ? sc_pos[j] : st.es_end;
+	if (!ok) return;
+	pic.first_slice_sc = first;
+	for (uint32_t k = first; k < j; k++) sc_owner[k] = p;
+	pic.n_slices = j - first;
 	pic.end_sc = j;
 }
 

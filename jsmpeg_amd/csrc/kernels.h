@@ -159,9 +159,9 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st);
 /* workgroups (tiles) k_recon takes per picture of this geometry */
 uint32_t jm_recon_tiles_per_picture(const JmGeom &g);
 
-/* 64-bit content hash of each frame's 1.5 * coded_size plane bytes */
+/* 64-bit content hash of each frame's 1.5 * coded_size plane bytes; slots (device memory, or null): frame f is pool slot slots[f] */
 hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,
-                          uint64_t *out, hipStream_t st);
+                          uint64_t *out, hipStream_t st, const uint32_t *slots = nullptr);
 
 /* Y | Cr | Cb frames -> RGBA (reference src/canvas2d.js:53-122), display size, rows packed */
 struct JmRgbaBufs {

@@ -519,7 +519,7 @@ static __device__ __forceinline__ void jm_parse_body(const JmParseBufs &b) {
 				const uint32_t rel = (uint32_t)(pic.tok_off & (JM_TK_GROUP - 1));
 				const uint32_t slot = (rel + (pos - pic.pos) * JM_TOKENS_PER_BYTE + JM_TK_GROUP - 1) & ~(uint32_t)(JM_TK_GROUP - 1);
 				jm_lane_init(L, reinterpret_cast<const uint4_like_t *>(b.es), pos + 4, limit_bytes, b.sc_code[i], c,
-				             b.mb + (size_t)p * b.mb_size,
+				             b.mb + (size_t)pic.mb_index * b.mb_size,
 				             reinterpret_cast<uint4_like_t *>(b.tokens) + ((pic.tok_off - rel) >> 3), slot, rel);
 				mine = true;
 			}
@@ -1107,10 +1107,10 @@ hipError_t jm_launch_recon(const JmReconBufs &b, hipStream_t st) {
  * Y | Cr | Cb.  Mirrored in numpy by jsmpeg_amd/hashing.py.
  * ---------------------------------------------------------------------- */
 __global__ __launch_bounds__(JM_WG) void k_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t n_words,
-                                               uint32_t blocks_per_frame, uint64_t *out) {
+                                               uint32_t blocks_per_frame, uint64_t *out, const uint32_t *slots) {
 	__shared__ uint64_t part[4];
 	const uint32_t f = blockIdx.x / blocks_per_frame, blk = blockIdx.x % blocks_per_frame;
-	const uint64_t *w = reinterpret_cast<const uint64_t *>(pool + (uint64_t)f * frame_bytes);
+	const uint64_t *w = reinterpret_cast<const uint64_t *>(pool + (uint64_t)(slots ? slots[f] : f) * frame_bytes);
 	uint64_t h = 0;
 	for (uint32_t i = blk * JM_WG + threadIdx.x; i < n_words; i += blocks_per_frame * JM_WG) {
 		uint64_t t = w[i] ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull);
@@ -1131,14 +1131,14 @@ __global__ __launch_bounds__(JM_WG) void k_hash(const uint8_t *pool, uint64_t fr
 }
 
 hipError_t jm_launch_hash(const uint8_t *pool, uint64_t frame_bytes, uint32_t hashed_bytes, uint32_t n_frames,
-                          uint64_t *out, hipStream_t st) {
+                          uint64_t *out, hipStream_t st, const uint32_t *slots) {
 	if (n_frames == 0) return hipSuccess;
 	hipError_t e = hipMemsetAsync(out, 0, (size_t)n_frames * 8, st);
 	if (e != hipSuccess) return e;
 	uint32_t n_words = hashed_bytes / 8;
 	uint32_t bpf = (n_words + JM_WG * 16 - 1) / (JM_WG * 16);
 	if (bpf == 0) bpf = 1;
-	hipLaunchKernelGGL(k_hash, dim3(n_frames * bpf), dim3(JM_WG), 0, st, pool, frame_bytes, n_words, bpf, out);
+	hipLaunchKernelGGL(k_hash, dim3(n_frames * bpf), dim3(JM_WG), 0, st, pool, frame_bytes, n_words, bpf, out, slots);
 	return hipGetLastError();
 }
 

@@ -72,15 +72,26 @@ struct JmStream {
 	uint32_t seq_sc;               /* start-code index of the first sequence header, JM_NONE if none */
 	uint32_t sc_lo, sc_hi;         /* this stream's range in the start-code list  */
 	uint32_t pic_lo, pic_hi;       /* this stream's range in the picture list     */
-	int32_t valid;                 /* header found and dimensions match the batch */
+	int32_t valid;                 /* header found and dimensions match the batch (-1, live streams only: a header BEGINS at byte `width` of the
+	                                  ES buffer and waits for the rest of its bytes, index_tables.h) */
 	int32_t width, height;
 	int32_t mb_width, mb_height, mb_size;
 	int32_t rate_code;
-	int32_t pad_[2];               /* intra_q | nonintra_q: 128 contiguous bytes at a 16-byte aligned offset (k_recon stages them with eight 16-byte loads) */
+	/* LIVE streams (engine.hip, jsmpeg_hip_live_*: a batch pass over what has arrived of streams that go on) -- 0 / 0 for
+	 * every other batch.  live_flags: JM_LIVE_HOLD = a picture no start code ends yet (its end_sc is the end of the stream's
+	 * range) is HELD: not decoded in this pass, it waits for more data; JM_LIVE_HEADER = the sequence header is already in
+	 * this record (parsed in an earlier pass: only the first one counts, mpeg1.c:812-819): none is looked for, every
+	 * picture of the range comes after it.  live_limit > 0: only the first so many picture start codes of the range are
+	 * looked at in this pass, the others are held.  (These two words also keep intra_q | nonintra_q -- 128 contiguous
+	 * bytes -- at a 16-byte aligned offset: k_recon stages them with eight 16-byte loads.) */
+	int32_t live_flags, live_limit;
 	uint8_t intra_q[64];           /* raster order (de-zig-zagged, mpeg1.c:887-904) */
 	uint8_t nonintra_q[64];
 };
 static_assert(offsetof(JmStream, intra_q) % 16 == 0 && offsetof(JmStream, nonintra_q) == offsetof(JmStream, intra_q) + 64 && sizeof(JmStream) % 16 == 0, "JmStream layout");
+
+#define JM_LIVE_HOLD 1
+#define JM_LIVE_HEADER 2
 
 /* One picture start code of a batch. */
 struct JmPic {
@@ -96,6 +107,13 @@ struct JmPic {
 	int32_t fwd;                   /* picture index whose planes are the forward reference, -1 if none */
 	uint32_t end_sc;               /* start-code index that ended the picture (first non-slice code), or the stream's sc_hi */
 	uint32_t pos;                  /* byte position of the picture start code in the ES buffer */
+	uint32_t end_pos;              /* byte position of the start code that ended the picture -- where the reference's cursor rests when
+	                                  decode() returns (mpeg1.c:980-984) --, the end of the stream's range if none did; JM_NONE: the
+	                                  picture is HELD (JmStream::live_flags / live_limit): not looked at in this pass */
+	uint32_t mb_index;             /* the picture's macroblock records are the mb_index-th set of mb_size records (= the picture's own
+	                                  number; live streams: stream * live_limit + the picture's place in the pass's range -- a pass over
+	                                  live streams may SEE far more picture start codes than it decodes, and only those need records) */
+	uint32_t pad_;
 	uint64_t tok_off;              /* first token slot of the picture in the token buffer */
 };
 

@@ -1,0 +1,157 @@
+"""ctypes front-end of the live-stream interface of include/jsmpeg_hip.h (part 5): N streams that go on, every pending
+picture of every stream in one pass of the batch engine per tick.  Host-side plumbing only (tests, bench.py); the Node
+host is jsmpeg_amd/js/live-hip.js over the same C ABI.  Loading fails loudly when the library is missing."""
+import ctypes
+
+import numpy as np
+
+from . import batch as _batch
+
+FLUSH = 1
+
+LIVE_SYMBOLS = ("jsmpeg_hip_live_create", "jsmpeg_hip_live_destroy", "jsmpeg_hip_live_open", "jsmpeg_hip_live_close",
+                "jsmpeg_hip_live_write", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
+                "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_rgba",
+                "jsmpeg_hip_live_frame_hashes", "jsmpeg_hip_live_stream_info", "jsmpeg_hip_live_timings")
+
+
+class LiveConfig(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("max_streams", ctypes.c_uint32),
+                ("max_pictures_per_tick", ctypes.c_uint32), ("store_bytes", ctypes.c_uint32), ("device", ctypes.c_int32)]
+
+
+class LivePicture(ctypes.Structure):
+    _fields_ = [("stream", ctypes.c_uint32), ("type", ctypes.c_int32), ("pts", ctypes.c_double),
+                ("stream_offset", ctypes.c_uint64), ("device_frame", ctypes.c_void_p)]
+
+
+class LiveStreamInfo(ctypes.Structure):
+    _fields_ = [("has_sequence_header", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("frame_rate", ctypes.c_float), ("status", ctypes.c_int32), ("pending_bytes", ctypes.c_uint32),
+                ("bytes_written", ctypes.c_uint64), ("pictures", ctypes.c_uint64), ("evictions", ctypes.c_uint64)]
+
+
+_bound = False
+
+
+def lib():
+    global _bound
+    L = _batch.lib()
+    if not _bound:
+        vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int32
+        L.jsmpeg_hip_live_create.restype = vp
+        L.jsmpeg_hip_live_create.argtypes = [ctypes.POINTER(LiveConfig)]
+        L.jsmpeg_hip_live_destroy.restype = None
+        L.jsmpeg_hip_live_destroy.argtypes = [vp]
+        L.jsmpeg_hip_live_open.restype = ctypes.c_int
+        L.jsmpeg_hip_live_open.argtypes = [vp]
+        L.jsmpeg_hip_live_close.restype = ctypes.c_int
+        L.jsmpeg_hip_live_close.argtypes = [vp, u32]
+        L.jsmpeg_hip_live_write.restype = ctypes.c_int
+        L.jsmpeg_hip_live_write.argtypes = [vp, u32, ctypes.c_double, vp, u32]
+        L.jsmpeg_hip_live_tick.restype = ctypes.c_int
+        L.jsmpeg_hip_live_tick.argtypes = [vp, u32, vp]
+        L.jsmpeg_hip_live_picture_count.restype = u32
+        L.jsmpeg_hip_live_picture_count.argtypes = [vp]
+        L.jsmpeg_hip_live_picture.restype = ctypes.c_int
+        L.jsmpeg_hip_live_picture.argtypes = [vp, u32, ctypes.POINTER(LivePicture)]
+        L.jsmpeg_hip_live_geometry.restype = ctypes.c_int
+        L.jsmpeg_hip_live_geometry.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+        L.jsmpeg_hip_live_read_frame.restype = ctypes.c_int
+        L.jsmpeg_hip_live_read_frame.argtypes = [vp, u32, vp, vp, vp]
+        L.jsmpeg_hip_live_read_rgba.restype = ctypes.c_int
+        L.jsmpeg_hip_live_read_rgba.argtypes = [vp, u32, vp]
+        L.jsmpeg_hip_live_frame_hashes.restype = ctypes.c_int
+        L.jsmpeg_hip_live_frame_hashes.argtypes = [vp, vp]
+        L.jsmpeg_hip_live_stream_info.restype = ctypes.c_int
+        L.jsmpeg_hip_live_stream_info.argtypes = [vp, u32, ctypes.POINTER(LiveStreamInfo)]
+        L.jsmpeg_hip_live_timings.restype = ctypes.c_int
+        L.jsmpeg_hip_live_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        _bound = True
+    return L
+
+
+class Live:
+    """N live streams -> per tick, every pending picture's Y/Cr/Cb planes in HBM."""
+
+    def __init__(self, width, height, max_streams, pictures_per_tick=0, store_bytes=0, device=-1):
+        self.L = lib()
+        cfg = LiveConfig(width, height, max_streams, pictures_per_tick, store_bytes, device)
+        self.width, self.height = width, height
+        self.h = self.L.jsmpeg_hip_live_create(ctypes.byref(cfg))
+        if not self.h:
+            raise RuntimeError("jsmpeg_hip_live_create: " + _batch.last_error())
+        cw, ch, lu, chb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._ok(self.L.jsmpeg_hip_live_geometry(self.h, cw, ch, lu, chb))
+        self.coded_width, self.coded_height, self.luma_bytes, self.chroma_bytes = cw.value, ch.value, lu.value, chb.value
+
+    def _ok(self, rc):
+        if rc < 0:
+            raise RuntimeError(_batch.last_error())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.jsmpeg_hip_live_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def open(self):
+        return self._ok(self.L.jsmpeg_hip_live_open(self.h))
+
+    def close_stream(self, stream):
+        self._ok(self.L.jsmpeg_hip_live_close(self.h, stream))
+
+    def write(self, stream, data, pts=0.0):
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_live_write(self.h, stream, pts, a.ctypes.data, a.size))
+
+    def tick(self, flush=True, stream=None):
+        """one pass over what has been written; returns the pictures decoded (see pictures())"""
+        return self._ok(self.L.jsmpeg_hip_live_tick(self.h, FLUSH if flush else 0, stream))
+
+    @property
+    def picture_count(self):
+        return self.L.jsmpeg_hip_live_picture_count(self.h)
+
+    def pictures(self):
+        out = []
+        for i in range(self.picture_count):
+            p = LivePicture()
+            self._ok(self.L.jsmpeg_hip_live_picture(self.h, i, ctypes.byref(p)))
+            out.append(p)
+        return out
+
+    def read_frame(self, i):
+        y = np.empty(self.luma_bytes, dtype=np.uint8)
+        cr = np.empty(self.chroma_bytes, dtype=np.uint8)
+        cb = np.empty(self.chroma_bytes, dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_live_read_frame(self.h, i, y.ctypes.data, cr.ctypes.data, cb.ctypes.data))
+        return y, cr, cb
+
+    def read_rgba(self, i):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_live_read_rgba(self.h, i, out.ctypes.data))
+        return out
+
+    def frame_hashes(self):
+        n = self.picture_count
+        out = np.zeros(max(1, n), dtype=np.uint64)
+        self._ok(self.L.jsmpeg_hip_live_frame_hashes(self.h, out.ctypes.data))
+        return out[:n]
+
+    def stream_info(self, stream):
+        info = LiveStreamInfo()
+        self._ok(self.L.jsmpeg_hip_live_stream_info(self.h, stream, ctypes.byref(info)))
+        return info
+
+    def timings(self):
+        ms = (ctypes.c_float * 9)()
+        self._ok(self.L.jsmpeg_hip_live_timings(self.h, ms))
+        keys = ("stage_ms", "decode_call_ms", "wait_ms", "book_ms", "total_ms", "index_ms", "host_ms", "parse_ms", "recon_ms")
+        return dict(zip(keys, [float(x) for x in ms]))

@@ -338,4 +338,44 @@ int sim_plan_chains(uint32_t n_pics, uint32_t n_streams, const uint8_t *decoded,
 	return (int)n;
 }
 
+// The index phases (index_tables.h) over ONE stream's bytes with a live stream's flags (JmStream::live_flags / live_limit):
+// per picture start code out_pos / out_end_pos (0xffffffff: held) / out_decoded / out_mb_index, at most `cap`; hdr[0] = valid
+// (-1: a header has begun, hdr[1] = where), hdr[1] = width, hdr[2] = height, hdr[3] = 1 if a header was found in THIS range.
+// `known` non-null: the stream's record from an earlier pass (JM_LIVE_HEADER).  Returns the number of picture start codes.
+int sim_index_live(const uint8_t *es_in, uint32_t n, int width, int height, int live_flags, int live_limit, const void *known, void *record_out,
+                   uint32_t *out_pos, uint32_t *out_end_pos, uint8_t *out_decoded, uint32_t *out_mb_index, int32_t *out_fwd, uint32_t cap, int32_t *hdr) {
+	const uint32_t begin = 16;
+	std::vector<uint8_t> es(begin + n + JM_ES_PAD, 0xff);
+	memcpy(es.data() + begin, es_in, n);
+	const uint32_t total = begin + n;
+	std::vector<uint32_t> sc_pos, pic_sc;
+	std::vector<uint8_t> sc_code;
+	for (uint32_t i = 0; i + 3 < es.size(); i++)
+		if (i + 2 < total && es[i] == 0 && es[i + 1] == 0 && es[i + 2] == 1) {      /* like k_scan: the three bytes inside the data, the code byte whatever follows (the gap's 0xff) */
+			if (es[i + 3] == JM_CODE_PICTURE) pic_sc.push_back((uint32_t)sc_pos.size());
+			sc_pos.push_back(i); sc_code.push_back(es[i + 3]);
+		}
+	const uint32_t n_sc = (uint32_t)sc_pos.size(), n_pics = (uint32_t)pic_sc.size();
+	std::vector<uint32_t> owner(n_sc + 1, JM_NONE);
+	sc_pos.push_back(total); sc_code.push_back(0xB7); pic_sc.push_back(n_sc);
+	JmStream st;
+	memset(&st, 0, sizeof(st));
+	if (known) { memcpy(&st, known, sizeof(st)); live_flags |= JM_LIVE_HEADER; }
+	st.es_begin = begin; st.es_end = total; st.live_flags = live_flags; st.live_limit = live_limit;
+	jm_index_stream(st, es.data(), sc_pos.data(), sc_code.data(), n_sc, pic_sc.data(), n_pics, width, height);
+	std::vector<JmPic> pics(n_pics);
+	for (uint32_t p = st.pic_lo; p < st.pic_hi; p++)
+		jm_index_picture(pics[p], p, 0, st, es.data(), sc_pos.data(), sc_code.data(), pic_sc.data(), owner.data(), 0, 0);
+	jm_index_chain(st, pics.data());
+	for (uint32_t p = 0; p < n_pics && p < cap; p++) {
+		out_pos[p] = pics[p].pos - begin;
+		out_end_pos[p] = pics[p].end_pos == JM_NONE ? JM_NONE : pics[p].end_pos - begin;
+		out_decoded[p] = pics[p].decoded; out_mb_index[p] = pics[p].mb_index; out_fwd[p] = pics[p].fwd;
+	}
+	hdr[0] = st.valid; hdr[1] = st.valid == -1 ? st.width - (int32_t)begin : st.width; hdr[2] = st.height; hdr[3] = st.seq_sc != JM_NONE;
+	if (record_out) memcpy(record_out, &st, sizeof(st));
+	return (int)n_pics;
+}
+int sim_stream_record_bytes(void) { return (int)sizeof(JmStream); }
+
 }  // extern "C"

@@ -1,0 +1,290 @@
+"""LIVE streams (include/jsmpeg_hip.h part 5): streams that persist across calls, every pending picture of every stream in
+one pass of the batch engine per tick -- against the golden fixtures and against the oracle fed THE SAME write() calls
+(reference src/ts.js:205-210 -> decoder.js:36-47 -> buffer.js:64-104 -> mpeg1.c:853-864, 986-994).  Bit-exact.  Needs an MI355X."""
+import glob
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from jsmpeg_amd import cabi, hashing, live as jl, synth
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "frames_*.json")))
+IDS = [os.path.basename(p)[7:-5] for p in FIXTURES]
+
+
+def load_case(path):
+    fx = json.load(open(path))
+    es, offs = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["es_md5"]
+    return fx, es, [int(o) for o in offs]
+
+
+def md5_planes(planes):
+    h = hashlib.md5()
+    for p in planes:
+        h.update(p.tobytes())
+    return h.hexdigest()
+
+
+def picture_writes(es, offs):
+    """the elementary stream as the reference's demuxer hands it to a decoder: one write per picture (ts.js:205-210)"""
+    n = len(offs) - 1
+    return [es[offs[k]:(len(es) if k == n - 1 else offs[k + 1])] for k in range(n)]
+
+
+def drain(lv, got, per_stream=None):
+    """the last tick's pictures: md5 of the planes read back (and the device hash agrees with the host's)"""
+    pics = lv.pictures()
+    dev = lv.frame_hashes()
+    for i, p in enumerate(pics):
+        planes = lv.read_frame(i)
+        assert int(dev[i]) == hashing.frame_hash(*planes)
+        (got if per_stream is None else per_stream.setdefault(p.stream, [])).append(md5_planes(planes))
+    return pics
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_live_picture_by_picture_matches_golden(path, hip_lib):
+    """a picture written, a tick: how ts.js + Player.updateForStreaming drive a decoder -- every P picture predicts from a
+    frame an EARLIER tick left in the stream's ring, unwritten macroblocks show the ring's frame before that"""
+    fx, es, offs = load_case(path)
+    got = []
+    with jl.Live(fx["info"]["width"], fx["info"]["height"], 2, pictures_per_tick=2, store_bytes=max(1 << 16, 2 * len(es))) as lv:
+        s = lv.open()
+        for k, w in enumerate(picture_writes(es, offs)):
+            lv.write(s, w, pts=k / 30.0)
+            lv.tick(flush=True)
+            drain(lv, got)
+        info = lv.stream_info(s)
+        assert info.has_sequence_header and (info.width, info.height) == (fx["info"]["width"], fx["info"]["height"])
+        assert abs(info.frame_rate - fx["info"]["frame_rate"]) < 1e-6
+        assert info.pending_bytes == 0 and info.pictures == fx["n_frames"] and info.evictions == 0
+    assert got == fx["frame_md5"]
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_live_ragged_chunks_match_golden(path, hip_lib):
+    """bytes in arbitrary pieces, ticks that decode only COMPLETE pictures (flags 0), a FLUSH tick at the end: the
+    pictures of the whole stream decoded in one piece, whatever the pieces were -- start codes, picture headers and
+    slices cut anywhere, pieces of a few bytes and pieces of several pictures"""
+    fx, es, offs = load_case(path)
+    if fx["info"]["width"] * fx["info"]["height"] > 1280 * 720:
+        pytest.skip("the small fixtures cover the cuts; the large ones go picture by picture above")
+    rng = random.Random(len(es))
+    mean = max(64, len(es) // (3 * fx["n_frames"]))
+    got, at, ticks = [], 0, 0
+    with jl.Live(fx["info"]["width"], fx["info"]["height"], 1, pictures_per_tick=3, store_bytes=2 * len(es) + 4096) as lv:
+        s = lv.open()
+        while at < len(es):
+            n = min(len(es) - at, rng.choice([1, 2, 3, 5, 17, mean // 2, mean, mean, 2 * mean, 7 * mean]))
+            lv.write(s, es[at:at + n])
+            at += n
+            if rng.random() < 0.7:
+                lv.tick(flush=False)
+                drain(lv, got)
+                ticks += 1
+        for _ in range(fx["n_frames"]):          # (at most three picture start codes per tick)
+            lv.tick(flush=False)
+            drain(lv, got)
+        assert got == fx["frame_md5"][:len(got)] and len(got) >= fx["n_frames"] - 1, (len(got), fx["n_frames"])
+        lv.tick(flush=True)                      # the last picture: nothing ends it but the end of the data
+        drain(lv, got)
+        assert lv.stream_info(s).pending_bytes == 0
+    assert got == fx["frame_md5"] and ticks > 0
+
+
+def test_live_three_pictures_at_a_time(hip_lib):
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_long_gop_p_chain.json"))
+    writes = picture_writes(es, offs)
+    got, counts = [], []
+    with jl.Live(fx["info"]["width"], fx["info"]["height"], 1, pictures_per_tick=3, store_bytes=1 << 20) as lv:
+        s = lv.open()
+        for k in range(0, len(writes), 3):
+            for j, w in enumerate(writes[k:k + 3]):
+                lv.write(s, w, pts=(k + j) / 25.0)
+            counts.append(lv.tick(flush=True))
+            pics = drain(lv, got)
+            assert [round(p.pts * 25) for p in pics] == list(range(k, min(k + 3, len(writes))))   # a picture carries its write's pts
+            assert [p.type for p in pics] == [1 if (k + j) % 40 == 0 else 2 for j in range(len(pics))]
+    assert got == fx["frame_md5"] and counts == [3] * (len(writes) // 3) + ([len(writes) % 3] if len(writes) % 3 else [])
+
+
+def test_live_picture_limit_per_tick(hip_lib):
+    """more pictures buffered than a tick takes: the rest wait, in order, whether the tick flushes or not"""
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_custom_quant_escapes.json"))
+    got, counts = [], []
+    with jl.Live(fx["info"]["width"], fx["info"]["height"], 1, pictures_per_tick=2, store_bytes=2 * len(es)) as lv:
+        s = lv.open()
+        lv.write(s, es)
+        for _ in range(fx["n_frames"]):
+            n = lv.tick(flush=True)
+            if n == 0:
+                break
+            counts.append(n)
+            drain(lv, got)
+    assert got == fx["frame_md5"] and counts == [2] * (fx["n_frames"] // 2) + [1] * (fx["n_frames"] % 2)
+
+
+def oracle_fed(libs, writes_per_tick, store_bytes):
+    """the oracle's decoder (EVICT store, the reference's streaming mode) fed the same writes, `while (decode());` per tick"""
+    out, last = [], None
+    with cabi.Mpeg1Decoder(libs["oracle"], store_bytes, cabi.MODE_EVICT) as dec:
+        for writes in writes_per_tick:
+            for w in writes:
+                dec.write(w)
+            tick = []
+            while dec.decode():
+                # decode() is also true for a picture the reference consumes WITHOUT decoding (B / D pictures, f_code 0:
+                # mpeg1.c:955-967): the planes are the same as before -- not a picture of the live interface, which lists what
+                # was decoded.  (Two decoded pictures in a row with identical planes do not occur in this content.)
+                h = md5_planes(dec.planes())
+                if h != last:
+                    tick.append(h)
+                last = h
+            out.append(tick)
+    return out
+
+
+def test_live_eight_streams_join_and_leave(hip_lib, libs):
+    """8 streams with distinct content in one live batch, fed picture by picture; stream 5 joins at tick 4 (mid-run: the
+    others are in the middle of their GOPs), stream 2 leaves at tick 9 and its id is taken by a NEW stream at tick 11
+    (a fresh decoder: no header, zeroed planes); some ticks bring a stream nothing, some two pictures.  Every picture of
+    every tick == the oracle fed the same writes."""
+    W, H, N = 352, 288, 16
+    def content(seed, **kw):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=N, stream=seed, width=W, height=H, **kw)
+        return picture_writes(es, [int(o) for o in offs])
+    plans = {s: content(100 + s) for s in range(8)}
+    plans[3] = content(103, mv_jitter=1, f_code_max=1, coded_permille=60, ac_max=1, gop=2)          # unwritten last macroblocks (coherent pan)
+    plans[6] = content(106, syntax_quirks=2)                                                         # B / D pictures, f_code 0 between the decoded ones
+    newcomer = content(999, gop=4)
+    join = {s: 0 for s in range(8)}
+    join[5] = 4
+    rng = random.Random(7)
+    # per tick and stream: how many of its pictures arrive (0, 1 or 2)
+    ticks = []
+    given = {s: 0 for s in list(range(8)) + ["new"]}
+    for t in range(3 * N):
+        row = {}
+        for s in range(8):
+            if t < join[s] or (s == 2 and t >= 9):
+                continue
+            k = rng.choice([0, 1, 1, 1, 2])
+            row[s] = plans[s][given[s]:given[s] + k]
+            given[s] += len(row[s])
+        if t >= 11:
+            k = rng.choice([1, 1, 2])
+            row["new"] = newcomer[given["new"]:given["new"] + k]
+            given["new"] += len(row["new"])
+        ticks.append(row)
+    store = 1 << 18
+    want = {s: oracle_fed(libs, [row.get(s, []) for row in ticks], store) for s in list(range(8)) + ["new"]}
+    with jl.Live(W, H, 8, pictures_per_tick=6, store_bytes=store) as lv:      # (the limit counts picture START CODES: stream 6's B / D pictures too)
+        ids = {}
+        for t, row in enumerate(ticks):
+            for s in range(8):
+                if join[s] == t:
+                    ids[s] = lv.open()
+            if t == 9:
+                lv.close_stream(ids.pop(2))
+            if t == 11:
+                ids["new"] = lv.open()
+                assert ids["new"] == 2                      # the id that was given back
+            for s, writes in row.items():
+                for w in writes:
+                    lv.write(ids[s], w, pts=float(t))
+            lv.tick(flush=True)
+            per = {}
+            pics = drain(lv, None, per)
+            assert [p.stream for p in pics] == sorted(p.stream for p in pics)
+            assert all(p.pts == float(t) for p in pics)
+            for s, i in ids.items():
+                assert per.get(i, []) == want[s][t], (t, s)
+        assert sum(len(x) for x in want[3]) > 0 and sum(len(x) for x in want["new"]) > 0
+
+
+def test_live_store_evicts_like_the_reference(hip_lib, libs):
+    """writes that outrun the ticks: a write that does not fit beside the UNDECODED bytes throws those away (buffer.js:37-56,
+    the 'emergency evac') and the decoder goes on with what it has -- a P picture whose reference was lost predicts from
+    the frame before, exactly as the reference does with the same writes"""
+    W, H = 352, 288
+    es, offs = synth.generate_config("cfg1_720p", n_frames=14, stream=11, width=W, height=H)
+    writes = picture_writes(es, [int(o) for o in offs])
+    store = int(max(len(w) for w in writes) * 2.5)
+    # a tick after picture 0, then pictures 1 .. 5 without a tick (the store holds two and a half), a tick, the rest one by one
+    ticks = [[writes[0]], writes[1:6]] + [[w] for w in writes[6:]]
+    want = oracle_fed(libs, ticks, store)
+    got = []
+    with jl.Live(W, H, 1, pictures_per_tick=4, store_bytes=store) as lv:
+        s = lv.open()
+        for ws in ticks:
+            for w in ws:
+                lv.write(s, w)
+            lv.tick(flush=True)
+            tick = []
+            drain(lv, tick)
+            got.append(tick)
+        assert lv.stream_info(s).evictions >= 1
+        with pytest.raises(RuntimeError):
+            lv.write(s, np.zeros(store + 1, dtype=np.uint8))
+    assert got == want and sum(len(t) for t in got) < 14
+
+
+def test_live_stream_of_another_size_is_refused_not_decoded(hip_lib):
+    es, offs = synth.generate_config("cfg1_720p", n_frames=3, width=176, height=144)
+    ok, offs_ok = synth.generate_config("cfg1_720p", n_frames=3, width=352, height=288)
+    with jl.Live(352, 288, 2) as lv:
+        a, b = lv.open(), lv.open()
+        lv.write(a, es)
+        lv.write(b, ok)
+        assert lv.tick(flush=True) == 3
+        assert {p.stream for p in lv.pictures()} == {b}
+        ia = lv.stream_info(a)
+        assert ia.status == 1 and ia.has_sequence_header and (ia.width, ia.height) == (176, 144) and ia.pending_bytes == 0
+        lv.write(a, es)
+        assert lv.tick(flush=True) == 0 and lv.stream_info(a).pending_bytes == 0
+
+
+def test_live_bytes_before_the_first_header_are_skipped(hip_lib, libs):
+    """a stream joined in the middle of a GOP: P pictures arrive before the first sequence header and are consumed
+    undecoded, like the reference's write() does before it has a header (mpeg1.c:812-819)"""
+    W, H = 352, 288
+    es, offs = synth.generate_config("cfg1_720p", n_frames=30, stream=3, width=W, height=H)
+    offs = [int(o) for o in offs]
+    writes = picture_writes(es, offs)[5:]                    # from the sixth picture of the first GOP on
+    want = oracle_fed(libs, [[w] for w in writes], 1 << 18)
+    got = []
+    with jl.Live(W, H, 1, store_bytes=1 << 18) as lv:
+        s = lv.open()
+        for w in writes:
+            lv.write(s, w)
+            lv.tick(flush=True)
+            tick = []
+            drain(lv, tick)
+            got.append(tick)
+    assert got == want and got[0] == [] and sum(len(t) for t in got) == 30 - 12
+
+
+def test_live_rgba_and_device_frames(hip_lib, libs):
+    """the RGBA stage on a live picture; device_frame is where the planes lie"""
+    from oracle import checkers
+    W, H = 352, 288
+    es, offs = synth.generate_config("cfg1_720p", n_frames=4, width=W, height=H)
+    frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
+    with jl.Live(W, H, 1) as lv:
+        s = lv.open()
+        lv.write(s, es)
+        assert lv.tick(flush=True) == 4
+        pics = lv.pictures()
+        assert len({p.device_frame for p in pics}) == 4 and all(p.device_frame for p in pics)
+        for i in (0, 3):
+            assert np.array_equal(lv.read_rgba(i), checkers.oracle_rgba(libs["oracle"], *frames[i], W, H))
+        t = lv.timings()
+        assert t["total_ms"] > 0 and t["parse_ms"] > 0 and t["recon_ms"] > 0
