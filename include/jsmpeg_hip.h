@@ -482,6 +482,10 @@ int jsmpeg_hip_live_close(jsmpeg_hip_live_t *l, uint32_t stream);
  * reference's "emergency evac") and the write starts an empty store.  n > store_bytes is refused (the reference's typed
  * array throws a RangeError there).  Returns 0 or < 0. */
 int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n);
+/* The same write with its bytes in several pieces -- the `buffers` array of write(pts, buffers) (ts.js hands a PES over
+ * as the payloads of its TS packets): ONE write of the total length (the store's rule looks at the total, buffer.js:66-92). */
+int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths,
+                            uint32_t n_buffers);
 /* The tick: ONE pass of the batch engine over what has been written.  Per stream, in stream order, it decodes
  *   JSMPEG_HIP_LIVE_FLUSH: every buffered picture, the last one included -- it ends where the data ends, exactly like the
  *       reference's decode() (mpeg1.c:853-864, 947-995), so per stream this is `while (decoder.decode());` after the same

@@ -117,7 +117,7 @@ def check_kernel_resources():
 
 def build_addon(force=False):
     """N-API addon: thin glue from the Node host side to the C ABI."""
-    src = [os.path.join(CSRC, "napi_addon.c")]
+    src = [os.path.join(CSRC, "napi_addon.c")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("napi_") and f.endswith(".c") and f != "napi_addon.c")
     if not os.path.exists(src[0]) or not os.path.isdir(NODE_INCLUDE):
         return None
     build_hip(force)

@@ -1337,14 +1337,16 @@ static void live_compact_stage(jsmpeg_hip_live_t *l) {
 	l->stage_used = at;
 }
 
-/* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict */
-extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n) {
+/* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict: ONE write of the buffers' total length */
+extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths, uint32_t n_buffers) {
 	g_err[0] = 0;
 	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("write: stream %u is not open", stream);
-	if (n == 0) return 0;
-	if (!bytes) return fail("write: null buffer");
+	uint64_t total = 0;
+	for (uint32_t i = 0; i < n_buffers; i++) { if (lengths[i] && !buffers[i]) return fail("write: null buffer"); total += lengths[i]; }
+	if (total == 0) return 0;
+	if (total > l->cfg.store_bytes) return fail("write of %llu bytes > the stream's store of %u bytes (the reference's store throws a RangeError there)", (unsigned long long)total, l->cfg.store_bytes);
+	const uint32_t n = (uint32_t)total;
 	LiveStream &S = l->streams[stream];
-	if (n > l->cfg.store_bytes) return fail("write of %u bytes > the stream's store of %u bytes (the reference's store throws a RangeError there)", n, l->cfg.store_bytes);
 	if ((uint64_t)S.tail_bytes + S.new_bytes + n > l->cfg.store_bytes) {
 		/* buffer.js:37-56: decoded bytes never stand in the way here (a tick drops them), so a write that does not fit finds
 		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store */
@@ -1361,13 +1363,17 @@ extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, doub
 		off = l->stage_used + ((residue - l->stage_used) & 15u);
 		if ((uint64_t)off + n > l->stage_cap) return fail("write: the staging buffer is full (%u bytes written since the last tick): call jsmpeg_hip_live_tick", l->stage_used);
 	}
-	memcpy(l->h_stage + off, bytes, n);
+	for (uint32_t i = 0, at = off; i < n_buffers; at += lengths[i], i++) if (lengths[i]) memcpy(l->h_stage + at, buffers[i], lengths[i]);
 	if (!l->segs.empty() && l->segs.back().stream == stream && l->segs.back().bytes && l->segs.back().stage_off + l->segs.back().bytes == off) l->segs.back().bytes += n;
 	else l->segs.push_back(LiveSeg{ stream, off, n });
 	l->stage_used = off + n;
 	S.stamps.push_back(LiveStamp{ S.written, pts });
 	S.written += n; S.new_bytes += n;
 	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n) {
+	return jsmpeg_hip_live_write_v(l, stream, pts, &bytes, &n, 1);
 }
 
 /* Inside jsmpeg_hip_batch_decode, once the pass's picture table is on the host: picture p of the pass is written to the

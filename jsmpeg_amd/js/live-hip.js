@@ -1,0 +1,163 @@
+// JSMpeg.HIPLive -- N LIVE streams on one GPU: the server-side counterpart of jsmpeg's main use, MPEG-TS over a
+// WebSocket into a Player in streaming mode (reference src/player.js:222-228 updateForStreaming: "decode everything we
+// have buffered", every tick; src/ts.js:205-210 hands the decoder one PES = one picture per write(pts, buffers);
+// src/buffer.js:64-104 the EVICT store; src/wasm/mpeg1.c:986-994 the two plane sets that carry from picture to picture).
+// A stream object has the decoder's surface -- write(pts, buffers), connect(destination), destroy(), frameRate,
+// hasSequenceHeader, currentTime -- so the reference's own demuxer feeds it unchanged:
+//
+//     const { HIPLive } = require('./live-hip.js').install(JSMpeg);
+//     const live = new HIPLive({ width: 1920, height: 1080, maxStreams: 64 });     // throws without a GPU
+//     const video = live.open({ onVideoDecode });                                   // a stream joins (any time)
+//     const demuxer = new JSMpeg.Demuxer.TS({});  demuxer.connect(JSMpeg.Demuxer.TS.STREAM.VIDEO_1, video);
+//     socket.on('message', (data) => demuxer.write(data));                          // untouched ts.js in front
+//     setInterval(() => live.tick({ onFrame(frame) { ... } }), 1000 / 30);          // ONE pass of the GPU for all streams
+//
+// What a tick does per stream is what `while (video.decode());` does in the reference (flush: true, the default: writes
+// carry whole pictures, as ts.js's do) -- or, with {flush: false}, it takes only the pictures a following start code has
+// completed (bytes that arrive in arbitrary pieces).  All streams' pending pictures are decoded in ONE pass of the batch
+// engine (include/jsmpeg_hip.h part 5); a stream's undecoded bytes, its first sequence header and its last two frames
+// stay on the GPU between ticks.  Thin JS over jsmpeg_amd/csrc/napi_live.c; no JS / CPU decode exists behind it.
+'use strict';
+const path = require('path');
+
+function install(JSMpeg, options) {
+  JSMpeg = JSMpeg || {};
+  const injected = options && options.binding;
+  let native = injected || null;
+  const binding = () => native || (native = require(path.join(__dirname, 'jsmpeg_hip.node')));
+  const now = JSMpeg.Now || (() => Number(process.hrtime.bigint()) / 1e9);
+
+  function HIPLive(opts) {
+    opts = opts || {};
+    if (!(opts.width > 0 && opts.height > 0)) throw new Error('HIPLive: width and height of the streams are required');
+    this.width = opts.width | 0;
+    this.height = opts.height | 0;
+    this.maxStreams = opts.maxStreams || 64;
+    this.picturesPerTick = opts.picturesPerTick || 4;             // picture start codes a tick takes per stream; the rest wait
+    this.videoBufferSize = opts.videoBufferSize || 512 * 1024;    // per stream, the reference's option (mpeg1-wasm.js:9)
+    this.device = opts.device === undefined || opts.device === null ? -1 : (opts.device | 0);
+    this.native = binding();
+    this.handle = this.native.liveCreate(this.width, this.height, this.maxStreams, this.picturesPerTick, this.videoBufferSize, this.device);
+    const g = this.native.liveGeometry(this.handle);
+    this.codedWidth = g.codedWidth; this.codedHeight = g.codedHeight;
+    this.lumaBytes = g.lumaBytes; this.chromaBytes = g.chromaBytes;
+    this.codedSize = g.lumaBytes;
+    this.streams = new Map();                                      // id -> HIPLiveStream
+    this.pictures = 0;
+    this.planes = null; this.rgba = null;
+  }
+
+  HIPLive.prototype.destroy = function () {
+    if (!this.handle) return;
+    for (const s of this.streams.values()) s.live = null;
+    this.streams.clear();
+    this.native.liveDestroy(this.handle);
+    this.handle = null;
+  };
+
+  // A stream joins.  options: onVideoDecode(stream, elapsed) like the decoder classes'.
+  HIPLive.prototype.open = function (options) {
+    const id = this.native.liveOpen(this.handle);                 // throws when maxStreams are open
+    const s = new HIPLiveStream(this, id, options || {});
+    this.streams.set(id, s);
+    return s;
+  };
+
+  // ONE pass over everything written since the last tick.  opts.flush (default true), opts.rgba (hand out Canvas2D-identical
+  // RGBA instead of planes), opts.onFrame(frame): frame.stream (the HIPLiveStream), .pts, .type, .width, .height,
+  // .y / .cr / .cb or .rgba (valid during the call).  A stream with a connected destination gets resize() / render() exactly
+  // like a decoder's destination.  Returns the number of pictures decoded.
+  HIPLive.prototype.tick = function (opts) {
+    opts = opts || {};
+    const t0 = now();
+    const n = this.native.liveTick(this.handle, opts.flush !== false);
+    this.pictures = n;
+    const elapsed = now() - t0;
+    for (const s of this.streams.values()) if (!s.hasSequenceHeader && s.bytesWritten) s.pollSequenceHeader();
+    if (!n) return 0;
+    const wantPixels = opts.onFrame || Array.from(this.streams.values()).some((s) => s.destination);
+    for (let i = 0; i < n; i++) {
+      const p = this.native.livePicture(this.handle, i);
+      const s = this.streams.get(p.stream);
+      if (!s) continue;
+      const frame = { stream: s, index: s.pictures, pts: p.pts, type: p.type, streamOffset: p.streamOffset, width: this.width, height: this.height,
+                      codedWidth: this.codedWidth, codedHeight: this.codedHeight };
+      if (wantPixels && (opts.onFrame || s.destination)) {
+        if (opts.rgba && !s.destination) {
+          if (!this.rgba) this.rgba = new Uint8ClampedArray(this.width * this.height * 4);
+          this.native.liveReadRGBA(this.handle, i, this.rgba, this.rgba.length);
+          frame.rgba = this.rgba;
+        } else {
+          if (!this.planes) this.planes = { y: new Uint8Array(this.lumaBytes), cr: new Uint8Array(this.chromaBytes), cb: new Uint8Array(this.chromaBytes) };
+          this.native.liveReadPlanes(this.handle, i, this.planes.y, this.planes.cr, this.planes.cb);
+          frame.y = this.planes.y; frame.cr = this.planes.cr; frame.cb = this.planes.cb;
+          // (y, cr, cb, isClampedArray): the decoder classes' render call (reference src/mpeg1-wasm.js:109-119)
+          if (s.destination) s.destination.render(frame.y, frame.cr, frame.cb, false);
+        }
+      }
+      s.pictures++;
+      s.decodedTime += 1 / s.frameRate;                          // decoder.js:73-104 in streaming mode: no time stamps are collected
+      if (s.onDecodeCallback) s.onDecodeCallback(s, elapsed / n);
+      if (opts.onFrame) opts.onFrame(frame);
+    }
+    return n;
+  };
+
+  HIPLive.prototype.frameHashes = function () {                    // 16 hex digits per picture of the last tick (device-computed)
+    const raw = new Uint8Array(new ArrayBuffer(8 * Math.max(1, this.pictures)));
+    this.native.liveFrameHashes(this.handle, raw);
+    const out = new Array(this.pictures);
+    for (let p = 0; p < this.pictures; p++) {
+      let h = '';
+      for (let k = 7; k >= 0; k--) h += (raw[8 * p + k] + 256).toString(16).slice(1);
+      out[p] = h;
+    }
+    return out;
+  };
+  HIPLive.prototype.picture = function (i) { return this.native.livePicture(this.handle, i); };
+  HIPLive.prototype.timings = function () { return this.native.liveTimings(this.handle); };
+
+  // ---- one stream: the decoder's surface (reference src/decoder.js:3-106, src/mpeg1-wasm.js:3-130) ----
+  function HIPLiveStream(live, id, opts) {
+    this.live = live; this.id = id;
+    this.destination = null;
+    this.canPlay = false;
+    this.onDecodeCallback = opts.onVideoDecode;
+    this.hasSequenceHeader = false;
+    this.frameRate = 30; this.width = 0; this.height = 0; this.codedSize = 0;
+    this.bytesWritten = 0; this.pictures = 0;
+    this.startTime = 0; this.decodedTime = 0;
+    Object.defineProperty(this, 'currentTime', { get: () => this.decodedTime });
+  }
+  HIPLiveStream.prototype.connect = function (destination) { this.destination = destination; };
+  // decoder.js:36-47 + mpeg1-wasm.js:72-78: the buffers are copied during the call
+  HIPLiveStream.prototype.write = function (pts, buffers) {
+    if (!this.live) throw new Error('HIPLiveStream: the stream is closed');
+    this.bytesWritten += this.live.native.liveWrite(this.live.handle, this.id, pts, buffers);
+    this.canPlay = true;
+  };
+  // mpeg1-wasm.js:80-93 loadSequenceHeader (the header is parsed by the tick that first sees it, on the device)
+  HIPLiveStream.prototype.pollSequenceHeader = function () {
+    const info = this.info();
+    if (!info.hasSequenceHeader) return;
+    this.hasSequenceHeader = true;
+    this.frameRate = info.frameRate; this.width = info.width; this.height = info.height;
+    this.codedSize = this.live.codedSize;
+    if (info.status) throw new Error('HIPLive: stream ' + this.id + ' is ' + info.width + ' x ' + info.height + ', the batch decodes ' + this.live.width + ' x ' + this.live.height);
+    if (this.destination) this.destination.resize(this.width, this.height);
+  };
+  HIPLiveStream.prototype.info = function () { return this.live.native.liveStreamInfo(this.live.handle, this.id); };
+  HIPLiveStream.prototype.decode = function () { return false; };   // pictures come out of HIPLive.tick(), all streams at once
+  HIPLiveStream.prototype.seek = function () {};                    // streaming decoders do not seek (decoder.js:49-52)
+  HIPLiveStream.prototype.destroy = function () {
+    if (!this.live) return;
+    this.live.native.liveClose(this.live.handle, this.id);
+    this.live.streams.delete(this.id);
+    this.live = null;
+  };
+
+  JSMpeg.HIPLive = HIPLive;
+  return { HIPLive, HIPLiveStream, JSMpeg };
+}
+
+module.exports = { install };

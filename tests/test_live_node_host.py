@@ -1,0 +1,115 @@
+"""The Node.js host of the LIVE-stream interface: jsmpeg_amd/js/live-hip.js (JSMpeg.HIPLive) over napi_live.c.
+CPU: the class logic over an injected binding, the addon's exports, loud failure without a GPU.  GPU: TS files through a
+demuxer per stream (the reference's own Demuxer.TS from its shipped bundle where that is there) into live streams, a tick
+per round of writes, every picture against the oracle."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+from jsmpeg_amd import build, cabi, synth
+
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
+
+
+def test_addon_exports_the_live_functions():
+    addon = build.build_addon()
+    out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
+    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveTick", "livePicture", "liveReadPlanes", "liveReadRGBA",
+            "liveFrameHashes", "liveStreamInfo", "liveGeometry", "liveTimings"} <= set(json.loads(out))
+
+
+def test_live_class_fails_loudly_without_gpu():
+    from conftest import have_gpu
+    if have_gpu():
+        pytest.skip("a GPU is present")
+    build.build_addon()
+    script = ("const {install}=require(%r);const {HIPLive}=install();"
+              "try{new HIPLive({width:320,height:240});console.log('NO THROW')}catch(e){console.log('THROWS:'+e.message)}"
+              % os.path.join(ROOT, "jsmpeg_amd", "js", "live-hip.js"))
+    out = subprocess.check_output([NODE, "-e", script]).decode()
+    assert out.startswith("THROWS:") and "no CPU fallback" in out
+
+
+def test_live_class_logic_over_an_injected_binding():
+    """a stream has the decoder's surface (reference src/decoder.js:3-106, src/mpeg1-wasm.js:72-128): write copies through as
+    ONE write, the header is polled after the tick that saw it -> destination.resize once, render(y, cr, cb, false) per
+    picture, onVideoDecode, decodedTime += 1 / frameRate; tick() passes flush on, hands out frames, RGBA on request"""
+    out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "live_class_fake.js")]))
+    assert out["calls"] == [["liveCreate", 30, 15, 2, 3, 4096, 1], ["liveOpen"], ["liveOpen"], ["liveWrite", 0, 0.5, 140], ["liveTick", True],
+                            ["liveTick", True], ["liveWrite", 1, 7, 8], ["liveTick", False], ["liveReadRGBA", 1, 30 * 15 * 4], ["liveClose", 1], ["liveDestroy"]]
+    assert out["log"] == [["tick", 0], ["resize", 30, 15], ["render", 10, 1, 2, False, 512, 128], ["decoded", 0], ["frame", 0, 0, 0.5, 1, True], ["tick", 1],
+                          ["render", 20, 1, 2, False, 512, 128], ["decoded", 0], ["frame", 0, 1, 0.6, 2, None, 20], ["frame", 1, 0, 7, 1, 99, None], ["tick", 2],
+                          ["hash", "01000000000000ef"], ["state", True, 25, 30, 15, 512, 0.08, True, 140, True, 0.04], ["decode", False], ["closedThrows", True, 1]]
+
+
+def _ts_files(n, frames, w, h):
+    paths, want, es_all = [], [], []
+    oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
+    for s in range(n):
+        kw = dict(mv_jitter=1, f_code_max=1, coded_permille=60, ac_max=1, gop=2) if s == 1 else {}     # stream 1: unwritten last macroblocks
+        es, offs = synth.generate_config("cfg1_720p", n_frames=frames, stream=40 + s, width=w, height=h, **kw)
+        f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+        f.write(synth.mux_ts(es, offs).tobytes())
+        f.close()
+        paths.append(f.name)
+        want.append(cabi.decode_stream(oracle, es)[0])            # checker: md5(Y|Cr|Cb) per picture
+        es_all.append(es)
+    return paths, want, es_all
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("demuxer", ["ts-demux.js", "reference bundle"])
+def test_node_live_streams_on_gpu(demuxer, hip_lib):
+    """4 TS files -> a demuxer per stream -> JSMpeg.HIPLive over the real addon, fed in ragged pieces round-robin, a tick per
+    round; the last stream joins 5 rounds late.  Every rendered picture of every stream == the oracle's; pts as the demuxer
+    reported them; one resize per stream."""
+    build.build_addon()
+    extra = []
+    if demuxer == "reference bundle":
+        if not os.path.exists(build.JS_REF):
+            pytest.skip("oracle/_ref/jsmpeg_ref.min.js not there (made from /root/reference by oracle/Makefile)")
+        extra = ["--bundle", build.JS_REF]
+    paths, want, _ = _ts_files(4, 14, 352, 288)
+    try:
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_ts.js"), "352", "288"] + extra +
+                                                 ["--late", "5", "--packets", "24"] + paths, timeout=300))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["pictures"] == 4 * 14 == out["hashesSeen"]
+    for s in range(4):
+        st = out["streams"][s]
+        assert st["planes"] == want[s], s
+        assert st["sizes"] == [[352, 288]] and st["callbacks"] == 14
+        assert len(st["pts"]) == 14 and abs(st["pts"][0] - 0.1) < 1e-6 and abs(st["pts"][5] - st["pts"][4] - 1 / 30) < 1e-4
+        assert st["types"] == [1 if k % (2 if s == 1 else 12) == 0 else 2 for k in range(14)]
+        assert abs(out["decodedTimes"][s] - 14 / 30) < 1e-5 and abs(out["frameRates"][s] - 30) < 1e-6
+    assert out["pending"] == [0] * 4 and out["evictions"] == [0] * 4 and out["closedStreamThrows"]
+    assert out["rounds"] > 14                                   # (pieces of ~24 packets: pictures arrive over several rounds)
+
+
+@pytest.mark.gpu
+def test_node_live_rgba_frames(hip_lib):
+    """tick({rgba: true}): frames as Canvas2D-identical RGBA, converted on the device"""
+    import numpy as np
+    from oracle import checkers
+    build.build_addon()
+    paths, _, es_all = _ts_files(2, 5, 352, 288)
+    oracle = build.LIB_ORACLE
+    want = []
+    for es in es_all:
+        frames, _, _ = cabi.decode_stream(oracle, es, keep="planes")
+        want.append([hashlib.md5(np.ascontiguousarray(checkers.oracle_rgba(oracle, *f, 352, 288)).tobytes()).hexdigest() for f in frames])
+    try:
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_ts.js"), "352", "288", "--rgba"] + paths, timeout=300))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert [st["rgba"] for st in out["streams"]] == want
