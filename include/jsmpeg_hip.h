@@ -200,6 +200,10 @@ int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b);
 
 uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b);
 int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t picture, jsmpeg_hip_picture_info_t *out);
+/* What stream `stream`'s FIRST sequence header said, as the last decode read it (mpeg1.c:872-944; any pointer may be NULL):
+ * display size and mpeg1_decoder_get_frame_rate's value (the decoder's clock advances by 1 / frame_rate per picture,
+ * mpeg1.js:57).  Returns 1, 0 if the stream had no sequence header, or < 0. */
+int jsmpeg_hip_batch_stream_info(jsmpeg_hip_batch_t *b, uint32_t stream, int32_t *width, int32_t *height, float *frame_rate);
 /* Geometry of a frame in the pool: Y at 0, Cr at luma_bytes, Cb at
  * luma_bytes + chroma_bytes; frame p at pool + p * frame_stride. */
 int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *coded_width, int32_t *coded_height,

@@ -26,7 +26,7 @@ BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_
                  "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_recon_info", "jsmpeg_hip_batch_link_streams", "jsmpeg_hip_batch_seed_stream", "jsmpeg_hip_batch_uncovered", "jsmpeg_hip_batch_render_rgba",
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
-                 "jsmpeg_hip_batch_read_es",
+                 "jsmpeg_hip_batch_read_es", "jsmpeg_hip_batch_stream_info",
                  "jsmpeg_hip_decoder_render_rgba", "jsmpeg_hip_last_error",
                  "jsmpeg_hip_device_count", "jsmpeg_hip_decoder_get_device_frame", "jsmpeg_hip_decoder_ahead_stats")
 
@@ -291,6 +291,15 @@ class Batch:
         fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         self._ok(fn(self.h, c))
         return dict(launches=c[0], group=c[1], waits=c[2], status=c[3])
+
+    def stream_info(self, stream):
+        """(has a sequence header, width, height, frame rate) of the stream's first sequence header as the last decode read it"""
+        fn = self.L.jsmpeg_hip_batch_stream_info
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float)]
+        w, h, r = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float()
+        has = self._ok(fn(self.h, stream, w, h, r))
+        return bool(has), w.value, h.value, r.value
 
     @property
     def frame_pool_ptr(self):

@@ -974,6 +974,21 @@ extern "C" int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t pic
 	return 0;
 }
 
+extern "C" int jsmpeg_hip_batch_stream_info(jsmpeg_hip_batch_t *b, uint32_t stream, int32_t *width, int32_t *height, float *frame_rate) {
+	g_err[0] = 0;
+	if (!b || stream >= b->n_streams) return fail("bad stream index");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	JmStream s;
+	HIP_TRY(hipMemcpy(&s, b->d_streams + stream, sizeof(s), hipMemcpyDeviceToHost));
+	static const float rates[16] = MPEG1_PICTURE_RATE_INIT;
+	const bool has = s.seq_sc != JM_NONE || (s.live_flags & JM_LIVE_HEADER);
+	if (width) *width = has ? s.width : 0;
+	if (height) *height = has ? s.height : 0;
+	if (frame_rate) *frame_rate = has ? rates[s.rate_code & 15] : 0.f;
+	return has ? 1 : 0;
+}
+
 extern "C" int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *cw, int32_t *ch, uint32_t *luma,
                                          uint32_t *chroma, uint64_t *stride) {
 	if (!b) return fail("null batch");

@@ -34,6 +34,7 @@
  *   batchReadPlanes(handle, p, y, cr, cb)   (Uint8Arrays of coded size) jsmpeg_hip_batch_read_frame
  *   batchReadRGBA(handle, p, Uint8ClampedArray)                      jsmpeg_hip_batch_read_rgba
  *   batchGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
+ *   batchStreamInfo(handle, stream) -> {hasSequenceHeader, width, height, frameRate}   jsmpeg_hip_batch_stream_info
  *   batchTimings(handle) -> {indexMs, hostMs, parseMs, reconMs, totalMs}
  *   batchFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures    jsmpeg_hip_batch_frame_hashes (device-side 64-bit plane hashes)
  *
@@ -570,6 +571,24 @@ static napi_value fn_batch_geometry(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* batchStreamInfo(handle, stream) -> {hasSequenceHeader, width, height, frameRate}: what the stream's first sequence header said */
+static napi_value fn_batch_stream_info(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t s = 0;
+	if (!b) return NULL;
+	NAPI_OK(napi_get_value_uint32(env, argv[1], &s));
+	int32_t w = 0, h = 0; float rate = 0;
+	const int rc = jsmpeg_hip_batch_stream_info(b, s, &w, &h, &rate);
+	if (rc < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_object(env, &out));
+	if (!set_u32(env, out, "hasSequenceHeader", rc) || !set_u32(env, out, "width", w) || !set_u32(env, out, "height", h) ||
+	    !set_u32(env, out, "frameRate", rate)) { napi_throw_error(env, NULL, "jsmpeg_hip: cannot build the stream info"); return NULL; }
+	return out;
+}
+
 static napi_value fn_batch_timings(napi_env env, napi_callback_info info) {
 	size_t argc = 1;
 	napi_value argv[1], out;
@@ -933,7 +952,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
 		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },
-		{ "batchGeometry", fn_batch_geometry }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
+		{ "batchGeometry", fn_batch_geometry }, { "batchStreamInfo", fn_batch_stream_info }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },
 		{ "mp2GetIndex", fn_mp2_get_index }, { "mp2SetIndex", fn_mp2_set_index }, { "mp2GetSampleRate", fn_mp2_get_sample_rate },
 		{ "mp2Decode", fn_mp2_decode }, { "mp2GetChannels", fn_mp2_get_channels },

@@ -164,9 +164,12 @@ function install(JSMpeg, options) {
     const planes = opts.rgba ? null : this.readPlanes(0, null);
     let n = 0;
     for (const [stream, list] of Array.from(perStream.entries()).sort((a, b) => a[0] - b[0])) {
+      // without time stamps (elementary streams) the clock is the decoder's own: 1 / frameRate of the stream's sequence header
+      // per picture (reference src/mpeg1.js:57, decoder.js:73-104) -- the rate the index kernel read, not an assumed one
+      const rate = this.writes && this.writes[stream] ? 0 : this.native.batchStreamInfo(this.handle, stream).frameRate;
       list.forEach((p, index) => {
         const w = this.writes && this.writes[stream] && this.writes[stream][index];
-        const frame = { stream, index, picture: p, pts: w ? w.pts : index / 30, width: this.width, height: this.height,
+        const frame = { stream, index, picture: p, pts: w ? w.pts : index / (rate || 30), width: this.width, height: this.height,
                         codedWidth: this.codedWidth, codedHeight: this.codedHeight };
         if (rgba) frame.rgba = this.readRGBA(p, rgba);
         else { this.readPlanes(p, planes); frame.y = planes.y; frame.cr = planes.cr; frame.cb = planes.cb; }
@@ -189,8 +192,106 @@ function install(JSMpeg, options) {
     return opts.onFrame ? this.forEachFrame(opts, opts.onFrame) : this.pictures;
   };
 
+  // ---- streams of SEVERAL picture sizes behind one call ----
+  // A batch decodes one geometry (include/jsmpeg_hip.h: jsmpeg_hip_batch_config_t).  The router keeps one HIPBatch per
+  // (width, height) it meets in the streams' sequence headers and hands every buffer to the batch of its size:
+  //     const router = new HIPBatchRouter({ maxPicturesPerStream: 120, maxBytesPerStream: 8e6 });
+  //     router.decodeTS(tsBuffers, { onFrame(frame) { /* frame.stream = index into tsBuffers, frame.width / .height of ITS stream */ } });
+  // A buffer whose header cannot be found (no sequence header in its first packets) is reported in `skipped`, not guessed at.
+  function HIPBatchRouter(opts) {
+    this.opts = opts || {};
+    this.batches = new Map();          // "WxH" -> HIPBatch
+    this.skipped = [];
+  }
+  // The (width, height) of a stream's FIRST sequence header -- 00 00 01 B3, then 12 + 12 bits (mpeg1.c:872-880) -- read from
+  // the first bytes of an elementary stream ...
+  HIPBatchRouter.probeES = function (es, limit) {
+    const n = Math.min(es.length - 6, limit || es.length);
+    for (let i = 0; i < n; i++) {
+      if (es[i] === 0 && es[i + 1] === 0 && es[i + 2] === 1 && es[i + 3] === 0xB3)
+        return { width: (es[i + 4] << 4) | (es[i + 5] >> 4), height: ((es[i + 5] & 15) << 8) | es[i + 6] };
+    }
+    return null;
+  };
+  // ... or of an MPEG-TS buffer: the payload bytes of the first packets that carry PES stream `streamId` (ts.js:43-147:
+  // sync byte every 188 bytes, payload_unit_start + 00 00 01 <id> names the PID, the adaptation field is skipped)
+  HIPBatchRouter.probeTS = function (ts, streamId, maxPackets) {
+    streamId = streamId || 0xE0;
+    let at = 0;
+    while (at + 188 * 5 <= ts.length && !(ts[at] === 0x47 && ts[at + 188] === 0x47 && ts[at + 376] === 0x47)) at++;
+    const payload = new Uint8Array(188 * (maxPackets || 64));
+    let used = 0, pid = -1;
+    for (let k = 0; k < (maxPackets || 64) && at + 188 <= ts.length && ts[at] === 0x47; k++, at += 188) {
+      const start = (ts[at + 1] & 0x40) !== 0, p = ((ts[at + 1] & 0x1f) << 8) | ts[at + 2], afc = (ts[at + 3] >> 4) & 3;
+      if (!(afc & 1)) continue;
+      let o = at + 4;
+      if (afc & 2) o += 1 + ts[at + 4];
+      if (o >= at + 188) continue;
+      if (start && ts[o] === 0 && ts[o + 1] === 0 && ts[o + 2] === 1) {
+        if (ts[o + 3] !== streamId) { if (p === pid) pid = -1; continue; }
+        pid = p;
+        o += 9 + ts[o + 8];            // the PES header: 6 + 3 + PES_header_data_length
+      }
+      if (p !== pid || o >= at + 188) continue;
+      payload.set(ts.subarray(o, at + 188), used);
+      used += at + 188 - o;
+      const hit = HIPBatchRouter.probeES(payload.subarray(0, used));
+      if (hit) return hit;
+    }
+    return null;
+  };
+  HIPBatchRouter.prototype.batchFor = function (width, height, streams) {
+    const key = width + 'x' + height;
+    let b = this.batches.get(key);
+    if (b && b.maxStreams < streams) { b.destroy(); b = null; }
+    if (!b) {
+      const o = this.opts, n = Math.max(streams, o.minStreams || 1);
+      b = new HIPBatch({ width, height, maxStreams: n, maxPictures: n * (o.maxPicturesPerStream || 64),
+                         maxBytes: n * (o.maxBytesPerStream || 16 * 1024 * 1024), device: o.device, audio: o.audio });
+      this.batches.set(key, b);
+    }
+    return b;
+  };
+  // decodeTS / decode: like HIPBatch's, for buffers of any mix of sizes.  Returns the number of frames handed out (or pictures decoded).
+  HIPBatchRouter.prototype.route = function (buffers, probe, run) {
+    const groups = new Map();
+    this.skipped = [];
+    buffers.forEach((buf, i) => {
+      const g = probe(buf);
+      if (!g || !(g.width > 0 && g.height > 0)) { this.skipped.push(i); return; }
+      const key = g.width + 'x' + g.height;
+      if (!groups.has(key)) groups.set(key, { width: g.width, height: g.height, index: [] });
+      groups.get(key).index.push(i);
+    });
+    let n = 0;
+    for (const g of groups.values()) {
+      const batch = this.batchFor(g.width, g.height, g.index.length);
+      n += run(batch, g.index.map((i) => buffers[i]), g.index);
+    }
+    return n;
+  };
+  HIPBatchRouter.prototype.decodeTS = function (buffers, opts) {
+    opts = opts || {};
+    return this.route(buffers, (b) => HIPBatchRouter.probeTS(b, opts.streamId), (batch, bufs, index) => batch.decodeTS(bufs, Object.assign({}, opts, {
+      onFrame: opts.onFrame && ((f) => { f.batchStream = f.stream; f.stream = index[f.stream]; opts.onFrame(f); }),
+      onAudio: opts.onAudio && ((a) => { a.stream = index[a.stream]; opts.onAudio(a); }),
+    })));
+  };
+  HIPBatchRouter.prototype.decode = function (buffers, opts) {      // elementary streams
+    opts = opts || {};
+    return this.route(buffers, (b) => HIPBatchRouter.probeES(b, 1 << 16), (batch, bufs, index) => {
+      batch.upload(bufs).decode();
+      return opts.onFrame ? batch.forEachFrame(opts, (f) => { f.batchStream = f.stream; f.stream = index[f.stream]; opts.onFrame(f); }) : batch.pictures;
+    });
+  };
+  HIPBatchRouter.prototype.destroy = function () {
+    for (const b of this.batches.values()) b.destroy();
+    this.batches.clear();
+  };
+
   JSMpeg.HIPBatch = HIPBatch;
-  return { HIPBatch, JSMpeg };
+  JSMpeg.HIPBatchRouter = HIPBatchRouter;
+  return { HIPBatch, HIPBatchRouter, JSMpeg };
 }
 
 module.exports = { install };

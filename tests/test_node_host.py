@@ -234,3 +234,63 @@ def test_the_references_own_player_drives_the_hip_classes_on_the_gpu(mode, hip_l
     assert out["sameLogAsWasmPlayer"], out
     assert out["samePlanesAsWasm"] and out["samePlanesAsJsDecoder"], out
     assert out["frames"] >= 15 and out["audio"] >= 10 and out["pictures"] >= 15
+
+
+def test_router_probes_the_picture_size_on_the_host():
+    """HIPBatchRouter.probeTS / probeES read the 12 + 12 bits behind the first 00 00 01 B3 (mpeg1.c:872-880) out of the first
+    packets / bytes -- routing, not decoding; no GPU needed"""
+    script = os.path.join(ROOT, "tests", "js", "_probe_tmp.js")
+    out = []
+    for (w, h) in ((176, 144), (1920, 1080), (17, 33)):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=2, width=w, height=h)
+        with tempfile.NamedTemporaryFile(suffix=".ts", delete=False) as f, tempfile.NamedTemporaryFile(suffix=".es", delete=False) as g:
+            f.write(synth.mux_ts(es, offs).tobytes())
+            g.write(es.tobytes())
+        code = ("const {install}=require(%r);const {HIPBatchRouter}=install({}, {binding:{}});const fs=require('fs');"
+                "console.log(JSON.stringify([HIPBatchRouter.probeTS(fs.readFileSync(%r)),HIPBatchRouter.probeES(fs.readFileSync(%r)),HIPBatchRouter.probeES(new Uint8Array(64))]))"
+                % (os.path.join(ROOT, "jsmpeg_amd", "js", "batch-hip.js"), f.name, g.name))
+        try:
+            out.append(json.loads(subprocess.check_output([NODE, "-e", code])))
+        finally:
+            os.unlink(f.name)
+            os.unlink(g.name)
+    assert out == [[{"width": w, "height": h}, {"width": w, "height": h}, None] for (w, h) in ((176, 144), (1920, 1080), (17, 33))]
+
+
+@pytest.mark.gpu
+def test_node_router_mixed_geometries_and_the_decoders_clock(hip_lib):
+    """five TS files of three picture sizes in one decodeTS call: JSMpeg.HIPBatchRouter keeps a HIPBatch per size, every frame
+    comes back under ITS buffer's index with its own size and pts, bit-exact to the oracle; and elementary streams (no time
+    stamps) get the decoder's own clock: 1 / frameRate of the stream's sequence header per picture (mpeg1.js:57) -- here 25 fps"""
+    build.build_addon()
+    sizes = [(352, 288), (176, 144), (352, 288), (320, 192), (176, 144)]
+    paths, want = [], []
+    es25 = None
+    try:
+        for s, (w, h) in enumerate(sizes):
+            es, offs = synth.generate_config("cfg1_720p", n_frames=7, stream=70 + s, width=w, height=h)
+            f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+            f.write(synth.mux_ts(es, offs).tobytes())
+            f.close()
+            paths.append(f.name)
+            want.append(cabi_md5_frames(es))
+            if s == 0:
+                es25 = es.copy()
+                assert bytes(es25[:4]) == b"\x00\x00\x01\xb3"
+                es25[7] = (es25[7] & 0xF0) | 3                   # picture_rate code 3 = 25 fps (mpeg1.c:988-991); only the first header counts
+        g = tempfile.NamedTemporaryFile(suffix=".m1v", delete=False)
+        g.write(es25.tobytes())
+        g.close()
+        paths.append(g.name)
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_router.js"), "--es", g.name] + paths[:-1], timeout=300))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["frames"] == 5 * 7 and out["batches"] == ["176x144", "320x192", "352x288"] and out["skipped"] == []
+    for s, (w, h) in enumerate(sizes):
+        st = out["streams"][s]
+        assert st["planes"] == want[s] and st["sizes"] == [[w, h]] * 7
+        assert abs(st["pts"][0] - 0.1) < 1e-6 and abs(st["pts"][3] - st["pts"][2] - 1 / 30) < 1e-4
+    assert out["esFrames"] == 7 and out["esPlanes"] == want[0]
+    assert out["esPts"] == [round(k / 25.0, 6) for k in range(7)]
+    assert out["skippedLater"] == [0]
