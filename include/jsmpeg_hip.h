@@ -426,6 +426,18 @@ int jsmpeg_hip_dist_gather(jsmpeg_hip_dist_t *d, int32_t dst_rank, const void *s
 int jsmpeg_hip_dist_allgather(jsmpeg_hip_dist_t *d, const void *src_dev, void *dst_dev, uint64_t bytes_per_rank,
                               void *hip_stream);
 
+/* Device buffers for hosts that bring no tensor library (the Node host, jsmpeg_amd/js/shard-hip.js; a Python host hands the
+ * calls above torch tensors' addresses): plain allocations and synchronous copies on the default stream -- the buffers the
+ * exchange steps read and write, nothing of the decode path.  fill: a byte value (0xff for buffers that will hold packed
+ * units: the gaps between units must not complete a start code), < 0: uninitialised.  device: HIP ordinal, -1 = current. */
+void *jsmpeg_hip_device_alloc(uint64_t bytes, int32_t device, int32_t fill);
+void jsmpeg_hip_device_free(void *p);
+int jsmpeg_hip_device_write(void *dst, const void *host, uint64_t n);
+int jsmpeg_hip_device_read(void *host, const void *src, uint64_t n);
+int jsmpeg_hip_device_copy(void *dst, const void *src, uint64_t n);
+int jsmpeg_hip_device_fill(void *dst, int32_t byte, uint64_t n);
+int jsmpeg_hip_device_synchronize(void);
+
 /* ------------------------------------------------------------------ part 5
  * LIVE streams: N streams that GO ON (jsmpeg's main use: MPEG-TS over a WebSocket, reference src/player.js:222-228
  * updateForStreaming -- "decode what has arrived", every tick; src/ts.js:205-210 hands a decoder one PES = one picture

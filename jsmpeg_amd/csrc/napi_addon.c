@@ -38,7 +38,7 @@
  *   batchTimings(handle) -> {indexMs, hostMs, parseMs, reconMs, totalMs}
  *   batchFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures    jsmpeg_hip_batch_frame_hashes (device-side 64-bit plane hashes)
  *
- * Live streams (include/jsmpeg_hip.h part 5): napi_live.c.
+ * Live streams (include/jsmpeg_hip.h part 5): napi_live.c.  Shards across the GPUs of a node (part 4): napi_shard.c.
  *
  * MP2 audio (include/jsmpeg_hip.h part 3; what module.instance.exports._mp2_decoder_* is for the reference's
  * src/mp2-wasm.js:21-104), used by jsmpeg_amd/js/mp2-hip.js:
@@ -940,6 +940,8 @@ static napi_value fn_mp2_batch_read_pcm(napi_env env, napi_callback_info info) {
 
 /* the other files of the addon: napi_live.c (include/jsmpeg_hip.h part 5) */
 int jm_napi_register_live(napi_env env, napi_value exports);
+/* ... and napi_shard.c (part 4: shards across the GPUs of a node) */
+int jm_napi_register_shard(napi_env env, napi_value exports);
 
 static napi_value init(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
@@ -969,7 +971,7 @@ static napi_value init(napi_env env, napi_value exports) {
 			return NULL;
 		}
 	}
-	if (jm_napi_register_live(env, exports) != 0) {
+	if (jm_napi_register_live(env, exports) != 0 || jm_napi_register_shard(env, exports) != 0) {
 		napi_throw_error(env, NULL, "jsmpeg_hip: addon init failed");
 		return NULL;
 	}

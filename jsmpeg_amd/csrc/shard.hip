@@ -243,6 +243,8 @@ static int rccl_load(void) {
 struct jsmpeg_hip_dist_t {
 	int rank, world, device;
 	ncclComm_t comm;
+	uint64_t *check_dev;         /* jsmpeg_hip_dist_check_exchange's buffer: this rank's row + every rank's, made with the communicator so that
+	                                the check itself allocates nothing (a rank that failed before the collective would leave the others waiting in it) */
 };
 
 static_assert(JSMPEG_HIP_DIST_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
@@ -263,18 +265,22 @@ extern "C" jsmpeg_hip_dist_t *jsmpeg_hip_dist_create(int32_t rank, int32_t world
 	if (rccl_load() != 0) return nullptr;
 	if (device >= 0 && hipSetDevice(device) != hipSuccess) { sfail("hipSetDevice(%d) failed", device); return nullptr; }
 	jsmpeg_hip_dist_t *d = new jsmpeg_hip_dist_t();
-	d->rank = rank; d->world = world; d->comm = nullptr;
+	d->rank = rank; d->world = world; d->comm = nullptr; d->check_dev = nullptr;
 	if (hipGetDevice(&d->device) != hipSuccess) { sfail("hipGetDevice failed"); delete d; return nullptr; }
+	if (hipMalloc((void **)&d->check_dev, (2 * (size_t)world + 2 * (size_t)world * world) * sizeof(uint64_t)) != hipSuccess) {
+		(void)hipGetLastError(); sfail("cannot allocate the communicator's check buffer"); delete d; return nullptr;
+	}
 	ncclUniqueId u;
 	memcpy(&u, id, sizeof u);
 	ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, u, rank);
-	if (r != ncclSuccess) { sfail("ncclCommInitRank: %s", g_rccl.GetErrorString(r)); delete d; return nullptr; }
+	if (r != ncclSuccess) { sfail("ncclCommInitRank: %s", g_rccl.GetErrorString(r)); (void)hipFree(d->check_dev); delete d; return nullptr; }
 	return d;
 }
 
 extern "C" void jsmpeg_hip_dist_destroy(jsmpeg_hip_dist_t *d) {
 	if (!d) return;
 	if (d->comm) { hipSetDevice(d->device); hipDeviceSynchronize(); g_rccl.CommDestroy(d->comm); }
+	(void)hipFree(d->check_dev);
 	delete d;
 }
 
@@ -367,24 +373,28 @@ extern "C" int jsmpeg_hip_dist_exchange(jsmpeg_hip_dist_t *d, const void *src_de
  * rank), then the whole matrix on the host -- so every rank reaches the same verdict and all refuse together. */
 extern "C" int jsmpeg_hip_dist_check_exchange(jsmpeg_hip_dist_t *d, const uint64_t *send_bytes, const uint64_t *recv_bytes, void *hip_stream) {
 	jm_clear_error();
-	if (!d || !send_bytes || !recv_bytes) return sfail("bad exchange check arguments");
-	SHIP_TRY(hipSetDevice(d->device));
+	if (!d) return sfail("bad exchange check arguments");
+	/* EVERY rank enters the collective, whatever happened to it on the way there (round 5 advisor): a rank that returned
+	 * early would leave the others waiting in the all-gather for ever -- the hang this check exists to prevent.  A rank
+	 * that cannot contribute its tables (null tables, the device refused it) contributes a row of ~0 instead, and every
+	 * rank reads that as "rank a could not take part": all refuse together. */
 	hipStream_t st = (hipStream_t)hip_stream;
 	const size_t w = (size_t)d->world, row = 2 * w;
-	std::vector<uint64_t> mine(row), all(row * w);
-	for (size_t r = 0; r < w; r++) { mine[r] = send_bytes[r]; mine[w + r] = recv_bytes[r]; }
-	uint64_t *dev = nullptr;
-	SHIP_TRY(hipMalloc((void **)&dev, (row + row * w) * sizeof(uint64_t)));
-	int rc = 0;
-	do {
-		if (hipMemcpyAsync(dev, mine.data(), row * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) { rc = sfail("exchange check: copy in failed"); break; }
-		const ncclResult_t r = g_rccl.AllGather(dev, dev + row, row * sizeof(uint64_t), ncclUint8, d->comm, st);
-		if (r != ncclSuccess) { rc = sfail("ncclAllGather: %s", g_rccl.GetErrorString(r)); break; }
-		if (hipMemcpyAsync(all.data(), dev + row, row * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-		    hipStreamSynchronize(st) != hipSuccess) { rc = sfail("exchange check: copy out failed"); break; }
-	} while (0);
-	(void)hipFree(dev);
-	if (rc) return rc;
+	std::vector<uint64_t> mine(row, ~0ull), all(row * w);
+	bool local_ok = send_bytes && recv_bytes && hipSetDevice(d->device) == hipSuccess;
+	if (local_ok) for (size_t r = 0; r < w; r++) { mine[r] = send_bytes[r]; mine[w + r] = recv_bytes[r]; }
+	uint64_t *dev = d->check_dev;
+	if (hipMemcpyAsync(dev, mine.data(), row * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+		(void)hipGetLastError(); local_ok = false;
+		(void)hipMemsetAsync(dev, 0xff, row * sizeof(uint64_t), st);           /* the poisoned row without the host's help */
+	}
+	const ncclResult_t gr = g_rccl.AllGather(dev, dev + row, row * sizeof(uint64_t), ncclUint8, d->comm, st);
+	if (gr != ncclSuccess) return sfail("ncclAllGather: %s", g_rccl.GetErrorString(gr));
+	if (hipMemcpyAsync(all.data(), dev + row, row * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+	    hipStreamSynchronize(st) != hipSuccess) return sfail("exchange check: copy out failed");
+	for (size_t a = 0; a < w; a++)
+		if (all[a * row] == ~0ull && all[a * row + row - 1] == ~0ull)
+			return sfail("exchange plan refused: rank %zu could not take part in the check%s", a, (int)a == d->rank && !local_ok ? " (this rank: bad tables or the device refused the copy)" : "");
 	char msg[220];
 	size_t used = 0, bad = 0;
 	msg[0] = 0;
@@ -407,5 +417,49 @@ extern "C" int jsmpeg_hip_dist_allgather(jsmpeg_hip_dist_t *d, const void *src_d
 	if (!d || !src_dev || !dst_dev) return sfail("bad all-gather arguments");
 	SHIP_TRY(hipSetDevice(d->device));
 	RCCL_TRY(g_rccl.AllGather(src_dev, dst_dev, bytes_per_rank, ncclUint8, d->comm, (hipStream_t)hip_stream));
+	return 0;
+}
+
+/* ------------------------------------------------------------------ device buffers for hosts without a tensor library
+ * The exchange steps above move bytes between DEVICE buffers.  A Python host has torch tensors for those; the Node host
+ * (jsmpeg_amd/js/shard-hip.js over napi_shard.c) has these: plain allocations and copies, nothing of the decode path. */
+extern "C" void *jsmpeg_hip_device_alloc(uint64_t bytes, int32_t device, int32_t fill) {
+	jm_clear_error();
+	if (device >= 0 && hipSetDevice(device) != hipSuccess) { sfail("hipSetDevice(%d) failed", device); return nullptr; }
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); sfail("cannot allocate %llu bytes of device memory", (unsigned long long)bytes); return nullptr; }
+	if (fill >= 0 && bytes && (hipMemset(p, fill & 255, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+		(void)hipFree(p); sfail("cannot fill the new device buffer"); return nullptr;
+	}
+	return p;
+}
+extern "C" void jsmpeg_hip_device_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int jsmpeg_hip_device_write(void *dst, const void *host, uint64_t n) {
+	jm_clear_error();
+	if (n && (!dst || !host)) return sfail("null buffer");
+	if (n) SHIP_TRY(hipMemcpy(dst, host, n, hipMemcpyHostToDevice));
+	return 0;
+}
+extern "C" int jsmpeg_hip_device_read(void *host, const void *src, uint64_t n) {
+	jm_clear_error();
+	if (n && (!src || !host)) return sfail("null buffer");
+	if (n) SHIP_TRY(hipMemcpy(host, src, n, hipMemcpyDeviceToHost));
+	return 0;
+}
+extern "C" int jsmpeg_hip_device_copy(void *dst, const void *src, uint64_t n) {
+	jm_clear_error();
+	if (n && (!dst || !src)) return sfail("null buffer");
+	if (n) SHIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice));
+	return 0;
+}
+extern "C" int jsmpeg_hip_device_fill(void *dst, int32_t byte, uint64_t n) {
+	jm_clear_error();
+	if (n && !dst) return sfail("null buffer");
+	if (n) { SHIP_TRY(hipMemset(dst, byte & 255, n)); SHIP_TRY(hipDeviceSynchronize()); }
+	return 0;
+}
+extern "C" int jsmpeg_hip_device_synchronize(void) {
+	jm_clear_error();
+	SHIP_TRY(hipDeviceSynchronize());
 	return 0;
 }

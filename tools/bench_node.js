@@ -8,12 +8,39 @@
 // calls, then K timed ones (each returns when the GPU is through: batchDecode = jsmpeg_hip_batch_decode + _sync); then the
 // device-computed plane hashes of every picture against expected.json ({"<stream>": ["<16 hex digits>", ...]}: what
 // bench.py's oracle said).  One JSON line on stdout.
+//
+// N > 1 (--gpus N): north_star's N-GPU program in its own host language -- this process only LAUNCHES: N ranks of
+// tools/shard_rank.js, one process per GPU (jsmpeg_amd/js/shard-hip.js: child_process.fork, the RCCL id over IPC), rank 0
+// cutting the job's streams (--dir holds ALL of them) at their closed GOPs and scattering the units over RCCL every step.
+// --rehearse: the N ranks share the visible device(s) and the bytes travel over the control plane (a TEST mode, never a number).
 'use strict';
 const fs = require('fs');
 const path = require('path');
 
 const opt = {};
-for (let i = 2; i < process.argv.length; i += 2) opt[process.argv[i].replace(/^--/, '')] = process.argv[i + 1];
+for (let i = 2; i < process.argv.length; i += (process.argv[i] === '--rehearse' ? 1 : 2)) opt[process.argv[i].replace(/^--/, '')] = process.argv[i] === '--rehearse' ? '1' : process.argv[i + 1];
+if (parseInt(opt.gpus || '1', 10) > 1 || opt.rehearse) {
+  const world = parseInt(opt.gpus || '1', 10);
+  const { launch } = require(path.join(__dirname, '..', 'jsmpeg_amd', 'js', 'shard-hip.js'));
+  const args = [];
+  for (const k of ['dir', 'streams', 'width', 'height', 'steps', 'warmup', 'hashes', 'plan']) if (opt[k] !== undefined) args.push('--' + k, opt[k]);
+  const visible = parseInt(opt.visible || String(world), 10);
+  launch({ world, script: path.join(__dirname, 'shard_rank.js'), args, rehearse: !!opt.rehearse,
+           devices: Array.from({ length: world }, (_, r) => (opt.rehearse ? r % Math.max(1, visible) : r)) })
+    .then((ranks) => {
+      const bad = ranks.filter((r) => !r || r.error);
+      const r0 = ranks[0] || {};
+      const out = bad.length ? { error: (bad[0] && bad[0].error) || 'a rank reported nothing' } :
+        { value: r0.value, unit: 'frames/s', n_gpus: world, ms_per_step: r0.msPerStep, pictures_per_step: r0.jobPictures, units: r0.units,
+          data_plane: r0.dataPlane, history: r0.history, parity: r0.parity, pictures_differing_from_unsplit_streams: r0.picturesDifferingFromUnsplitStreams,
+          per_rank: ranks.map((r) => ({ rank: r.rank, device: r.device, units: r.myUnits, pictures: r.myPictures, piece_bytes: r.pieceBytes, seconds: r.seconds })),
+          host: 'Node ' + process.version + ', one process per GPU (jsmpeg_amd/js/shard-hip.js over jsmpeg_hip.node)' + (opt.rehearse ? ' -- REHEARSAL, not a measurement' : '') };
+      process.stdout.write(JSON.stringify(out) + '\n');
+      process.exit(out.error || out.pictures_differing_from_unsplit_streams ? 1 : 0);
+    })
+    .catch((e) => { process.stdout.write(JSON.stringify({ error: String(e && e.message || e) }) + '\n'); process.exit(1); });
+  return;
+}
 const n = parseInt(opt.streams, 10), width = parseInt(opt.width, 10), height = parseInt(opt.height, 10);
 const frames = parseInt(opt.frames, 10), steps = parseInt(opt.steps || '10', 10), warmup = parseInt(opt.warmup || '2', 10);
 
