@@ -1101,6 +1101,63 @@ def main():
     if multi:
         totals = [None] * world
         dist.all_gather_object(totals, (es_bytes, stats["macroblocks"], stats["predicted"], deviating, uncovered, phase["total_ms"] / max(1, args.steps)))
+    # N > 1: north_star's N-GPU program in its own host language -- one Node process per GPU (tools/bench_node.js --gpus N ->
+    # jsmpeg_amd/js/shard-hip.js: child_process.fork, the RCCL id over IPC, rank 0 cuts the job's streams at their closed GOPs and
+    # scatters the units over RCCL every step), the same streams, every picture against the oracle's unsplit streams.  The Python
+    # ranks wait meanwhile (their GPUs idle).  A reported extra, never `value`.
+    napi_multi = None
+    if multi and world > 1 and not args.no_napi:
+        import shutil
+        import tempfile
+        td = None
+        try:
+            box = [tempfile.mkdtemp(prefix="jsmpeg_napi_") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            td = box[0]
+            hs = {}
+            for k_, es_ in enumerate(streams):
+                g_ = rank * n_streams + k_
+                es_.tofile(os.path.join(td, "s%d.m1v" % g_))
+                if k_ in check:
+                    hs[str(g_)] = ["%016x" % h for h in oracle_hashes(("stream", k_), es_)]
+            json.dump(hs, open(os.path.join(td, "hashes_%d.json" % rank), "w"))
+            dist.barrier()
+            if rank == 0:
+                merged = {}
+                for r_ in range(world):
+                    merged.update(json.load(open(os.path.join(td, "hashes_%d.json" % r_))))
+                json.dump(merged, open(os.path.join(td, "hashes.json"), "w"))
+                cmd = ["node", os.path.join(ROOT, "tools", "bench_node.js"), "--gpus", str(world), "--dir", td, "--streams", str(world * n_streams),
+                       "--width", str(width), "--height", str(height), "--steps", str(args.steps), "--warmup", str(args.warmup), "--hashes", os.path.join(td, "hashes.json")]
+                if args.rehearse_on_one_gpu:
+                    cmd += ["--rehearse", "--visible", str(visible)]
+                # bounded: an extra must never cost the line (a hang here would keep every Python rank at the barrier below)
+                import signal
+                p_n = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+                try:
+                    so_n, se_n = p_n.communicate(timeout=int(os.environ.get("JSMPEG_BENCH_NAPI_TIMEOUT", "300")))
+                    lines_n = [ln for ln in so_n.decode().splitlines() if ln.startswith("{")]
+                    r_n = json.loads(lines_n[-1]) if lines_n else {"error": "no result (rc %d): %s" % (p_n.returncode, se_n.decode()[-300:])}
+                except subprocess.TimeoutExpired:
+                    os.killpg(p_n.pid, signal.SIGKILL)          # the launcher AND the ranks it forked (its own session: exactly these processes)
+                    p_n.communicate()
+                    r_n = {"error": "tools/bench_node.js --gpus %d did not finish in time" % world}
+                if "value" in r_n and r_n["value"]:
+                    r_n["value"] = round(r_n["value"], 1)
+                    r_n["ms_per_step"] = round(r_n["ms_per_step"], 3)
+                    r_n["note"] = ("tools/bench_node.js --gpus %d: one Node process per GPU (jsmpeg_amd/js/shard-hip.js over jsmpeg_hip.node), the job's %d streams cut at "
+                                   "their closed GOPs by rank 0 and scattered over %s every step (single source), %d warm-up and %d timed steps on the host clock (the "
+                                   "slowest rank's), every picture of %d streams against the oracle's UNSPLIT streams"
+                                   % (world, world * n_streams, "the control plane (REHEARSAL)" if args.rehearse_on_one_gpu else "RCCL", args.warmup, args.steps, len(merged)))
+                napi_multi = r_n
+                log("Node-hosted N-rank run: %s" % (r_n.get("value", r_n.get("error")),))
+            dist.barrier()
+        except Exception as e:
+            log("Node-hosted N-rank run failed: %r" % (e,))
+            napi_multi = {"error": repr(e)[:300]}
+        finally:
+            if rank == 0 and td:
+                shutil.rmtree(td, ignore_errors=True)
     if rank != 0:
         if multi:
             D.close()
@@ -1348,6 +1405,10 @@ def main():
         except Exception as e:
             log("Node-hosted run failed: %r" % (e,))
             line["value_via_napi"] = {"error": repr(e)[:300]}
+    if napi_multi is not None:
+        if napi_multi.get("value"):
+            napi_multi["over_value"] = round(napi_multi["value"] / fps, 4)
+        line["value_via_napi"] = napi_multi
     if world == 1 and not args.no_other_configs:
         try:
             b.close()                       # the headline batch's 24 GB frame pool, before the other shapes take theirs

@@ -86,7 +86,24 @@ def build_hip(force=False):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
               "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
               "-o", LIB_HIP] + defs + src)
+        if not os.environ.get("JSMPEG_HIP_SKIP_ISA_CHECK"):      # (tuning experiments with other -D sets may skip it; the product build never does)
+            try:
+                check_parse_isa(defs)
+            except Exception:
+                os.unlink(LIB_HIP)                               # a library whose parse kernels may read registers in flight is not left lying around
+                raise
     return LIB_HIP
+
+
+def check_parse_isa(defs=()):
+    """The slice parse issues loads in one asm statement and waits for them in another (slice_parse.h: the carried bit window,
+    the refill in two halves); correct only while the compiler puts nothing that touches those registers in between.
+    tools/check_parse_isa.py reads the gfx950 assembly of both parse kernels for exactly that -- part of every build of the
+    library (round 5 advisor): another hipcc must fail HERE, not decode garbage on the GPU."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_parse_isa.py")] + list(defs), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("tools/check_parse_isa.py: the parse kernels touch registers that are in flight:\n" + r.stdout[-2000:])
+    return r.stdout
 
 
 def check_kernel_resources():

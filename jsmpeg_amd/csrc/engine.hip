@@ -118,7 +118,13 @@ struct jsmpeg_hip_batch_t {
 	uint32_t *d_covered, *h_covered;   /* macroblock records written per picture (k_parse); h_covered pinned */
 	uint32_t desc_cap, n_uncovered;
 	hipEvent_t ev_cov;
-	hipEvent_t ev_idx;           /* the index's counters and picture table have arrived on the host (the slice order runs on beside the host's turn-around) */
+	hipEvent_t ev_idx;           /* the index's counters and picture table have arrived on the host (the slice order runs on beside the host's turn-around).
+	                                SAME-STREAM RULE: the order's kernels are enqueued before the host has looked at the counters, and they share
+	                                d_order_hist with the parse that follows (its ticket and per-CU counters sit behind the histogram) -- with no host
+	                                barrier between one decode's parse and the next decode's order.  That is safe because everything of a batch is
+	                                enqueued on ONE stream at a time (jsmpeg_hip_batch_decode's hip_stream; a caller that changes streams between decodes
+	                                synchronises the old one first -- jsmpeg_hip_batch_sync) and because the kernels clamp what they read from the counters
+	                                to the tables' capacity (order_dims): a pass the host then refuses (overflow) has touched nothing outside them */
 	/* ordered reconstruct (one launch per batch, recon_plan.h jm_plan_ordered): per-picture tile counts, the launch's
 	 * status words (kernels.h JM_RECON_STATUS_WORDS; h_: pinned), and how the last decode went */
 	uint32_t *d_done, *d_rstatus, *h_rstatus;

@@ -392,6 +392,7 @@ hipError_t jm_launch_order(const JmOrderBufs &b, hipStream_t st) {
 	const uint32_t cap_groups = (b.sc_cap + JM_WG - 1) / JM_WG;
 	if (groups > cap_groups) groups = cap_groups;
 	if (groups > 2048u) groups = 2048u;
+	if (groups == 0) return hipSuccess;          /* (a batch whose tables hold no start code at all: sc_cap 0) */
 	hipLaunchKernelGGL(k_order_count, dim3(groups), dim3(JM_WG), 0, st, b);
 	hipLaunchKernelGGL(k_order_place, dim3(groups), dim3(JM_WG), 0, st, b);
 	return hipGetLastError();

@@ -278,15 +278,18 @@ ShardRank.prototype.setup = async function (streams) {
   if (this.rank === 0) {
     // the packed source: every unit at its place in its owner's piece, the stream's FIRST sequence header in front of every
     // later unit (only the first one counts, mpeg1.js:32), 0xff everywhere else (a gap must not complete a start code)
-    const host = Buffer.alloc(this.source.total, 0xff);
-    this.pieces.forEach((p, r) => p.units.forEach((u, k) => {
-      const [s, g] = this.table[u], c = cut[s], unit = c.units[g];
-      let at = this.source.offsets[r] + p.begin[k];
-      if (unit.needsHeader) { host.set(c.header, at); at += c.header.length; }
-      host.set(streams[s].subarray(unit.offset, unit.offset + unit.bytes), at);
-    }));
-    this.src = n.deviceAlloc(this.source.total, this.device, -1);
-    n.deviceWrite(this.src, 0, new Uint8Array(host.buffer, host.byteOffset, host.length));
+    // (piece by piece: the whole job's bytes may exceed what one Node Buffer holds)
+    this.src = n.deviceAlloc(this.source.total, this.device, 0xff);
+    this.pieces.forEach((p, r) => {
+      const host = Buffer.alloc(p.size, 0xff);
+      p.units.forEach((u, k) => {
+        const [s, g] = this.table[u], c = cut[s], unit = c.units[g];
+        let at = p.begin[k];
+        if (unit.needsHeader) { host.set(c.header, at); at += c.header.length; }
+        host.set(streams[s].subarray(unit.offset, unit.offset + unit.bytes), at);
+      });
+      n.deviceWrite(this.src, this.source.offsets[r], new Uint8Array(host.buffer, host.byteOffset, host.length));
+    });
   }
   this.piece = n.deviceAlloc(mine.size + 256, this.device, 0xff);       // (+ 256: the attach form's read-ahead)
   this.nStreams = mine.units.length;

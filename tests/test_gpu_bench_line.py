@@ -111,3 +111,14 @@ def test_rehearsal_with_every_cut_crossing_ranks_resolves_the_history_across_rea
     single = ex["history_by_mode"]["single_source"]
     assert single["cross_rank_units_needing_history"] > 0 and single["history_resolution"]["rounds"] >= 1
     assert "test overrides" in d["data"]
+
+
+def test_rehearsal_runs_the_node_hosts_n_rank_program_too():
+    """N > 1 without --no-napi: after the Python ranks' timed runs the same job goes through north_star's own host -- one Node
+    process per rank (tools/bench_node.js --gpus N, jsmpeg_amd/js/shard-hip.js) -- and `value_via_napi` appears in the N > 1 line,
+    every picture against the oracle's unsplit streams (here: a rehearsal, two processes sharing the GPU, bytes over IPC)"""
+    d = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--no-cpu-baseline", "--no-counters", "--streams", "3")
+    v = d["value_via_napi"]
+    assert "error" not in v, v
+    assert v["n_gpus"] == 2 and v["units"] == 12 and v["pictures_per_step"] == 6 * 24 and v["pictures_differing_from_unsplit_streams"] == 0
+    assert v["value"] > 0 and "REHEARSAL" in v["host"] and len(v["per_rank"]) == 2
