@@ -833,18 +833,29 @@ struct LdsSlot {
 static __device__ __forceinline__ void jm_recon_wait(const JmReconBufs &b, uint32_t pic, uint32_t lane) {
 	JM_GLOBAL const uint32_t *w = (JM_GLOBAL const uint32_t *)b.done + (size_t)JM_DONE_STRIDE * pic;
 	uint32_t spins = 0;
-	if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*w) < b.need) for (;;) {
-		uint32_t seen = 0;
-		if (lane == 0) seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) >= b.need) break;
-		__builtin_amdgcn_s_sleep(16);
-		if (spins == 0 && lane == 0) atomicAdd(b.status + 1, 1u);
-		if ((spins & 63u) == 63u) {
-			uint32_t flagged = 0;
-			if (lane == 0) flagged = __hip_atomic_load((JM_GLOBAL const uint32_t *)b.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (__builtin_amdgcn_readfirstlane((int)flagged) != 0) break;
+	if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*w) < b.need) {
+		for (;;) {
+			uint32_t seen = 0;
+			if (lane == 0) seen = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) >= b.need) break;
+			__builtin_amdgcn_s_sleep(16);
+			if (spins == 0 && lane == 0) atomicAdd(b.status + 1, 1u);
+			if ((spins & 63u) == 63u) {
+				uint32_t flagged = 0;
+				if (lane == 0) flagged = __hip_atomic_load((JM_GLOBAL const uint32_t *)b.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (__builtin_amdgcn_readfirstlane((int)flagged) != 0) break;
+			}
+			if (++spins > b.patience) { if (lane == 0) atomicOr(b.status, 1u); break; }
 		}
-		if (++spins > b.patience) { if (lane == 0) atomicOr(b.status, 1u); break; }
+#if !defined(JM_ORDERED_FENCES) && !defined(JM_ORDERED_NO_SLOW_ACQUIRE)
+		/* THE BELT (round 6, the round-5 review's item 5b): a wavefront that really had to POLL -- its picture was still being
+		 * written when it first looked: ~5 k of a step's 1.5 M tiles -- takes the memory model's acquire after all (agent scope:
+		 * this CU's vector L1 is dropped), so that nothing it reads of the forward frame can come from a line the CU took in
+		 * while the frame was unfinished.  The design's argument says no such line exists; on THIS path, the only one on which
+		 * the frame and the tile were in flight together, the argument is not relied on.  Free: wave-uniform, rare
+		 * (profiles/r06_soak.txt: cfg2 with / without it). */
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 	}
 #ifdef JM_ORDERED_FENCES
 	/* the memory model's way of saying it (round 4 advisor): an agent-scope acquire = buffer_inv sc1, this CU's WHOLE vector

@@ -85,6 +85,14 @@
 #ifndef JM_EXTRA_DC
 #define JM_EXTRA_DC 0      /* (turn-structure experiments on the CPU simulator: further DC steps per turn) */
 #endif
+/* The ring service tops a lane up only when it has room for at least this many 16-byte chunks (or is blocked).  1 (rounds 1-5): a
+ * lane took whatever fitted, usually ONE chunk per service -- its 128-byte line was asked for eight times, and with 33 MB of
+ * resident lanes' lines against 32 MB of L2 most of those requests went to the fabric again: 8.2 x the compressed bytes
+ * fetched per pass.  2 (round 6): the line is asked for four times -- 5.0 x, and the pass is 1.5 % FASTER (fewer load
+ * instructions in the service); 3 = "only when blocked" in practice (profiles/r06_parse_notes.md). */
+#ifndef JM_REFILL_MIN
+#define JM_REFILL_MIN 2
+#endif
 #define JM_STEP_BITS (116 + 16 * JM_EXTRA_DC + JM_PAIR_BITS * JM_COEF_REPEAT) /* a turn consumes at most this many bits per lane: COLD 11 + 6 + 5 + 2 * 17 + 9, DC 16, SLOW 28, COEF 10 each */
 #define JM_COEF_SLOTS 3    /* token slots a COEF step may use: two tokens and the alignment slot of an odd run */
 #define JM_RING_STRIDE 64  /* the ES ring is a [row][lane] tile of dwords of one wavefront: conflict-free for any per-lane row */
@@ -267,6 +275,9 @@ JM_D void jm_lane_refill(JmLane &L) {
 	jm_u32x4 v0, v1, v2, v3;
 	const uint32_t f = L.fillc;
 	const uint4_like_t *src = L.es16 + f;
+#if JM_REFILL_MIN > 1   /* a lane that has room for fewer than JM_REFILL_MIN chunks and is not blocked waits for a later service: see JM_REFILL_MIN */
+	if (target - f < (uint32_t)JM_REFILL_MIN && f < target && !(L.fillc * 128u - L.bp < JM_STEP_BITS + 32)) return;
+#endif
 	if (f < target) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v0) : "v"(src));
 	if (f + 1 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v1) : "v"(src));
 	if (f + 2 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(v2) : "v"(src));
@@ -287,6 +298,9 @@ JM_D void jm_lane_refill(JmLane &L) {
 #else
 JM_HD void jm_lane_refill(JmLane &L) {       /* the simulator's: the same chunks into the same rows */
 	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;
+#if JM_REFILL_MIN > 1
+	if (target - L.fillc < (uint32_t)JM_REFILL_MIN && L.fillc < target && !(L.fillc * 128u - L.bp < JM_STEP_BITS + 32)) return;
+#endif
 	for (uint32_t ch = L.fillc; ch < target && ch < L.fillc + JM_ES_RING_DW / 4; ch++) {
 		const uint4_like_t v = L.es16[ch];
 		const uint32_t row = (ch & (JM_ES_RING_DW / 4 - 1)) * 4;
@@ -310,6 +324,9 @@ JM_D void jm_lane_request(JmLane &L) {
 	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;
 	const uint32_t f = L.fillc;
 	const uint4_like_t *src = L.es16 + f;
+#if JM_REFILL_MIN > 1
+	if (target - f < (uint32_t)JM_REFILL_MIN && f < target && !(L.fillc * 128u - L.bp < JM_STEP_BITS + 32)) { L.pend_t = 0; return; }
+#endif
 	if (f < target) asm volatile("global_load_dwordx4 %0, %1, off ; jm_req" : "+v"(L.pv0) : "v"(src));
 	if (f + 1 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:16 ; jm_req" : "+v"(L.pv1) : "v"(src));
 	if (f + 2 < target) asm volatile("global_load_dwordx4 %0, %1, off offset:32 ; jm_req" : "+v"(L.pv2) : "v"(src));
@@ -334,7 +351,13 @@ JM_D void jm_lane_land(JmLane &L) {
 }
 JM_D void jm_lane_settle(JmLane &L) { asm volatile("s_waitcnt vmcnt(0) ; jm_land" : "+v"(L.pv0), "+v"(L.pv1), "+v"(L.pv2), "+v"(L.pv3)); }
 #else
-JM_HD void jm_lane_request(JmLane &L) { L.pend_t = (L.bp >> 7) + JM_ES_RING_DW / 4; }
+JM_HD void jm_lane_request(JmLane &L) {
+	const uint32_t target = (L.bp >> 7) + JM_ES_RING_DW / 4;
+#if JM_REFILL_MIN > 1
+	if (target - L.fillc < (uint32_t)JM_REFILL_MIN && L.fillc < target && !(L.fillc * 128u - L.bp < JM_STEP_BITS + 32)) { L.pend_t = 0; return; }
+#endif
+	L.pend_t = target;
+}
 JM_HD void jm_lane_land(JmLane &L) {
 	const uint32_t target = L.pend_t;
 	for (uint32_t ch = L.fillc; ch < target && ch < L.fillc + JM_ES_RING_DW / 4; ch++) {
@@ -357,7 +380,7 @@ JM_HD void jm_lane_drain(JmLane &L) {
 		a.x = jm_tk_get2(L, s0); a.y = jm_tk_get2(L, s0 + 2); a.z = jm_tk_get2(L, s0 + 4); a.w = jm_tk_get2(L, s0 + 6);
 		b.x = jm_tk_get2(L, s0 + 8); b.y = jm_tk_get2(L, s0 + 10); b.z = jm_tk_get2(L, s0 + 12); b.w = jm_tk_get2(L, s0 + 14);
 		uint4_like_t *dst = L.tokens + (L.tf7 >> (JM_TW_SHIFT + 3));      /* 32-byte aligned: two dwordx4 stores */
-		dst[0] = a; dst[1] = b;
+		dst[0] = a; dst[1] = b;       /* (non-temporal token / record stores, to spare the L2 for the compressed data: fetch -29 %, the pass 2.2 x slower -- profiles/r06_parse_notes.md) */
 		L.tf7 += JM_TK_GROUP * JM_TW_UNIT;
 	}
 }
