@@ -502,6 +502,19 @@ int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, con
  * as the payloads of its TS packets): ONE write of the total length (the store's rule looks at the total, buffer.js:66-92). */
 int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths,
                             uint32_t n_buffers);
+/* The stream handed over as MPEG-TS bytes, in any pieces: the reference's demuxer (src/ts.js:25-210) runs in front of the
+ * write above, with its state kept per stream between calls -- the leftover bytes of a cut packet (ts.js:25-41), resync
+ * after garbage, the PES being collected, completion by PES_packet_length or by the padded last packet of a video frame
+ * (ts.js:127-147).  Every PES of `stream_id` (0xE0: the first video stream) that the reference's demuxer would hand its
+ * destination is one jsmpeg_hip_live_write(pts of the PES, its payload).  Returns 0 or < 0 (a write that was refused: the
+ * first one's message; the demuxer's state moves on regardless, like ts.js's). */
+int jsmpeg_hip_live_write_ts(jsmpeg_hip_live_t *l, uint32_t stream, const void *bytes, uint32_t n, uint32_t stream_id);
+/* That demuxer by itself (host code, no device): `ts` handed over in write() calls of write_bytes[0 .. n_writes) bytes
+ * (n_writes == 0: one write) -> the payload bytes of `stream_id` in `es` (at most es_cap) and, per destination.write call
+ * the reference's demuxer would make, its pts and byte range (at most `cap` entries; any array may be NULL).  Returns the
+ * number of such calls or < 0; *es_bytes: the bytes they carried. */
+int jsmpeg_hip_ts_demux_host(const uint8_t *ts, uint64_t ts_bytes, const uint64_t *write_bytes, uint32_t n_writes, uint32_t stream_id,
+                             uint8_t *es, uint64_t es_cap, uint64_t *es_bytes, double *pts, uint64_t *offset, uint32_t *length, uint32_t cap);
 /* The tick: ONE pass of the batch engine over what has been written.  Per stream, in stream order, it decodes
  *   JSMPEG_HIP_LIVE_FLUSH: every buffered picture, the last one included -- it ends where the data ends, exactly like the
  *       reference's decode() (mpeg1.c:853-864, 947-995), so per stream this is `while (decoder.decode());` after the same

@@ -1222,6 +1222,16 @@ extern "C" int jsmpeg_hip_batch_debug_read(jsmpeg_hip_batch_t *b, int what, void
 
 struct LiveSeg { uint32_t stream, stage_off, bytes; };
 struct LiveStamp { uint64_t at; double pts; };
+/* a live stream fed as MPEG-TS (jsmpeg_hip_live_write_ts): the reference demuxer's state between write() calls (ts.js:3-41) */
+struct LiveTs {
+	std::vector<uint8_t> left;                         /* leftoverBytes */
+	std::vector<std::pair<uint16_t, uint8_t>> pids;    /* pidsToStreamIds */
+	uint32_t cur_len, total_len;                       /* pesPacketInfo[stream id]: currentLength, totalLength, pts, buffers */
+	double pts;
+	std::vector<uint8_t> pes;
+	std::vector<uint8_t> joined;                       /* scratch: leftover + the new bytes */
+	uint64_t writes;                                   /* destination.write calls made so far */
+};
 struct LiveStream {
 	bool open, has_header;
 	int status;
@@ -1232,6 +1242,7 @@ struct LiveStream {
 	uint32_t head, have;                /* ring slot of the picture decoded last; pictures decoded so far (saturates at 2) */
 	std::deque<LiveStamp> stamps;       /* write(): stream offset, pts */
 	uint64_t pictures, evictions;
+	LiveTs *ts;                         /* made by the first jsmpeg_hip_live_write_ts */
 };
 struct LivePicture { uint32_t stream, slot; int32_t type; double pts; uint64_t at; };
 
@@ -1253,6 +1264,7 @@ struct jsmpeg_hip_live_t {
 
 static void live_free(jsmpeg_hip_live_t *l) {
 	if (!l) return;
+	for (LiveStream &S : l->streams) { delete S.ts; S.ts = nullptr; }
 	if (l->b) { hipSetDevice(l->b->device); hipDeviceSynchronize(); l->b->live = nullptr; batch_free(l->b); }
 	if (l->h_stage) hipHostFree(l->h_stage);
 	if (l->h_tab) hipHostFree(l->h_tab);
@@ -1310,7 +1322,7 @@ extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_confi
 	l->stage_cap = (uint32_t)((all_stores + 16ull * 1024 + 255) & ~255ull);
 	l->es_off[0] = l->stage_cap; l->es_off[1] = l->stage_cap + l->es_cap;
 	l->streams.assign(l->cfg.max_streams, LiveStream());
-	for (LiveStream &S : l->streams) { S.open = false; S.has_header = false; S.status = 0; }
+	for (LiveStream &S : l->streams) { S.open = false; S.has_header = false; S.status = 0; S.ts = nullptr; }
 	if (live_alloc(l) != 0) { live_free(l); return nullptr; }
 	return l;
 }
@@ -1330,6 +1342,7 @@ extern "C" int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l) {
 		S = LiveStream();
 		S.open = true; S.has_header = false; S.status = 0; memset(&S.hdr, 0, sizeof(S.hdr));
 		S.tail_off = S.tail_bytes = S.new_bytes = 0; S.written = S.consumed = 0; S.head = 0; S.have = 0; S.pictures = S.evictions = 0;
+		S.ts = nullptr;
 		return (int)s;
 	}
 	return fail("all %u streams are open", (unsigned)l->streams.size());
@@ -1339,6 +1352,7 @@ extern "C" int jsmpeg_hip_live_close(jsmpeg_hip_live_t *l, uint32_t stream) {
 	g_err[0] = 0;
 	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("close: stream %u is not open", stream);
 	l->streams[stream].open = false;
+	delete l->streams[stream].ts; l->streams[stream].ts = nullptr;
 	live_drop_staged(l, stream);
 	return 0;
 }
@@ -1395,6 +1409,113 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 
 extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n) {
 	return jsmpeg_hip_live_write_v(l, stream, pts, &bytes, &n, 1);
+}
+
+/* The stream as MPEG-TS: the reference's demuxer in front of write() (src/ts.js:25-147), with its state between calls --
+ * leftover bytes of a cut packet (ts.js:25-41), the PID -> stream id table, the PES being collected (currentLength, totalLength,
+ * pts) -- kept per live stream.  Host code like the ingest stage's framing pre-pass (ts_sync.h, shared): it looks at packet
+ * HEADERS and moves payload bytes; every completed PES goes to `on_pes(pts, bytes, n)` (ts.js:189-194 packetComplete ->
+ * destination.write(pts, buffers)).  Where the packets lie -- sync bytes, resync after garbage, what a write leaves over --
+ * is jm_ts_sync_runs' restatement of ts.js:43-50, 150-187. */
+template <class F>
+static void live_ts_feed(LiveTs &T, const uint8_t *buf, uint64_t len, uint32_t stream_id, F &&on_pes) {
+	if (!T.left.empty()) {
+		T.joined.assign(T.left.begin(), T.left.end());
+		T.joined.insert(T.joined.end(), buf, buf + len);
+		buf = T.joined.data(); len = T.joined.size();
+	}
+	std::vector<JmTsRun> runs;
+	uint64_t rest = 0;
+	jm_ts_sync_runs(buf, len, nullptr, 0, runs, &rest);
+	auto complete = [&]() {                                       /* ts.js:189-194 */
+		on_pes(T.pts, T.pes.data(), (uint32_t)T.pes.size());
+		T.writes++;
+		T.total_len = 0; T.cur_len = 0; T.pes.clear();
+	};
+	for (const JmTsRun &r : runs) {
+		for (uint32_t k = 0; k < r.packets; k++) {
+			const uint8_t *p = buf + r.src + 188ull * k;
+			const bool start = (p[1] & 0x40) != 0;
+			const uint16_t pid = (uint16_t)(((p[1] & 0x1f) << 8) | p[2]);
+			const uint32_t af = (p[3] >> 4) & 3u;
+			uint32_t sid = 0;
+			for (const auto &e : T.pids) if (e.first == pid) sid = e.second;
+			if (start && sid == stream_id && T.cur_len) complete();        /* a new payload of the stream: the frame before it is over (ts.js:65-73) */
+			if (!(af & 1)) continue;
+			uint32_t at = 4;
+			if (af & 2) at = 5u + p[4];
+			if (at >= 188) continue;                                        /* (a header that runs past its packet: outside what a muxer writes; nothing of it is payload) */
+			if (start && at + 9 <= 188 && p[at] == 0 && p[at + 1] == 0 && p[at + 2] == 1) {
+				sid = p[at + 3];
+				bool known = false;
+				for (auto &e : T.pids) if (e.first == pid) { e.second = (uint8_t)sid; known = true; }
+				if (!known) T.pids.push_back({ pid, (uint8_t)sid });
+				const uint32_t packet_length = ((uint32_t)p[at + 4] << 8) | p[at + 5], flags = p[at + 7] >> 6, header_length = p[at + 8];
+				if (sid == stream_id) {
+					double pts = 0;
+					if ((flags & 2) && at + 14 <= 188) {                    /* the 33-bit PTS in its five bytes (ts.js:96-113) */
+						const uint8_t *q = p + at + 9;
+						const double p32_30 = (q[0] >> 1) & 7, p29_15 = (((uint32_t)q[1] << 8) | q[2]) >> 1, p14_0 = (((uint32_t)q[3] << 8) | q[4]) >> 1;
+						pts = (p32_30 * 1073741824.0 + p29_15 * 32768.0 + p14_0) / 90000.0;
+					}
+					T.total_len = packet_length ? packet_length - header_length - 3 : 0;      /* packetStart (ts.js:189-193) */
+					T.cur_len = 0; T.pts = pts;
+				}
+				at += 9 + header_length;
+			}
+			if (sid != stream_id) continue;
+			if (at < 188) { T.pes.insert(T.pes.end(), p + at, p + 188); T.cur_len += 188 - at; }
+			const bool full = T.total_len != 0 && T.cur_len >= T.total_len;
+			const bool padded = !start && (af & 2);                                     /* the video frame end guess (ts.js:127-147) */
+			if (full || padded) complete();
+		}
+	}
+	T.left.assign(buf + rest, buf + len);
+}
+
+extern "C" int jsmpeg_hip_live_write_ts(jsmpeg_hip_live_t *l, uint32_t stream, const void *bytes, uint32_t n, uint32_t stream_id) {
+	g_err[0] = 0;
+	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("write_ts: stream %u is not open", stream);
+	if (stream_id == 0 || stream_id > 255) return fail("stream id %u out of range", stream_id);
+	if (n && !bytes) return fail("write_ts: null buffer");
+	LiveStream &S = l->streams[stream];
+	if (!S.ts) { S.ts = new LiveTs(); S.ts->cur_len = S.ts->total_len = 0; S.ts->pts = 0; S.ts->writes = 0; }
+	int rc = 0;
+	char first_err[sizeof(g_err)] = "";
+	live_ts_feed(*S.ts, (const uint8_t *)bytes, n, stream_id, [&](double pts, const uint8_t *pes, uint32_t m) {
+		if (jsmpeg_hip_live_write(l, stream, pts, pes, m) < 0 && rc == 0) { rc = -1; memcpy(first_err, g_err, sizeof(g_err)); }
+	});
+	if (rc < 0) memcpy(g_err, first_err, sizeof(g_err));
+	return rc;
+}
+
+/* The same demuxer by itself (host code, no device): `ts` handed over in write() calls of write_bytes[0 .. n_writes) bytes
+ * (n_writes == 0: one write) -> the bytes of stream `stream_id` in `es` (at most es_cap), and per destination.write call
+ * its pts and byte range (at most `cap` entries; any array may be NULL).  What jsmpeg_hip_live_write_ts hands a live
+ * stream, observable without one: tests hold it against the reference's ts.js (tests/golden/ts_*.json) on the CPU.
+ * Returns the number of destination.write calls or < 0; *es_bytes: the bytes they carried. */
+extern "C" int jsmpeg_hip_ts_demux_host(const uint8_t *ts, uint64_t ts_bytes, const uint64_t *write_bytes, uint32_t n_writes, uint32_t stream_id,
+                                        uint8_t *es, uint64_t es_cap, uint64_t *es_bytes, double *pts, uint64_t *offset, uint32_t *length, uint32_t cap) {
+	g_err[0] = 0;
+	if (!ts && ts_bytes) return fail("null buffer");
+	if (stream_id == 0 || stream_id > 255) return fail("stream id %u out of range", stream_id);
+	LiveTs T;
+	T.cur_len = T.total_len = 0; T.pts = 0; T.writes = 0;
+	uint64_t total = 0, at = 0;
+	uint32_t calls = 0;
+	const uint64_t one = ts_bytes;
+	if (n_writes == 0) { write_bytes = &one; n_writes = 1; }
+	for (uint32_t w = 0; w < n_writes && at < ts_bytes; w++) {
+		const uint64_t n = std::min(write_bytes[w], ts_bytes - at);
+		live_ts_feed(T, ts + at, n, stream_id, [&](double p, const uint8_t *pes, uint32_t m) {
+			if (calls < cap) { if (pts) pts[calls] = p; if (offset) offset[calls] = total; if (length) length[calls] = m; }
+			if (es && total + m <= es_cap) memcpy(es + total, pes, m);
+			total += m; calls++;
+		});
+		at += n;
+	}
+	if (es_bytes) *es_bytes = total;
+	return (int)calls;
 }
 
 /* Inside jsmpeg_hip_batch_decode, once the pass's picture table is on the host: picture p of the pass is written to the

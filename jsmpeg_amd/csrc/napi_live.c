@@ -8,6 +8,7 @@
  *   liveOpen(handle) -> stream id / liveClose(handle, id)                          jsmpeg_hip_live_open / _close
  *   liveWrite(handle, id, pts, [Uint8Array, ...]) -> bytes                         jsmpeg_hip_live_write_v: the decoder's
  *                                                                                  write(pts, buffers) (decoder.js:36-47)
+ *   liveWriteTS(handle, id, Uint8Array[, streamId]) -> bytes                       jsmpeg_hip_live_write_ts: the demuxer's write(buffer)
  *   liveTick(handle, flush) -> pictures                                            jsmpeg_hip_live_tick
  *   livePicture(handle, i) -> {stream, type, pts, streamOffset}                    jsmpeg_hip_live_picture
  *   liveReadPlanes(handle, i, y, cr, cb) / liveReadRGBA(handle, i, Uint8ClampedArray)
@@ -148,6 +149,23 @@ static napi_value fn_live_write(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* liveWriteTS(handle, id, Uint8Array[, streamId = 0xE0]): MPEG-TS bytes in any pieces; the reference's demuxer (its state kept per stream) in front of liveWrite */
+static napi_value fn_live_write_ts(napi_env env, napi_callback_info info) {
+	size_t argc = 4;
+	napi_value argv[4], out;
+	uint32_t id = 0, sid = 0xE0;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (argc < 3 || napi_get_value_uint32(env, argv[1], &id) != napi_ok || napi_get_typedarray_info(env, argv[2], &t, &len, &data, &ab, &off) != napi_ok ||
+	    (t != napi_uint8_array && t != napi_uint8_clamped_array) || len > 0xffffffffu) { napi_throw_type_error(env, NULL, "jsmpeg_hip: liveWriteTS(handle, stream, Uint8Array[, streamId])"); return NULL; }
+	if (argc > 3) napi_get_value_uint32(env, argv[3], &sid);
+	if (jsmpeg_hip_live_write_ts(l, id, data, (uint32_t)len, sid) < 0) return throw_last(env);
+	NAPI_OK(napi_create_double(env, (double)len, &out));
+	return out;
+}
+
 static napi_value fn_live_tick(napi_env env, napi_callback_info info) {
 	size_t argc = 2;
 	napi_value argv[2], out;
@@ -285,7 +303,7 @@ static napi_value fn_live_timings(napi_env env, napi_callback_info info) {
 int jm_napi_register_live(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "liveCreate", fn_live_create }, { "liveDestroy", fn_live_destroy }, { "liveOpen", fn_live_open }, { "liveClose", fn_live_close },
-		{ "liveWrite", fn_live_write }, { "liveTick", fn_live_tick }, { "livePicture", fn_live_picture },
+		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "livePicture", fn_live_picture },
 		{ "liveReadPlanes", fn_live_read_planes }, { "liveReadRGBA", fn_live_read_rgba }, { "liveFrameHashes", fn_live_frame_hashes },
 		{ "liveStreamInfo", fn_live_stream_info }, { "liveGeometry", fn_live_geometry }, { "liveTimings", fn_live_timings },
 	};

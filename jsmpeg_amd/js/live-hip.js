@@ -136,6 +136,14 @@ function install(JSMpeg, options) {
     this.bytesWritten += this.live.native.liveWrite(this.live.handle, this.id, pts, buffers);
     this.canPlay = true;
   };
+  // the stream as MPEG-TS bytes in any pieces: the library's own restatement of ts.js (state kept per stream) in front of write() --
+  // for hosts that do not have jsmpeg's demuxer loaded; with it loaded, demuxer.connect(VIDEO_1, stream) is the same thing
+  HIPLiveStream.prototype.writeTS = function (buffer, streamId) {
+    if (!this.live) throw new Error('HIPLiveStream: the stream is closed');
+    this.live.native.liveWriteTS(this.live.handle, this.id, buffer, streamId || 0xE0);
+    this.bytesWritten = this.info().bytesWritten;
+    this.canPlay = this.canPlay || this.bytesWritten > 0;
+  };
   // mpeg1-wasm.js:80-93 loadSequenceHeader (the header is parsed by the tick that first sees it, on the device)
   HIPLiveStream.prototype.pollSequenceHeader = function () {
     const info = this.info();

@@ -10,7 +10,7 @@ from . import batch as _batch
 FLUSH = 1
 
 LIVE_SYMBOLS = ("jsmpeg_hip_live_create", "jsmpeg_hip_live_destroy", "jsmpeg_hip_live_open", "jsmpeg_hip_live_close",
-                "jsmpeg_hip_live_write", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
+                "jsmpeg_hip_live_write", "jsmpeg_hip_live_write_v", "jsmpeg_hip_live_write_ts", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
                 "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_rgba",
                 "jsmpeg_hip_live_frame_hashes", "jsmpeg_hip_live_stream_info", "jsmpeg_hip_live_timings")
 
@@ -49,6 +49,8 @@ def lib():
         L.jsmpeg_hip_live_close.argtypes = [vp, u32]
         L.jsmpeg_hip_live_write.restype = ctypes.c_int
         L.jsmpeg_hip_live_write.argtypes = [vp, u32, ctypes.c_double, vp, u32]
+        L.jsmpeg_hip_live_write_ts.restype = ctypes.c_int
+        L.jsmpeg_hip_live_write_ts.argtypes = [vp, u32, vp, u32, u32]
         L.jsmpeg_hip_live_tick.restype = ctypes.c_int
         L.jsmpeg_hip_live_tick.argtypes = [vp, u32, vp]
         L.jsmpeg_hip_live_picture_count.restype = u32
@@ -110,6 +112,11 @@ class Live:
     def write(self, stream, data, pts=0.0):
         a = np.ascontiguousarray(data, dtype=np.uint8)
         self._ok(self.L.jsmpeg_hip_live_write(self.h, stream, pts, a.ctypes.data, a.size))
+
+    def write_ts(self, stream, data, stream_id=0xE0):
+        """MPEG-TS bytes in any pieces: the reference's demuxer in front of write(), its state kept per stream"""
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        self._ok(self.L.jsmpeg_hip_live_write_ts(self.h, stream, a.ctypes.data, a.size, stream_id))
 
     def tick(self, flush=True, stream=None):
         """one pass over what has been written; returns the pictures decoded (see pictures())"""

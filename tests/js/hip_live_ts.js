@@ -10,13 +10,14 @@ const { install } = require('../../jsmpeg_amd/js/live-hip.js');
 
 const args = process.argv.slice(2);
 const width = +args.shift(), height = +args.shift();
-let bundle = null, late = 0, packets = 40, rgba = false;
+let bundle = null, late = 0, packets = 40, rgba = false, nativeTS = false;
 while (args.length && args[0].startsWith('--')) {
   const k = args.shift();
   if (k === '--bundle') bundle = args.shift();
   else if (k === '--late') late = +args.shift();
   else if (k === '--packets') packets = +args.shift();
   else if (k === '--rgba') rgba = true;
+  else if (k === '--native-ts') nativeTS = true;     // no JS demuxer at all: HIPLiveStream.writeTS (the library's ts.js restatement, state kept per stream)
 }
 const files = args.map((f) => fs.readFileSync(f));
 
@@ -52,8 +53,8 @@ function join(i) {
       out[i].planes.push(h.digest('hex'));
     },
   });
-  const demuxer = makeDemuxer();
-  demuxer.connect(VIDEO_1, video);
+  const demuxer = nativeTS ? { write: (data) => video.writeTS(data) } : makeDemuxer();
+  if (!nativeTS) demuxer.connect(VIDEO_1, video);
   streams[i] = { video, demuxer, at: 0 };
 }
 const ticks = [];
@@ -84,7 +85,7 @@ for (;; round++) {
   if (!fed) break;
 }
 const info = streams.map((s) => s.video.info());
-const result = { demuxer: demuxerName, rounds: round, pictures, hashesSeen, streams: out,
+const result = { demuxer: nativeTS ? 'jsmpeg_hip_live_write_ts' : demuxerName, rounds: round, pictures, hashesSeen, streams: out,
                  frameRates: streams.map((s) => s.video.frameRate), decodedTimes: streams.map((s) => +s.video.decodedTime.toFixed(6)),
                  ids: streams.map((s) => s.video.id), pending: info.map((x) => x.pendingBytes), evictions: info.map((x) => x.evictions),
                  medianTickMs: ticks.sort((a, b) => a - b)[ticks.length >> 1] };

@@ -288,3 +288,43 @@ def test_live_rgba_and_device_frames(hip_lib, libs):
             assert np.array_equal(lv.read_rgba(i), checkers.oracle_rgba(libs["oracle"], *frames[i], W, H))
         t = lv.timings()
         assert t["total_ms"] > 0 and t["parse_ms"] > 0 and t["recon_ms"] > 0
+
+
+def test_live_streams_fed_as_transport_streams(hip_lib, libs):
+    """jsmpeg_hip_live_write_ts: three streams as MPEG-TS bytes in ragged pieces (cut packets: the demuxer's leftover bytes),
+    round-robin, a tick per round -- the library's ts.js restatement in front of every stream, its state kept between calls.
+    Every picture == the oracle's decode of the stream, pts as the PES headers say, bytes as the reference demuxer delivers them."""
+    from oracle import checkers
+    W, H, N = 352, 288, 14
+    tss, want, want_pts, want_bytes = [], [], [], []
+    for s in range(3):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=N, stream=300 + s, width=W, height=H)
+        ts = synth.mux_ts(es, offs)
+        tss.append(ts)
+        demuxed, writes = checkers.oracle_ts_demux(libs["oracle"], ts, 0xE0)
+        want_pts.append([round(w[0], 6) for w in writes])
+        want_bytes.append(sum(w[2] for w in writes))
+        frames, _, _ = cabi.decode_stream(libs["oracle"], demuxed)
+        want.append(frames)
+    rng = random.Random(3)
+    got, pts = {0: [], 1: [], 2: []}, {0: [], 1: [], 2: []}
+    with jl.Live(W, H, 3, pictures_per_tick=4, store_bytes=1 << 18) as lv:
+        ids = [lv.open() for _ in range(3)]
+        at = [0, 0, 0]
+        while any(at[s] < len(tss[s]) for s in range(3)):
+            for s in range(3):
+                n = min(len(tss[s]) - at[s], rng.choice([1, 187, 188, 189, 1000, 4000, 9000]))
+                if n:
+                    lv.write_ts(ids[s], tss[s][at[s]:at[s] + n])
+                    at[s] += n
+            lv.tick(flush=True)
+            per = {}
+            for p in drain(lv, None, per):
+                pts[ids.index(p.stream)].append(round(p.pts, 6))
+            for i, frames in per.items():
+                got[ids.index(i)] += frames
+        for s in range(3):
+            assert lv.stream_info(ids[s]).bytes_written == want_bytes[s]
+    for s in range(3):
+        assert got[s] == want[s], s
+        assert pts[s] == want_pts[s], s

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_addon_exports_the_live_functions():
     addon = build.build_addon()
     out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
-    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveTick", "livePicture", "liveReadPlanes", "liveReadRGBA",
+    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveWriteTS", "liveTick", "livePicture", "liveReadPlanes", "liveReadRGBA",
             "liveFrameHashes", "liveStreamInfo", "liveGeometry", "liveTimings"} <= set(json.loads(out))
 
 
@@ -65,7 +65,7 @@ def _ts_files(n, frames, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("demuxer", ["ts-demux.js", "reference bundle"])
+@pytest.mark.parametrize("demuxer", ["ts-demux.js", "reference bundle", "the library's own (writeTS)"])
 def test_node_live_streams_on_gpu(demuxer, hip_lib):
     """4 TS files -> a demuxer per stream -> JSMpeg.HIPLive over the real addon, fed in ragged pieces round-robin, a tick per
     round; the last stream joins 5 rounds late.  Every rendered picture of every stream == the oracle's; pts as the demuxer
@@ -76,6 +76,8 @@ def test_node_live_streams_on_gpu(demuxer, hip_lib):
         if not os.path.exists(build.JS_REF):
             pytest.skip("oracle/_ref/jsmpeg_ref.min.js not there (made from /root/reference by oracle/Makefile)")
         extra = ["--bundle", build.JS_REF]
+    if demuxer.startswith("the library"):
+        extra = ["--native-ts"]
     paths, want, _ = _ts_files(4, 14, 352, 288)
     try:
         out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_ts.js"), "352", "288"] + extra +

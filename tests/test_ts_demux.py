@@ -135,3 +135,62 @@ def test_ts_in_planes_out(hip_lib, libs):
             per_stream.setdefault(info.stream, []).append(int(dev[p]))
         for s in range(5):
             assert per_stream[s] == want[s], "stream %d" % s
+
+
+def host_demux(L, ts, stream_id, write_sizes=None):
+    import ctypes
+    ts = np.ascontiguousarray(ts, dtype=np.uint8)
+    es = np.zeros(len(ts) + 16, dtype=np.uint8)
+    cap = len(ts) // 94 + 16
+    pts, off, ln = np.zeros(cap, np.float64), np.zeros(cap, np.uint64), np.zeros(cap, np.uint32)
+    n_es = ctypes.c_uint64()
+    ws = (ctypes.c_uint64 * max(1, len(write_sizes or [])))(*[int(x) for x in (write_sizes or [])])
+    fn = L.jsmpeg_hip_ts_demux_host
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                   ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    n = fn(ts.ctypes.data, len(ts), ws, len(write_sizes or []), stream_id, es.ctypes.data, len(es), ctypes.byref(n_es), pts.ctypes.data, off.ctypes.data, ln.ctypes.data, cap)
+    assert 0 <= n <= cap
+    return es[:n_es.value].copy(), [(float(pts[i]), int(off[i]), int(ln[i])) for i in range(n)]
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=IDS)
+def test_live_streams_host_demuxer_matches_reference_fixture(path, hip_lib):
+    """the demuxer a LIVE stream keeps in front of its write() (jsmpeg_hip_live_write_ts: ts.js's state carried between calls --
+    leftover bytes, resync, the PES being collected), run by itself on the host (jsmpeg_hip_ts_demux_host): the same
+    destination.write calls as the unmodified ts.js under Node, for every fixture and its write() sizes"""
+    from jsmpeg_amd import batch as jb
+    fx, ts = load_case(path)
+    es, writes = host_demux(jb.lib(), ts, fx["stream_id"], fx.get("write_sizes"))
+    assert as_fixture_writes(es, writes) == fx["writes"]
+    assert hashlib.md5(es.tobytes()).hexdigest() == fx["total_md5"]
+
+
+def test_live_streams_host_demuxer_on_random_damage_and_pieces(libs, hip_lib):
+    """... and against the restatement (pinned to ts.js by the fixtures) on random junk spliced into a TS, truncated ends and
+    random write() sizes: same bytes, same write() boundaries, same pts"""
+    from jsmpeg_amd import batch as jb
+    rng = np.random.RandomState(9)
+    base = ts_craft.case_video_audio_null()
+    for trial in range(200):
+        parts, at = [], 0
+        for cut in sorted(rng.choice(np.arange(1, len(base) // 188), size=rng.randint(0, 4), replace=False)):
+            parts.append(base[at:cut * 188])
+            junk = rng.randint(0, 256, size=rng.randint(1, 1300)).astype(np.uint8)
+            if trial % 3 == 0:
+                junk[junk == 0x47] = 0x48
+            parts.append(junk)
+            at = cut * 188
+        parts.append(base[at:len(base) - rng.randint(0, 400)])
+        ts = np.ascontiguousarray(np.concatenate(parts))
+        sizes, left = [], len(ts)
+        if trial % 4:
+            while left > 0:
+                n = int(min(left, rng.randint(1, 4000)))
+                sizes.append(n)
+                left -= n
+        sid = 0xE0 if trial % 5 else 0xC0
+        want_es, want_w = checkers.oracle_ts_demux(libs["oracle"], ts, sid, sizes or None)
+        got_es, got_w = host_demux(jb.lib(), ts, sid, sizes or None)
+        assert got_w == want_w, trial
+        assert np.array_equal(got_es, want_es[:len(got_es)]) and len(got_es) == sum(w[2] for w in want_w), trial
