@@ -1424,7 +1424,9 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import live_bench
-            lt = live_bench.run(streams=64, pictures=37, config=CONFIG, per_tick=1, check=True, abi_streams=4, verbose=False)
+            lt = live_bench.run(streams=64, pictures=37, config=CONFIG, per_tick=1, check=True, abi_streams=4, verbose=False, via_node=not args.no_napi)
+            if lt.get("via_napi", {}).get("error"):
+                log("live tick from Node: %s" % lt["via_napi"]["error"])
             if lt.get("pictures_differing_from_oracle"):
                 raise RuntimeError("PARITY FAILURE: %d live pictures differ from the oracle" % lt["pictures_differing_from_oracle"])
             lt["note"] = ("tools/live_bench.py: %d live streams (jsmpeg_hip_live_*), every tick = one write() per stream (a whole picture, as ts.js delivers them) + ONE "

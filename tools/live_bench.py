@@ -23,7 +23,7 @@ def picture_writes(es, offs):
     return [es[int(offs[k]):(len(es) if k == n - 1 else int(offs[k + 1]))] for k in range(n)]
 
 
-def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, abi_streams=4, width=None, height=None, verbose=True):
+def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, abi_streams=4, width=None, height=None, verbose=True, via_node=False):
     say = print if verbose else (lambda *a, **k: None)
     kw = {}
     if width:
@@ -109,7 +109,33 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         out["live_over_one_picture_abi"] = out["pictures_per_s"] / out["one_picture_abi"]["pictures_per_s"] if out["pictures_per_s"] else None
         say("one-picture ABI (write a picture, decode(), planes to the host), %d decoders in turn: %.3f ms per P picture, %.0f pictures/s -> live tick = %.1f x"
             % (k_abi, p_ms, out["one_picture_abi"]["pictures_per_s"], out["live_over_one_picture_abi"] or -1))
+    if via_node and want is not None:
+        out["via_napi"] = node_run(gen, want, streams, W, H)
+        if "ms_per_tick_p_pictures" in out["via_napi"]:
+            say("  the same from Node (JSMpeg.HIPLive over the N-API addon): %.3f ms per tick of P pictures, %.0f pictures/s"
+                % (out["via_napi"]["ms_per_tick_p_pictures"], out["via_napi"]["pictures_per_s"]))
     return out
+
+
+def node_run(gen, want, streams, W, H):
+    """the same ticks from the host north_star names: tools/live_bench_node.js (JSMpeg.HIPLive), hashes against the same oracle vectors"""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("node") or not os.path.exists(os.path.join(ROOT, "jsmpeg_amd", "js", "jsmpeg_hip.node")):
+        return {"error": "node or the addon is not there"}
+    td = tempfile.mkdtemp(prefix="jsmpeg_live_")
+    try:
+        for s in range(streams):
+            gen[s][0].tofile(os.path.join(td, "s%d.m1v" % s))
+        json.dump([[int(x) for x in gen[s][1]] for s in range(streams)], open(os.path.join(td, "offsets.json"), "w"))
+        json.dump({str(s): ["%016x" % h for h in want[s]] for s in range(streams)}, open(os.path.join(td, "hashes.json"), "w"))
+        p = subprocess.run(["node", os.path.join(ROOT, "tools", "live_bench_node.js"), "--dir", td, "--streams", str(streams), "--width", str(W), "--height", str(H)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"error": "no result (rc %d): %s" % (p.returncode, p.stderr.decode()[-300:])}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 if __name__ == "__main__":
@@ -119,9 +145,10 @@ if __name__ == "__main__":
     ap.add_argument("--config", default="cfg2_1080p")
     ap.add_argument("--pictures-per-tick", type=int, default=1)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--node", action="store_true", help="also run the same ticks from Node (tools/live_bench_node.js)")
     ap.add_argument("--json")
     a = ap.parse_args()
-    res = run(a.streams, a.pictures, a.config, a.pictures_per_tick, check=not a.no_check)
+    res = run(a.streams, a.pictures, a.config, a.pictures_per_tick, check=not a.no_check, via_node=a.node)
     if a.json:
         os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump(res, open(a.json, "w"), indent=1)

@@ -1,0 +1,46 @@
+// LIVE streams from the host north_star names: Node.js, JSMpeg.HIPLive (jsmpeg_amd/js/live-hip.js) over the N-API addon -- S streams,
+// every tick a write(pts, [picture]) per stream (what ts.js hands a decoder) and ONE live.tick(); every picture's device hash
+// against expected.json (the oracle's, from tools/live_bench.py).  One JSON line: ms per tick of P pictures / I pictures, pictures/s.
+//   node tools/live_bench_node.js --dir <s0.m1v ... + offsets.json + hashes.json> --streams S --width w --height h
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const opt = {};
+for (let i = 2; i < process.argv.length; i += 2) opt[process.argv[i].replace(/^--/, '')] = process.argv[i + 1];
+const S = parseInt(opt.streams, 10), width = parseInt(opt.width, 10), height = parseInt(opt.height, 10);
+const { HIPLive } = require(path.join(__dirname, '..', 'jsmpeg_amd', 'js', 'live-hip.js')).install();
+const offsets = JSON.parse(fs.readFileSync(path.join(opt.dir, 'offsets.json'), 'utf8'));
+const want = JSON.parse(fs.readFileSync(path.join(opt.dir, 'hashes.json'), 'utf8'));
+const streams = [];
+let biggest = 0;
+for (let s = 0; s < S; s++) {
+  const b = fs.readFileSync(path.join(opt.dir, 's' + s + '.m1v')), es = new Uint8Array(b.buffer, b.byteOffset, b.length), o = offsets[s], w = [];
+  for (let k = 0; k + 1 < o.length; k++) { w.push(es.subarray(o[k], k + 2 === o.length ? es.length : o[k + 1])); biggest = Math.max(biggest, w[k].length); }
+  streams.push(w);
+}
+let out;
+try {
+  const live = new HIPLive({ width, height, maxStreams: S, picturesPerTick: 1, videoBufferSize: Math.max(512 * 1024, 2 * biggest) });
+  const vids = streams.map(() => live.open());
+  const n = streams[0].length, ms = [], got = streams.map(() => []);
+  let pictures = 0;
+  for (let k = 0; k < n; k++) {
+    const t0 = process.hrtime.bigint();
+    for (let s = 0; s < S; s++) if (k < streams[s].length) vids[s].write(k / 30, [streams[s][k]]);
+    const c = live.tick({ flush: true });
+    ms.push(Number(process.hrtime.bigint() - t0) / 1e6);
+    pictures += c;
+    const h = live.frameHashes();
+    for (let i = 0; i < c; i++) got[vids.findIndex((v) => v.id === live.picture(i).stream)].push(h[i]);
+  }
+  let bad = 0;
+  for (let s = 0; s < S; s++) { const w = want[String(s)] || []; if (w.length !== got[s].length) bad += Math.abs(w.length - got[s].length); for (let k = 0; k < Math.min(w.length, got[s].length); k++) if (w[k] !== got[s][k]) bad++; }
+  const med = (a) => { const b = a.slice().sort((x, y) => x - y); return b.length ? b[b.length >> 1] : null; };
+  const pTicks = ms.filter((_, k) => k % 12 !== 0), iTicks = ms.filter((_, k) => k % 12 === 0 && k > 0);
+  const total = ms.slice(1).reduce((a, b) => a + b, 0);
+  out = { ms_per_tick_p_pictures: med(pTicks), ms_per_tick_i_pictures: med(iTicks), pictures_per_s: (pictures - S) / total * 1e3, ticks: n, pictures,
+          pictures_differing_from_oracle: bad, host: 'Node ' + process.version + ', JSMpeg.HIPLive over jsmpeg_hip.node (N-API): ' + S + ' write(pts, buffers) calls + one tick() per tick' };
+  live.destroy();
+  if (bad) out.error = 'PARITY FAILURE: ' + bad + ' live pictures differ from the oracle';
+} catch (e) { out = { error: String(e && e.message || e) }; }
+process.stdout.write(JSON.stringify(out) + '\n');
