@@ -1372,6 +1372,28 @@ static void live_compact_stage(jsmpeg_hip_live_t *l) {
 	l->stage_used = at;
 }
 
+/* the stream's staged writes (host memory: no tick has taken them) hold its first sequence header?  Then the stream has it
+ * from now on, as if a tick had read it (see jsmpeg_hip_live_write_v) */
+static void live_header_from_staged(jsmpeg_hip_live_t *l, uint32_t stream) {
+	LiveStream &S = l->streams[stream];
+	for (const LiveSeg &g : l->segs) {
+		if (g.stream != stream || g.bytes < 4) continue;
+		const uint8_t *p = l->h_stage + g.stage_off;
+		for (uint32_t q = 0; q + 3 < g.bytes; q++) {
+			if (p[q] != 0 || p[q + 1] != 0 || p[q + 2] != 1 || p[q + 3] != JM_CODE_SEQUENCE) continue;
+			JmStream T;
+			memset(&T, 0, sizeof(T));
+			T.es_begin = 0; T.es_end = g.bytes;                  /* what lies beyond the write reads as 0, like the reference's typed array */
+			const uint32_t sc_pos = q, no_pic = 0;
+			const uint8_t sc_code = JM_CODE_SEQUENCE;
+			jm_index_stream(T, p, &sc_pos, &sc_code, 1, &no_pic, 0, l->cfg.width, l->cfg.height);
+			if (T.seq_sc == JM_NONE) return;
+			S.has_header = true; S.hdr = T; S.status = T.valid ? 0 : 1;
+			return;
+		}
+	}
+}
+
 /* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict: ONE write of the buffers' total length */
 extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths, uint32_t n_buffers) {
 	g_err[0] = 0;
@@ -1384,7 +1406,13 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 	LiveStream &S = l->streams[stream];
 	if ((uint64_t)S.tail_bytes + S.new_bytes + n > l->cfg.store_bytes) {
 		/* buffer.js:37-56: decoded bytes never stand in the way here (a tick drops them), so a write that does not fit finds
-		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store */
+		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store.
+		 * ONE thing of them stays: the reference looks for its sequence header inside write() (mpeg1.c:812-819), so bytes no
+		 * tick has seen may still have given it one -- a decoder that lost its first picture this way decodes the next ones
+		 * all the same.  Here headers are read by the tick's index kernel; for bytes that go before any tick saw them the host
+		 * looks itself, with the kernel's own function (index_tables.h jm_index_stream: host and device): the only time the
+		 * host reads a stream byte (found by tools/fuzz_live.py: stores of 1.2 pictures, three writes in a tick). */
+		if (!S.has_header) live_header_from_staged(l, stream);
 		S.tail_bytes = 0; S.new_bytes = 0;
 		live_drop_staged(l, stream);
 		S.consumed = S.written;
@@ -1628,7 +1656,20 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 	/* ---- 4. one pass of the batch engine ---- */
 	const auto t_decode = std::chrono::steady_clock::now();
 	const int n_pics = jsmpeg_hip_batch_decode(b, st);
-	if (n_pics < 0) return -1;                                       /* nothing has been consumed: the writes are still staged, the tails where they were */
+	if (n_pics < 0) {
+		/* the pass was refused (its tables overflowed: more start codes than any stream of pictures carries) or the device failed.
+		 * The same bytes would be refused again, so they go -- every stream's store is emptied, like the reference's store when
+		 * a write no longer fits (buffer.js:48-56) -- and the streams go on with what is written next. */
+		char why[sizeof(g_err)];
+		memcpy(why, g_err, sizeof(why));
+		(void)hipStreamSynchronize(st);
+		for (uint32_t i = 0; i < n; i++) {
+			LiveStream &S = l->streams[l->pass_stream[i]];
+			S.consumed += (uint64_t)S.tail_bytes + S.new_bytes; S.tail_bytes = S.new_bytes = 0; S.stamps.clear(); S.evictions++;
+		}
+		l->segs.clear(); l->stage_used = 0;
+		return fail("live tick refused, the pending bytes of its %u streams were dropped: %.300s", n, why);
+	}
 	if (need_back) HIP_TRY(hipMemcpyAsync(l->h_back, b->d_streams, sizeof(JmStream) * n, hipMemcpyDeviceToHost, st));
 	l->ms[1] = (float)live_ms_since(t_decode);
 	const auto t_wait = std::chrono::steady_clock::now();

@@ -328,3 +328,47 @@ def test_live_streams_fed_as_transport_streams(hip_lib, libs):
     for s in range(3):
         assert got[s] == want[s], s
         assert pts[s] == want_pts[s], s
+
+
+def test_live_damaged_streams_do_not_disturb_their_neighbours(hip_lib, libs):
+    """streams are independent: three streams fed noise, bit-flipped and truncated data beside three good ones, every tick --
+    no fault, no hang, and the good streams' pictures are the oracle's, picture by picture"""
+    W, H, N = 352, 288, 18
+    rng = np.random.RandomState(21)
+    good = []
+    for s in range(3):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=N, stream=700 + s, width=W, height=H)
+        good.append(picture_writes(es, [int(o) for o in offs]))
+    want = [oracle_fed(libs, [[w] for w in good[s]], 1 << 18) for s in range(3)]
+    es_b, offs_b = synth.generate_config("cfg1_720p", n_frames=N, stream=777, width=W, height=H)
+    bad_src = picture_writes(es_b, [int(o) for o in offs_b])
+    with jl.Live(W, H, 6, pictures_per_tick=4, store_bytes=1 << 18) as lv:
+        g = [lv.open() for _ in range(3)]
+        noise, flipped, cut = lv.open(), lv.open(), lv.open()
+        for k in range(N):
+            for s in range(3):
+                lv.write(g[s], good[s][k])
+            lv.write(noise, rng.randint(0, 256, size=rng.randint(1, 20000)).astype(np.uint8))
+            w = bad_src[k].copy()
+            if k:                                               # (the first write carries the sequence header: keep it, damage what follows)
+                for _ in range(8):
+                    w[rng.randint(0, len(w))] ^= 1 << rng.randint(0, 8)
+            lv.write(flipped, w)
+            lv.write(cut, bad_src[k][:max(1, len(bad_src[k]) - rng.randint(0, len(bad_src[k]) // 2))])
+            lv.tick(flush=True)
+            per = {}
+            drain(lv, None, per)
+            for s in range(3):
+                assert per.get(g[s], []) == want[s][k], (k, s)
+        assert lv.stream_info(noise).pictures == 0
+        assert all(lv.stream_info(i).pending_bytes == 0 for i in (noise, flipped, cut))
+
+
+def test_live_fuzz_short_run(hip_lib, libs):
+    """tools/fuzz_live.py: random sizes / syntax / feeding (whole pictures with small stores that evict, arbitrary byte pieces,
+    TS in pieces), streams joining at random ticks -- a short run of the sweep whose long runs are profiles/r06_fuzz_live.txt"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live.py"), "30", "77"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
