@@ -446,8 +446,8 @@ int jsmpeg_hip_device_synchronize(void);
  * undecoded bytes, its FIRST sequence header (only the first one counts, mpeg1.c:812-819) and the frames of its last two
  * decoded pictures stay in HBM, and one jsmpeg_hip_live_tick decodes the pending pictures of EVERY stream in ONE pass
  * of the batch engine (all their slices parsed at once, one reconstruct launch) -- per stream exactly the pictures the
- * reference's decoder gives for the same write() calls.  Nothing is copied on the way: a write() lands in a pinned
- * staging buffer, one transfer per tick takes all of them to the device, a picture is reconstructed into its stream's
+ * reference's decoder gives for the same write() calls (held against it with the same writes and ticks, evictions
+ * included: tools/fuzz_live.py).  Nothing is copied on the way: a write() lands in a pinned staging buffer, one transfer per tick takes all of them to the device, a picture is reconstructed into its stream's
  * ring of frames, and the next tick predicts from those frames where they lie.
  *
  *     id = jsmpeg_hip_live_open(l);                                   a stream joins (any time)

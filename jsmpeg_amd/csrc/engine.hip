@@ -653,12 +653,21 @@ static int recon_by_levels(jsmpeg_hip_batch_t *b, JmReconBufs &rb, const std::ve
 	 * levels -- a picture after its forward reference and, with unwritten macroblocks, after its `stale` frame (a
 	 * root with unwritten macroblocks is done again at its level) -- and one launch per level ---- */
 	tr.mark("roots-enqueued");
+	{
+		/* a pass in which no decoded picture has a forward reference or a `stale` frame INSIDE the pass (a live tick of one
+		 * picture per stream: its references are the streams' rings) has nothing behind its roots whatever the parse reports:
+		 * no wait for it here -- the call returns with everything enqueued; the statistics that need the counts are worked out
+		 * when somebody asks (batch_settle) */
+		bool may_deepen = false;
+		for (uint32_t p = 0; p < b->n_pics && !may_deepen; p++) may_deepen = b->h_pics[p].decoded && (b->h_pics[p].fwd >= 0 || stale[p] >= 0);
+		if (!may_deepen) { b->n_levels = n_roots ? 1 : 0; b->stats_pending = true; return 0; }
+	}
 	HIP_TRY(hipEventSynchronize(b->ev_cov));
 	tr.mark("parse-done");
 	{
 		std::vector<int32_t> level;
 		const uint32_t n_levels = jm_plan_levels(b->h_pics, b->n_pics, stale, b->h_covered, (uint32_t)b->g.mb_size, level, &b->n_uncovered);
-		b->n_levels = n_levels;
+		b->n_levels = n_levels; b->stats_pending = false;
 		std::vector<uint32_t> off(n_levels + 1, 0);
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded && level[p] > 0) off[level[p] + 1]++;
 		for (uint32_t l = 0; l < n_levels; l++) off[l + 1] += off[l];
@@ -916,8 +925,7 @@ static int batch_redo_by_levels(jsmpeg_hip_batch_t *b) {
 	if (recon_by_levels(b, rb, stale, n_roots, b->stream, tr) < 0) return -1;
 	HIP_TRY(hipEventRecord(b->ev_level[b->n_level_ev], b->stream));
 	HIP_TRY(hipStreamSynchronize(b->stream));
-	b->stats_pending = false;
-	return 0;
+	return 0;                     /* (recon_by_levels has said whether the statistics still wait for the parse's counts) */
 }
 
 static int batch_settle(jsmpeg_hip_batch_t *b) {
@@ -1372,26 +1380,38 @@ static void live_compact_stage(jsmpeg_hip_live_t *l) {
 	l->stage_used = at;
 }
 
-/* the stream's staged writes (host memory: no tick has taken them) hold its first sequence header?  Then the stream has it
- * from now on, as if a tick had read it (see jsmpeg_hip_live_write_v) */
-static void live_header_from_staged(jsmpeg_hip_live_t *l, uint32_t stream) {
-	LiveStream &S = l->streams[stream];
-	for (const LiveSeg &g : l->segs) {
-		if (g.stream != stream || g.bytes < 4) continue;
-		const uint8_t *p = l->h_stage + g.stage_off;
-		for (uint32_t q = 0; q + 3 < g.bytes; q++) {
-			if (p[q] != 0 || p[q + 1] != 0 || p[q + 2] != 1 || p[q + 3] != JM_CODE_SEQUENCE) continue;
-			JmStream T;
-			memset(&T, 0, sizeof(T));
-			T.es_begin = 0; T.es_end = g.bytes;                  /* what lies beyond the write reads as 0, like the reference's typed array */
-			const uint32_t sc_pos = q, no_pic = 0;
-			const uint8_t sc_code = JM_CODE_SEQUENCE;
-			jm_index_stream(T, p, &sc_pos, &sc_code, 1, &no_pic, 0, l->cfg.width, l->cfg.height);
-			if (T.seq_sc == JM_NONE) return;
-			S.has_header = true; S.hdr = T; S.status = T.valid ? 0 : 1;
-			return;
+/* The reference looks for its sequence header INSIDE write() (mpeg1.c:812-819): the first 00 00 01 B3 at or behind the cursor
+ * is parsed then and there, and the cursor moves behind it -- so the header survives bytes that are thrown away before
+ * anything was decoded, and the bytes up to its end no longer count against the store (tools/fuzz_live.py found both with
+ * stores of 1.2 pictures).  So a stream WITHOUT a header has the bytes of each write looked at for one, on the host, with the
+ * index kernel's own function (index_tables.h jm_index_stream: host and device) -- the one place the host reads stream
+ * bytes, and only until the stream has its header.  A header that the write cuts short is left to the tick (the index
+ * kernel takes it when it is all there).  Returns the bytes of the write that are consumed by this (0: no header in it). */
+static uint32_t live_header_at_write(jsmpeg_hip_live_t *l, LiveStream &S, const uint8_t *p, uint32_t n) {
+	for (uint32_t q = 0; q + 12 <= n; q++) {
+		if (p[q] != 0 || p[q + 1] != 0 || p[q + 2] != 1 || p[q + 3] != JM_CODE_SEQUENCE) continue;
+		/* 12 + 12 + 4 + 4 + 18 + 1 + 10 + 1 bits, load_intra_quantiser_matrix (+ 64 bytes), load_non_intra_quantiser_matrix (+ 64 bytes):
+		 * 12, 76 or 140 bytes with the start code (mpeg1.c:872-915) */
+		uint32_t end = q + 12;
+		bool non_intra = (p[q + 11] & 1) != 0;
+		if (p[q + 11] & 2) {
+			end += 64;
+			if (end > n) return 0;
+			non_intra = (p[end - 1] & 1) != 0;
 		}
+		if (non_intra) end += 64;
+		if (end > n) return 0;
+		JmStream T;
+		memset(&T, 0, sizeof(T));
+		T.es_begin = 0; T.es_end = n;
+		const uint32_t sc_pos = q, no_pic = 0;
+		const uint8_t sc_code = JM_CODE_SEQUENCE;
+		jm_index_stream(T, p, &sc_pos, &sc_code, 1, &no_pic, 0, l->cfg.width, l->cfg.height);
+		if (T.seq_sc == JM_NONE) return 0;
+		S.has_header = true; S.hdr = T; S.status = T.valid ? 0 : 1;
+		return end;
 	}
+	return 0;
 }
 
 /* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict: ONE write of the buffers' total length */
@@ -1407,12 +1427,7 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 	if ((uint64_t)S.tail_bytes + S.new_bytes + n > l->cfg.store_bytes) {
 		/* buffer.js:37-56: decoded bytes never stand in the way here (a tick drops them), so a write that does not fit finds
 		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store.
-		 * ONE thing of them stays: the reference looks for its sequence header inside write() (mpeg1.c:812-819), so bytes no
-		 * tick has seen may still have given it one -- a decoder that lost its first picture this way decodes the next ones
-		 * all the same.  Here headers are read by the tick's index kernel; for bytes that go before any tick saw them the host
-		 * looks itself, with the kernel's own function (index_tables.h jm_index_stream: host and device): the only time the
-		 * host reads a stream byte (found by tools/fuzz_live.py: stores of 1.2 pictures, three writes in a tick). */
-		if (!S.has_header) live_header_from_staged(l, stream);
+		 * (A sequence header they held is not lost with them: live_header_at_write.) */
 		S.tail_bytes = 0; S.new_bytes = 0;
 		live_drop_staged(l, stream);
 		S.consumed = S.written;
@@ -1427,6 +1442,20 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 		if ((uint64_t)off + n > l->stage_cap) return fail("write: the staging buffer is full (%u bytes written since the last tick): call jsmpeg_hip_live_tick", l->stage_used);
 	}
 	for (uint32_t i = 0, at = off; i < n_buffers; at += lengths[i], i++) if (lengths[i]) memcpy(l->h_stage + at, buffers[i], lengths[i]);
+	uint32_t skip = 0;
+	/* (only into an EMPTY store: undecoded bytes in front of this write may end with the beginning of a header that a write cut
+	 * short -- a tick that takes only what is complete is holding it, or will -- and then the header in THIS write is not the
+	 * stream's first; the tick's index kernel sorts that out) */
+	if (!S.has_header && S.tail_bytes + S.new_bytes == 0 && (skip = live_header_at_write(l, S, l->h_stage + off, n)) != 0) {
+		/* the stream's first sequence header: everything in front of it and the header itself are behind the reference's cursor
+		 * now (mpeg1.c:812-819) -- what was pending goes (without a header the reference's cursor was at the end of its data
+		 * after every write), this write's bytes count from the header's end */
+		S.tail_bytes = 0; S.new_bytes = 0;
+		live_drop_staged(l, stream);
+		S.stamps.clear();
+		S.consumed = S.written + skip;
+	}
+	if (skip) { S.stamps.push_back(LiveStamp{ S.written, pts }); S.written += n; if (n > skip) { l->segs.push_back(LiveSeg{ stream, off + skip, n - skip }); S.new_bytes = n - skip; } l->stage_used = off + n; return 0; }
 	if (!l->segs.empty() && l->segs.back().stream == stream && l->segs.back().bytes && l->segs.back().stage_off + l->segs.back().bytes == off) l->segs.back().bytes += n;
 	else l->segs.push_back(LiveSeg{ stream, off, n });
 	l->stage_used = off + n;

@@ -175,3 +175,19 @@ def test_node_shard_program_two_gpus_over_rccl(hip_lib):
         assert out["data_plane"] == "rccl" and out["pictures_differing_from_unsplit_streams"] == 0 and out["n_gpus"] == 2
     finally:
         shutil.rmtree(td)
+
+
+def test_control_plane_collectives_and_a_rank_that_dies():
+    """the launcher's side of the control plane (jsmpeg_amd/js/shard-hip.js launch / Control) with real processes and no GPU:
+    all-gather, broadcast and barrier in call order across 4 ranks; a rank that dies makes launch() reject (and takes the others down)
+    instead of leaving them in a collective for ever"""
+    script = os.path.join(ROOT, "tests", "js", "control_rank.js")
+    code = ("const {launch}=require(%r);launch({world:4,script:%r,args:[process.argv[1]],devices:[3,2,1,0],rehearse:true})"
+            ".then(r=>console.log(JSON.stringify({ok:r}))).catch(e=>console.log(JSON.stringify({error:String(e.message)})))"
+            % (os.path.join(ROOT, "jsmpeg_amd", "js", "shard-hip.js"), script))
+    out = json.loads(subprocess.check_output([NODE, "-e", code, "ok"], timeout=60))
+    assert [r["a"] for r in out["ok"]] == [[0, 1, 4, 9]] * 4
+    assert [r["b"] for r in out["ok"]] == ["from 2"] * 4 and [r["d"] for r in out["ok"]] == [[100, 101, 102, 103]] * 4
+    assert [r["device"] for r in out["ok"]] == [3, 2, 1, 0] and all(r["rehearse"] == "1" for r in out["ok"])
+    out = json.loads(subprocess.check_output([NODE, "-e", code, "crash"], timeout=60))
+    assert "rank 1 ended with code 7" in out["error"]

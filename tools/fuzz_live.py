@@ -90,7 +90,7 @@ for c in range(cases):
             t += 1
         want = [oracle_ticks([row.get(s, []) for row in plan], store) for s in range(n_streams)]
         with jl.Live(ov["width"], ov["height"], n_streams, pictures_per_tick=16, store_bytes=store) as lv:    # (the limit counts picture start codes: B / D pictures too)
-            ids = {}
+            ids, last_live = {}, {}
             for t, row in enumerate(plan):
                 for s in range(n_streams):
                     if join[s] == t or (t == 0 and join[s] == 0):
@@ -102,7 +102,11 @@ for c in range(cases):
                 hs = lv.frame_hashes()
                 per = {}
                 for i, p in enumerate(lv.pictures()):
-                    per.setdefault(p.stream, []).append(int(hs[i]))
+                    # (a decoded picture identical to the one before it -- nothing coded, zero vectors -- is dropped on both sides: the
+                    # oracle's list cannot tell it from a consumed-not-decoded picture's repeat)
+                    if int(hs[i]) != last_live.get(p.stream):
+                        per.setdefault(p.stream, []).append(int(hs[i]))
+                    last_live[p.stream] = int(hs[i])
                 pictures += len(hs)
                 for s, i in ids.items():
                     if per.get(i, []) != want[s][t]:
@@ -159,24 +163,20 @@ for c in range(cases):
                         break
                     before = now
         for s in range(n_streams):
+            got[s] = [x for k, x in enumerate(got[s]) if k == 0 or x != got[s][k - 1]]
             if got[s] != want[s]:
                 why.append("stream %d: %d vs %d pictures, first diff %s" % (s, len(got[s]), len(want[s]), [i for i, (a, b) in enumerate(zip(got[s], want[s])) if a != b][:3]))
     else:
         tss = [synth.mux_ts(g[0], g[1]) for g in gen]
-        want, want_pts = [], []
-        for ts in tss:
-            demuxed, writes = checkers.oracle_ts_demux(ORACLE, ts, 0xE0)
-            given = demuxed[:sum(x[2] for x in writes)]
-            # a decoder fed the demuxer's writes, `while (decode());` after each: what a FLUSH tick per round gives in total
-            hs = [x for tick in oracle_ticks([[given[o:o + ln]] for _, o, ln in writes], 2 * len(given) + 4096) for x in tick]
-            want.append(hs)
         got = [[] for _ in range(n_streams)]
+        rounds = [[] for _ in range(n_streams)]             # per stream: the piece it was handed in every round (0: none)
         with jl.Live(ov["width"], ov["height"], n_streams, pictures_per_tick=16, store_bytes=2 * max(len(g[0]) for g in gen) + 4096) as lv:
             ids = [lv.open() for _ in range(n_streams)]
             at = [0] * n_streams
             while any(at[s] < len(tss[s]) for s in range(n_streams)):
                 for s in range(n_streams):
                     k = min(len(tss[s]) - at[s], int(rng.choice([1, 50, 187, 188, 189, 1000, 5000])))
+                    rounds[s].append(k)
                     if k > 0:
                         lv.write_ts(ids[s], tss[s][at[s]:at[s] + k])
                         at[s] += k
@@ -185,10 +185,39 @@ for c in range(cases):
                 for i, p in enumerate(lv.pictures()):
                     got[ids.index(p.stream)].append(int(hs[i]))
                 pictures += len(hs)
+            # (a tick looks at 16 picture start codes per stream: a piece of 5000 bytes can bring more of these tiny pictures)
+            before = None
+            for _ in range(8 * n + 8):
+                now = [lv.stream_info(i).pending_bytes for i in ids]
+                if now == before or not any(now):
+                    break
+                before = now
+                lv.tick(flush=True)
+                hs = lv.frame_hashes()
+                for i, p in enumerate(lv.pictures()):
+                    got[ids.index(p.stream)].append(int(hs[i]))
+                pictures += len(hs)
         for s in range(n_streams):
-            # ticks fall at other places than the oracle's (whole PES at a time vs pieces): compare the streams' pictures in order
-            if got[s] != want[s]:
-                why.append("ts stream %d: %d vs %d pictures" % (s, len(got[s]), len(want[s])))
+            # the oracle's decoder fed what the reference demuxer's restatement delivers for the same pieces, `while (decode());`
+            # at the same points: after the writes each round completed
+            sizes = [k for k in rounds[s] if k]
+            demuxed, writes = checkers.oracle_ts_demux(ORACLE, tss[s], 0xE0, sizes)
+            done_after, cum = [], 0
+            for k in rounds[s]:
+                if k:
+                    cum += k
+                    n_w = len(checkers.oracle_ts_demux(ORACLE, tss[s][:cum], 0xE0, [x for x in sizes[:len([y for y in rounds[s][:len(done_after) + 1] if y])]])[1])
+                else:
+                    n_w = done_after[-1] if done_after else 0
+                done_after.append(n_w)
+            groups, prev = [], 0
+            for n_w in done_after:
+                groups.append([demuxed[o:o + ln] for _, o, ln in writes[prev:n_w]])
+                prev = n_w
+            want_s = [x for tick in oracle_ticks(groups, 2 * max(len(g[0]) for g in gen) + 4096) for x in tick]
+            got[s] = [x for k, x in enumerate(got[s]) if k == 0 or x != got[s][k - 1]]
+            if got[s] != want_s:
+                why.append("ts stream %d: %d vs %d pictures" % (s, len(got[s]), len(want_s)))
     if why:
         bad += 1
         print("case %d MISMATCH [%s] (%s): frames=%d streams=%d K=%d params=%r" % (c, mode, "; ".join(why[:4]), n, n_streams, K, ov), flush=True)
