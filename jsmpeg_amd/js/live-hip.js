@@ -135,6 +135,9 @@ function install(JSMpeg, options) {
     if (!this.live) throw new Error('HIPLiveStream: the stream is closed');
     this.bytesWritten += this.live.native.liveWrite(this.live.handle, this.id, pts, buffers);
     this.canPlay = true;
+    // mpeg1-wasm.js:72-78: the header is polled after every write until it is there (the library takes a header that a write
+    // brings whole at write time, like the reference; one that arrives in pieces when a tick has seen all of it)
+    if (!this.hasSequenceHeader) this.pollSequenceHeader();
   };
   // the stream as MPEG-TS bytes in any pieces: the library's own restatement of ts.js (state kept per stream) in front of write() --
   // for hosts that do not have jsmpeg's demuxer loaded; with it loaded, demuxer.connect(VIDEO_1, stream) is the same thing
