@@ -159,7 +159,7 @@ struct jsmpeg_hip_batch_t {
 	bool timed;
 	uint32_t *h_counters; /* pinned */
 	/* LIVE (jsmpeg_hip_live_t below: a batch pass over what has arrived of streams that go on): the pool holds
-	 * `pool_frames` frames (>= max_pictures), and picture p of a pass is written to pool slot slot[p] -- a live stream
+	 * `pool_frames` frames (the streams' rings), and picture p of a pass is written to pool slot slot[p] -- a live stream
 	 * owns a ring of slots, so that the frames of its last two decoded pictures are still there, untouched, when the next
 	 * pass predicts from them.  slot empty: picture p = slot p (every other batch). */
 	uint32_t pool_frames;
@@ -230,7 +230,8 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(hipMemset(b->d_mb, 0, mb_bytes));
 	HIP_TRY(hipDeviceSynchronize());   /* the memsets ran on the null stream; decode may use a stream that is not ordered against it */
 	HIP_TRY(jm_malloc(&b->d_tokens, b->es_cap * JM_TOKENS_PER_BYTE * sizeof(uint16_t)));
-	b->pool_frames = std::max(b->pool_frames, std::max(1u, c.max_pictures));
+	/* live: the rings and nothing else (max_pictures there counts the start codes a pass may SEE, a thousand per stream) */
+	if (!b->pool_frames) b->pool_frames = std::max(1u, c.max_pictures);
 	size_t pool_bytes = (size_t)b->g.frame_bytes * b->pool_frames + 2 * POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_pool_alloc, pool_bytes));
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
@@ -1259,6 +1260,10 @@ struct jsmpeg_hip_live_t {
 	jsmpeg_hip_batch_t *b;
 	uint32_t ring;                      /* frames per stream */
 	uint8_t *h_stage; uint32_t stage_cap, stage_used;
+	/* staged bytes go to the device WHILE the host is still writing (a copy stream of the handle's own, a chunk at a time): a
+	 * tick then uploads only what the last chunk left.  stage_sent: bytes of h_stage already enqueued (0 again after anything
+	 * moved staged bytes); the tick's stream waits for ev_sent before it reads the arena */
+	hipStream_t up_stream; hipEvent_t ev_sent; uint32_t stage_sent, up_chunk;
 	uint8_t *d_arena; uint32_t es_off[2], es_cap; int cur;
 	uint32_t *h_tab, *d_tab; uint32_t tab_cap;   /* placement tables of a pass: source offsets | destination offsets | lengths */
 	std::vector<LiveSeg> segs;
@@ -1274,6 +1279,8 @@ static void live_free(jsmpeg_hip_live_t *l) {
 	if (!l) return;
 	for (LiveStream &S : l->streams) { delete S.ts; S.ts = nullptr; }
 	if (l->b) { hipSetDevice(l->b->device); hipDeviceSynchronize(); l->b->live = nullptr; batch_free(l->b); }
+	if (l->up_stream) hipStreamDestroy(l->up_stream);
+	if (l->ev_sent) hipEventDestroy(l->ev_sent);
 	if (l->h_stage) hipHostFree(l->h_stage);
 	if (l->h_tab) hipHostFree(l->h_tab);
 	if (l->h_back) hipHostFree(l->h_back);
@@ -1284,6 +1291,8 @@ static void live_free(jsmpeg_hip_live_t *l) {
 static int live_alloc(jsmpeg_hip_live_t *l) {
 	const uint32_t ms = l->cfg.max_streams;
 	HIP_TRY(hipHostMalloc(&l->h_stage, l->stage_cap, hipHostMallocDefault));
+	HIP_TRY(hipStreamCreateWithFlags(&l->up_stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&l->ev_sent, hipEventDisableTiming));
 	HIP_TRY(jm_malloc(&l->d_arena, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
 	HIP_TRY(hipMemset(l->d_arena, 0xff, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
 	l->tab_cap = 4 * ms + 64;
@@ -1292,6 +1301,20 @@ static int live_alloc(jsmpeg_hip_live_t *l) {
 	HIP_TRY(hipHostMalloc(&l->h_back, sizeof(JmStream) * (size_t)ms, hipHostMallocDefault));
 	HIP_TRY(jm_malloc(&l->d_slots, sizeof(uint32_t) * (size_t)ms * (l->ring - 2)));
 	HIP_TRY(jm_malloc(&l->d_hashes, sizeof(uint64_t) * (size_t)ms * (l->ring - 2)));
+	/* the copy stream's first copies and the runtime's growing pools of completion signals cost milliseconds each (measured: 9 ms
+	 * in the first tick's writes, 8 ms once more some thirty copies later): paid here, not in a tick */
+	if (l->up_chunk) {
+		const uint32_t piece = std::min(l->stage_cap / 2, l->up_chunk);
+		for (int tick = 0; tick < 12; tick++) {                      /* the shape of a tick's traffic: chunks beside the host, the rest and the tables' way back on the tick's stream */
+			for (int i = 0; i < 4; i++) HIP_TRY(hipMemcpyAsync(l->d_arena, l->h_stage, piece, hipMemcpyHostToDevice, l->up_stream));
+			HIP_TRY(hipEventRecord(l->ev_sent, l->up_stream));
+			HIP_TRY(hipStreamWaitEvent(nullptr, l->ev_sent, 0));
+			HIP_TRY(hipMemcpyAsync(l->d_arena + piece, l->h_stage + piece, piece, hipMemcpyHostToDevice, nullptr));
+			HIP_TRY(hipMemcpyAsync(l->h_back, l->d_arena, std::min<size_t>(sizeof(JmStream) * (size_t)ms, piece), hipMemcpyDeviceToHost, nullptr));
+			HIP_TRY(hipStreamSynchronize(nullptr));
+		}
+		HIP_TRY(hipMemsetAsync(l->d_arena, 0xff, 2 * (size_t)piece, nullptr));
+	}
 	HIP_TRY(hipDeviceSynchronize());
 	return 0;
 }
@@ -1308,6 +1331,8 @@ extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_confi
 	if (!l->cfg.store_bytes) l->cfg.store_bytes = 512 * 1024;          /* mpeg1-wasm.js:9 */
 	l->b = nullptr; l->h_stage = nullptr; l->d_arena = nullptr; l->h_tab = nullptr; l->d_tab = nullptr; l->h_back = nullptr;
 	l->d_slots = nullptr; l->d_hashes = nullptr; l->d_rgba = nullptr; l->stage_used = 0; l->cur = 0; l->tab_cap = 0;
+	l->up_stream = nullptr; l->ev_sent = nullptr; l->stage_sent = 0;
+	{ const char *v = getenv("JSMPEG_HIP_LIVE_UPLOAD_CHUNK"); l->up_chunk = v ? (uint32_t)strtoul(v, nullptr, 0) : (1u << 20); }   /* 0: everything at the tick */
 	for (float &m : l->ms) m = 0.f;
 	const uint64_t all_stores = (uint64_t)l->cfg.max_streams * l->cfg.store_bytes;
 	const uint64_t per_tick = (uint64_t)l->cfg.max_streams * l->cfg.max_pictures_per_tick;
@@ -1378,6 +1403,16 @@ static void live_compact_stage(jsmpeg_hip_live_t *l) {
 	}
 	l->segs.resize(k);
 	l->stage_used = at;
+	l->stage_sent = 0;            /* what was sent lies elsewhere now: the next copy (behind the ones in flight, same stream) sends it all again */
+}
+
+/* a chunk's worth of staged bytes is waiting: send it now, beside the host's next writes */
+static inline int live_send_staged(jsmpeg_hip_live_t *l) {
+	if (!l->up_chunk || l->stage_used - l->stage_sent < l->up_chunk) return 0;
+	HIP_TRY(hipSetDevice(l->b->device));
+	HIP_TRY(hipMemcpyAsync(l->d_arena + l->stage_sent, l->h_stage + l->stage_sent, l->stage_used - l->stage_sent, hipMemcpyHostToDevice, l->up_stream));
+	l->stage_sent = l->stage_used;
+	return 0;
 }
 
 /* The reference looks for its sequence header INSIDE write() (mpeg1.c:812-819): the first 00 00 01 B3 at or behind the cursor
@@ -1455,13 +1490,13 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 		S.stamps.clear();
 		S.consumed = S.written + skip;
 	}
-	if (skip) { S.stamps.push_back(LiveStamp{ S.written, pts }); S.written += n; if (n > skip) { l->segs.push_back(LiveSeg{ stream, off + skip, n - skip }); S.new_bytes = n - skip; } l->stage_used = off + n; return 0; }
+	if (skip) { S.stamps.push_back(LiveStamp{ S.written, pts }); S.written += n; if (n > skip) { l->segs.push_back(LiveSeg{ stream, off + skip, n - skip }); S.new_bytes = n - skip; } l->stage_used = off + n; return live_send_staged(l); }
 	if (!l->segs.empty() && l->segs.back().stream == stream && l->segs.back().bytes && l->segs.back().stage_off + l->segs.back().bytes == off) l->segs.back().bytes += n;
 	else l->segs.push_back(LiveSeg{ stream, off, n });
 	l->stage_used = off + n;
 	S.stamps.push_back(LiveStamp{ S.written, pts });
 	S.written += n; S.new_bytes += n;
-	return 0;
+	return live_send_staged(l);
 }
 
 extern "C" int jsmpeg_hip_live_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *bytes, uint32_t n) {
@@ -1620,7 +1655,7 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 		if (S.tail_bytes + S.new_bytes) l->pass_stream.push_back(s);
 	}
 	const uint32_t n = (uint32_t)l->pass_stream.size();
-	if (n == 0) { l->segs.clear(); l->stage_used = 0; return 0; }
+	if (n == 0) { l->segs.clear(); l->stage_used = 0; l->stage_sent = 0; return 0; }
 
 	/* ---- 2. the pass's ES buffer: per stream the tail the last tick left, then the new writes in order ---- */
 	const int cur = l->cur;
@@ -1664,7 +1699,11 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 		max_len = std::max(max_len, g.bytes); n_tab++;
 	}
 	uint8_t *es = l->d_arena + l->es_off[cur];
-	if (l->stage_used) HIP_TRY(hipMemcpyAsync(l->d_arena, l->h_stage, l->stage_used, hipMemcpyHostToDevice, st));
+	if (l->stage_sent) {                                             /* the chunks sent while the host was writing: this stream reads the arena behind them */
+		HIP_TRY(hipEventRecord(l->ev_sent, l->up_stream));
+		HIP_TRY(hipStreamWaitEvent(st, l->ev_sent, 0));
+	}
+	if (l->stage_used > l->stage_sent) HIP_TRY(hipMemcpyAsync(l->d_arena + l->stage_sent, l->h_stage + l->stage_sent, l->stage_used - l->stage_sent, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(l->d_tab, l->h_tab, sizeof(uint32_t) * 3 * (size_t)l->tab_cap, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(es, 0xff, (size_t)total + JM_ES_PAD, st));
 	HIP_TRY(jm_launch_place(l->d_arena, es, l->d_tab, l->d_tab + l->tab_cap, l->d_tab + 2 * (size_t)l->tab_cap, n_tab, max_len, st));
@@ -1696,7 +1735,7 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 			LiveStream &S = l->streams[l->pass_stream[i]];
 			S.consumed += (uint64_t)S.tail_bytes + S.new_bytes; S.tail_bytes = S.new_bytes = 0; S.stamps.clear(); S.evictions++;
 		}
-		l->segs.clear(); l->stage_used = 0;
+		l->segs.clear(); l->stage_used = 0; l->stage_sent = 0;
 		return fail("live tick refused, the pending bytes of its %u streams were dropped: %.300s", n, why);
 	}
 	if (need_back) HIP_TRY(hipMemcpyAsync(l->h_back, b->d_streams, sizeof(JmStream) * n, hipMemcpyDeviceToHost, st));
@@ -1741,7 +1780,7 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 		while (S.stamps.size() > 1 && S.stamps[1].at <= S.consumed) S.stamps.pop_front();
 		S.head = (S.head + n_dec) % l->ring; S.have = std::min(2u, S.have + n_dec); S.pictures += n_dec;
 	}
-	l->segs.clear(); l->stage_used = 0; l->cur = cur ^ 1;
+	l->segs.clear(); l->stage_used = 0; l->stage_sent = 0; l->cur = cur ^ 1;
 	l->ms[3] = (float)live_ms_since(t_book);
 	l->ms[4] = (float)live_ms_since(t_begin);
 	float bt[5];

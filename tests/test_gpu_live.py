@@ -364,11 +364,18 @@ def test_live_damaged_streams_do_not_disturb_their_neighbours(hip_lib, libs):
         assert all(lv.stream_info(i).pending_bytes == 0 for i in (noise, flipped, cut))
 
 
-def test_live_fuzz_short_run(hip_lib, libs):
+@pytest.mark.parametrize("chunk", [None, "3000"], ids=["default", "staged_bytes_sent_every_3000"])
+def test_live_fuzz_short_run(hip_lib, libs, chunk):
     """tools/fuzz_live.py: random sizes / syntax / feeding (whole pictures with small stores that evict, arbitrary byte pieces,
-    TS in pieces), streams joining at random ticks -- a short run of the sweep whose long runs are profiles/r06_fuzz_live.txt"""
+    TS in pieces), streams joining at random ticks -- a short run of the sweep whose long runs are profiles/r06_fuzz_live.txt.
+    Second form: the staged bytes go to the device in chunks while the host is still writing (engine.hip live_send_staged;
+    1 MiB by default, more than these small pictures ever stage) -- with a chunk of 3000 bytes every case sends many, around
+    evacuations and compactions of the staging buffer."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live.py"), "30", "77"], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ)
+    if chunk:
+        env["JSMPEG_HIP_LIVE_UPLOAD_CHUNK"] = chunk
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live.py"), "30", "77"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout

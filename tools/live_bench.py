@@ -77,7 +77,8 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         i_ticks = [i for i in range(len(ticks)) if gop and i % gop == 0 and i > 0]
         med = lambda xs: float(np.median(xs)) if len(xs) else None
         out.update(ticks=len(ticks), pictures=n_out, pictures_differing_from_oracle=bad if check else None,
-                   ms_per_tick_median=med(all_ms[1:]), ms_per_tick_p_pictures=med(all_ms[p_ticks]), ms_per_tick_i_pictures=med(all_ms[i_ticks]),
+                   ms_per_tick_median=med(all_ms[1:]), ms_per_tick_max=float(all_ms[1:].max()) if len(all_ms) > 1 else None,
+                   ms_per_tick_each=[round(float(x), 3) for x in all_ms], ms_writes_each=[round(t[1] * 1e3, 3) for t in ticks], ms_per_tick_p_pictures=med(all_ms[p_ticks]), ms_per_tick_i_pictures=med(all_ms[i_ticks]),
                    ms_writes_median=med([ticks[i][1] * 1e3 for i in p_ticks]), ms_tick_call_median=med([ticks[i][2] * 1e3 for i in p_ticks]),
                    pictures_per_s=n_out / sum(t[0] for t in ticks[1:]) * (len(ticks) - 1) / len(ticks) if len(ticks) > 1 else None,
                    parts_ms_p_tick={k2: med([parts[i][k2] for i in p_ticks]) for k2 in parts[0]},
@@ -89,6 +90,10 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         "%.0f pictures/s overall; differing from the oracle: %s" % (streams, per_tick, out["ms_per_tick_p_pictures"] or -1, out["ms_writes_median"] or -1, out["ms_tick_call_median"] or -1,
                                                                    out["ms_per_tick_i_pictures"] or -1, out["pictures_per_s"] or -1, out["pictures_differing_from_oracle"]))
     say("      parts of a P tick (ms):", {k2: round(v, 3) for k2, v in out["parts_ms_p_tick"].items()})
+    say("      every tick (ms):", out["ms_per_tick_each"])
+    say("      its writes (ms):", out["ms_writes_each"])
+    worst = int(np.argmax(all_ms[1:])) + 1 if len(all_ms) > 1 else 0
+    say("      the slowest tick (%d) in parts:" % worst, {k2: round(v, 3) for k2, v in parts[worst].items()})
     # the one-picture ABI driven the same way: a decoder per stream, a picture written, a picture decoded (planes to the host)
     if abi_streams:
         k_abi = min(abi_streams, streams)
