@@ -527,6 +527,16 @@ int jsmpeg_hip_ts_demux_host(const uint8_t *ts, uint64_t ts_bytes, const uint64_
  * Returns the number of pictures decoded in this tick (all streams) or < 0. */
 #define JSMPEG_HIP_LIVE_FLUSH 1u
 int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream);
+/* The same tick in two halves, for a host that has better things to do than wait for the GPU (a Node event loop; the
+ * sockets the next pictures arrive on).  _begin lays the pass out, uploads it and enqueues all of it (it returns after the
+ * start-code index's turn-around: about a fifth of the tick), _end waits and does the book-keeping and returns what
+ * jsmpeg_hip_live_tick returns.  BETWEEN them jsmpeg_hip_live_write / _write_v / _write_ts are allowed and are what they
+ * always are to the streams -- writes made right behind the tick: their bytes are copied to the staging buffer at once
+ * (that is the work), their place in the stream's store (buffer.js:37-104: room, evacuation, the first header) is
+ * decided when the tick has ended, in order.  Any other call on the handle between the halves ends the tick first (and
+ * sees its pictures); a second _begin is an error.  _end without a tick in flight returns the last tick's count. */
+int jsmpeg_hip_live_tick_begin(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream);
+int jsmpeg_hip_live_tick_end(jsmpeg_hip_live_t *l);
 /* The pictures of the last tick: stream by stream (ascending id), in decode order inside a stream. */
 uint32_t jsmpeg_hip_live_picture_count(jsmpeg_hip_live_t *l);
 int jsmpeg_hip_live_picture(jsmpeg_hip_live_t *l, uint32_t i, jsmpeg_hip_live_picture_t *out);

@@ -1241,12 +1241,14 @@ struct LiveTs {
 	std::vector<uint8_t> joined;                       /* scratch: leftover + the new bytes */
 	uint64_t writes;                                   /* destination.write calls made so far */
 };
+struct LiveDeferred { uint32_t stream; double pts; uint32_t off, n; };
 struct LiveStream {
 	bool open, has_header;
 	int status;
 	JmStream hdr;                       /* the index kernel's record of the stream's first sequence header */
 	uint32_t tail_off, tail_bytes;      /* undecoded bytes the last tick left: arena offset, length */
 	uint32_t new_bytes;                 /* written since (in the staging buffer) */
+	uint32_t defer_bytes;               /* written while a tick is in flight (staged, not yet accounted for) */
 	uint64_t written, consumed;         /* bytes ever written; stream offset of the first pending byte */
 	uint32_t head, have;                /* ring slot of the picture decoded last; pictures decoded so far (saturates at 2) */
 	std::deque<LiveStamp> stamps;       /* write(): stream offset, pts */
@@ -1264,6 +1266,12 @@ struct jsmpeg_hip_live_t {
 	 * tick then uploads only what the last chunk left.  stage_sent: bytes of h_stage already enqueued (0 again after anything
 	 * moved staged bytes); the tick's stream waits for ev_sent before it reads the arena */
 	hipStream_t up_stream; hipEvent_t ev_sent; uint32_t stage_sent, up_chunk;
+	/* a tick in two halves (jsmpeg_hip_live_tick_begin / _end): between them the pass is on the device and the host may go on
+	 * WRITING -- such a write is staged at once (the copy is the work) and ACCOUNTED for when the tick has ended, in order, by the
+	 * same rules as any write (live_account_write): to the streams it is a write made right behind the tick */
+	bool in_flight; int last_n;
+	struct { uint32_t n; int cur, n_pics; bool flush, need_back; std::chrono::steady_clock::time_point t_begin; } fl;
+	std::vector<LiveDeferred> deferred;
 	uint8_t *d_arena; uint32_t es_off[2], es_cap; int cur;
 	uint32_t *h_tab, *d_tab; uint32_t tab_cap;   /* placement tables of a pass: source offsets | destination offsets | lengths */
 	std::vector<LiveSeg> segs;
@@ -1274,6 +1282,10 @@ struct jsmpeg_hip_live_t {
 	uint32_t *d_slots; uint64_t *d_hashes; uint8_t *d_rgba;
 	float ms[9];
 };
+
+static int live_tick_end_impl(jsmpeg_hip_live_t *l);
+/* anything but a write finds the tick ended (its pictures are what the call then sees) */
+static inline int live_settle(jsmpeg_hip_live_t *l) { return l && l->in_flight ? (live_tick_end_impl(l) < 0 ? -1 : 0) : 0; }
 
 static void live_free(jsmpeg_hip_live_t *l) {
 	if (!l) return;
@@ -1332,6 +1344,7 @@ extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_confi
 	l->b = nullptr; l->h_stage = nullptr; l->d_arena = nullptr; l->h_tab = nullptr; l->d_tab = nullptr; l->h_back = nullptr;
 	l->d_slots = nullptr; l->d_hashes = nullptr; l->d_rgba = nullptr; l->stage_used = 0; l->cur = 0; l->tab_cap = 0;
 	l->up_stream = nullptr; l->ev_sent = nullptr; l->stage_sent = 0;
+	l->in_flight = false; l->last_n = 0;
 	{ const char *v = getenv("JSMPEG_HIP_LIVE_UPLOAD_CHUNK"); l->up_chunk = v ? (uint32_t)strtoul(v, nullptr, 0) : (1u << 20); }   /* 0: everything at the tick */
 	for (float &m : l->ms) m = 0.f;
 	const uint64_t all_stores = (uint64_t)l->cfg.max_streams * l->cfg.store_bytes;
@@ -1369,6 +1382,7 @@ static void live_drop_staged(jsmpeg_hip_live_t *l, uint32_t stream) {
 extern "C" int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l) {
 	g_err[0] = 0;
 	if (!l) return fail("null live handle");
+	if (live_settle(l) < 0) return -1;
 	for (uint32_t s = 0; s < l->streams.size(); s++) {
 		LiveStream &S = l->streams[s];
 		if (S.open) continue;
@@ -1384,6 +1398,7 @@ extern "C" int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l) {
 extern "C" int jsmpeg_hip_live_close(jsmpeg_hip_live_t *l, uint32_t stream) {
 	g_err[0] = 0;
 	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("close: stream %u is not open", stream);
+	if (live_settle(l) < 0) return -1;
 	l->streams[stream].open = false;
 	delete l->streams[stream].ts; l->streams[stream].ts = nullptr;
 	live_drop_staged(l, stream);
@@ -1449,34 +1464,31 @@ static uint32_t live_header_at_write(jsmpeg_hip_live_t *l, LiveStream &S, const 
 	return 0;
 }
 
-/* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict: ONE write of the buffers' total length */
-extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths, uint32_t n_buffers) {
-	g_err[0] = 0;
-	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("write: stream %u is not open", stream);
-	uint64_t total = 0;
-	for (uint32_t i = 0; i < n_buffers; i++) { if (lengths[i] && !buffers[i]) return fail("write: null buffer"); total += lengths[i]; }
-	if (total == 0) return 0;
-	if (total > l->cfg.store_bytes) return fail("write of %llu bytes > the stream's store of %u bytes (the reference's store throws a RangeError there)", (unsigned long long)total, l->cfg.store_bytes);
-	const uint32_t n = (uint32_t)total;
+/* bytes of a stream that has no sequence header yet: could a header BEGIN in them (a 00 00 01 B3 that live_header_at_write
+ * did not take: cut short by the write's end) or at their very end (a start code's first one to three bytes)? */
+static bool live_may_begin_header(const uint8_t *p, uint32_t n) {
+	for (uint32_t q = 0; q + 4 <= n; q++) if (p[q] == 0 && p[q + 1] == 0 && p[q + 2] == 1 && p[q + 3] == JM_CODE_SEQUENCE) return true;
+	if (n >= 3 && p[n - 3] == 0 && p[n - 2] == 0 && p[n - 1] == 1) return true;
+	if (n >= 2 && p[n - 2] == 0 && p[n - 1] == 0) return true;
+	return n >= 1 && p[n - 1] == 0;
+}
+
+/* buffer.js:37-56: decoded bytes never stand in the way of a write (a tick drops them), so a write that does not fit finds
+ * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store.
+ * (A sequence header they held is not lost with them: live_header_at_write.) */
+static inline void live_make_room(jsmpeg_hip_live_t *l, uint32_t stream, uint32_t n) {
 	LiveStream &S = l->streams[stream];
-	if ((uint64_t)S.tail_bytes + S.new_bytes + n > l->cfg.store_bytes) {
-		/* buffer.js:37-56: decoded bytes never stand in the way here (a tick drops them), so a write that does not fit finds
-		 * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store.
-		 * (A sequence header they held is not lost with them: live_header_at_write.) */
-		S.tail_bytes = 0; S.new_bytes = 0;
-		live_drop_staged(l, stream);
-		S.consumed = S.written;
-		S.stamps.clear();
-		S.evictions++;
-	}
-	const uint32_t residue = (S.tail_bytes + S.new_bytes) & 15u;      /* where the bytes will lie in the pass's ES buffer, modulo 16 */
-	uint32_t off = l->stage_used + ((residue - l->stage_used) & 15u);
-	if ((uint64_t)off + n > l->stage_cap) {
-		live_compact_stage(l);
-		off = l->stage_used + ((residue - l->stage_used) & 15u);
-		if ((uint64_t)off + n > l->stage_cap) return fail("write: the staging buffer is full (%u bytes written since the last tick): call jsmpeg_hip_live_tick", l->stage_used);
-	}
-	for (uint32_t i = 0, at = off; i < n_buffers; at += lengths[i], i++) if (lengths[i]) memcpy(l->h_stage + at, buffers[i], lengths[i]);
+	if ((uint64_t)S.tail_bytes + S.new_bytes + n <= l->cfg.store_bytes) return;
+	S.tail_bytes = 0; S.new_bytes = 0;
+	live_drop_staged(l, stream);
+	S.consumed = S.written;
+	S.stamps.clear();
+	S.evictions++;
+}
+
+/* the bytes of a write lie at h_stage + off: what they are to the stream (header, stamps, the segment the tick will place) */
+static void live_account_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, uint32_t off, uint32_t n) {
+	LiveStream &S = l->streams[stream];
 	uint32_t skip = 0;
 	/* (only into an EMPTY store: undecoded bytes in front of this write may end with the beginning of a header that a write cut
 	 * short -- a tick that takes only what is complete is holding it, or will -- and then the header in THIS write is not the
@@ -1489,13 +1501,60 @@ extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, do
 		live_drop_staged(l, stream);
 		S.stamps.clear();
 		S.consumed = S.written + skip;
+		S.stamps.push_back(LiveStamp{ S.written, pts });
+		S.written += n;
+		if (n > skip) { l->segs.push_back(LiveSeg{ stream, off + skip, n - skip }); S.new_bytes = n - skip; }
+		return;
 	}
-	if (skip) { S.stamps.push_back(LiveStamp{ S.written, pts }); S.written += n; if (n > skip) { l->segs.push_back(LiveSeg{ stream, off + skip, n - skip }); S.new_bytes = n - skip; } l->stage_used = off + n; return live_send_staged(l); }
+	/* no header, none in sight, and nothing in these bytes that could be the beginning of one: the reference's write() has
+	 * searched them and left its cursor at their end (mpeg1.c:812-819, buffer.c:73-86) -- they are behind it, they do not count
+	 * against the store (found by a test with noise in front of the video and a store of 1.2 pictures) */
+	if (!S.has_header && S.tail_bytes + S.new_bytes == 0 && !live_may_begin_header(l->h_stage + off, n)) {
+		S.written += n; S.consumed = S.written;
+		return;
+	}
 	if (!l->segs.empty() && l->segs.back().stream == stream && l->segs.back().bytes && l->segs.back().stage_off + l->segs.back().bytes == off) l->segs.back().bytes += n;
 	else l->segs.push_back(LiveSeg{ stream, off, n });
-	l->stage_used = off + n;
 	S.stamps.push_back(LiveStamp{ S.written, pts });
 	S.written += n; S.new_bytes += n;
+}
+
+/* decoder.js:36-47 write(pts, buffers) -> buffer.js:64-104 write / evict: ONE write of the buffers' total length */
+extern "C" int jsmpeg_hip_live_write_v(jsmpeg_hip_live_t *l, uint32_t stream, double pts, const void *const *buffers, const uint32_t *lengths, uint32_t n_buffers) {
+	g_err[0] = 0;
+	if (!l || stream >= l->streams.size() || !l->streams[stream].open) return fail("write: stream %u is not open", stream);
+	uint64_t total = 0;
+	for (uint32_t i = 0; i < n_buffers; i++) { if (lengths[i] && !buffers[i]) return fail("write: null buffer"); total += lengths[i]; }
+	if (total == 0) return 0;
+	if (total > l->cfg.store_bytes) return fail("write of %llu bytes > the stream's store of %u bytes (the reference's store throws a RangeError there)", (unsigned long long)total, l->cfg.store_bytes);
+	const uint32_t n = (uint32_t)total;
+	LiveStream &S = l->streams[stream];
+	if (l->in_flight) {
+		/* a tick is on the device (the staging buffer is free again: the pass has its bytes): the copy now, the accounting when
+		 * the tick has ended.  Where the bytes will lie modulo 16 is a guess (the tick usually leaves nothing behind); a
+		 * wrong one costs the placement its 16-byte form for this piece, nothing else */
+		const uint32_t residue = S.defer_bytes & 15u;
+		const uint32_t off = l->stage_used + ((residue - l->stage_used) & 15u);
+		if ((uint64_t)off + n <= l->stage_cap) {
+			for (uint32_t i = 0, at = off; i < n_buffers; at += lengths[i], i++) if (lengths[i]) memcpy(l->h_stage + at, buffers[i], lengths[i]);
+			l->deferred.push_back(LiveDeferred{ stream, pts, off, n });
+			S.defer_bytes += n;
+			l->stage_used = off + n;
+			return live_send_staged(l);
+		}
+		if (live_tick_end_impl(l) < 0) return -1;                    /* no room beside the tick: the write waits for it (its pictures stay readable) */
+	}
+	live_make_room(l, stream, n);
+	const uint32_t residue = (S.tail_bytes + S.new_bytes) & 15u;      /* where the bytes will lie in the pass's ES buffer, modulo 16 */
+	uint32_t off = l->stage_used + ((residue - l->stage_used) & 15u);
+	if ((uint64_t)off + n > l->stage_cap) {
+		live_compact_stage(l);
+		off = l->stage_used + ((residue - l->stage_used) & 15u);
+		if ((uint64_t)off + n > l->stage_cap) return fail("write: the staging buffer is full (%u bytes written since the last tick): call jsmpeg_hip_live_tick", l->stage_used);
+	}
+	for (uint32_t i = 0, at = off; i < n_buffers; at += lengths[i], i++) if (lengths[i]) memcpy(l->h_stage + at, buffers[i], lengths[i]);
+	l->stage_used = off + n;
+	live_account_write(l, stream, pts, off, n);
 	return live_send_staged(l);
 }
 
@@ -1631,9 +1690,10 @@ static inline double live_ms_since(std::chrono::steady_clock::time_point t0) {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream) {
-	g_err[0] = 0;
-	if (!l) return fail("null live handle");
+/* The first half of a tick: the pass is laid out, uploaded and ENQUEUED (index, the host's turn-around, slice parse,
+ * reconstruct); what is left for the second half is the wait and the book-keeping.  When this returns the staging buffer is
+ * free again (the pass's bytes are in its ES buffer: the decode call waited for the index). */
+static int live_tick_begin_impl(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream) {
 	jsmpeg_hip_batch_t *b = l->b;
 	const auto t_begin = std::chrono::steady_clock::now();
 	HIP_TRY(hipSetDevice(b->device));
@@ -1655,6 +1715,7 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 		if (S.tail_bytes + S.new_bytes) l->pass_stream.push_back(s);
 	}
 	const uint32_t n = (uint32_t)l->pass_stream.size();
+	l->last_n = 0;
 	if (n == 0) { l->segs.clear(); l->stage_used = 0; l->stage_sent = 0; return 0; }
 
 	/* ---- 2. the pass's ES buffer: per stream the tail the last tick left, then the new writes in order ---- */
@@ -1740,10 +1801,41 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 	}
 	if (need_back) HIP_TRY(hipMemcpyAsync(l->h_back, b->d_streams, sizeof(JmStream) * n, hipMemcpyDeviceToHost, st));
 	l->ms[1] = (float)live_ms_since(t_decode);
+	l->segs.clear(); l->stage_used = 0; l->stage_sent = 0;          /* the staging buffer is the next writes' */
+	for (LiveStream &S : l->streams) S.defer_bytes = 0;
+	l->deferred.clear();
+	l->fl.n = n; l->fl.cur = cur; l->fl.n_pics = n_pics; l->fl.flush = flush; l->fl.need_back = need_back; l->fl.t_begin = t_begin;
+	l->in_flight = true;
+	return 0;
+}
+
+/* The second half: wait for the pass, then what it decoded and where each stream's cursor rests; then the writes that were
+ * made meanwhile take their place behind it. */
+static int live_tick_end_impl(jsmpeg_hip_live_t *l) {
+	if (!l->in_flight) return l->last_n;
+	jsmpeg_hip_batch_t *b = l->b;
+	const uint32_t n = l->fl.n;
+	const int cur = l->fl.cur, n_pics = l->fl.n_pics;
+	const bool flush = l->fl.flush;
+	const auto t_begin = l->fl.t_begin;
+	l->in_flight = false;
 	const auto t_wait = std::chrono::steady_clock::now();
-	if (jsmpeg_hip_batch_sync(b) < 0) return -1;
+	const int synced = jsmpeg_hip_batch_sync(b);
 	l->ms[2] = (float)live_ms_since(t_wait);
 	const auto t_book = std::chrono::steady_clock::now();
+	if (synced < 0) {
+		/* the device failed under the pass: its streams' pending bytes go with it (as when a pass is refused) */
+		char why[sizeof(g_err)];
+		memcpy(why, g_err, sizeof(why));
+		for (uint32_t i = 0; i < n; i++) {
+			LiveStream &S = l->streams[l->pass_stream[i]];
+			S.consumed += (uint64_t)S.tail_bytes + S.new_bytes; S.tail_bytes = S.new_bytes = 0; S.stamps.clear(); S.evictions++;
+		}
+		for (const LiveDeferred &d : l->deferred) if (l->streams[d.stream].open) { live_make_room(l, d.stream, d.n); live_account_write(l, d.stream, d.pts, d.off, d.n); }
+		l->deferred.clear();
+		l->last_n = -1;
+		return fail("%.400s", why);
+	}
 
 	/* ---- 5. what the pass decoded, and where each stream's cursor rests ---- */
 	uint32_t p = 0;
@@ -1780,18 +1872,48 @@ extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *
 		while (S.stamps.size() > 1 && S.stamps[1].at <= S.consumed) S.stamps.pop_front();
 		S.head = (S.head + n_dec) % l->ring; S.have = std::min(2u, S.have + n_dec); S.pictures += n_dec;
 	}
-	l->segs.clear(); l->stage_used = 0; l->stage_sent = 0; l->cur = cur ^ 1;
+	l->cur = cur ^ 1;
+	/* the writes made while the pass was on the device: staged then, accounted for now -- in order, by the rules of any write */
+	for (const LiveDeferred &d : l->deferred) {
+		if (!l->streams[d.stream].open) continue;
+		live_make_room(l, d.stream, d.n);
+		live_account_write(l, d.stream, d.pts, d.off, d.n);
+	}
+	l->deferred.clear();
 	l->ms[3] = (float)live_ms_since(t_book);
 	l->ms[4] = (float)live_ms_since(t_begin);
 	float bt[5];
 	if (jsmpeg_hip_batch_timings(b, bt) == 0) { l->ms[5] = bt[0]; l->ms[6] = bt[1]; l->ms[7] = bt[2]; l->ms[8] = bt[3]; }
 	g_err[0] = 0;
-	return (int)l->out.size();
+	l->last_n = (int)l->out.size();
+	return l->last_n;
 }
 
-extern "C" uint32_t jsmpeg_hip_live_picture_count(jsmpeg_hip_live_t *l) { return l ? (uint32_t)l->out.size() : 0; }
+extern "C" int jsmpeg_hip_live_tick_begin(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	if (l->in_flight) return fail("a tick is in flight: jsmpeg_hip_live_tick_end first");
+	return live_tick_begin_impl(l, flags, hip_stream);
+}
+
+extern "C" int jsmpeg_hip_live_tick_end(jsmpeg_hip_live_t *l) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	return live_tick_end_impl(l);
+}
+
+extern "C" int jsmpeg_hip_live_tick(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_stream) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	if (l->in_flight && live_tick_end_impl(l) < 0) return -1;
+	if (live_tick_begin_impl(l, flags, hip_stream) < 0) return -1;
+	return live_tick_end_impl(l);
+}
+
+extern "C" uint32_t jsmpeg_hip_live_picture_count(jsmpeg_hip_live_t *l) { return l && live_settle(l) == 0 ? (uint32_t)l->out.size() : 0; }
 
 extern "C" int jsmpeg_hip_live_picture(jsmpeg_hip_live_t *l, uint32_t i, jsmpeg_hip_live_picture_t *out) {
+	if (live_settle(l) < 0) return -1;
 	if (!l || !out || i >= l->out.size()) return fail("bad picture index");
 	const LivePicture &P = l->out[i];
 	out->stream = P.stream; out->type = P.type; out->pts = P.pts; out->stream_offset = P.at;
@@ -1806,6 +1928,7 @@ extern "C" int jsmpeg_hip_live_geometry(jsmpeg_hip_live_t *l, int32_t *cw, int32
 
 extern "C" int jsmpeg_hip_live_read_frame(jsmpeg_hip_live_t *l, uint32_t i, void *y, void *cr, void *cb) {
 	g_err[0] = 0;
+	if (live_settle(l) < 0) return -1;
 	if (!l || i >= l->out.size()) return fail("bad picture index");
 	const jsmpeg_hip_batch_t *b = l->b;
 	HIP_TRY(hipSetDevice(b->device));
@@ -1818,6 +1941,7 @@ extern "C" int jsmpeg_hip_live_read_frame(jsmpeg_hip_live_t *l, uint32_t i, void
 
 extern "C" int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void *host_rgba) {
 	g_err[0] = 0;
+	if (live_settle(l) < 0) return -1;
 	if (!l || !host_rgba || i >= l->out.size()) return fail("bad picture index");
 	jsmpeg_hip_batch_t *b = l->b;
 	HIP_TRY(hipSetDevice(b->device));
@@ -1837,6 +1961,7 @@ extern "C" int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void 
 extern "C" int jsmpeg_hip_live_frame_hashes(jsmpeg_hip_live_t *l, uint64_t *out) {
 	g_err[0] = 0;
 	if (!l || !out) return fail("null argument");
+	if (live_settle(l) < 0) return -1;
 	jsmpeg_hip_batch_t *b = l->b;
 	const uint32_t n = (uint32_t)l->out.size();
 	if (!n) return 0;
@@ -1852,6 +1977,7 @@ extern "C" int jsmpeg_hip_live_frame_hashes(jsmpeg_hip_live_t *l, uint64_t *out)
 
 extern "C" int jsmpeg_hip_live_stream_info(jsmpeg_hip_live_t *l, uint32_t stream, jsmpeg_hip_live_stream_info_t *out) {
 	if (!l || !out || stream >= l->streams.size() || !l->streams[stream].open) return fail("stream %u is not open", stream);
+	if (live_settle(l) < 0) return -1;
 	const LiveStream &S = l->streams[stream];
 	static const float rates[16] = MPEG1_PICTURE_RATE_INIT;
 	out->has_sequence_header = S.has_header ? 1 : 0;

@@ -10,6 +10,7 @@
  *                                                                                  write(pts, buffers) (decoder.js:36-47)
  *   liveWriteTS(handle, id, Uint8Array[, streamId]) -> bytes                       jsmpeg_hip_live_write_ts: the demuxer's write(buffer)
  *   liveTick(handle, flush) -> pictures                                            jsmpeg_hip_live_tick
+ *   liveTickBegin(handle, flush) / liveTickEnd(handle) -> pictures                 jsmpeg_hip_live_tick_begin / _end (writes may go on between them)
  *   livePicture(handle, i) -> {stream, type, pts, streamOffset}                    jsmpeg_hip_live_picture
  *   liveReadPlanes(handle, i, y, cr, cb) / liveReadRGBA(handle, i, Uint8ClampedArray)
  *   liveFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures                  jsmpeg_hip_live_frame_hashes
@@ -180,6 +181,31 @@ static napi_value fn_live_tick(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+static napi_value fn_live_tick_begin(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2], out;
+	bool flush = true;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	if (argc > 1) napi_get_value_bool(env, argv[1], &flush);
+	if (jsmpeg_hip_live_tick_begin(l, flush ? JSMPEG_HIP_LIVE_FLUSH : 0u, NULL) < 0) return throw_last(env);
+	NAPI_OK(napi_get_undefined(env, &out));
+	return out;
+}
+
+static napi_value fn_live_tick_end(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	const int n = jsmpeg_hip_live_tick_end(l);
+	if (n < 0) return throw_last(env);
+	NAPI_OK(napi_create_int32(env, n, &out));
+	return out;
+}
+
 static napi_value fn_live_picture(napi_env env, napi_callback_info info) {
 	size_t argc = 2;
 	napi_value argv[2], out;
@@ -303,7 +329,7 @@ static napi_value fn_live_timings(napi_env env, napi_callback_info info) {
 int jm_napi_register_live(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "liveCreate", fn_live_create }, { "liveDestroy", fn_live_destroy }, { "liveOpen", fn_live_open }, { "liveClose", fn_live_close },
-		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "livePicture", fn_live_picture },
+		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "liveTickBegin", fn_live_tick_begin }, { "liveTickEnd", fn_live_tick_end }, { "livePicture", fn_live_picture },
 		{ "liveReadPlanes", fn_live_read_planes }, { "liveReadRGBA", fn_live_read_rgba }, { "liveFrameHashes", fn_live_frame_hashes },
 		{ "liveStreamInfo", fn_live_stream_info }, { "liveGeometry", fn_live_geometry }, { "liveTimings", fn_live_timings },
 	};

@@ -45,10 +45,12 @@ function install(JSMpeg, options) {
     this.streams = new Map();                                      // id -> HIPLiveStream
     this.pictures = 0;
     this.planes = null; this.rgba = null;
+    this.inFlight = false; this.flight = null;
   }
 
   HIPLive.prototype.destroy = function () {
     if (!this.handle) return;
+    this.inFlight = false; this.flight = null;
     for (const s of this.streams.values()) s.live = null;
     this.streams.clear();
     this.native.liveDestroy(this.handle);
@@ -69,10 +71,42 @@ function install(JSMpeg, options) {
   // like a decoder's destination.  Returns the number of pictures decoded.
   HIPLive.prototype.tick = function (opts) {
     opts = opts || {};
+    if (this.inFlight) this.tickEnd();                              // (a tick begun and not ended: its pictures go to its own options)
     const t0 = now();
     const n = this.native.liveTick(this.handle, opts.flush !== false);
+    return this.deliver(n, opts, now() - t0);
+  };
+
+  // The tick in two halves, for an event loop that has sockets to serve while the GPU decodes: tickBegin() puts the pass on
+  // the device and returns (about a fifth of the tick); tickEnd() waits for it and hands out the pictures.  Between them
+  // the streams may be written to (write / writeTS / a demuxer's destination.write): such writes are writes made right
+  // behind the tick.  tickAsync(opts) is the two halves around one turn of the event loop (setImmediate), as a Promise.
+  HIPLive.prototype.tickBegin = function (opts) {
+    opts = opts || {};
+    if (this.inFlight) throw new Error('HIPLive: a tick is in flight (tickEnd first)');
+    this.flight = { opts, t0: now() };
+    this.native.liveTickBegin(this.handle, opts.flush !== false);
+    this.flight.tBegun = now() - this.flight.t0;
+    this.inFlight = true;
+  };
+  HIPLive.prototype.tickEnd = function (opts) {
+    if (!this.inFlight) return 0;
+    const f = this.flight;
+    this.inFlight = false; this.flight = null;
+    const t1 = now();
+    const n = this.native.liveTickEnd(this.handle);
+    // (elapsed: the host's time inside the two calls, not what it did between them)
+    const elapsed = f.tBegun + (now() - t1);
+    for (const s of this.streams.values()) if (s.bytesStale) { s.bytesStale = false; s.bytesWritten = s.info().bytesWritten; }
+    return this.deliver(n, opts || f.opts, elapsed);
+  };
+  HIPLive.prototype.tickAsync = function (opts) {
+    this.tickBegin(opts);
+    return new Promise((resolve, reject) => setImmediate(() => { try { resolve(this.tickEnd()); } catch (e) { reject(e); } }));
+  };
+
+  HIPLive.prototype.deliver = function (n, opts, elapsed) {
     this.pictures = n;
-    const elapsed = now() - t0;
     for (const s of this.streams.values()) if (!s.hasSequenceHeader && s.bytesWritten) s.pollSequenceHeader();
     if (!n) return 0;
     const wantPixels = opts.onFrame || Array.from(this.streams.values()).some((s) => s.destination);
@@ -137,15 +171,17 @@ function install(JSMpeg, options) {
     this.canPlay = true;
     // mpeg1-wasm.js:72-78: the header is polled after every write until it is there (the library takes a header that a write
     // brings whole at write time, like the reference; one that arrives in pieces when a tick has seen all of it)
-    if (!this.hasSequenceHeader) this.pollSequenceHeader();
+    // (not beside a tick in flight: asking the library anything but a write ends the tick first; tickEnd polls)
+    if (!this.hasSequenceHeader && !this.live.inFlight) this.pollSequenceHeader();
   };
   // the stream as MPEG-TS bytes in any pieces: the library's own restatement of ts.js (state kept per stream) in front of write() --
   // for hosts that do not have jsmpeg's demuxer loaded; with it loaded, demuxer.connect(VIDEO_1, stream) is the same thing
   HIPLiveStream.prototype.writeTS = function (buffer, streamId) {
     if (!this.live) throw new Error('HIPLiveStream: the stream is closed');
     this.live.native.liveWriteTS(this.live.handle, this.id, buffer, streamId || 0xE0);
-    this.bytesWritten = this.info().bytesWritten;
-    this.canPlay = this.canPlay || this.bytesWritten > 0;
+    if (this.live.inFlight) this.bytesStale = true;                // (counted when the tick has ended)
+    else this.bytesWritten = this.info().bytesWritten;
+    this.canPlay = this.canPlay || this.bytesWritten > 0 || !!this.bytesStale;
   };
   // mpeg1-wasm.js:80-93 loadSequenceHeader (the header is parsed by the tick that first sees it, on the device)
   HIPLiveStream.prototype.pollSequenceHeader = function () {

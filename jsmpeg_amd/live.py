@@ -10,7 +10,7 @@ from . import batch as _batch
 FLUSH = 1
 
 LIVE_SYMBOLS = ("jsmpeg_hip_live_create", "jsmpeg_hip_live_destroy", "jsmpeg_hip_live_open", "jsmpeg_hip_live_close",
-                "jsmpeg_hip_live_write", "jsmpeg_hip_live_write_v", "jsmpeg_hip_live_write_ts", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
+                "jsmpeg_hip_live_write", "jsmpeg_hip_live_write_v", "jsmpeg_hip_live_write_ts", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_tick_begin", "jsmpeg_hip_live_tick_end", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
                 "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_rgba",
                 "jsmpeg_hip_live_frame_hashes", "jsmpeg_hip_live_stream_info", "jsmpeg_hip_live_timings")
 
@@ -53,6 +53,10 @@ def lib():
         L.jsmpeg_hip_live_write_ts.argtypes = [vp, u32, vp, u32, u32]
         L.jsmpeg_hip_live_tick.restype = ctypes.c_int
         L.jsmpeg_hip_live_tick.argtypes = [vp, u32, vp]
+        L.jsmpeg_hip_live_tick_begin.restype = ctypes.c_int
+        L.jsmpeg_hip_live_tick_begin.argtypes = [vp, u32, vp]
+        L.jsmpeg_hip_live_tick_end.restype = ctypes.c_int
+        L.jsmpeg_hip_live_tick_end.argtypes = [vp]
         L.jsmpeg_hip_live_picture_count.restype = u32
         L.jsmpeg_hip_live_picture_count.argtypes = [vp]
         L.jsmpeg_hip_live_picture.restype = ctypes.c_int
@@ -121,6 +125,14 @@ class Live:
     def tick(self, flush=True, stream=None):
         """one pass over what has been written; returns the pictures decoded (see pictures())"""
         return self._ok(self.L.jsmpeg_hip_live_tick(self.h, FLUSH if flush else 0, stream))
+
+    def tick_begin(self, flush=True, stream=None):
+        """the tick's first half: the pass is on the device when this returns; write() / write_ts() may go on meanwhile"""
+        self._ok(self.L.jsmpeg_hip_live_tick_begin(self.h, FLUSH if flush else 0, stream))
+
+    def tick_end(self):
+        """the second half: waits for the pass; returns the pictures decoded (the writes made meanwhile are behind it)"""
+        return self._ok(self.L.jsmpeg_hip_live_tick_end(self.h))
 
     @property
     def picture_count(self):

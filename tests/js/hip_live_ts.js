@@ -1,7 +1,9 @@
 // GPU test helper: N .ts files -> a TS demuxer per stream (the reference's own JSMpeg.Demuxer.TS from its shipped bundle
 // when --bundle is given, else jsmpeg_amd/js/ts-demux.js) -> JSMpeg.HIPLive streams (real addon) -> one tick per round of
 // writes.  Every stream's rendered planes as md5, in order; the last stream joins `--late` rounds after the others.
-//   node hip_live_ts.js <width> <height> [--bundle jsmpeg.min.js] [--late n] [--packets n] [--rgba] a.ts b.ts ...
+//   node hip_live_ts.js <width> <height> [--bundle jsmpeg.min.js] [--late n] [--packets n] [--rgba] [--overlap] a.ts b.ts ...
+// --overlap: a round's pieces are written WHILE the tick of the round before is on the device (live.tickAsync: tickBegin, one
+// turn of the event loop, tickEnd) -- the same pictures, the same rounds.
 'use strict';
 const fs = require('fs');
 const vm = require('vm');
@@ -10,13 +12,14 @@ const { install } = require('../../jsmpeg_amd/js/live-hip.js');
 
 const args = process.argv.slice(2);
 const width = +args.shift(), height = +args.shift();
-let bundle = null, late = 0, packets = 40, rgba = false, nativeTS = false;
+let bundle = null, late = 0, packets = 40, rgba = false, nativeTS = false, overlap = false;
 while (args.length && args[0].startsWith('--')) {
   const k = args.shift();
   if (k === '--bundle') bundle = args.shift();
   else if (k === '--late') late = +args.shift();
   else if (k === '--packets') packets = +args.shift();
   else if (k === '--rgba') rgba = true;
+  else if (k === '--overlap') overlap = true;
   else if (k === '--native-ts') nativeTS = true;     // no JS demuxer at all: HIPLiveStream.writeTS (the library's ts.js restatement, state kept per stream)
 }
 const files = args.map((f) => fs.readFileSync(f));
@@ -59,7 +62,7 @@ function join(i) {
 }
 const ticks = [];
 let round = 0, pictures = 0, hashesSeen = 0;
-for (;; round++) {
+function feed(round) {
   let fed = false;
   for (let i = 0; i < files.length; i++) {
     if (!streams[i]) { if (i === files.length - 1 && round < late) continue; join(i); }
@@ -71,27 +74,54 @@ for (;; round++) {
     s.at += n;
     fed = true;
   }
-  const byId = new Map(streams.filter(Boolean).map((s, i) => [s.video.id, s]));
-  const n = live.tick({
-    flush: true, rgba,
-    onFrame(frame) {
-      const i = streams.findIndex((s) => s && s.video === frame.stream);
-      out[i].pts.push(+frame.pts.toFixed(6)); out[i].types.push(frame.type);
-      if (rgba) out[i].rgba.push(crypto.createHash('md5').update(Buffer.from(frame.rgba.buffer, frame.rgba.byteOffset, frame.rgba.length)).digest('hex'));
-    },
-  });
+  return fed;
+}
+const tickOptions = {
+  flush: true, rgba,
+  onFrame(frame) {
+    const i = streams.findIndex((s) => s && s.video === frame.stream);
+    out[i].pts.push(+frame.pts.toFixed(6)); out[i].types.push(frame.type);
+    if (rgba) out[i].rgba.push(crypto.createHash('md5').update(Buffer.from(frame.rgba.buffer, frame.rgba.byteOffset, frame.rgba.length)).digest('hex'));
+  },
+};
+function ticked(n) {
   pictures += n;
   if (n) { hashesSeen += live.frameHashes().length; ticks.push(live.timings().totalMs); }
-  if (!fed) break;
 }
-const info = streams.map((s) => s.video.info());
-const result = { demuxer: nativeTS ? 'jsmpeg_hip_live_write_ts' : demuxerName, rounds: round, pictures, hashesSeen, streams: out,
-                 frameRates: streams.map((s) => s.video.frameRate), decodedTimes: streams.map((s) => +s.video.decodedTime.toFixed(6)),
-                 ids: streams.map((s) => s.video.id), pending: info.map((x) => x.pendingBytes), evictions: info.map((x) => x.evictions),
-                 medianTickMs: ticks.sort((a, b) => a - b)[ticks.length >> 1] };
-streams[0].video.destroy();
-let threw = false;
-try { streams[0].video.write(0, [new Uint8Array(4)]); } catch (e) { threw = true; }
-result.closedStreamThrows = threw;
-live.destroy();
-process.stdout.write(JSON.stringify(result) + '\n');
+function finish() {
+  const info = streams.map((s) => s.video.info());
+  const result = { demuxer: nativeTS ? 'jsmpeg_hip_live_write_ts' : demuxerName, rounds: round, pictures, hashesSeen, streams: out, overlap,
+                   frameRates: streams.map((s) => s.video.frameRate), decodedTimes: streams.map((s) => +s.video.decodedTime.toFixed(6)),
+                   ids: streams.map((s) => s.video.id), pending: info.map((x) => x.pendingBytes), evictions: info.map((x) => x.evictions),
+                   bytesWritten: streams.map((s) => s.video.bytesWritten), bytesWrittenInfo: info.map((x) => x.bytesWritten),
+                   medianTickMs: ticks.sort((a, b) => a - b)[ticks.length >> 1] };
+  streams[0].video.destroy();
+  let threw = false;
+  try { streams[0].video.write(0, [new Uint8Array(4)]); } catch (e) { threw = true; }
+  result.closedStreamThrows = threw;
+  live.destroy();
+  process.stdout.write(JSON.stringify(result) + '\n');
+}
+if (!overlap) {
+  for (;; round++) {
+    const fed = feed(round);
+    ticked(live.tick(tickOptions));
+    if (!fed) break;
+  }
+  finish();
+} else {
+  (async () => {
+    let fed = feed(0), inFlightWrites = 0;
+    for (;; round++) {
+      const p = live.tickAsync(tickOptions);           // the pass is on the device when this returns
+      if (!live.inFlight && fed) throw new Error('tickAsync left nothing in flight');
+      const fedNext = fed ? feed(round + 1) : false;   // ... and these writes are made beside it
+      if (live.inFlight) inFlightWrites++;
+      ticked(await p);
+      if (!fed) break;
+      fed = fedNext;
+    }
+    if (!inFlightWrites) throw new Error('no write was made beside a tick in flight');
+    finish();
+  })().catch((e) => { console.error(e); process.exit(1); });
+}

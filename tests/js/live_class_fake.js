@@ -5,8 +5,10 @@
 'use strict';
 const { install } = require('../../jsmpeg_amd/js/live-hip.js');
 const calls = [];
-const script = [[], [{ stream: 0, type: 1, pts: 0.5, streamOffset: 140 }], [{ stream: 0, type: 2, pts: 0.6, streamOffset: 900 }, { stream: 1, type: 1, pts: 7, streamOffset: 0 }]];
-let tickNo = -1, open = 0;
+const script = [[], [{ stream: 0, type: 1, pts: 0.5, streamOffset: 140 }], [{ stream: 0, type: 2, pts: 0.6, streamOffset: 900 }, { stream: 1, type: 1, pts: 7, streamOffset: 0 }],
+                [{ stream: 1, type: 2, pts: 8, streamOffset: 8 }], []];
+let tickNo = -1, open = 0, inFlight = false;
+const written = {};
 const headers = { 0: false, 1: false };
 const binding = {
   liveCreate(...a) { calls.push(['liveCreate', ...a]); return { h: 1 }; },
@@ -16,10 +18,13 @@ const binding = {
   liveDestroy() { calls.push(['liveDestroy']); },
   liveWrite(h, id, pts, buffers) { let n = 0; for (const b of buffers) n += b.length; calls.push(['liveWrite', id, pts, n]); return n; },
   liveTick(h, flush) { tickNo++; calls.push(['liveTick', flush]); for (const p of script[tickNo]) headers[p.stream] = true; return script[tickNo].length; },
+  liveTickBegin(h, flush) { tickNo++; inFlight = true; calls.push(['liveTickBegin', flush]); },
+  liveTickEnd(h) { inFlight = false; calls.push(['liveTickEnd']); return script[tickNo].length; },
+  liveWriteTS(h, id, buf, sid) { calls.push(['liveWriteTS', id, buf.length, sid]); written[id] = (written[id] || 0) + 100; return buf.length; },
   livePicture(h, i) { return script[tickNo][i]; },
   liveReadPlanes(h, i, y, cr, cb) { y[0] = 10 * tickNo + i; cr[0] = 1; cb[0] = 2; },
   liveReadRGBA(h, i, out, n) { calls.push(['liveReadRGBA', i, n]); out[0] = 99; },
-  liveStreamInfo(h, id) { return { hasSequenceHeader: headers[id] ? 1 : 0, width: 30, height: 15, frameRate: 25, status: 0, pendingBytes: 0, bytesWritten: 0, pictures: 0, evictions: 0 }; },
+  liveStreamInfo(h, id) { if (inFlight) calls.push(['liveStreamInfo beside a tick in flight', id]); return { hasSequenceHeader: headers[id] ? 1 : 0, width: 30, height: 15, frameRate: 25, status: 0, pendingBytes: 0, bytesWritten: written[id] || 0, pictures: 0, evictions: 0 }; },
   liveFrameHashes(h, raw) { raw[0] = 0xef; raw[7] = 0x01; },
   liveTimings() { return { totalMs: 1 }; },
 };
@@ -37,9 +42,22 @@ log.push(['tick', live.tick({ flush: false, rgba: true, onFrame: (f) => log.push
 log.push(['hash', live.frameHashes()[0]]);
 log.push(['state', a.hasSequenceHeader, a.frameRate, a.width, a.height, a.codedSize, +a.currentTime.toFixed(6), a.canPlay, a.bytesWritten, b.hasSequenceHeader, +b.currentTime.toFixed(6)]);
 log.push(['decode', a.decode()]);
+// the tick in two halves: writes between them go through, nothing else is asked of the library until the tick has ended
+live.tickBegin({ onFrame: (f) => log.push(['frame', f.stream.id, f.index, f.pts]) });
+let second = false;
+try { live.tickBegin(); } catch (e) { second = true; }
+b.write(9, [new Uint8Array(5)]);
+b.writeTS(new Uint8Array(188));
+log.push(['beside', second, live.inFlight, b.bytesWritten]);
+log.push(['tickEnd', live.tickEnd(), live.inFlight, b.bytesWritten, live.tickEnd()]);
+const later = [];
+const promise = live.tickAsync().then((n) => { later.push(['async', n, live.inFlight]); });
+later.push(['begun', live.inFlight]);
 b.destroy();
 let threw = false;
 try { b.write(0, [new Uint8Array(1)]); } catch (e) { threw = true; }
 log.push(['closedThrows', threw, live.streams.size]);
-live.destroy();
-process.stdout.write(JSON.stringify({ calls, log }) + '\n');
+promise.then(() => {
+  live.destroy();
+  process.stdout.write(JSON.stringify({ calls, log, later }) + '\n');
+});

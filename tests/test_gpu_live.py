@@ -237,6 +237,98 @@ def test_live_store_evicts_like_the_reference(hip_lib, libs):
     assert got == want and sum(len(t) for t in got) < 14
 
 
+def test_live_writes_beside_a_tick_in_flight(hip_lib, libs):
+    """the tick in two halves (jsmpeg_hip_live_tick_begin / _end): the writes of tick t + 1 are made while tick t is on the
+    device.  To the streams they are writes made right behind the tick -- so every tick's pictures == the oracle fed the
+    writes tick by tick, with stores small enough that writes evict (room is decided when the tick has ended, not when the
+    bytes were copied), a stream that joins mid-run (open() ends the tick first) and one whose first bytes are not video"""
+    W, H, N = 352, 288, 18
+    rng = random.Random(23)
+    plans = {}
+    for s in range(4):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=N, stream=40 + s, width=W, height=H, **({"syntax_quirks": 2} if s == 2 else {}))
+        plans[s] = picture_writes(es, [int(o) for o in offs])
+    plans[1] = [np.frombuffer(bytes(rng.randrange(256) for _ in range(700)), dtype=np.uint8)] + plans[1]   # noise before the first header
+    store = int(max(len(w) for ws in plans.values() for w in ws) * 1.2) + 64
+    join = {0: 0, 1: 0, 2: 0, 3: 5}
+    given = {s: 0 for s in plans}
+    ticks = []
+    while any(given[s] < len(plans[s]) for s in plans):
+        row = {}
+        for s in plans:
+            if len(ticks) < join[s]:
+                continue
+            k = rng.choice([0, 1, 1, 2, 3, 5])                    # several pictures into a store of 1.2 of the largest: evacuations
+            row[s] = plans[s][given[s]:given[s] + k]
+            given[s] += len(row[s])
+        ticks.append(row)
+    want = {s: oracle_fed(libs, [row.get(s, []) for row in ticks], store) for s in plans}
+    got = {s: [] for s in plans}
+    with jl.Live(W, H, 4, pictures_per_tick=8, store_bytes=store) as lv:
+        ids = {}
+        def feed(t):
+            for s in plans:
+                if join[s] == t:
+                    ids[s] = lv.open()                            # (between the halves: ends the tick, its pictures stay readable)
+            for s, ws in ticks[t].items():
+                for w in ws:
+                    lv.write(ids[s], w, pts=float(t))
+        def collect(t):
+            per = {}
+            pics = drain(lv, None, per)
+            assert all(p.pts == float(t) for p in pics)
+            for s, i in ids.items():
+                if join[s] <= t:
+                    got[s].append(per.get(i, []))
+        feed(0)
+        for t in range(len(ticks)):
+            lv.tick_begin(flush=True)
+            if t + 1 < len(ticks):
+                feed(t + 1)                                       # while tick t is on the device
+            n = lv.tick_end()
+            assert n == lv.picture_count
+            collect(t)
+        assert lv.tick_end() == n                                 # no tick in flight: the last count again
+        lv.tick_begin()                                           # nothing pending: nothing in flight
+        lv.write(ids[0], plans[0][0])
+        lv.tick_begin()
+        with pytest.raises(RuntimeError):
+            lv.tick_begin()                                       # a second tick beside the first
+        assert lv.tick_end() == 1
+        assert sum(lv.stream_info(i).evictions for i in ids.values()) >= 1
+    for s in plans:
+        assert got[s] == want[s][join[s]:], s
+    assert sum(len(x) for x in got[3]) > 0
+
+
+@pytest.mark.parametrize("name", ["cfg0_240p_intra", "skipped_pictures_352x288", "uncovered_first_p_118x197", "odd_size_17x33", "long_gop_p_chain"])
+def test_live_ragged_pieces_beside_ticks_in_flight(name, hip_lib):
+    """bytes in arbitrary pieces written WHILE ticks that take only complete pictures are on the device: still the pictures of
+    the whole stream decoded in one piece (the held tail, the cursor and the stamps are the tick's; the pieces wait their turn)"""
+    fx, es, offs = load_case(os.path.join(ROOT, "tests", "golden", "frames_%s.json" % name))
+    rng = random.Random(len(es))
+    mean = max(64, len(es) // (3 * fx["n_frames"]))
+    got, at = [], 0
+    with jl.Live(fx["info"]["width"], fx["info"]["height"], 1, pictures_per_tick=3, store_bytes=2 * len(es) + 4096) as lv:
+        s = lv.open()
+        lv.write(s, es[:10]); at = 10
+        while at < len(es):
+            lv.tick_begin(flush=False)
+            for _ in range(rng.choice([0, 1, 2, 4])):
+                n = min(len(es) - at, rng.choice([1, 3, 17, mean // 2, mean, 2 * mean, 5 * mean]))
+                lv.write(s, es[at:at + n])
+                at += n
+            lv.tick_end()
+            drain(lv, got)
+        for _ in range(fx["n_frames"]):
+            lv.tick(flush=False)
+            drain(lv, got)
+        lv.tick(flush=True)
+        drain(lv, got)
+        assert lv.stream_info(s).pending_bytes == 0
+    assert got == fx["frame_md5"]
+
+
 def test_live_stream_of_another_size_is_refused_not_decoded(hip_lib):
     es, offs = synth.generate_config("cfg1_720p", n_frames=3, width=176, height=144)
     ok, offs_ok = synth.generate_config("cfg1_720p", n_frames=3, width=352, height=288)

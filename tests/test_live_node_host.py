@@ -21,7 +21,7 @@ pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_addon_exports_the_live_functions():
     addon = build.build_addon()
     out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
-    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveWriteTS", "liveTick", "livePicture", "liveReadPlanes", "liveReadRGBA",
+    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveWriteTS", "liveTick", "liveTickBegin", "liveTickEnd", "livePicture", "liveReadPlanes", "liveReadRGBA",
             "liveFrameHashes", "liveStreamInfo", "liveGeometry", "liveTimings"} <= set(json.loads(out))
 
 
@@ -40,13 +40,20 @@ def test_live_class_fails_loudly_without_gpu():
 def test_live_class_logic_over_an_injected_binding():
     """a stream has the decoder's surface (reference src/decoder.js:3-106, src/mpeg1-wasm.js:72-128): write copies through as
     ONE write, the header is polled after the tick that saw it -> destination.resize once, render(y, cr, cb, false) per
-    picture, onVideoDecode, decodedTime += 1 / frameRate; tick() passes flush on, hands out frames, RGBA on request"""
+    picture, onVideoDecode, decodedTime += 1 / frameRate; tick() passes flush on, hands out frames, RGBA on request.
+    The tick in two halves: a second tickBegin throws, writes between the halves go through and the library is asked nothing
+    else meanwhile (any other call would end the tick), writeTS's byte count is caught up at tickEnd, tickAsync resolves a
+    turn of the event loop later"""
     out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "live_class_fake.js")]))
     assert out["calls"] == [["liveCreate", 30, 15, 2, 3, 4096, 1], ["liveOpen"], ["liveOpen"], ["liveWrite", 0, 0.5, 140], ["liveTick", True],
-                            ["liveTick", True], ["liveWrite", 1, 7, 8], ["liveTick", False], ["liveReadRGBA", 1, 30 * 15 * 4], ["liveClose", 1], ["liveDestroy"]]
+                            ["liveTick", True], ["liveWrite", 1, 7, 8], ["liveTick", False], ["liveReadRGBA", 1, 30 * 15 * 4],
+                            ["liveTickBegin", True], ["liveWrite", 1, 9, 5], ["liveWriteTS", 1, 188, 224], ["liveTickEnd"], ["liveTickBegin", True], ["liveClose", 1],
+                            ["liveTickEnd"], ["liveDestroy"]]
     assert out["log"] == [["tick", 0], ["resize", 30, 15], ["render", 10, 1, 2, False, 512, 128], ["decoded", 0], ["frame", 0, 0, 0.5, 1, True], ["tick", 1],
                           ["render", 20, 1, 2, False, 512, 128], ["decoded", 0], ["frame", 0, 1, 0.6, 2, None, 20], ["frame", 1, 0, 7, 1, 99, None], ["tick", 2],
-                          ["hash", "01000000000000ef"], ["state", True, 25, 30, 15, 512, 0.08, True, 140, True, 0.04], ["decode", False], ["closedThrows", True, 1]]
+                          ["hash", "01000000000000ef"], ["state", True, 25, 30, 15, 512, 0.08, True, 140, True, 0.04], ["decode", False],
+                          ["beside", True, True, 13], ["frame", 1, 1, 8], ["tickEnd", 1, False, 100, 0], ["closedThrows", True, 1]]
+    assert out["later"] == [["begun", True], ["async", 0, False]]
 
 
 def _ts_files(n, frames, w, h):
@@ -65,11 +72,13 @@ def _ts_files(n, frames, w, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [False, True], ids=["tick", "pieces_written_beside_tickAsync"])
 @pytest.mark.parametrize("demuxer", ["ts-demux.js", "reference bundle", "the library's own (writeTS)"])
-def test_node_live_streams_on_gpu(demuxer, hip_lib):
+def test_node_live_streams_on_gpu(demuxer, overlap, hip_lib):
     """4 TS files -> a demuxer per stream -> JSMpeg.HIPLive over the real addon, fed in ragged pieces round-robin, a tick per
     round; the last stream joins 5 rounds late.  Every rendered picture of every stream == the oracle's; pts as the demuxer
-    reported them; one resize per stream."""
+    reported them; one resize per stream.  Second form: a round's pieces are written while the tick of the round before is
+    on the device (live.tickAsync = tickBegin, a turn of the event loop, tickEnd): the same pictures in the same rounds."""
     build.build_addon()
     extra = []
     if demuxer == "reference bundle":
@@ -78,6 +87,8 @@ def test_node_live_streams_on_gpu(demuxer, hip_lib):
         extra = ["--bundle", build.JS_REF]
     if demuxer.startswith("the library"):
         extra = ["--native-ts"]
+    if overlap:
+        extra.append("--overlap")
     paths, want, _ = _ts_files(4, 14, 352, 288)
     try:
         out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_ts.js"), "352", "288"] + extra +
@@ -94,6 +105,7 @@ def test_node_live_streams_on_gpu(demuxer, hip_lib):
         assert st["types"] == [1 if k % (2 if s == 1 else 12) == 0 else 2 for k in range(14)]
         assert abs(out["decodedTimes"][s] - 14 / 30) < 1e-5 and abs(out["frameRates"][s] - 30) < 1e-6
     assert out["pending"] == [0] * 4 and out["evictions"] == [0] * 4 and out["closedStreamThrows"]
+    assert out["overlap"] == overlap and out["bytesWritten"] == out["bytesWrittenInfo"]
     assert out["rounds"] > 14                                   # (pieces of ~24 packets: pictures arrive over several rounds)
 
 

@@ -21,7 +21,8 @@ from jsmpeg_amd import build, cabi, hashing, live as jl, synth  # noqa: E402
 from oracle import checkers  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
 ORACLE = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
 
 
@@ -47,7 +48,30 @@ def oracle_ticks(writes_per_tick, store):
     return out
 
 
+class Ticker:
+    """a tick and the collection of its pictures -- or, overlapped, the tick's first half now and its second half (and the
+    collection) just before the next tick: everything written in between is written while the pass is on the device"""
+    def __init__(self, lv, overlap, collect):
+        self.lv, self.overlap, self.collect, self.inflight = lv, overlap, collect, False
+
+    def tick(self, flush):
+        if not self.overlap:
+            self.lv.tick(flush=flush)
+            self.collect()
+            return
+        self.finish()
+        self.lv.tick_begin(flush=flush)
+        self.inflight = True
+
+    def finish(self):
+        if self.inflight:
+            self.lv.tick_end()
+            self.collect()
+            self.inflight = False
+
+
 bad = 0
+n_overlap = 0
 modes = {"flush": 0, "pieces": 0, "ts": 0}
 pictures = 0
 for c in range(cases):
@@ -68,6 +92,10 @@ for c in range(cases):
     if os.environ.get("FUZZ_VERBOSE"):
         print("case %d: %s frames=%d streams=%d K=%d %r" % (c, mode, n, n_streams, K, ov), flush=True)
     modes[mode] += 1
+    # every other case: the writes are made WHILE the tick before them is on the device (jsmpeg_hip_live_tick_begin / _end)
+    overlap = (c % 2 == 1) if os.environ.get("FUZZ_OVERLAP") is None else os.environ["FUZZ_OVERLAP"] == "1"
+    n_overlap += overlap
+    noise_rng = np.random.default_rng([seed, c, 99])
     why = []
     biggest = max(len(x) for g in gen for x in picture_writes(g[0], g[1]))
     if mode == "flush":
@@ -77,6 +105,7 @@ for c in range(cases):
         plan = []                                         # per tick {stream: [writes]}
         given = [0] * n_streams
         all_w = [picture_writes(g[0], g[1]) for g in gen]
+        noise = {s: noise_rng.integers(0, 256, size=int(noise_rng.integers(1, 900)), dtype=np.uint8) for s in range(n_streams) if noise_rng.random() < 0.25}
         t = 0
         while any(given[s] < n for s in range(n_streams)) and t < 200:
             row = {}
@@ -86,19 +115,32 @@ for c in range(cases):
                 k = int(rng.choice([0, 1, 1, 1, 2, 3]))
                 row[s] = all_w[s][given[s]:given[s] + k]
                 given[s] += len(row[s])
+                if s in noise and t == join[s]:
+                    row[s] = [noise[s]] + row[s]             # bytes that are not video before the stream's first header
             plan.append(row)
             t += 1
         want = [oracle_ticks([row.get(s, []) for row in plan], store) for s in range(n_streams)]
         with jl.Live(ov["width"], ov["height"], n_streams, pictures_per_tick=16, store_bytes=store) as lv:    # (the limit counts picture start codes: B / D pictures too)
             ids, last_live = {}, {}
-            for t, row in enumerate(plan):
+
+            def feed(t):
                 for s in range(n_streams):
                     if join[s] == t or (t == 0 and join[s] == 0):
                         ids.setdefault(s, lv.open())
-                for s, ws in row.items():
+                for s, ws in plan[t].items():
                     for x in ws:
                         lv.write(ids[s], x, pts=float(t))
-                lv.tick(flush=True)
+            if overlap and plan:
+                feed(0)
+            for t, row in enumerate(plan):
+                if overlap:
+                    lv.tick_begin(flush=True)
+                    if t + 1 < len(plan):
+                        feed(t + 1)                          # while tick t is on the device
+                    lv.tick_end()
+                else:
+                    feed(t)
+                    lv.tick(flush=True)
                 hs = lv.frame_hashes()
                 per = {}
                 for i, p in enumerate(lv.pictures()):
@@ -109,6 +151,8 @@ for c in range(cases):
                     last_live[p.stream] = int(hs[i])
                 pictures += len(hs)
                 for s, i in ids.items():
+                    if join[s] > t:
+                        continue                             # (opened ahead, beside tick t)
                     if per.get(i, []) != want[s][t]:
                         why.append("tick %d stream %d: %d vs %d pictures" % (t, s, len(per.get(i, [])), len(want[s][t])))
                         if os.environ.get("FUZZ_VERBOSE"):
@@ -143,6 +187,7 @@ for c in range(cases):
                 for i, p in enumerate(lv.pictures()):
                     got[ids.index(p.stream)].append(int(hs[i]))
                 pictures += len(hs)
+            tk = Ticker(lv, overlap, collect)
             while any(at[s] < len(gen[s][0]) for s in range(n_streams)):
                 for s in range(n_streams):
                     k = min(len(gen[s][0]) - at[s], int(rng.choice([1, 2, 3, 4, 7, mean // 3, mean, mean, 3 * mean, 9 * mean])))
@@ -150,14 +195,13 @@ for c in range(cases):
                         lv.write(ids[s], gen[s][0][at[s]:at[s] + k])
                         at[s] += k
                 if rng.random() < 0.7:
-                    lv.tick(flush=False)
-                    collect()
+                    tk.tick(False)
             # drain: a tick may decode nothing and still move on (K picture START CODES per tick: a B / D picture uses one up)
             for fl in (False, True):
                 before = None
                 for _ in range(8 * n + 8):
-                    lv.tick(flush=fl)
-                    collect()
+                    tk.tick(fl)
+                    tk.finish()
                     now = [lv.stream_info(i).pending_bytes for i in ids]
                     if now == before:
                         break
@@ -173,6 +217,14 @@ for c in range(cases):
         with jl.Live(ov["width"], ov["height"], n_streams, pictures_per_tick=16, store_bytes=2 * max(len(g[0]) for g in gen) + 4096) as lv:
             ids = [lv.open() for _ in range(n_streams)]
             at = [0] * n_streams
+
+            def collect_ts():
+                global pictures
+                hs = lv.frame_hashes()
+                for i, p in enumerate(lv.pictures()):
+                    got[ids.index(p.stream)].append(int(hs[i]))
+                pictures += len(hs)
+            tk = Ticker(lv, overlap, collect_ts)
             while any(at[s] < len(tss[s]) for s in range(n_streams)):
                 for s in range(n_streams):
                     k = min(len(tss[s]) - at[s], int(rng.choice([1, 50, 187, 188, 189, 1000, 5000])))
@@ -180,11 +232,8 @@ for c in range(cases):
                     if k > 0:
                         lv.write_ts(ids[s], tss[s][at[s]:at[s] + k])
                         at[s] += k
-                lv.tick(flush=True)
-                hs = lv.frame_hashes()
-                for i, p in enumerate(lv.pictures()):
-                    got[ids.index(p.stream)].append(int(hs[i]))
-                pictures += len(hs)
+                tk.tick(True)
+            tk.finish()
             # (a tick looks at 16 picture start codes per stream: a piece of 5000 bytes can bring more of these tiny pictures)
             before = None
             for _ in range(8 * n + 8):
@@ -221,5 +270,5 @@ for c in range(cases):
     if why:
         bad += 1
         print("case %d MISMATCH [%s] (%s): frames=%d streams=%d K=%d params=%r" % (c, mode, "; ".join(why[:4]), n, n_streams, K, ov), flush=True)
-print("%d cases (%s), %d live pictures compared, %d mismatches" % (cases, ", ".join("%s %d" % kv for kv in modes.items()), pictures, bad))
+print("%d cases (%s; %d of them written beside ticks in flight), %d live pictures compared, %d mismatches" % (cases, ", ".join("%s %d" % kv for kv in modes.items()), n_overlap, pictures, bad))
 sys.exit(1 if bad else 0)

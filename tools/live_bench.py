@@ -23,7 +23,7 @@ def picture_writes(es, offs):
     return [es[int(offs[k]):(len(es) if k == n - 1 else int(offs[k + 1]))] for k in range(n)]
 
 
-def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, abi_streams=4, width=None, height=None, verbose=True, via_node=False):
+def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, abi_streams=4, width=None, height=None, verbose=True, via_node=False, overlap=False, also_overlapped=False, _want=None):
     say = print if verbose else (lambda *a, **k: None)
     kw = {}
     if width:
@@ -33,8 +33,8 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
     writes = [picture_writes(es, offs) for es, offs in gen]
     biggest = max(len(w) for ws in writes for w in ws)
     store = max(512 * 1024, 2 * per_tick * biggest)
-    want = None
-    if check:
+    want = _want
+    if check and want is None:
         oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
         t0 = time.perf_counter()
         from concurrent.futures import ThreadPoolExecutor
@@ -45,22 +45,35 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
             want = list(ex.map(one, range(streams)))
         say("oracle: %d streams x %d pictures in %.1f s" % (streams, pictures, time.perf_counter() - t0))
-    out = dict(config=config, streams=streams, pictures_per_stream=pictures, pictures_per_stream_per_tick=per_tick, width=W, height=H,
+    out = dict(writes_beside_the_tick=bool(overlap), config=config, streams=streams, pictures_per_stream=pictures, pictures_per_stream_per_tick=per_tick, width=W, height=H,
                bytes_per_picture=int(np.mean([len(w) for ws in writes for w in ws])))
     with jl.Live(W, H, streams, pictures_per_tick=max(per_tick, 1), store_bytes=store) as lv:
         ids = [lv.open() for _ in range(streams)]
         ticks, bad, n_out = [], 0, 0
         parts = []
         got = [[] for _ in range(streams)]
-        for k in range(0, pictures, per_tick):
-            t0 = time.perf_counter()
+        def feed(k):
             for s in range(streams):
                 for w in writes[s][k:k + per_tick]:
                     lv.write(ids[s], w, pts=k / 30.0)
-            t1 = time.perf_counter()
-            n = lv.tick(flush=True)
-            t2 = time.perf_counter()
-            ticks.append((t2 - t0, t1 - t0, t2 - t1, n))
+        if overlap:
+            feed(0)                                   # (overlapped: tick k's pictures are written while tick k - 1 is on the device)
+        for k in range(0, pictures, per_tick):
+            t0 = time.perf_counter()
+            if overlap:
+                lv.tick_begin(flush=True)
+                tb = time.perf_counter()
+                feed(k + per_tick)
+                t1 = time.perf_counter()
+                n = lv.tick_end()
+                t2 = time.perf_counter()
+                ticks.append((t2 - t0, t1 - tb, (tb - t0) + (t2 - t1), n))
+            else:
+                feed(k)
+                t1 = time.perf_counter()
+                n = lv.tick(flush=True)
+                t2 = time.perf_counter()
+                ticks.append((t2 - t0, t1 - t0, t2 - t1, n))
             parts.append(lv.timings())
             n_out += n
             if check:
@@ -86,8 +99,8 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         # pictures per second over everything but the first tick (allocation, first-touch)
         tot = sum(t[0] for t in ticks[1:])
         out["pictures_per_s"] = sum(t[3] for t in ticks[1:]) / tot if tot > 0 else None
-    say("live: %d streams, %d picture(s) per stream per tick: %.3f ms per tick of P pictures (writes %.3f + tick %.3f), %.3f per tick of I pictures; "
-        "%.0f pictures/s overall; differing from the oracle: %s" % (streams, per_tick, out["ms_per_tick_p_pictures"] or -1, out["ms_writes_median"] or -1, out["ms_tick_call_median"] or -1,
+    say("live%s: %d streams, %d picture(s) per stream per tick: %.3f ms per tick of P pictures (writes %.3f + tick %.3f), %.3f per tick of I pictures; "
+        "%.0f pictures/s overall; differing from the oracle: %s" % (" (writes beside the tick in flight: tick = its two calls)" if overlap else "", streams, per_tick, out["ms_per_tick_p_pictures"] or -1, out["ms_writes_median"] or -1, out["ms_tick_call_median"] or -1,
                                                                    out["ms_per_tick_i_pictures"] or -1, out["pictures_per_s"] or -1, out["pictures_differing_from_oracle"]))
     say("      parts of a P tick (ms):", {k2: round(v, 3) for k2, v in out["parts_ms_p_tick"].items()})
     say("      every tick (ms):", out["ms_per_tick_each"])
@@ -114,6 +127,13 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         out["live_over_one_picture_abi"] = out["pictures_per_s"] / out["one_picture_abi"]["pictures_per_s"] if out["pictures_per_s"] else None
         say("one-picture ABI (write a picture, decode(), planes to the host), %d decoders in turn: %.3f ms per P picture, %.0f pictures/s -> live tick = %.1f x"
             % (k_abi, p_ms, out["one_picture_abi"]["pictures_per_s"], out["live_over_one_picture_abi"] or -1))
+    if also_overlapped and not overlap:
+        # the same ticks with tick k + 1's pictures written while tick k is on the device (jsmpeg_hip_live_tick_begin / _end)
+        r2 = run(streams, pictures, config, per_tick, check=check, abi_streams=0, width=width, height=height, verbose=verbose, overlap=True, _want=want)
+        out["writes_beside_the_tick_in_flight"] = {k2: r2[k2] for k2 in ("ms_per_tick_p_pictures", "ms_per_tick_i_pictures", "ms_per_tick_median", "ms_per_tick_max", "ms_writes_median",
+                                                                         "ms_tick_call_median", "pictures_per_s", "pictures_differing_from_oracle", "pictures")}
+        if out.get("one_picture_abi") and r2["pictures_per_s"]:
+            out["writes_beside_the_tick_in_flight"]["over_one_picture_abi"] = r2["pictures_per_s"] / out["one_picture_abi"]["pictures_per_s"]
     if via_node and want is not None:
         out["via_napi"] = node_run(gen, want, streams, W, H)
         if "ms_per_tick_p_pictures" in out["via_napi"]:
@@ -151,10 +171,12 @@ if __name__ == "__main__":
     ap.add_argument("--pictures-per-tick", type=int, default=1)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--node", action="store_true", help="also run the same ticks from Node (tools/live_bench_node.js)")
+    ap.add_argument("--overlap", action="store_true", help="tick k + 1's pictures are written between jsmpeg_hip_live_tick_begin and _end of tick k")
+    ap.add_argument("--both", action="store_true", help="the plain ticks, then the same with the writes beside the tick in flight")
     ap.add_argument("--json")
     a = ap.parse_args()
-    res = run(a.streams, a.pictures, a.config, a.pictures_per_tick, check=not a.no_check, via_node=a.node)
+    res = run(a.streams, a.pictures, a.config, a.pictures_per_tick, check=not a.no_check, via_node=a.node, overlap=a.overlap, also_overlapped=a.both)
     if a.json:
         os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump(res, open(a.json, "w"), indent=1)
-    sys.exit(1 if res.get("pictures_differing_from_oracle") else 0)
+    sys.exit(1 if res.get("pictures_differing_from_oracle") or (res.get("writes_beside_the_tick_in_flight") or {}).get("pictures_differing_from_oracle") else 0)
