@@ -447,8 +447,12 @@ int jsmpeg_hip_device_synchronize(void);
  * decoded pictures stay in HBM, and one jsmpeg_hip_live_tick decodes the pending pictures of EVERY stream in ONE pass
  * of the batch engine (all their slices parsed at once, one reconstruct launch) -- per stream exactly the pictures the
  * reference's decoder gives for the same write() calls (held against it with the same writes and ticks, evictions
- * included: tools/fuzz_live.py).  Nothing is copied on the way: a write() lands in a pinned staging buffer, one transfer per tick takes all of them to the device, a picture is reconstructed into its stream's
- * ring of frames, and the next tick predicts from those frames where they lie.
+ * included: tools/fuzz_live.py).  Nothing is copied twice on the way: a write() lands in a pinned staging buffer, which goes
+ * to the device a MiB at a time beside the host's next writes (what is left of it with the tick); a picture is reconstructed
+ * into its stream's ring of frames, and the next tick predicts from those frames where they lie.  A handle is one
+ * thread's at a time (like a decoder of the reference: single-threaded JS); handles are independent of each other.
+ * Device memory: per stream (max_pictures_per_tick + 2) frames, 11 x store_bytes, ~0.2 MB of records per picture and tick
+ * -- 25 MB per 1080p stream at the defaults, 15 MB with one picture per tick.
  *
  *     id = jsmpeg_hip_live_open(l);                                   a stream joins (any time)
  *     jsmpeg_hip_live_write(l, id, pts, bytes, n);                    == video.write(pts, [bytes])   (ts.js:205-210)
