@@ -1266,6 +1266,7 @@ struct jsmpeg_hip_live_t {
 	 * tick then uploads only what the last chunk left.  stage_sent: bytes of h_stage already enqueued (0 again after anything
 	 * moved staged bytes); the tick's stream waits for ev_sent before it reads the arena */
 	hipStream_t up_stream; hipEvent_t ev_sent; uint32_t stage_sent, up_chunk;
+	bool up_pending;                    /* chunks were enqueued on up_stream that no tick's stream has waited for yet */
 	/* a tick in two halves (jsmpeg_hip_live_tick_begin / _end): between them the pass is on the device and the host may go on
 	 * WRITING -- such a write is staged at once (the copy is the work) and ACCOUNTED for when the tick has ended, in order, by the
 	 * same rules as any write (live_account_write): to the streams it is a write made right behind the tick */
@@ -1344,7 +1345,7 @@ extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_confi
 	l->b = nullptr; l->h_stage = nullptr; l->d_arena = nullptr; l->h_tab = nullptr; l->d_tab = nullptr; l->h_back = nullptr;
 	l->d_slots = nullptr; l->d_hashes = nullptr; l->d_rgba = nullptr; l->stage_used = 0; l->cur = 0; l->tab_cap = 0;
 	l->up_stream = nullptr; l->ev_sent = nullptr; l->stage_sent = 0;
-	l->in_flight = false; l->last_n = 0;
+	l->in_flight = false; l->last_n = 0; l->up_pending = false;
 	{ const char *v = getenv("JSMPEG_HIP_LIVE_UPLOAD_CHUNK"); l->up_chunk = v ? (uint32_t)strtoul(v, nullptr, 0) : (1u << 20); }   /* 0: everything at the tick */
 	for (float &m : l->ms) m = 0.f;
 	const uint64_t all_stores = (uint64_t)l->cfg.max_streams * l->cfg.store_bytes;
@@ -1427,6 +1428,7 @@ static inline int live_send_staged(jsmpeg_hip_live_t *l) {
 	HIP_TRY(hipSetDevice(l->b->device));
 	HIP_TRY(hipMemcpyAsync(l->d_arena + l->stage_sent, l->h_stage + l->stage_sent, l->stage_used - l->stage_sent, hipMemcpyHostToDevice, l->up_stream));
 	l->stage_sent = l->stage_used;
+	l->up_pending = true;
 	return 0;
 }
 
@@ -1760,9 +1762,12 @@ static int live_tick_begin_impl(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_
 		max_len = std::max(max_len, g.bytes); n_tab++;
 	}
 	uint8_t *es = l->d_arena + l->es_off[cur];
-	if (l->stage_sent) {                                             /* the chunks sent while the host was writing: this stream reads the arena behind them */
+	if (l->up_pending) {
+		/* the chunks sent while the host was writing: this stream reads -- and, where a compaction has moved staged bytes since,
+		 * overwrites -- the arena behind them (up_pending, not stage_sent: a chunk still on its way must not land on the copy below) */
 		HIP_TRY(hipEventRecord(l->ev_sent, l->up_stream));
 		HIP_TRY(hipStreamWaitEvent(st, l->ev_sent, 0));
+		l->up_pending = false;
 	}
 	if (l->stage_used > l->stage_sent) HIP_TRY(hipMemcpyAsync(l->d_arena + l->stage_sent, l->h_stage + l->stage_sent, l->stage_used - l->stage_sent, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(l->d_tab, l->h_tab, sizeof(uint32_t) * 3 * (size_t)l->tab_cap, hipMemcpyHostToDevice, st));

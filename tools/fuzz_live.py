@@ -105,7 +105,7 @@ for c in range(cases):
         plan = []                                         # per tick {stream: [writes]}
         given = [0] * n_streams
         all_w = [picture_writes(g[0], g[1]) for g in gen]
-        noise = {s: noise_rng.integers(0, 256, size=int(noise_rng.integers(1, 900)), dtype=np.uint8) for s in range(n_streams) if noise_rng.random() < 0.25}
+        noise = {s: noise_rng.integers(0, 256, size=int(min(store, noise_rng.integers(1, 900))), dtype=np.uint8) for s in range(n_streams) if noise_rng.random() < 0.25}
         t = 0
         while any(given[s] < n for s in range(n_streams)) and t < 200:
             row = {}
