@@ -1108,6 +1108,7 @@ def main():
                           "ms_per_step": round(dt / max(2, args.steps) * 1e3, 3),
                           "h2d_ms": round(sum(a.elapsed_time(bb) for a, bb in h2d_ms) / max(1, len(h2d_ms)), 3),
                           "h2d_bytes": shard_len,
+                          "phases_ms": {kk: round((phase[kk] - saved[kk]) / max(2, args.steps), 4) for kk in phase},
                           "note": "every step starts with the packed compressed streams in pinned HOST memory: one PCIe copy (double-buffered, on its own stream: the copy of step k+1 runs beside the kernels of step k) + the device-side placement, then the same path; never `value`"}
         args.h2d = False
         phase.update(saved)

@@ -158,6 +158,7 @@ struct jsmpeg_hip_batch_t {
 	uint32_t n_level_ev;
 	bool timed;
 	uint32_t *h_counters; /* pinned */
+	void *h_counters_dev, *h_pics_dev;   /* the device's addresses of h_counters and h_pics (written by k_to_host) */
 	/* LIVE (jsmpeg_hip_live_t below: a batch pass over what has arrived of streams that go on): the pool holds
 	 * `pool_frames` frames (the streams' rings), and picture p of a pass is written to pool slot slot[p] -- a live stream
 	 * owns a ring of slots, so that the frames of its last two decoded pictures are still there, untouched, when the next
@@ -212,7 +213,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(jm_malloc(&b->d_slice_order, sizeof(uint32_t) * b->sc_cap));
 	HIP_TRY(jm_malloc(&b->d_order_hist, sizeof(uint32_t) * (2 * JM_ORDER_BINS + 16 + JM_PARSE_CU_KEYS)));   /* + the parse pass's ticket counter + its per-CU arrival counters */
 	HIP_TRY(jm_malloc(&b->d_counters, JM_N_COUNTERS * sizeof(uint32_t)));
-	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures)));
+	HIP_TRY(jm_malloc(&b->d_pics, sizeof(JmPic) * std::max(1u, c.max_pictures) + 16));      /* (+ 16: the table goes to the host in 16-byte pieces) */
 	b->desc_cap = 2 * std::max(1u, c.max_pictures) + 64;   /* every picture once, the ones without a forward reference twice (steps 4a, 4b); ordered: padding of up to 8 % */
 	HIP_TRY(jm_malloc(&b->d_desc, sizeof(JmReconDesc) * b->desc_cap));
 	HIP_TRY(jm_malloc(&b->d_done, (size_t)JM_DONE_STRIDE * sizeof(uint32_t) * std::max(1u, c.max_pictures)));   /* a 128-byte line per picture's count */
@@ -220,7 +221,7 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	HIP_TRY(hipHostMalloc(&b->h_rstatus, sizeof(uint32_t) * JM_RECON_STATUS_WORDS, hipHostMallocDefault));
 	HIP_TRY(jm_malloc(&b->d_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_covered, sizeof(uint32_t) * std::max(1u, c.max_pictures), hipHostMallocDefault));
-	HIP_TRY(hipHostMalloc(&b->h_pics, sizeof(JmPic) * std::max(1u, c.max_pictures), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc(&b->h_pics, sizeof(JmPic) * std::max(1u, c.max_pictures) + 16, hipHostMallocDefault));
 	HIP_TRY(hipHostMalloc(&b->h_desc, sizeof(JmReconDesc) * b->desc_cap, hipHostMallocDefault));
 	HIP_TRY(hipEventCreate(&b->ev_cov));
 	HIP_TRY(hipEventCreateWithFlags(&b->ev_idx, hipEventDisableTiming));
@@ -237,6 +238,8 @@ static int batch_alloc(jsmpeg_hip_batch_t *b) {
 	b->d_pool = b->d_pool_alloc + POOL_GUARD;
 	HIP_TRY(jm_malloc(&b->d_hashes, sizeof(uint64_t) * std::max(1u, c.max_pictures)));
 	HIP_TRY(hipHostMalloc(&b->h_counters, JM_N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
+	HIP_TRY(hipHostGetDevicePointer(&b->h_counters_dev, b->h_counters, 0));
+	HIP_TRY(hipHostGetDevicePointer(&b->h_pics_dev, b->h_pics, 0));
 	for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
 	for (auto &e : b->ev_level) HIP_TRY(hipEventCreate(&e));
 	return 0;
@@ -720,8 +723,16 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	HIP_TRY(hipEventRecord(b->ev[1], st));
 
 	/* ---- 2. the one host turn-around: sizes + level order ---- */
-	HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * b->pics_first_copy, hipMemcpyDeviceToHost, st));
+	/* written by a kernel into the pinned tables, not copied by a DMA engine: a DMA job waits for the engines' other jobs -- a
+	 * host that uploads the NEXT pass's streams meanwhile (0.5 GB over PCIe on its own stream) held this turn-around for
+	 * 0.76 ms of every step (bench.py's value_incl_h2d).  JSMPEG_HIP_TURNAROUND_MEMCPY=1: the copies, for measurements */
+	static const bool turnaround_memcpy = getenv("JSMPEG_HIP_TURNAROUND_MEMCPY") != nullptr;
+	if (turnaround_memcpy) {
+		HIP_TRY(hipMemcpyAsync(b->h_counters, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(b->h_pics, b->d_pics, sizeof(JmPic) * b->pics_first_copy, hipMemcpyDeviceToHost, st));
+	} else {
+		HIP_TRY(jm_launch_to_host(b->h_counters_dev, b->d_counters, JM_N_COUNTERS * sizeof(uint32_t), b->h_pics_dev, b->d_pics, sizeof(JmPic) * b->pics_first_copy, st));
+	}
 	HIP_TRY(hipEventRecord(b->ev_idx, st));
 	/* the slice order (longest first: kernels.hip) goes in behind the copies and runs WHILE the host reads them and lays out
 	 * the parse: its kernels take their sizes from the device's counters, so nothing of it waits for the host -- 0.08 ms of

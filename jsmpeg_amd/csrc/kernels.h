@@ -39,6 +39,8 @@ struct JmScanBufs {
 hipError_t jm_launch_scan(const JmScanBufs &b, hipStream_t st);
 
 /* n byte ranges of a device buffer -> their places in the batch ES buffer (tables in device memory) */
+/* two device tables to pinned host memory by a kernel (sizes rounded up to 16 bytes: both sides are allocated so) */
+hipError_t jm_launch_to_host(void *host_a, const void *dev_a, size_t bytes_a, void *host_b, const void *dev_b, size_t bytes_b, hipStream_t st);
 hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src_begin, const uint32_t *dst_begin, const uint32_t *len,
                            uint32_t n_streams, uint32_t max_len, hipStream_t st);
 

@@ -261,6 +261,26 @@ __global__ __launch_bounds__(JM_WG) void k_place(const uint8_t *src, uint8_t *ds
 	}
 }
 
+/* ------------------------------------------------------------------------
+ * The index's results on their way to the host: two small tables written by
+ * a KERNEL into pinned host memory.  (As hipMemcpyAsync they are DMA jobs, and
+ * a DMA job queues behind whatever the copy engines are doing -- the next
+ * step's 0.5 GB of compressed streams arriving over PCIe on another stream
+ * held the host's turn-around for 0.76 ms of every step.)  16-byte pieces.
+ * ---------------------------------------------------------------------- */
+__global__ __launch_bounds__(JM_WG) void k_to_host(uint4 *dst_a, const uint4 *src_a, uint32_t n_a, uint4 *dst_b, const uint4 *src_b, uint32_t n_b) {
+	const uint32_t i = blockIdx.x * JM_WG + threadIdx.x;
+	if (i < n_a) dst_a[i] = src_a[i];
+	else if (i - n_a < n_b) dst_b[i - n_a] = src_b[i - n_a];
+}
+
+hipError_t jm_launch_to_host(void *host_a, const void *dev_a, size_t bytes_a, void *host_b, const void *dev_b, size_t bytes_b, hipStream_t st) {
+	const uint32_t n_a = (uint32_t)((bytes_a + 15) / 16), n_b = (uint32_t)((bytes_b + 15) / 16);
+	if (n_a + n_b == 0) return hipSuccess;
+	hipLaunchKernelGGL(k_to_host, dim3((n_a + n_b + JM_WG - 1) / JM_WG), dim3(JM_WG), 0, st, (uint4 *)host_a, (const uint4 *)dev_a, n_a, (uint4 *)host_b, (const uint4 *)dev_b, n_b);
+	return hipGetLastError();
+}
+
 hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src_begin, const uint32_t *dst_begin, const uint32_t *len,
                            uint32_t n_streams, uint32_t max_len, hipStream_t st) {
 	if (n_streams == 0 || max_len == 0) return hipSuccess;
