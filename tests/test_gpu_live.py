@@ -460,7 +460,7 @@ def test_live_damaged_streams_do_not_disturb_their_neighbours(hip_lib, libs):
 def test_live_fuzz_short_run(hip_lib, libs, chunk):
     """tools/fuzz_live.py: random sizes / syntax / feeding (whole pictures with small stores that evict, arbitrary byte pieces,
     TS in pieces), streams joining at random ticks -- a short run of the sweep whose long runs are profiles/r06_fuzz_live.txt.
-    Second form: the staged bytes go to the device in chunks while the host is still writing (engine.hip live_send_staged;
+    Second form: the staged bytes go to the device in chunks while the host is still writing (live.hip live_send_staged;
     1 MiB by default, more than these small pictures ever stage) -- with a chunk of 3000 bytes every case sends many, around
     evacuations and compactions of the staging buffer."""
     import subprocess

@@ -117,7 +117,7 @@ def test_limit_holds_the_rest_and_a_known_header_needs_no_header(sim):
     tail = index(sim, es[at:], W, H, HOLD, limit=4, known=rec)
     assert tail["valid"] == 1 and tail["found"] == 0
     assert tail["decoded"] == [1, 1, 1, 1, 0] and [e + at for e in tail["end"][:4]] == full["end"][4:8] and tail["end"][4] == NONE
-    assert tail["fwd"][:4] == [-1, 0, 1, 2]                  # (the first P picture's reference is the ring's frame: engine.hip seeds it)
+    assert tail["fwd"][:4] == [-1, 0, 1, 2]                  # (the first P picture's reference is the ring's frame: live.hip seeds it)
     without = index(sim, es[at:], W, H, HOLD, limit=4)
     assert without["valid"] == 0 and not any(without["decoded"])
     # a header of another size makes the stream invalid: nothing is decoded
