@@ -742,6 +742,41 @@ extern "C" int jsmpeg_hip_live_read_frame(jsmpeg_hip_live_t *l, uint32_t i, void
 	return 0;
 }
 
+extern "C" int jsmpeg_hip_live_read_frames(jsmpeg_hip_live_t *l, uint32_t first, uint32_t count, void *host, uint64_t stride) {
+	g_err[0] = 0;
+	if (live_settle(l) < 0) return -1;
+	if (!l || (count && !host) || (uint64_t)first + count > l->out.size()) return fail("bad picture range %u + %u of %u", first, count, l ? (unsigned)l->out.size() : 0u);
+	const jsmpeg_hip_batch_t *b = l->b;
+	const size_t planes = (size_t)b->g.luma_bytes + 2 * (size_t)b->g.chroma_bytes;
+	if (count && stride < planes) return fail("stride %llu < the %llu bytes of a picture's planes", (unsigned long long)stride, (unsigned long long)planes);
+	HIP_TRY(hipSetDevice(b->device));
+	for (uint32_t k = 0; k < count; k++)
+		HIP_TRY(hipMemcpyAsync((uint8_t *)host + (uint64_t)k * stride, b->d_pool + (uint64_t)l->out[first + k].slot * b->g.frame_bytes, planes, hipMemcpyDeviceToHost, b->stream));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+extern "C" void *jsmpeg_hip_host_alloc(uint64_t bytes) {
+	g_err[0] = 0;
+	void *p = nullptr;
+	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+	if (e != hipSuccess) { fail("hipHostMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e)); return nullptr; }
+	return p;
+}
+extern "C" void jsmpeg_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int jsmpeg_hip_host_register(void *p, uint64_t bytes) {
+	g_err[0] = 0;
+	if (!p || !bytes) return fail("host_register: null or empty");
+	HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+	return 0;
+}
+extern "C" int jsmpeg_hip_host_unregister(void *p) {
+	g_err[0] = 0;
+	if (!p) return 0;
+	HIP_TRY(hipHostUnregister(p));
+	return 0;
+}
+
 extern "C" int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void *host_rgba) {
 	g_err[0] = 0;
 	if (live_settle(l) < 0) return -1;

@@ -13,6 +13,8 @@
  *   liveTickBegin(handle, flush) / liveTickEnd(handle) -> pictures                 jsmpeg_hip_live_tick_begin / _end (writes may go on between them)
  *   livePicture(handle, i) -> {stream, type, pts, streamOffset}                    jsmpeg_hip_live_picture
  *   liveReadPlanes(handle, i, y, cr, cb) / liveReadRGBA(handle, i, Uint8ClampedArray)
+ *   liveReadFrames(handle, first, count, Uint8Array, stride) -> count              jsmpeg_hip_live_read_frames (all of a tick's pictures in one call)
+ *   hostRegister(Uint8Array) / hostUnregister(Uint8Array)                          jsmpeg_hip_host_register / _unregister (pinned: the link's rate)
  *   liveFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures                  jsmpeg_hip_live_frame_hashes
  *   liveStreamInfo(handle, id) -> {hasSequenceHeader, width, height, frameRate, status, pendingBytes, bytesWritten, pictures, evictions}
  *   liveGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
@@ -247,6 +249,52 @@ static napi_value fn_live_read_planes(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* liveReadFrames(handle, first, count, Uint8Array out, stride): pictures first .. first + count - 1 of the last tick, each one's
+ * Y | Cr | Cb at out + k * stride, in one call (jsmpeg_hip_live_read_frames); `out` at the link's rate once hostRegister()ed */
+static napi_value fn_live_read_frames(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	uint32_t first = 0, count = 0;
+	double stride = 0;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	if (argc < 5 || napi_get_value_uint32(env, argv[1], &first) != napi_ok || napi_get_value_uint32(env, argv[2], &count) != napi_ok ||
+	    napi_get_value_double(env, argv[4], &stride) != napi_ok || stride < 0) { napi_throw_type_error(env, NULL, "jsmpeg_hip: liveReadFrames(handle, first, count, Uint8Array, stride)"); return NULL; }
+	uint32_t luma = 0, chroma = 0;
+	int32_t cw, ch;
+	jsmpeg_hip_live_geometry(l, &cw, &ch, &luma, &chroma);
+	const double need = count ? (double)(count - 1) * stride + (double)luma + 2.0 * chroma : 0;
+	void *data = u8_arg(env, argv[3], (size_t)need);
+	if (!data && count) { napi_throw_range_error(env, NULL, "jsmpeg_hip: the target must hold (count - 1) * stride + a picture's planes"); return NULL; }
+	if (jsmpeg_hip_live_read_frames(l, first, count, data, (uint64_t)stride) < 0) return throw_last(env);
+	NAPI_OK(napi_create_uint32(env, count, &out));
+	return out;
+}
+
+/* hostRegister(Uint8Array) / hostUnregister(Uint8Array): the array's memory pinned for the copy engines (jsmpeg_hip_host_register);
+ * the caller keeps the array alive until it has unregistered it */
+static napi_value fn_host_register(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (argc < 1 || napi_get_typedarray_info(env, argv[0], &t, &len, &data, &ab, &off) != napi_ok || !len) { napi_throw_type_error(env, NULL, "jsmpeg_hip: hostRegister(Uint8Array)"); return NULL; }
+	if (jsmpeg_hip_host_register(data, (uint64_t)len) < 0) return throw_last(env);
+	NAPI_OK(napi_get_boolean(env, true, &out));
+	return out;
+}
+static napi_value fn_host_unregister(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	void *data = NULL; size_t len = 0; napi_typedarray_type t; napi_value ab; size_t off;
+	if (argc < 1 || napi_get_typedarray_info(env, argv[0], &t, &len, &data, &ab, &off) != napi_ok) { napi_throw_type_error(env, NULL, "jsmpeg_hip: hostUnregister(Uint8Array)"); return NULL; }
+	if (jsmpeg_hip_host_unregister(data) < 0) return throw_last(env);
+	NAPI_OK(napi_get_boolean(env, true, &out));
+	return out;
+}
+
 static napi_value fn_live_read_rgba(napi_env env, napi_callback_info info) {
 	size_t argc = 4;
 	napi_value argv[4], out;
@@ -329,7 +377,7 @@ static napi_value fn_live_timings(napi_env env, napi_callback_info info) {
 int jm_napi_register_live(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "liveCreate", fn_live_create }, { "liveDestroy", fn_live_destroy }, { "liveOpen", fn_live_open }, { "liveClose", fn_live_close },
-		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "liveTickBegin", fn_live_tick_begin }, { "liveTickEnd", fn_live_tick_end }, { "livePicture", fn_live_picture },
+		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "liveTickBegin", fn_live_tick_begin }, { "liveTickEnd", fn_live_tick_end }, { "livePicture", fn_live_picture }, { "liveReadFrames", fn_live_read_frames }, { "hostRegister", fn_host_register }, { "hostUnregister", fn_host_unregister },
 		{ "liveReadPlanes", fn_live_read_planes }, { "liveReadRGBA", fn_live_read_rgba }, { "liveFrameHashes", fn_live_frame_hashes },
 		{ "liveStreamInfo", fn_live_stream_info }, { "liveGeometry", fn_live_geometry }, { "liveTimings", fn_live_timings },
 	};

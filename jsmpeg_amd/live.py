@@ -11,7 +11,8 @@ FLUSH = 1
 
 LIVE_SYMBOLS = ("jsmpeg_hip_live_create", "jsmpeg_hip_live_destroy", "jsmpeg_hip_live_open", "jsmpeg_hip_live_close",
                 "jsmpeg_hip_live_write", "jsmpeg_hip_live_write_v", "jsmpeg_hip_live_write_ts", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_tick_begin", "jsmpeg_hip_live_tick_end", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
-                "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_rgba",
+                "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_frames", "jsmpeg_hip_live_read_rgba",
+                "jsmpeg_hip_host_alloc", "jsmpeg_hip_host_free", "jsmpeg_hip_host_register", "jsmpeg_hip_host_unregister",
                 "jsmpeg_hip_live_frame_hashes", "jsmpeg_hip_live_stream_info", "jsmpeg_hip_live_timings")
 
 
@@ -65,6 +66,16 @@ def lib():
         L.jsmpeg_hip_live_geometry.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
         L.jsmpeg_hip_live_read_frame.restype = ctypes.c_int
         L.jsmpeg_hip_live_read_frame.argtypes = [vp, u32, vp, vp, vp]
+        L.jsmpeg_hip_live_read_frames.restype = ctypes.c_int
+        L.jsmpeg_hip_live_read_frames.argtypes = [vp, u32, u32, vp, ctypes.c_uint64]
+        L.jsmpeg_hip_host_alloc.restype = vp
+        L.jsmpeg_hip_host_alloc.argtypes = [ctypes.c_uint64]
+        L.jsmpeg_hip_host_free.restype = None
+        L.jsmpeg_hip_host_free.argtypes = [vp]
+        L.jsmpeg_hip_host_register.restype = ctypes.c_int
+        L.jsmpeg_hip_host_register.argtypes = [vp, ctypes.c_uint64]
+        L.jsmpeg_hip_host_unregister.restype = ctypes.c_int
+        L.jsmpeg_hip_host_unregister.argtypes = [vp]
         L.jsmpeg_hip_live_read_rgba.restype = ctypes.c_int
         L.jsmpeg_hip_live_read_rgba.argtypes = [vp, u32, vp]
         L.jsmpeg_hip_live_frame_hashes.restype = ctypes.c_int
@@ -97,6 +108,9 @@ class Live:
         return rc
 
     def close(self):
+        if getattr(self, "_pin", None):
+            self.L.jsmpeg_hip_host_free(self._pin)
+            self._pin, self._pin_bytes = None, 0
         if self.h:
             self.L.jsmpeg_hip_live_destroy(self.h)
             self.h = None
@@ -152,6 +166,25 @@ class Live:
         cb = np.empty(self.chroma_bytes, dtype=np.uint8)
         self._ok(self.L.jsmpeg_hip_live_read_frame(self.h, i, y.ctypes.data, cr.ctypes.data, cb.ctypes.data))
         return y, cr, cb
+
+    def read_frames(self, first=0, count=None):
+        """every picture of the last tick in one go, into pinned memory of the object's own (grown on demand): an array
+        [count, luma_bytes + 2 * chroma_bytes] -- row k is Y | Cr | Cb of picture first + k -- valid until the next call"""
+        n = self.picture_count - first if count is None else count
+        planes = self.luma_bytes + 2 * self.chroma_bytes
+        if n <= 0:
+            return np.empty((0, planes), dtype=np.uint8)
+        if getattr(self, "_pin_bytes", 0) < n * planes:
+            if getattr(self, "_pin", None):
+                self.L.jsmpeg_hip_host_free(self._pin)
+            self._pin_bytes = max(n, 2 * getattr(self, "_pin_pictures", 0)) * planes
+            self._pin_pictures = self._pin_bytes // planes
+            self._pin = self.L.jsmpeg_hip_host_alloc(self._pin_bytes)
+            if not self._pin:
+                self._pin_bytes = 0
+                raise RuntimeError("jsmpeg_hip_host_alloc: " + _batch.last_error())
+        self._ok(self.L.jsmpeg_hip_live_read_frames(self.h, first, n, self._pin, planes))
+        return np.ctypeslib.as_array((ctypes.c_uint8 * (n * planes)).from_address(self._pin)).reshape(n, planes)
 
     def read_rgba(self, i):
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

@@ -9,6 +9,7 @@ const script = [[], [{ stream: 0, type: 1, pts: 0.5, streamOffset: 140 }], [{ st
                 [{ stream: 1, type: 2, pts: 8, streamOffset: 8 }], []];
 let tickNo = -1, open = 0, inFlight = false;
 const written = {};
+const reads = [], pins = [];
 const headers = { 0: false, 1: false };
 const binding = {
   liveCreate(...a) { calls.push(['liveCreate', ...a]); return { h: 1 }; },
@@ -23,6 +24,9 @@ const binding = {
   liveWriteTS(h, id, buf, sid) { calls.push(['liveWriteTS', id, buf.length, sid]); written[id] = (written[id] || 0) + 100; return buf.length; },
   livePicture(h, i) { return script[tickNo][i]; },
   liveReadPlanes(h, i, y, cr, cb) { y[0] = 10 * tickNo + i; cr[0] = 1; cb[0] = 2; },
+  liveReadFrames(h, first, count, out, stride) { reads.push([first, count, out.length, stride]); for (let k = 0; k < count; k++) { out[k * stride] = 10 * tickNo + first + k; out[k * stride + 512] = 1; out[k * stride + 640] = 2; } return count; },
+  hostRegister(a) { pins.push(['pin', a.length]); return true; },
+  hostUnregister(a) { pins.push(['unpin', a.length]); return true; },
   liveReadRGBA(h, i, out, n) { calls.push(['liveReadRGBA', i, n]); out[0] = 99; },
   liveStreamInfo(h, id) { if (inFlight) calls.push(['liveStreamInfo beside a tick in flight', id]); return { hasSequenceHeader: headers[id] ? 1 : 0, width: 30, height: 15, frameRate: 25, status: 0, pendingBytes: 0, bytesWritten: written[id] || 0, pictures: 0, evictions: 0 }; },
   liveFrameHashes(h, raw) { raw[0] = 0xef; raw[7] = 0x01; },
@@ -59,5 +63,5 @@ try { b.write(0, [new Uint8Array(1)]); } catch (e) { threw = true; }
 log.push(['closedThrows', threw, live.streams.size]);
 promise.then(() => {
   live.destroy();
-  process.stdout.write(JSON.stringify({ calls, log, later }) + '\n');
+  process.stdout.write(JSON.stringify({ calls, log, later, reads, pins }) + '\n');
 });

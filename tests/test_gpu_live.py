@@ -364,6 +364,38 @@ def test_live_bytes_before_the_first_header_are_skipped(hip_lib, libs):
     assert got == want and got[0] == [] and sum(len(t) for t in got) == 30 - 12
 
 
+def test_live_read_frames_all_at_once(hip_lib):
+    """jsmpeg_hip_live_read_frames: every picture of a tick in one call into pinned memory == the per-picture reads; ranges,
+    a stride wider than the planes, refusals"""
+    W, H = 352, 288
+    gen = [synth.generate_config("cfg1_720p", n_frames=4, stream=70 + s, width=W, height=H) for s in range(5)]
+    with jl.Live(W, H, 5, pictures_per_tick=3) as lv:
+        ids = [lv.open() for _ in range(5)]
+        for s, (es, offs) in enumerate(gen):
+            for w in picture_writes(es, [int(o) for o in offs])[:1 + s % 3]:
+                lv.write(ids[s], w)
+        n = lv.tick(flush=True)
+        assert n == sum(1 + s % 3 for s in range(5))
+        one_by_one = [np.concatenate(lv.read_frame(i)) for i in range(n)]
+        allf = lv.read_frames()
+        assert allf.shape == (n, lv.luma_bytes + 2 * lv.chroma_bytes)
+        assert all((allf[i] == one_by_one[i]).all() for i in range(n))
+        part = lv.read_frames(2, 3).copy()
+        assert all((part[k] == one_by_one[2 + k]).all() for k in range(3))
+        assert lv.read_frames(n, 0).shape[0] == 0
+        planes = lv.luma_bytes + 2 * lv.chroma_bytes
+        wide = np.full((n, planes + 64), 0xEE, dtype=np.uint8)          # pageable memory, a stride with room behind each picture
+        assert lv.L.jsmpeg_hip_live_read_frames(lv.h, 0, n, wide.ctypes.data, planes + 64) == 0
+        assert all((wide[i, :planes] == one_by_one[i]).all() for i in range(n)) and (wide[:, planes:] == 0xEE).all()
+        assert lv.L.jsmpeg_hip_host_register(wide.ctypes.data, wide.nbytes) == 0        # the caller's own memory, pinned
+        wide[:] = 0
+        assert lv.L.jsmpeg_hip_live_read_frames(lv.h, 0, n, wide.ctypes.data, planes + 64) == 0
+        assert all((wide[i, :planes] == one_by_one[i]).all() for i in range(n))
+        assert lv.L.jsmpeg_hip_host_unregister(wide.ctypes.data) == 0
+        assert lv.L.jsmpeg_hip_live_read_frames(lv.h, 1, n, wide.ctypes.data, planes + 64) < 0     # past the last picture
+        assert lv.L.jsmpeg_hip_live_read_frames(lv.h, 0, 1, wide.ctypes.data, planes - 1) < 0      # pictures would overlap
+
+
 def test_live_rgba_and_device_frames(hip_lib, libs):
     """the RGBA stage on a live picture; device_frame is where the planes lie"""
     from oracle import checkers

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_addon_exports_the_live_functions():
     addon = build.build_addon()
     out = subprocess.check_output([NODE, "-e", "const a=require(%r);console.log(JSON.stringify(Object.keys(a)))" % addon])
-    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveWriteTS", "liveTick", "liveTickBegin", "liveTickEnd", "livePicture", "liveReadPlanes", "liveReadRGBA",
+    assert {"liveCreate", "liveDestroy", "liveOpen", "liveClose", "liveWrite", "liveWriteTS", "liveTick", "liveTickBegin", "liveTickEnd", "livePicture", "liveReadFrames", "hostRegister", "hostUnregister", "liveReadPlanes", "liveReadRGBA",
             "liveFrameHashes", "liveStreamInfo", "liveGeometry", "liveTimings"} <= set(json.loads(out))
 
 
@@ -54,6 +54,8 @@ def test_live_class_logic_over_an_injected_binding():
                           ["hash", "01000000000000ef"], ["state", True, 25, 30, 15, 512, 0.08, True, 140, True, 0.04], ["decode", False],
                           ["beside", True, True, 13], ["frame", 1, 1, 8], ["tickEnd", 1, False, 100, 0], ["closedThrows", True, 1]]
     assert out["later"] == [["begun", True], ["async", 0, False]]
+    # the planes of a tick's pictures come in ONE call into one array, pinned once, unpinned at destroy; frames are views into it
+    assert out["reads"] == [[0, 1, 768, 768], [0, 1, 768, 768]] and out["pins"] == [["pin", 768], ["unpin", 768]]
 
 
 def _ts_files(n, frames, w, h):
