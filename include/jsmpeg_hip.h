@@ -216,6 +216,11 @@ int jsmpeg_hip_batch_geometry(jsmpeg_hip_batch_t *b, int32_t *coded_width, int32
 void *jsmpeg_hip_batch_frame_pool(jsmpeg_hip_batch_t *b);
 /* Device-to-host copy of one picture's planes (any of y/cr/cb may be NULL). */
 int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t picture, void *y, void *cr, void *cb);
+/* Pictures first .. first + count - 1 in one go: picture first + k's planes (Y | Cr | Cb, luma_bytes + 2 * chroma_bytes contiguous
+ * bytes) at host + k * stride -- one strided copy, at the link's rate when `host` is pinned (jsmpeg_hip_host_alloc /
+ * jsmpeg_hip_host_register, part 5): 49 GB/s against 27 picture by picture into pageable memory.  Pictures that were not
+ * decoded (jsmpeg_hip_batch_picture: decoded 0) are copied like the others; what they hold is undefined. */
+int jsmpeg_hip_batch_read_frames(jsmpeg_hip_batch_t *b, uint32_t first, uint32_t count, void *host, uint64_t stride);
 /* 64-bit content hash of every picture's planes, computed on the device
  * (jsmpeg_amd/hashing.py gives the same value for host planes). out[picture_count]. */
 int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *out);

@@ -23,7 +23,7 @@ class PictureInfo(ctypes.Structure):
 BATCH_SYMBOLS = ("jsmpeg_hip_batch_create", "jsmpeg_hip_batch_destroy", "jsmpeg_hip_batch_upload",
                  "jsmpeg_hip_batch_upload_device", "jsmpeg_hip_batch_attach_device", "jsmpeg_hip_batch_decode", "jsmpeg_hip_batch_sync",
                  "jsmpeg_hip_batch_picture_count", "jsmpeg_hip_batch_picture_info", "jsmpeg_hip_batch_geometry",
-                 "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_frame_hashes",
+                 "jsmpeg_hip_batch_frame_pool", "jsmpeg_hip_batch_read_frame", "jsmpeg_hip_batch_read_frames", "jsmpeg_hip_batch_frame_hashes",
                  "jsmpeg_hip_batch_timings", "jsmpeg_hip_batch_level_timings", "jsmpeg_hip_batch_counters", "jsmpeg_hip_batch_recon_info", "jsmpeg_hip_batch_link_streams", "jsmpeg_hip_batch_seed_stream", "jsmpeg_hip_batch_uncovered", "jsmpeg_hip_batch_render_rgba",
                  "jsmpeg_hip_batch_read_rgba", "jsmpeg_hip_batch_render_rgba_gl", "jsmpeg_hip_batch_read_rgba_gl", "jsmpeg_hip_batch_upload_ts", "jsmpeg_hip_batch_upload_ts_writes", "jsmpeg_hip_batch_ts_writes",
                  "jsmpeg_hip_batch_read_es", "jsmpeg_hip_batch_stream_info",
@@ -67,6 +67,12 @@ def lib():
         L.jsmpeg_hip_batch_frame_pool.argtypes = [vp]
         L.jsmpeg_hip_batch_read_frame.restype = ctypes.c_int
         L.jsmpeg_hip_batch_read_frame.argtypes = [vp, u32, vp, vp, vp]
+        L.jsmpeg_hip_batch_read_frames.restype = ctypes.c_int
+        L.jsmpeg_hip_batch_read_frames.argtypes = [vp, u32, u32, vp, ctypes.c_uint64]
+        L.jsmpeg_hip_host_alloc.restype = vp
+        L.jsmpeg_hip_host_alloc.argtypes = [ctypes.c_uint64]
+        L.jsmpeg_hip_host_free.restype = None
+        L.jsmpeg_hip_host_free.argtypes = [vp]
         L.jsmpeg_hip_batch_frame_hashes.restype = ctypes.c_int
         L.jsmpeg_hip_batch_frame_hashes.argtypes = [vp, vp]
         L.jsmpeg_hip_batch_render_rgba.restype = ctypes.c_int
@@ -121,6 +127,9 @@ class Batch:
         return rc
 
     def close(self):
+        if getattr(self, "_pin", None):
+            self.L.jsmpeg_hip_host_free(self._pin)
+            self._pin, self._pin_bytes = None, 0
         if self.h:
             self.L.jsmpeg_hip_batch_destroy(self.h)
             self.h = None
@@ -209,6 +218,23 @@ class Batch:
         cb = np.empty(self.chroma_bytes, dtype=np.uint8)
         self._ok(self.L.jsmpeg_hip_batch_read_frame(self.h, p, y.ctypes.data, cr.ctypes.data, cb.ctypes.data))
         return y, cr, cb
+
+    def read_frames(self, first, count):
+        """pictures first .. first + count - 1 in one strided copy into pinned memory of the object's own (grown on demand):
+        an array [count, luma_bytes + 2 * chroma_bytes], row k = Y | Cr | Cb of picture first + k; valid until the next call"""
+        planes = self.luma_bytes + 2 * self.chroma_bytes
+        if count <= 0:
+            return np.empty((0, planes), dtype=np.uint8)
+        if getattr(self, "_pin_bytes", 0) < count * planes:
+            if getattr(self, "_pin", None):
+                self.L.jsmpeg_hip_host_free(self._pin)
+            self._pin_bytes = count * planes
+            self._pin = self.L.jsmpeg_hip_host_alloc(self._pin_bytes)
+            if not self._pin:
+                self._pin_bytes = 0
+                raise RuntimeError("jsmpeg_hip_host_alloc: " + last_error())
+        self._ok(self.L.jsmpeg_hip_batch_read_frames(self.h, first, count, self._pin, planes))
+        return np.ctypeslib.as_array((ctypes.c_uint8 * (count * planes)).from_address(self._pin)).reshape(count, planes)
 
     def frame_hashes(self):
         out = np.zeros(max(1, self.picture_count), dtype=np.uint64)

@@ -915,6 +915,24 @@ extern "C" int jsmpeg_hip_batch_read_frame(jsmpeg_hip_batch_t *b, uint32_t pictu
 	return 0;
 }
 
+extern "C" int jsmpeg_hip_batch_read_frames(jsmpeg_hip_batch_t *b, uint32_t first, uint32_t count, void *host, uint64_t stride) {
+	g_err[0] = 0;
+	if (!b || (count && !host) || (uint64_t)first + count > b->n_pics) return fail("bad picture range %u + %u of %u", first, count, b ? b->n_pics : 0u);
+	const size_t planes = (size_t)b->g.luma_bytes + 2 * (size_t)b->g.chroma_bytes;
+	if (count && stride < planes) return fail("stride %llu < the %llu bytes of a picture's planes", (unsigned long long)stride, (unsigned long long)planes);
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (batch_settle(b) < 0) return -1;
+	if (!count) return 0;
+	if (b->slot.empty()) {
+		HIP_TRY(hipMemcpy2DAsync(host, stride, frame_of(b, first), b->g.frame_bytes, planes, count, hipMemcpyDeviceToHost, b->stream));
+	} else {
+		for (uint32_t k = 0; k < count; k++) HIP_TRY(hipMemcpyAsync((uint8_t *)host + (uint64_t)k * stride, frame_of(b, first + k), planes, hipMemcpyDeviceToHost, b->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
 extern "C" int jsmpeg_hip_batch_frame_hashes(jsmpeg_hip_batch_t *b, uint64_t *out) {
 	g_err[0] = 0;
 	if (!b || !out) return fail("null argument");

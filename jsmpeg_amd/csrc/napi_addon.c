@@ -32,6 +32,7 @@
  *   batchPictureInfo(handle, p) -> {stream, esOffset, type, decoded, level, forward}
  *   batchTsWrites(handle, stream) -> [{pts, offset, length}, ...]   jsmpeg_hip_batch_ts_writes
  *   batchReadPlanes(handle, p, y, cr, cb)   (Uint8Arrays of coded size) jsmpeg_hip_batch_read_frame
+ *   batchReadFrames(handle, first, count, Uint8Array, stride)            jsmpeg_hip_batch_read_frames (one strided copy)
  *   batchReadRGBA(handle, p, Uint8ClampedArray)                      jsmpeg_hip_batch_read_rgba
  *   batchGeometry(handle) -> {codedWidth, codedHeight, lumaBytes, chromaBytes}
  *   batchStreamInfo(handle, stream) -> {hasSequenceHeader, width, height, frameRate}   jsmpeg_hip_batch_stream_info
@@ -523,6 +524,28 @@ static napi_value fn_batch_read_planes(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* batchReadFrames(handle, first, count, Uint8Array out, stride): jsmpeg_hip_batch_read_frames (one strided copy; `out` pinned by
+ * hostRegister for the link's rate) */
+static napi_value fn_batch_read_frames(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	uint32_t first = 0, count = 0, luma = 0, chroma = 0;
+	int32_t cw, ch; uint64_t fstride;
+	double stride = 0;
+	if (!b) return NULL;
+	if (argc < 5 || napi_get_value_uint32(env, argv[1], &first) != napi_ok || napi_get_value_uint32(env, argv[2], &count) != napi_ok ||
+	    napi_get_value_double(env, argv[4], &stride) != napi_ok || stride < 0) { napi_throw_type_error(env, NULL, "jsmpeg_hip: batchReadFrames(handle, first, count, Uint8Array, stride)"); return NULL; }
+	jsmpeg_hip_batch_geometry(b, &cw, &ch, &luma, &chroma, &fstride);
+	const double need = count ? (double)(count - 1) * stride + (double)luma + 2.0 * chroma : 0;
+	void *data = typed_arg(env, argv[3], (size_t)need);
+	if (!data && count) { napi_throw_range_error(env, NULL, "jsmpeg_hip: the target must hold (count - 1) * stride + a picture's planes"); return NULL; }
+	if (jsmpeg_hip_batch_read_frames(b, first, count, data, (uint64_t)stride) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	NAPI_OK(napi_create_uint32(env, count, &out));
+	return out;
+}
+
 static napi_value fn_batch_read_rgba(napi_env env, napi_callback_info info) {
 	size_t argc = 3;
 	napi_value argv[3], out;
@@ -953,7 +976,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error }, { "liveDecoders", fn_live_decoders },
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
 		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
-		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadRGBA", fn_batch_read_rgba },
+		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadFrames", fn_batch_read_frames }, { "batchReadRGBA", fn_batch_read_rgba },
 		{ "batchGeometry", fn_batch_geometry }, { "batchStreamInfo", fn_batch_stream_info }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },
 		{ "mp2GetIndex", fn_mp2_get_index }, { "mp2SetIndex", fn_mp2_set_index }, { "mp2GetSampleRate", fn_mp2_get_sample_rate },

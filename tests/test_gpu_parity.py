@@ -50,6 +50,14 @@ def test_batch_matches_golden(path, hip_lib):
         dev = b.frame_hashes()
         for p in (decoded[0], decoded[len(decoded) // 2], decoded[-1]):
             assert int(dev[p]) == hashing.frame_hash(*b.read_frame(p))
+        # every picture in ONE strided copy into pinned memory (jsmpeg_hip_batch_read_frames) == picture by picture
+        allf = b.read_frames(0, n)
+        lu, ch = b.luma_bytes, b.chroma_bytes
+        assert [md5_planes((allf[p, :lu], allf[p, lu:lu + ch], allf[p, lu + ch:])) for p in decoded] == fx["frame_md5"]
+        tail = b.read_frames(decoded[-1], 1).copy()
+        assert md5_planes((tail[0, :lu], tail[0, lu:lu + ch], tail[0, lu + ch:])) == fx["frame_md5"][-1]
+        with pytest.raises(RuntimeError):
+            b.read_frames(n, 1)
 
 
 @pytest.mark.parametrize("split", ["0", "1"], ids=["k_parse", "k_parse_split"])
