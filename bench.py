@@ -1452,7 +1452,7 @@ def main():
                           "(all streams start their GOPs together: the worst case for the I ticks); one_picture_abi: a decoder per stream, write a picture, decode(), "
                           "planes to the host -- what a live host had before; writes_beside_the_tick_in_flight: the same ticks as jsmpeg_hip_live_tick_begin, "
                           "the NEXT tick's writes, jsmpeg_hip_live_tick_end (the host writes while the pass is on the device), gated the same way" % lt["streams"])
-            for d in (lt, lt.get("writes_beside_the_tick_in_flight") or {}, lt.get("via_napi") or {}, (lt.get("via_napi") or {}).get("writes_beside_the_tick_in_flight") or {}):
+            for d in (lt, lt.get("writes_beside_the_tick_in_flight") or {}, lt.get("via_napi") or {}, (lt.get("via_napi") or {}).get("writes_beside_the_tick_in_flight") or {}, (lt.get("via_napi") or {}).get("with_planes_to_host") or {}):
                 for k in list(d):
                     if isinstance(d[k], float):
                         d[k] = round(d[k], 4)

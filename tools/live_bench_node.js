@@ -20,18 +20,18 @@ for (let s = 0; s < S; s++) {
 }
 const med = (a) => { const b = a.slice().sort((x, y) => x - y); return b.length ? b[b.length >> 1] : null; };
 // overlapped: tick k + 1's pictures are written between live.tickBegin() and live.tickEnd() of tick k (the pass is on the device meanwhile)
-function measure(overlapped) {
+function measure(overlapped, toHost) {
   const live = new HIPLive({ width, height, maxStreams: S, picturesPerTick: 1, videoBufferSize: Math.max(512 * 1024, 2 * biggest) });
   const vids = streams.map(() => live.open());
   const n = streams[0].length, ms = [], got = streams.map(() => []);
   const feed = (k) => { for (let s = 0; s < S; s++) if (k < streams[s].length) vids[s].write(k / 30, [streams[s][k]]); };
-  let pictures = 0;
+  let pictures = 0, seen = 0;
   if (overlapped) feed(0);
   for (let k = 0; k < n; k++) {
     const t0 = process.hrtime.bigint();
     let c;
     if (overlapped) { live.tickBegin({ flush: true }); feed(k + 1); c = live.tickEnd(); }
-    else { feed(k); c = live.tick({ flush: true }); }
+    else { feed(k); c = live.tick(toHost ? { flush: true, onFrame(f) { seen += f.y[0] + f.cb[f.cb.length - 1]; } } : { flush: true }); }
     ms.push(Number(process.hrtime.bigint() - t0) / 1e6);
     pictures += c;
     const h = live.frameHashes();
@@ -49,7 +49,9 @@ try {
   out = measure(false);
   out.host = 'Node ' + process.version + ', JSMpeg.HIPLive over jsmpeg_hip.node (N-API): ' + S + ' write(pts, buffers) calls + one tick() per tick';
   out.writes_beside_the_tick_in_flight = measure(true);
-  const bad = out.pictures_differing_from_oracle + out.writes_beside_the_tick_in_flight.pictures_differing_from_oracle;
+  // every picture's planes brought to the host as well (onFrame: y / cr / cb views into the pinned array liveReadFrames fills once per tick)
+  out.with_planes_to_host = measure(false, true);
+  const bad = out.pictures_differing_from_oracle + out.writes_beside_the_tick_in_flight.pictures_differing_from_oracle + out.with_planes_to_host.pictures_differing_from_oracle;
   if (bad) out.error = 'PARITY FAILURE: ' + bad + ' live pictures differ from the oracle';
 } catch (e) { out = { error: String(e && e.message || e) }; }
 process.stdout.write(JSON.stringify(out) + '\n');
