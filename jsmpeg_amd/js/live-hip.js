@@ -228,8 +228,109 @@ function install(JSMpeg, options) {
     this.live = null;
   };
 
+  // ---- live streams of SEVERAL picture sizes behind one object ----
+  // A HIPLive decodes one geometry (include/jsmpeg_hip.h: jsmpeg_hip_live_config_t).  The router keeps one HIPLive per (width,
+  // height) and finds out which one a stream belongs to from the stream itself: a stream it hands out HOLDS what is written to
+  // it until its first sequence header has shown (00 00 01 B3, 12 + 12 bits: mpeg1.c:872-880; writeTS: in the payload of the
+  // stream's first PES packets), then joins the HIPLive of that size and replays what it held, in order.
+  //     const router = new HIPLiveRouter({ maxStreamsPerSize: 64 });
+  //     const video = router.open();  demuxer.connect(VIDEO_1, video);          // any size
+  //     setInterval(() => router.tick({ onFrame(f) { /* f.stream === video, f.width / f.height of ITS size */ } }), 1000 / 30);
+  const probes = require('./batch-hip.js').install({}, options).HIPBatchRouter;
+  function HIPLiveRouter(opts) {
+    this.opts = opts || {};
+    this.lives = new Map();            // "WxH" -> HIPLive
+    this.waiting = new Set();          // streams whose size is not known yet
+    this.holdBytes = this.opts.holdBytes || 1 << 20;   // what a stream may hold before its header shows (beyond: the oldest writes go)
+  }
+  HIPLiveRouter.prototype.liveFor = function (width, height) {
+    const key = width + 'x' + height;
+    let live = this.lives.get(key);
+    if (!live) {
+      const o = this.opts;
+      live = new HIPLive({ width, height, maxStreams: o.maxStreamsPerSize || 64, picturesPerTick: o.picturesPerTick, videoBufferSize: o.videoBufferSize, device: o.device });
+      this.lives.set(key, live);
+    }
+    return live;
+  };
+  HIPLiveRouter.prototype.open = function (options) {
+    const s = new RoutedStream(this, options || {});
+    this.waiting.add(s);
+    return s;
+  };
+  const routedFrame = (opts) => Object.assign({}, opts, { onFrame: opts.onFrame && ((f) => { f.liveStream = f.stream; f.stream = f.stream.routed || f.stream; opts.onFrame(f); }) });
+  HIPLiveRouter.prototype.tick = function (opts) {
+    let n = 0;
+    for (const live of this.lives.values()) n += live.tick(routedFrame(opts || {}));
+    return n;
+  };
+  HIPLiveRouter.prototype.tickBegin = function (opts) { for (const live of this.lives.values()) live.tickBegin(routedFrame(opts || {})); };
+  HIPLiveRouter.prototype.tickEnd = function () { let n = 0; for (const live of this.lives.values()) n += live.tickEnd(); return n; };
+  HIPLiveRouter.prototype.tickAsync = function (opts) {
+    this.tickBegin(opts);
+    return new Promise((resolve, reject) => setImmediate(() => { try { resolve(this.tickEnd()); } catch (e) { reject(e); } }));
+  };
+  HIPLiveRouter.prototype.destroy = function () {
+    for (const live of this.lives.values()) live.destroy();
+    this.lives.clear(); this.waiting.clear();
+  };
+
+  // a stream of the router: the decoder's surface, like HIPLiveStream's, from the first write on
+  function RoutedStream(router, options) {
+    this.router = router; this.options = options;
+    this.bound = null;                 // the HIPLiveStream, once the size is known
+    this.held = []; this.heldBytes = 0;
+    this.destination = null;
+    this.bytesWritten = 0;
+    for (const k of ['hasSequenceHeader', 'frameRate', 'width', 'height', 'codedSize', 'pictures', 'decodedTime', 'currentTime', 'id'])
+      Object.defineProperty(this, k, { get: () => (this.bound ? this.bound[k] : (k === 'frameRate' ? 30 : k === 'hasSequenceHeader' ? false : 0)) });
+    Object.defineProperty(this, 'canPlay', { get: () => this.bytesWritten > 0 });
+  }
+  RoutedStream.prototype.connect = function (destination) { this.destination = destination; if (this.bound) this.bound.connect(destination); };
+  RoutedStream.prototype.bind = function (size) {
+    const live = this.router.liveFor(size.width, size.height);
+    this.bound = live.open(this.options);        // throws when that size's HIPLive is full
+    this.bound.routed = this;
+    if (this.destination) this.bound.connect(this.destination);
+    this.router.waiting.delete(this);
+    for (const h of this.held) { if (h.ts) this.bound.writeTS(h.bytes, h.streamId); else this.bound.write(h.pts, [h.bytes]); }
+    this.held = []; this.heldBytes = 0;
+  };
+  RoutedStream.prototype.hold = function (entry, probe) {
+    this.held.push(entry); this.heldBytes += entry.bytes.length;
+    while (this.heldBytes > this.router.holdBytes && this.held.length > 1) this.heldBytes -= this.held.shift().bytes.length;
+    const all = new Uint8Array(this.heldBytes);
+    let at = 0;
+    for (const h of this.held) { all.set(h.bytes, at); at += h.bytes.length; }
+    const size = probe(all);
+    if (size && size.width > 0 && size.height > 0) this.bind(size);
+  };
+  RoutedStream.prototype.write = function (pts, buffers) {
+    let n = 0;
+    for (const b of buffers) n += b.length;
+    this.bytesWritten += n;
+    if (this.bound) return this.bound.write(pts, buffers);
+    const bytes = new Uint8Array(n);              // (copied: the caller's buffers are its own again after write(), decoder.js:36-47)
+    let at = 0;
+    for (const b of buffers) { bytes.set(b, at); at += b.length; }
+    this.hold({ pts, bytes }, (all) => probes.probeES(all));
+  };
+  RoutedStream.prototype.writeTS = function (buffer, streamId) {
+    this.bytesWritten += buffer.length;
+    if (this.bound) return this.bound.writeTS(buffer, streamId);
+    this.hold({ ts: true, bytes: Uint8Array.from(buffer), streamId }, (all) => probes.probeTS(all, streamId, Math.ceil(all.length / 188)));
+  };
+  RoutedStream.prototype.decode = function () { return false; };
+  RoutedStream.prototype.seek = function () {};
+  RoutedStream.prototype.info = function () { return this.bound ? this.bound.info() : null; };
+  RoutedStream.prototype.destroy = function () {
+    if (this.bound) this.bound.destroy();
+    this.bound = null; this.held = []; this.router.waiting.delete(this);
+  };
+
   JSMpeg.HIPLive = HIPLive;
-  return { HIPLive, HIPLiveStream, JSMpeg };
+  JSMpeg.HIPLiveRouter = HIPLiveRouter;
+  return { HIPLive, HIPLiveStream, HIPLiveRouter, JSMpeg };
 }
 
 module.exports = { install };

@@ -58,6 +58,18 @@ def test_live_class_logic_over_an_injected_binding():
     assert out["reads"] == [[0, 1, 768, 768], [0, 1, 768, 768]] and out["pins"] == [["pin", 768], ["unpin", 768]]
 
 
+def test_live_router_logic_over_an_injected_binding():
+    """JSMpeg.HIPLiveRouter: a stream holds its writes until its first sequence header shows (also one cut by a write), joins
+    the HIPLive of that size -- made on demand, one per size -- and replays what it held in order; ticks reach every size,
+    frames name the router's stream"""
+    out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "live_router_fake.js")]))
+    assert out["calls"] == [["liveCreate", 32, 16, 7], ["liveOpen", 0], ["liveWrite", 0, 0, 1, 3, 9], ["liveWrite", 0, 0, 2, 5, 0], ["liveWrite", 0, 0, 3, 8, 0],
+                            ["liveCreate", 48, 32, 7], ["liveOpen", 1], ["liveWrite", 1, 0, 4, 12, 0], ["liveOpen", 0], ["liveWrite", 0, 1, 5, 12, 0],
+                            ["liveWrite", 0, 0, 6, 1, 5], ["liveTick", 0], ["liveTick", 1], ["liveClose", 0, 1], ["liveDestroy", 0], ["liveDestroy", 1]]
+    assert out["log"] == [["held", False, 3, 3, 0], ["resize a", 32, 16], ["bound", True, 32, 16, 48, 32, 0, 0, 1, 2, 0],
+                          ["frame", "c", 32, 16, 5], ["render a"], ["frame", "a", 32, 16, 3], ["frame", "b", 48, 32, 4], ["tick", 3]]
+
+
 def _ts_files(n, frames, w, h):
     paths, want, es_all = [], [], []
     oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
@@ -129,3 +141,32 @@ def test_node_live_rgba_frames(hip_lib):
         for p in paths:
             os.unlink(p)
     assert [st["rgba"] for st in out["streams"]] == want
+
+
+@pytest.mark.gpu
+def test_node_live_router_streams_of_several_sizes(hip_lib):
+    """JSMpeg.HIPLiveRouter over the real addon: five TS files of three picture sizes, fed in ragged pieces (ts-demux.js ->
+    write() for the even ones, writeTS for the odd ones); the router finds each stream's size in the stream, one HIPLive per
+    size; every rendered picture == the oracle's"""
+    build.build_addon()
+    oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
+    sizes = [(352, 288), (176, 144), (352, 288), (320, 192), (176, 144)]
+    paths, want = [], []
+    for s, (w, h) in enumerate(sizes):
+        es, offs = synth.generate_config("cfg1_720p", n_frames=9, stream=60 + s, width=w, height=h)
+        f = tempfile.NamedTemporaryFile(suffix=".ts", delete=False)
+        f.write(synth.mux_ts(es, offs).tobytes())
+        f.close()
+        paths.append(f.name)
+        want.append(cabi.decode_stream(oracle, es)[0])
+    try:
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_router.js")] + paths, timeout=300))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["handles"] == sorted("%dx%d" % wh for wh in set(sizes)) and out["waiting"] == 0
+    assert out["pictures"] == 5 * 9 and out["widths"] == [w for w, _ in sizes]
+    for s, (w, h) in enumerate(sizes):
+        st = out["streams"][s]
+        assert st["planes"] == want[s], s
+        assert st["sizes"] == [[w, h]] and st["frames"] == [[w, h]] * 9
