@@ -1121,7 +1121,20 @@ def main():
     # scatters the units over RCCL every step), the same streams, every picture against the oracle's unsplit streams.  The Python
     # ranks wait meanwhile (their GPUs idle).  A reported extra, never `value`.
     napi_multi = None
-    if multi and world > 1 and not args.no_napi:
+    napi_fits = True
+    if multi and world > 1 and not args.no_napi and args.rehearse_on_one_gpu:
+        # a rehearsal keeps ALL ranks on one device: the Python ranks (still holding their batches) and then as many Node ranks
+        # beside them.  Where that cannot fit the device's memory the Node run is left out and says so (on a node with a GPU per
+        # rank each device holds one of each: 2 x 26 GB for the headline's shape)
+        free_b, _total_b = torch.cuda.mem_get_info(dev)
+        need_b = world * (n_pictures * frame_stride + 16 * shard_len + (1 << 30))
+        fits = torch.tensor([1 if free_b > need_b else 0], dtype=torch.int64)
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        napi_fits = bool(fits.item())
+        if not napi_fits:
+            napi_multi = {"skipped": "rehearsal on one device: %d Node ranks of this shape need ~%.0f GB beside the Python ranks, %.0f GB are free" % (world, need_b / 1e9, free_b / 1e9)}
+            log("Node-hosted N-rank run: %s" % napi_multi["skipped"])
+    if multi and world > 1 and not args.no_napi and napi_fits:
         import shutil
         import tempfile
         td = None
