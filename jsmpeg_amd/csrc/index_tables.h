@@ -30,9 +30,14 @@ JM_HD uint32_t jm_lower_bound(const uint32_t *a, uint32_t n, uint32_t key) { /* 
 	return lo;
 }
 
-/* Phase A (one thread per stream): ranges + the first sequence header. */
-JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
-                           uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h) {
+/* Phase A (one thread per stream): ranges + the first sequence header.  In two pieces so that the device can read the two
+ * quantiser matrices with 64 lanes (128 dependent byte loads by one lane were most of k_index's time): the scalars --
+ * returns 1 when a header was parsed and its matrices are to be filled in (`intra_bit` / `nonintra_bit`: bit position of a
+ * matrix's first entry in the stream, JM_NO_MATRIX: the default one) -- and one entry of each matrix. */
+#define JM_NO_MATRIX (~0ull)
+JM_HD int jm_index_stream_scalars(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
+                                  uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h,
+                                  uint64_t *intra_bit, uint64_t *nonintra_bit) {
 	st.sc_lo = jm_lower_bound(sc_pos, n_sc, st.es_begin);
 	/* (a live stream whose last bytes are "00 00 01": the scan lists a start code there whose code byte is the gap's -- in a
 	 * pass that takes only what is complete, a start code whose fourth byte has not arrived is not one yet) */
@@ -40,16 +45,16 @@ JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_p
 	st.pic_lo = jm_lower_bound(pic_sc, n_pics, st.sc_lo);
 	st.pic_hi = jm_lower_bound(pic_sc, n_pics, st.sc_hi);
 	st.seq_sc = JM_NONE;
-	if (st.live_flags & JM_LIVE_HEADER) return;      /* a live stream whose first header an earlier pass parsed: the record holds it (valid included) */
+	if (st.live_flags & JM_LIVE_HEADER) return 0;    /* a live stream whose first header an earlier pass parsed: the record holds it (valid included) */
 	st.valid = 0;
 	for (uint32_t i = st.sc_lo; i < st.sc_hi; i++)
 		if (sc_code[i] == JM_CODE_SEQUENCE) { st.seq_sc = i; break; }
-	if (st.seq_sc == JM_NONE) return;
+	if (st.seq_sc == JM_NONE) return 0;
 	if ((st.live_flags & JM_LIVE_HOLD) && st.seq_sc + 1 >= st.sc_hi) {
 		/* a live stream's header that no start code ends yet may not be all there: it waits like a picture would --
 		 * valid = -1, width = where it begins (the host leaves its cursor there) */
 		st.valid = -1; st.width = (int32_t)sc_pos[st.seq_sc]; st.seq_sc = JM_NONE;
-		return;
+		return 0;
 	}
 	uint64_t bit = ((uint64_t)sc_pos[st.seq_sc] + 4) * 8;
 	st.width = (int32_t)jm_bits_at(es, st.es_end, bit, 12); bit += 12;
@@ -57,18 +62,29 @@ JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_p
 	bit += 4;
 	st.rate_code = (int32_t)jm_bits_at(es, st.es_end, bit, 4); bit += 4;
 	bit += 18 + 1 + 10 + 1;
-	const uint8_t zz[64] = MPEG1_ZIGZAG_INIT;
-	const uint8_t dq[64] = MPEG1_DEFAULT_INTRA_QUANT_INIT;
-	if (jm_bits_at(es, st.es_end, bit++, 1)) {
-		for (int i = 0; i < 64; i++, bit += 8) st.intra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, bit, 8);
-	} else for (int i = 0; i < 64; i++) st.intra_q[i] = dq[i];
-	if (jm_bits_at(es, st.es_end, bit++, 1)) {
-		for (int i = 0; i < 64; i++, bit += 8) st.nonintra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, bit, 8);
-	} else for (int i = 0; i < 64; i++) st.nonintra_q[i] = 16;
+	*intra_bit = JM_NO_MATRIX; *nonintra_bit = JM_NO_MATRIX;
+	if (jm_bits_at(es, st.es_end, bit++, 1)) { *intra_bit = bit; bit += 64 * 8; }
+	if (jm_bits_at(es, st.es_end, bit++, 1)) *nonintra_bit = bit;
 	st.mb_width = (st.width + 15) >> 4;
 	st.mb_height = (st.height + 15) >> 4;
 	st.mb_size = st.mb_width * st.mb_height;
 	st.valid = (st.width == want_w && st.height == want_h) ? 1 : 0;
+	return 1;
+}
+/* entry i (0 .. 63, in the order the stream carries them: zig-zag) of both matrices */
+JM_HD void jm_index_stream_matrix(JmStream &st, const uint8_t *es, int i, uint64_t intra_bit, uint64_t nonintra_bit) {
+	const uint8_t zz[64] = MPEG1_ZIGZAG_INIT;
+	const uint8_t dq[64] = MPEG1_DEFAULT_INTRA_QUANT_INIT;
+	if (intra_bit != JM_NO_MATRIX) st.intra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, intra_bit + 8ull * (uint32_t)i, 8);
+	else st.intra_q[i] = dq[i];
+	if (nonintra_bit != JM_NO_MATRIX) st.nonintra_q[zz[i]] = (uint8_t)jm_bits_at(es, st.es_end, nonintra_bit + 8ull * (uint32_t)i, 8);
+	else st.nonintra_q[i] = 16;
+}
+JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
+                           uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h) {
+	uint64_t intra_bit = JM_NO_MATRIX, nonintra_bit = JM_NO_MATRIX;
+	if (!jm_index_stream_scalars(st, es, sc_pos, sc_code, n_sc, pic_sc, n_pics, want_w, want_h, &intra_bit, &nonintra_bit)) return;
+	for (int i = 0; i < 64; i++) jm_index_stream_matrix(st, es, i, intra_bit, nonintra_bit);
 }
 
 /* Phase B (one thread per picture of the stream): header + slice ownership. */

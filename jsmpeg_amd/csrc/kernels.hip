@@ -291,8 +291,44 @@ hipError_t jm_launch_place(const uint8_t *src, uint8_t *dst, const uint32_t *src
 /* ------------------------------------------------------------------------
  * Tables: one workgroup per stream.
  * ---------------------------------------------------------------------- */
+/* inclusive scans over the workgroup's JM_WG values in LDS (Hillis-Steele: log2(JM_WG) rounds) */
+__device__ __forceinline__ int jm_wg_scan_add(int *buf, int v) {
+	buf[threadIdx.x] = v;
+	__syncthreads();
+	for (uint32_t d = 1; d < JM_WG; d <<= 1) {
+		const int t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+		__syncthreads();
+		buf[threadIdx.x] += t;
+		__syncthreads();
+	}
+	return buf[threadIdx.x];
+}
+__device__ __forceinline__ int jm_wg_scan_max(int *buf, int v) {
+	buf[threadIdx.x] = v;
+	__syncthreads();
+	for (uint32_t d = 1; d < JM_WG; d <<= 1) {
+		const int t = threadIdx.x >= d ? buf[threadIdx.x - d] : INT_MIN;
+		__syncthreads();
+		buf[threadIdx.x] = max(buf[threadIdx.x], t);
+		__syncthreads();
+	}
+	return buf[threadIdx.x];
+}
+
+/* The three phases of index_tables.h for one stream.  What one lane did alone in the first form -- the header's two matrices
+ * byte by byte, and jm_index_chain's walk over the stream's pictures in global memory, a dependent round trip per picture:
+ * 70 us of a 1080p batch's index, 0.15 of a 360-picture stream's 1.09 ms pass -- is the workgroup's now: the matrices by 64
+ * lanes, the chain as scans.  The chain in closed form (jm_index_chain is its definition, the simulator's and the tests'):
+ *   fwd(p)   = the decoded picture before p in the stream, for a decoded P picture that has one; else none
+ *   level(p) = decoded pictures in (a, p], a = the last ANCHOR at or before p -- a decoded picture that is not a P picture, or
+ *              the stream's first decoded picture
+ * over 256 pictures at a time, the counts and the last decoded picture carried from chunk to chunk. */
 __global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {
 	__shared__ JmStream st;
+	__shared__ uint64_t m_bits[2];
+	__shared__ int has_matrices;
+	__shared__ int scan[JM_WG];
+	__shared__ int carry[3];          /* decoded pictures so far | the last decoded picture | decoded pictures up to and with the last anchor */
 	const uint32_t s = blockIdx.x;
 	if (b.counters[2]) return;       /* more start codes / picture codes than the tables hold: the host fails the pass */
 	uint32_t n_sc = b.counters[0], n_pics = b.counters[1];
@@ -300,18 +336,48 @@ __global__ __launch_bounds__(JM_WG) void k_index(JmIndexBufs b) {
 	if (n_pics > b.pic_cap) n_pics = b.pic_cap;
 	if (threadIdx.x == 0) {
 		st = b.streams[s];
-		jm_index_stream(st, b.es, b.sc_pos, b.sc_code, n_sc, b.pic_sc, n_pics, b.width, b.height);
+		uint64_t ib = JM_NO_MATRIX, nb = JM_NO_MATRIX;
+		has_matrices = jm_index_stream_scalars(st, b.es, b.sc_pos, b.sc_code, n_sc, b.pic_sc, n_pics, b.width, b.height, &ib, &nb);
+		m_bits[0] = ib; m_bits[1] = nb;
+		carry[0] = 0; carry[1] = -1; carry[2] = 0;
 	}
 	__syncthreads();
-	for (uint32_t p = st.pic_lo + threadIdx.x; p < st.pic_hi; p += JM_WG) {
+	if (has_matrices && threadIdx.x < 64) jm_index_stream_matrix(st, b.es, (int)threadIdx.x, m_bits[0], m_bits[1]);
+	__syncthreads();
+	int deepest = -1;
+	for (uint32_t base = st.pic_lo; base < st.pic_hi; base += JM_WG) {
+		const uint32_t p = base + threadIdx.x;
+		const bool in = p < st.pic_hi;
 		JmPic pic;
-		jm_index_picture(pic, p, s, st, b.es, b.sc_pos, b.sc_code, b.pic_sc, b.sc_owner, 0, 0);
-		b.pics[p] = pic;
+		pic.decoded = 0; pic.type = 0;
+		if (in) jm_index_picture(pic, p, s, st, b.es, b.sc_pos, b.sc_code, b.pic_sc, b.sc_owner, 0, 0);
+		const bool dec = in && pic.decoded;
+		const int c0 = carry[0], last0 = carry[1], anchor0 = carry[2];
+		__syncthreads();                                             /* (the carries are read before the chunk's last lane rewrites them) */
+		const int count = c0 + jm_wg_scan_add(scan, dec ? 1 : 0);    /* decoded pictures up to and with p */
+		__syncthreads();
+		const int last_incl = max(last0, jm_wg_scan_max(scan, dec ? (int)p : -1));
+		__syncthreads();
+		/* the decoded picture BEFORE p: the inclusive scan's value one lane down */
+		scan[threadIdx.x] = last_incl;
+		__syncthreads();
+		const int prev = threadIdx.x ? scan[threadIdx.x - 1] : last0;
+		__syncthreads();
+		const bool anchor = dec && (pic.type != JM_PIC_PREDICTIVE || prev < 0);
+		const int at_anchor = max(anchor0, jm_wg_scan_max(scan, anchor ? count : 0));
+		__syncthreads();
+		if (dec) {
+			pic.level = count - at_anchor;
+			pic.fwd = (pic.type == JM_PIC_PREDICTIVE && prev >= 0) ? prev : -1;
+			deepest = max(deepest, pic.level);
+		}
+		if (in) b.pics[p] = pic;
+		if (threadIdx.x == JM_WG - 1) { carry[0] = count; carry[1] = last_incl; carry[2] = at_anchor; }
+		__syncthreads();
 	}
-	__threadfence_block();
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		int deepest = jm_index_chain(st, b.pics);
+	/* the workgroup's deepest level */
+	deepest = jm_wg_scan_max(scan, deepest);
+	if (threadIdx.x == JM_WG - 1) {
 		if (deepest >= 0) atomicMax(&b.counters_rw[3], (uint32_t)(deepest + 1));
 		b.streams[s] = st;
 	}
