@@ -294,3 +294,47 @@ def test_decode_ahead_stays_out_of_streaming_and_can_be_switched_off(hip_lib):
     finally:
         del os.environ["JSMPEG_HIP_DECODE_AHEAD"]
     assert frames == fx["frame_md5"] and idx == fx["bit_index_after_decode"]
+
+
+def test_index_chain_as_scans_over_long_streams(hip_lib, libs):
+    """k_index works a stream's forward references and dependency levels out as workgroup scans, 256 pictures at a time with
+    carries (kernels.hip); index_tables.h jm_index_chain is the definition.  Streams of 300-700 small pictures -- GOPs of 1 to
+    400, pictures the reference consumes without decoding (B / D, f_code 0) across the chunk boundaries, a stream whose first
+    decoded picture is a P picture -- : the table's forward / level fields == the chain restated here, pictures == the oracle"""
+    W, H = 64, 48
+    specs = [dict(n_frames=300, gop=1), dict(n_frames=700, gop=400), dict(n_frames=520, gop=7, syntax_quirks=2),
+             dict(n_frames=513, gop=256, syntax_quirks=3), dict(n_frames=257, gop=12)]
+    streams = [synth.generate_config("cfg1_720p", stream=300 + i, width=W, height=H, **kw)[0] for i, kw in enumerate(specs)]
+    # a stream that BEGINS with a P picture: the sequence header, then the stream from its second picture on
+    es, offs = synth.generate_config("cfg1_720p", stream=309, width=W, height=H, n_frames=300, gop=300)
+    offs = [int(o) for o in offs]
+    streams.append(np.concatenate([es[:offs[0]], es[offs[1]:]]) if offs[0] > 0 else es)
+    n_max = sum(s.tobytes().count(b"\x00\x00\x01\x00") for s in streams) + 16
+    with jb.Batch(W, H, len(streams), n_max, sum(len(s) for s in streams) + 65536) as b:
+        b.upload(streams)
+        n = b.decode()
+        pics = b.pictures()
+        last = {}
+        for p in range(n):
+            info = pics[p]
+            if not info.decoded:
+                continue
+            prev = last.get(info.stream)
+            if info.type == 2 and prev is not None:
+                want = (prev[0], prev[1] + 1)
+            else:
+                want = (-1, 0)
+            assert (info.forward, info.level) == want, (p, info.stream, info.type, info.forward, info.level, want)
+            last[info.stream] = (p, want[1])
+        assert max(pics[p].level for p in range(n) if pics[p].decoded) >= 399
+        dev = b.frame_hashes()
+        for s, es_s in enumerate(streams):
+            frames, _, _ = cabi.decode_stream(libs["oracle"], es_s, keep="planes")
+            want_h = [hashing.frame_hash(*f) for f in frames]
+            got_h = [int(dev[p]) for p in range(n) if pics[p].stream == s]
+            # (pictures the reference consumes without decoding repeat the planes before them in the oracle's list)
+            dec = [int(dev[p]) for p in range(n) if pics[p].stream == s and pics[p].decoded]
+            dedup = [x for k, x in enumerate(want_h) if k == 0 or x != want_h[k - 1]]
+            dd = [x for k, x in enumerate(dec) if k == 0 or x != dec[k - 1]]
+            assert dd == dedup, (s, len(dd), len(dedup))
+            assert len(got_h) >= len(dec)
