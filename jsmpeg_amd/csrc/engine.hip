@@ -633,8 +633,8 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		HIP_TRY(hipStreamSynchronize(st));
 	}
 	tr.mark("pics-copied");
-	/* ONE walk over the picture table for everything the parse's launch wants to know (19 200 pictures of configs[0]: three walks
-	 * were 0.09 ms of its 2.1 ms pass): decoded pictures, their slices, and how many slices are much longer than the mean (the
+	/* ONE walk over the picture table for everything the parse's launch wants to know (it was three; the passes did not notice):
+	 * decoded pictures, their slices, and how many slices are much longer than the mean (the
 	 * intra pictures' in an I + P batch: a picture's bytes / its slices against the batch's -- the slices come longest first,
 	 * jm_launch_parse gives that many fewer lanes per wavefront when the pass is of a size where it pays) */
 	uint64_t long_slices = 0;
