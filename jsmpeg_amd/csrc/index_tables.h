@@ -32,18 +32,26 @@ JM_HD uint32_t jm_lower_bound(const uint32_t *a, uint32_t n, uint32_t key) { /* 
 
 /* Phase A (one thread per stream): ranges + the first sequence header.  In two pieces so that the device can read the two
  * quantiser matrices with 64 lanes (128 dependent byte loads by one lane were most of k_index's time): the scalars --
- * returns 1 when a header was parsed and its matrices are to be filled in (`intra_bit` / `nonintra_bit`: bit position of a
+ * (after the ranges) returns 1 when a header was parsed and its matrices are to be filled in (`intra_bit` / `nonintra_bit`: bit position of a
  * matrix's first entry in the stream, JM_NO_MATRIX: the default one) -- and one entry of each matrix. */
 #define JM_NO_MATRIX (~0ull)
-JM_HD int jm_index_stream_scalars(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
-                                  uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h,
-                                  uint64_t *intra_bit, uint64_t *nonintra_bit) {
+/* the byte position behind the stream's last start code that counts: the end of its range -- for a live stream whose last
+ * bytes are "00 00 01" three bytes earlier (the scan lists a start code there whose code byte is the gap's: in a pass that
+ * takes only what is complete, a start code whose fourth byte has not arrived is not one yet) */
+JM_HD uint32_t jm_index_stream_hi_key(const JmStream &st) {
+	return (st.live_flags & JM_LIVE_HOLD) && st.es_end - st.es_begin >= 3 ? st.es_end - 3 : st.es_end;
+}
+/* the stream's ranges in the start-code list and the picture list: four binary searches (the device runs them two at a time
+ * in two lanes: kernels.hip k_index) */
+JM_HD void jm_index_stream_ranges(JmStream &st, const uint32_t *sc_pos, uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics) {
 	st.sc_lo = jm_lower_bound(sc_pos, n_sc, st.es_begin);
-	/* (a live stream whose last bytes are "00 00 01": the scan lists a start code there whose code byte is the gap's -- in a
-	 * pass that takes only what is complete, a start code whose fourth byte has not arrived is not one yet) */
-	st.sc_hi = jm_lower_bound(sc_pos, n_sc, (st.live_flags & JM_LIVE_HOLD) && st.es_end - st.es_begin >= 3 ? st.es_end - 3 : st.es_end);
+	st.sc_hi = jm_lower_bound(sc_pos, n_sc, jm_index_stream_hi_key(st));
 	st.pic_lo = jm_lower_bound(pic_sc, n_pics, st.sc_lo);
 	st.pic_hi = jm_lower_bound(pic_sc, n_pics, st.sc_hi);
+}
+/* (the ranges are in `st` already) */
+JM_HD int jm_index_stream_scalars(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
+                                  int want_w, int want_h, uint64_t *intra_bit, uint64_t *nonintra_bit) {
 	st.seq_sc = JM_NONE;
 	if (st.live_flags & JM_LIVE_HEADER) return 0;    /* a live stream whose first header an earlier pass parsed: the record holds it (valid included) */
 	st.valid = 0;
@@ -83,7 +91,8 @@ JM_HD void jm_index_stream_matrix(JmStream &st, const uint8_t *es, int i, uint64
 JM_HD void jm_index_stream(JmStream &st, const uint8_t *es, const uint32_t *sc_pos, const uint8_t *sc_code,
                            uint32_t n_sc, const uint32_t *pic_sc, uint32_t n_pics, int want_w, int want_h) {
 	uint64_t intra_bit = JM_NO_MATRIX, nonintra_bit = JM_NO_MATRIX;
-	if (!jm_index_stream_scalars(st, es, sc_pos, sc_code, n_sc, pic_sc, n_pics, want_w, want_h, &intra_bit, &nonintra_bit)) return;
+	jm_index_stream_ranges(st, sc_pos, n_sc, pic_sc, n_pics);
+	if (!jm_index_stream_scalars(st, es, sc_pos, sc_code, want_w, want_h, &intra_bit, &nonintra_bit)) return;
 	for (int i = 0; i < 64; i++) jm_index_stream_matrix(st, es, i, intra_bit, nonintra_bit);
 }
 
