@@ -577,6 +577,96 @@ int jsmpeg_hip_live_stream_info(jsmpeg_hip_live_t *l, uint32_t stream, jsmpeg_hi
  * own hipEvent timings of that pass: [5] index, [6] host turn-around, [7] slice parse, [8] reconstruct. */
 int jsmpeg_hip_live_timings(jsmpeg_hip_live_t *l, float out_ms[9]);
 
+/* ------------------------------------------------------------------ part 6
+ * LIVE AUDIO streams: the MP2 half of the same loop (reference src/player.js:230-242 updateForStreaming -- "do { decoded =
+ * this.audio.decode(); } while (decoded);" every tick; src/ts.js:205-210 hands the audio decoder one PES = a few whole frames
+ * per write(pts, buffers); src/mp2-wasm.js:13-16 the 128 KiB EVICT store; src/wasm/mp2.c:213-222 the synthesis ring V and
+ * its position v_pos, which carry from frame to frame).  Part 3's batch decodes whole streams from nothing; here a stream
+ * persists across calls: its undecoded bytes stay with the handle, its last fifteen matrixing vectors and its position in
+ * the synthesis ring stay in HBM, and one jsmpeg_hip_mp2_live_tick decodes the buffered frames of EVERY stream in one pass
+ * of the stage's three kernels (frame chain, side information + matrixing, windowing) with ONE wait -- the frame counts
+ * never come back to the host in between: a launch has max_frames_per_tick frame places per stream and the empty ones
+ * leave at once.  Per stream the samples are bit for bit those of the reference's decoder given the same write() calls.
+ * A handle is one thread's at a time; handles are independent of each other and of the video handles of part 5 (the same
+ * TS bytes go to both: video with stream id 0xE0, audio with 0xC0).
+ *
+ *     id = jsmpeg_hip_mp2_live_open(a);
+ *     jsmpeg_hip_mp2_live_write(a, id, pts, bytes, n);                == audio.write(pts, [bytes])   (ts.js:205-210)
+ *     n = jsmpeg_hip_mp2_live_tick(a, NULL);                          == for every stream: while (audio.decode()) ;
+ *     for (i < n) jsmpeg_hip_mp2_live_frame(a, i, &f);                f.device_pcm: float[2][1152] in HBM
+ */
+
+typedef struct jsmpeg_hip_mp2_live_t jsmpeg_hip_mp2_live_t;
+
+typedef struct jsmpeg_hip_mp2_live_config_t {
+	uint32_t max_streams;             /* streams open at a time */
+	uint32_t max_frames_per_tick;     /* per stream: a tick decodes at most this many frames of a stream, the rest wait for the
+	                                     next tick (0: 8 -- 0.2 s of sound at 44.1 kHz) */
+	uint32_t store_bytes;             /* capacity of a stream's compressed-data store = the reference's audioBufferSize
+	                                     (0: 128 KiB, mp2-wasm.js:13), with its EVICT rule: see jsmpeg_hip_mp2_live_write */
+	int32_t device;                   /* HIP device ordinal, -1 = current */
+} jsmpeg_hip_mp2_live_config_t;
+
+typedef struct jsmpeg_hip_mp2_live_frame_t {
+	uint32_t stream;                  /* id from jsmpeg_hip_mp2_live_open */
+	int32_t sample_rate;              /* of this frame's header */
+	double pts;                       /* of the write() in which the frame's first byte arrived */
+	uint64_t stream_offset;           /* byte offset of that byte in everything ever written to the stream */
+	uint32_t bytes;                   /* the frame's length (what mp2_decoder_decode returns for it) */
+	uint32_t reserved;
+	float *device_pcm;                /* DEVICE pointer: left[1152] | right[1152]; valid until the next tick */
+} jsmpeg_hip_mp2_live_frame_t;
+
+typedef struct jsmpeg_hip_mp2_live_stream_info_t {
+	int32_t sample_rate;              /* mp2_decoder_get_sample_rate: of the frame decoded last, 44100 before the first (mp2.c:234) */
+	uint32_t pending_bytes;           /* written and not decoded yet */
+	uint64_t bytes_written, frames;   /* totals */
+	uint64_t evictions;               /* writes that found the store full of UNDECODED bytes and threw them away (buffer.c:166-180) */
+	int32_t stalled;                  /* 1: the bytes at the cursor are not a frame header the reference accepts (mp2.c:283-302): its
+	                                     decode() returns 0 there for good, and so does every tick -- until a write that does not
+	                                     fit evacuates the store, exactly like the reference's */
+	int32_t reserved;
+} jsmpeg_hip_mp2_live_stream_info_t;
+
+jsmpeg_hip_mp2_live_t *jsmpeg_hip_mp2_live_create(const jsmpeg_hip_mp2_live_config_t *config);
+void jsmpeg_hip_mp2_live_destroy(jsmpeg_hip_mp2_live_t *a);
+/* A stream joins: returns its id (0 .. max_streams - 1) or < 0.  It starts like a fresh decoder (mp2.c:229-240): empty store,
+ * the synthesis ring all zeros. */
+int jsmpeg_hip_mp2_live_open(jsmpeg_hip_mp2_live_t *a);
+/* ... and leaves (its id is handed out again by a later open). */
+int jsmpeg_hip_mp2_live_close(jsmpeg_hip_mp2_live_t *a, uint32_t stream);
+/* One write(pts, buffers) of the reference's decoder (decoder.js:36-47): `n` bytes are appended to the stream's store (copied
+ * during the call).  The store is the reference's EVICT store (buffer.c:48-65, 166-189): decoded bytes make room; when the
+ * UNDECODED bytes + n exceed store_bytes, the undecoded bytes are thrown away first ("emergency evac") and the write starts an
+ * empty store.  n > store_bytes is refused (the reference writes past its allocation there).  Returns 0 or < 0. */
+int jsmpeg_hip_mp2_live_write(jsmpeg_hip_mp2_live_t *a, uint32_t stream, double pts, const void *bytes, uint32_t n);
+/* The same write with its bytes in several pieces (the `buffers` array): ONE write of the total length. */
+int jsmpeg_hip_mp2_live_write_v(jsmpeg_hip_mp2_live_t *a, uint32_t stream, double pts, const void *const *buffers,
+                                const uint32_t *lengths, uint32_t n_buffers);
+/* The stream handed over as MPEG-TS bytes, in any pieces: the reference's demuxer in front of the write above, its state
+ * kept per stream between calls (jsmpeg_hip_live_write_ts' function; stream_id 0xC0: the first audio stream, ts.js:212-222). */
+int jsmpeg_hip_mp2_live_write_ts(jsmpeg_hip_mp2_live_t *a, uint32_t stream, const void *bytes, uint32_t n, uint32_t stream_id);
+/* The tick: per stream, in stream order, every frame that is COMPLETELY buffered is decoded, from the cursor on, until a
+ * header the reference refuses (the stream then stalls, see `stalled`), at most max_frames_per_tick of them.  With writes
+ * that carry whole frames (ts.js completes a PES before it writes it) that is `while (mp2_decoder_decode(d));` after the
+ * same writes; with bytes in arbitrary pieces a frame waits for its last byte (the reference would decode it from whatever
+ * its store holds behind the written bytes) and per stream the frames are those of the whole stream decoded in one piece.
+ * Work is enqueued on `hip_stream` (void* hipStream_t, NULL = the handle's own) and has FINISHED when the call returns.
+ * Returns the number of frames decoded in this tick (all streams) or < 0. */
+int jsmpeg_hip_mp2_live_tick(jsmpeg_hip_mp2_live_t *a, void *hip_stream);
+/* The frames of the last tick: stream by stream (ascending id), in decode order inside a stream. */
+uint32_t jsmpeg_hip_mp2_live_frame_count(jsmpeg_hip_mp2_live_t *a);
+int jsmpeg_hip_mp2_live_frame(jsmpeg_hip_mp2_live_t *a, uint32_t i, jsmpeg_hip_mp2_live_frame_t *out);
+/* Frames first .. first + count - 1 of the last tick to the host: out[count][2][1152] floats (left, right) -- what
+ * destination.play(sampleRate, left, right) takes (mp2-wasm.js:93-103).  One copy per run of frames of a stream, one wait;
+ * at the link's rate when `out` is pinned (jsmpeg_hip_host_alloc / _register). */
+int jsmpeg_hip_mp2_live_read_pcm(jsmpeg_hip_mp2_live_t *a, uint32_t first, uint32_t count, float *out);
+int jsmpeg_hip_mp2_live_stream_info(jsmpeg_hip_mp2_live_t *a, uint32_t stream, jsmpeg_hip_mp2_live_stream_info_t *out);
+/* Host clock of the last tick, milliseconds: [0] packing the pending bytes + enqueueing, [1] waiting for the device,
+ * [2] book-keeping, [3] total; and the device's own hipEvent timings: [4] upload + frame chain, [5] side information +
+ * matrixing, [6] windowing + the tables' way back. */
+int jsmpeg_hip_mp2_live_timings(jsmpeg_hip_mp2_live_t *a, float out_ms[7]);
+
 /* Last error of the calling thread ("" if none). */
 const char *jsmpeg_hip_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). */

@@ -415,6 +415,12 @@ struct Mp2Bufs {
 	const uint32_t *n_abs_ptr;     /* if not null, n_abs_base is read from here instead (decoder ABI: a replayed hipGraph has fixed arguments) */
 	const float *window;           /* D[0..511] */
 	float *pcm;                    /* [n_frames][2][1152] */
+	/* LIVE streams (mp2_live.hip, C ABI part 6): a launch has live_cap frame places per stream -- frame f is frame f % live_cap
+	 * of stream f / live_cap, and it is there when the walk counted that many (no host turn-around between the walk and the
+	 * launches it sizes) -- and a stream's vectors lie in its OWN ring of live_ring vectors (a power of two >= 15 + 36 live_cap)
+	 * at their absolute sub-block number: the fifteen vectors a tick's first frame looks back on are where the tick before
+	 * left them.  live_cap == 0: not live. */
+	uint32_t live_cap, live_ring;  /* (live: n_abs_ptr is an array, [n_streams] sub-blocks each stream synthesised before this launch) */
 };
 
 /* k_mp2_walk, workgroup (one wavefront) = stream: the reference's decode() loop without the decoding (mp2.c:275-286:
@@ -473,6 +479,7 @@ MP2_HD void mp2_wg_walk_hop(const Mp2Bufs &b, uint32_t s, Mp2Walk &W) {
 
 /* Which stream a frame of the batch belongs to and its number inside it (frame_first = prefix sums of the counts). */
 MP2_HD void mp2_frame_place(const Mp2Bufs &b, uint32_t f, uint32_t &s, uint32_t &n) {
+	if (b.live_cap) { s = f / b.live_cap; n = f - s * b.live_cap; return; }
 	uint32_t lo = 0, hi = b.n_streams;
 	while (hi - lo > 1) {
 		const uint32_t mid = (lo + hi) >> 1;
@@ -480,10 +487,30 @@ MP2_HD void mp2_frame_place(const Mp2Bufs &b, uint32_t f, uint32_t &s, uint32_t 
 	}
 	s = lo; n = f - b.frame_first[lo];
 }
-/* index of the frame's first vector in W (masked at use) and sub-blocks of its stream before it */
-MP2_HD uint32_t mp2_n_abs_base(const Mp2Bufs &b) { return b.n_abs_ptr ? *b.n_abs_ptr : b.n_abs_base; }
-MP2_HD uint32_t mp2_frame_w_first(const Mp2Bufs &b, uint32_t f) { return mp2_n_abs_base(b) + 36u * f; }
-MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t n) { return mp2_n_abs_base(b) + 36u * n; }
+/* a live launch's frame place f: did the walk find a frame for it? (workgroup-uniform; the other launches have no empty places) */
+MP2_HD bool mp2_frame_there(const Mp2Bufs &b, uint32_t f) {
+	if (!b.live_cap) return true;
+	const uint32_t s = f / b.live_cap;
+	return f - s * b.live_cap < b.count[s];
+}
+/* where the frame's vectors lie in W -- sub-block v (v >= -15: the look-back) at base + ((first + v) & mask) -- and the
+ * sub-blocks of its stream before it */
+struct Mp2WPlace { uint32_t first, mask, base; };     /* (32 bits each: the live rings together are below 2^27 vectors, mp2_live.hip's limits) */
+/* (one select of values with the stream's index 0 outside live launches: a select between the live table's word and the other
+ * two forms made the compiler keep n_abs_base in scratch memory to have an address for it) */
+MP2_HD uint32_t mp2_n_abs_base(const Mp2Bufs &b, uint32_t s) { return b.n_abs_ptr ? b.n_abs_ptr[b.live_cap ? s : 0u] : b.n_abs_base; }
+MP2_HD Mp2WPlace mp2_frame_w(const Mp2Bufs &b, uint32_t f) {
+	Mp2WPlace w;
+	if (b.live_cap) {
+		const uint32_t s = f / b.live_cap;
+		w.first = mp2_n_abs_base(b, s) + 36u * (f - s * b.live_cap); w.mask = b.live_ring - 1u; w.base = s * b.live_ring;
+	} else {
+		w.first = mp2_n_abs_base(b, 0) + 36u * f; w.mask = b.w_mask; w.base = 0;
+	}
+	return w;
+}
+MP2_HD size_t mp2_w_index(const Mp2WPlace w, int v) { return w.base + (size_t)((w.first + (uint32_t)v) & w.mask); }
+MP2_HD uint32_t mp2_frame_n_abs0(const Mp2Bufs &b, uint32_t s, uint32_t n) { return mp2_n_abs_base(b, s) + 36u * n; }
 
 /* k_mp2_matrix, workgroup = frame.  Phases 0-4: side information (first 64 lanes; see mp2_side_*); then
  * samples / xs: [sub-block * 2 + channel][subband], rows padded to 33 words (the matrixing lanes all read the
@@ -556,11 +583,11 @@ MP2_HD void mp2_wg_matrix_run(int tid, int (&samples)[72][33]) {
 	for (int k = 0; k < 32; k++) samples[tid][k] = (int)mp2_float_to_bits(x[k]);
 }
 MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const int (&samples)[72][33]) {
-	const uint32_t w_first = mp2_frame_w_first(b, f);
+	const Mp2WPlace w = mp2_frame_w(b, f);
 	for (int idx = tid; idx < 72 * 32; idx += MP2_MATRIX_WG) {
 		const int v = idx >> 5, k = idx & 31;       /* v = sub-block * 2 + channel */
-		const uint32_t vec = (w_first + (uint32_t)(v >> 1)) & b.w_mask;
-		b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)((v & 1) * 32 + k)] = mp2_bits_to_float((uint32_t)samples[v][k]);
+		const size_t vec = mp2_w_index(w, v >> 1);
+		b.w[vec * MP2_VEC_FLOATS + (size_t)((v & 1) * 32 + k)] = mp2_bits_to_float((uint32_t)samples[v][k]);
 	}
 }
 
@@ -571,7 +598,8 @@ MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const int
 MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&xs)[MP2_STAGED][MP2_VEC_FLOATS], float (&win)[512]) {
 	uint32_t s, n;
 	mp2_frame_place(b, f, s, n);
-	const uint32_t w_first = mp2_frame_w_first(b, f), n_abs0 = mp2_frame_n_abs0(b, n);
+	const Mp2WPlace w = mp2_frame_w(b, f);
+	const uint32_t n_abs0 = mp2_frame_n_abs0(b, s, n);
 	for (int idx = tid; idx < 512; idx += MP2_WINDOW_WG) win[idx] = b.window[idx];
 	for (int idx = tid; idx < MP2_STAGED * MP2_VEC_FLOATS; idx += MP2_WINDOW_WG) {
 		const int v = idx >> 6, e = idx & 63, rel = v - MP2_LOOKBACK;
@@ -579,8 +607,8 @@ MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&x
 		const bool there = rel >= 0 || (uint32_t)(-rel) <= n_abs0;
 		/* no branch around the load (a lane without a vector reads the frame's first one): the thirteen loads of a lane
 		 * are issued back to back and awaited one by one */
-		const uint32_t vec = (w_first + (uint32_t)(there ? rel : 0)) & b.w_mask;
-		const float val = b.w[(size_t)vec * MP2_VEC_FLOATS + (size_t)e];
+		const size_t vec = mp2_w_index(w, there ? rel : 0);
+		const float val = b.w[vec * MP2_VEC_FLOATS + (size_t)e];
 		xs[v][e] = there ? val : 0.0f;
 	}
 }
@@ -588,7 +616,7 @@ MP2_HD void mp2_wg_window_run(const Mp2Bufs &b, uint32_t f, int tid, const float
                               const float (&win)[512]) {
 	uint32_t s, n;
 	mp2_frame_place(b, f, s, n);
-	const uint32_t n_abs0 = mp2_frame_n_abs0(b, n);
+	const uint32_t n_abs0 = mp2_frame_n_abs0(b, s, n);
 	const int wave = MP2_UNIFORM(tid >> 6), lane = tid & 63, ch = lane >> 5, i = lane & 31;
 	const Mp2VMap lo = mp2_v_map(i), hi = mp2_v_map(32 + i);
 	float *out = b.pcm + ((size_t)f * 2 + (size_t)ch) * MP2_SAMPLES_PER_FRAME + (size_t)i;

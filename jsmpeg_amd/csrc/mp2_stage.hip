@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "ts_sync.h"
 #include "mp2_dev.h"
+#include "mp2_internal.h"
 #include "mp2_window.h"
 
 int jm_set_error(const char *msg);      /* engine.hip: thread-local message behind jsmpeg_hip_last_error() */
@@ -36,6 +37,7 @@ static int mp2_fail(const char *fmt, const char *a = "", long b = 0) {
 /* ================================================================================================ kernels */
 
 /* Bodies: mp2_dev.h (mp2_wg_*), shared with the test-only simulator. */
+static int window_for_device(int dev, float **out);
 
 __global__ void __launch_bounds__(MP2_WALK_WG) k_mp2_walk(Mp2Bufs b) {
 	__shared__ Mp2Walk W;
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
 	__shared__ Mp2Frame F;
 	__shared__ int samples[72][33];          /* requantised samples, then (in place) the matrixing outputs */
 	const int tid = (int)threadIdx.x;
+	if (!mp2_frame_there(b, blockIdx.x)) return;      /* (a live launch's empty frame place: the whole workgroup leaves) */
 	mp2_wg_stage_frame(b, blockIdx.x, tid, F);
 	__syncthreads();
 	for (int phase = 0; phase < 5; phase++) {
@@ -72,6 +75,7 @@ __global__ void __launch_bounds__(MP2_WINDOW_WG) k_mp2_window(Mp2Bufs b) {
 	__shared__ float xs[MP2_STAGED][MP2_VEC_FLOATS];
 	__shared__ float win[512];
 	const int tid = (int)threadIdx.x;
+	if (!mp2_frame_there(b, blockIdx.x)) return;
 	mp2_wg_window_stage(b, blockIdx.x, tid, xs, win);
 	__syncthreads();
 	mp2_wg_window_run(b, blockIdx.x, tid, xs, win);
@@ -87,7 +91,22 @@ static hipError_t mp2_malloc(T **p, size_t bytes) {
 	return e;
 }
 
+/* the three launches for the other translation unit of the stage (mp2_live.hip: live streams) */
+hipError_t mp2_launch_walk(const Mp2Bufs &k, uint32_t n_streams, hipStream_t st) {
+	hipLaunchKernelGGL(k_mp2_walk, dim3(n_streams), dim3(MP2_WALK_WG), 0, st, k);
+	return hipGetLastError();
+}
+hipError_t mp2_launch_matrix(const Mp2Bufs &k, uint32_t n_frames, hipStream_t st) {
+	hipLaunchKernelGGL(k_mp2_matrix, dim3(n_frames), dim3(MP2_MATRIX_WG), 0, st, k);
+	return hipGetLastError();
+}
+hipError_t mp2_launch_window(const Mp2Bufs &k, uint32_t n_frames, hipStream_t st) {
+	hipLaunchKernelGGL(k_mp2_window, dim3(n_frames), dim3(MP2_WINDOW_WG), 0, st, k);
+	return hipGetLastError();
+}
+
 static float *g_window_dev[16] = { nullptr };
+int mp2_window_for_device(int dev, float **out) { return window_for_device(dev, out); }
 static int window_for_device(int dev, float **out) {
 	if (dev < 0 || dev >= 16) return mp2_fail("device ordinal %s%ld out of range", "", dev);
 	if (!g_window_dev[dev]) {
@@ -362,6 +381,7 @@ static Mp2Bufs batch_bufs(const jsmpeg_hip_mp2_batch_t *b) {
 	k.in = b->d_in; k.begin = b->d_begin; k.end = b->d_end; k.n_streams = b->n_streams; k.cap_first = b->d_cap_first;
 	k.frame_pos = b->d_frame_pos; k.frame_hdr = b->d_frame_hdr; k.count = b->d_count; k.frame_first = b->d_frame_first; k.n_frames = b->n_frames;
 	k.w = b->d_w; k.w_mask = 0xffffffffu; k.n_abs_base = 0; k.n_abs_ptr = nullptr; k.window = b->d_window; k.pcm = b->d_pcm;
+	k.live_cap = 0; k.live_ring = 0;
 	return k;
 }
 
@@ -584,7 +604,7 @@ static int mp2_dec_enqueue(mp2_decoder_t *d) {
 	k.in = d->d_stage + 4 * MP2_STAGE_WORDS; k.begin = t + 0; k.end = t + 1; k.n_streams = 1; k.cap_first = t + 2;
 	k.frame_first = t + 4; k.frame_pos = t + 6; k.frame_hdr = nullptr; k.count = t + 7; k.n_frames = 1;
 	k.w = d->d_w; k.w_mask = MP2_RING_VECTORS - 1; k.n_abs_base = 0; k.n_abs_ptr = t + 8; k.window = d->d_window;
-	k.pcm = d->d_pcm;
+	k.pcm = d->d_pcm; k.live_cap = 0; k.live_ring = 0;
 	hipLaunchKernelGGL(k_mp2_matrix, dim3(1), dim3(MP2_MATRIX_WG), 0, d->stream, k);
 	hipLaunchKernelGGL(k_mp2_window, dim3(1), dim3(MP2_WINDOW_WG), 0, d->stream, k);
 	MP2_TRY(hipGetLastError());

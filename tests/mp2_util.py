@@ -62,3 +62,41 @@ def sim_batch(streams):
     r = lib.sim_mp2_batch(ptrs, lens, n, ctypes.c_void_p(pcm.ctypes.data), cap, ctypes.c_void_p(ff.ctypes.data))
     assert r >= 0
     return [pcm[ff[i]:ff[i + 1]] for i in range(n)]
+
+
+class SimLive:
+    """The host side of jsmpeg_hip_mp2_live_* restated in a few lines (stores, cursors, sub-block counts) around the
+    simulator's sim_mp2_live_tick -- the kernels' LIVE placement (per-stream rings, frame places) on the CPU.  TEST ONLY."""
+
+    def __init__(self, n_streams, cap):
+        self.lib = sim_lib()
+        self.lib.sim_mp2_live_tick.restype = None
+        self.n, self.cap = n_streams, cap
+        self.ring = 64
+        while self.ring < 15 + 36 * cap:
+            self.ring *= 2
+        self.rings = np.zeros((n_streams, self.ring, 64), np.float32)
+        self.n_abs = np.zeros(n_streams, np.uint32)
+        self.store = [bytearray() for _ in range(n_streams)]
+
+    def write(self, s, data):
+        self.store[s] += bytes(data)
+
+    def tick(self):
+        """-> per stream float32[count, 2, 1152]"""
+        bufs = [np.frombuffer(bytes(b), np.uint8) for b in self.store]
+        ptrs = (ctypes.c_void_p * self.n)(*[b.ctypes.data if len(b) else None for b in bufs])
+        lens = np.array([len(b) for b in bufs], np.uint32)
+        pcm = np.zeros((self.n * self.cap, 2, 1152), np.float32)
+        count = np.zeros(self.n, np.uint32)
+        used = np.zeros(self.n, np.uint32)
+        self.lib.sim_mp2_live_tick(ptrs, ctypes.c_void_p(lens.ctypes.data), self.n, self.cap, self.ring, ctypes.c_void_p(self.rings.ctypes.data),
+                                   ctypes.c_void_p(self.n_abs.ctypes.data), ctypes.c_void_p(pcm.ctypes.data),
+                                   ctypes.c_void_p(count.ctypes.data), ctypes.c_void_p(used.ctypes.data))
+        out = []
+        for s in range(self.n):
+            assert count[s] <= self.cap
+            out.append(pcm[s * self.cap:s * self.cap + count[s]].copy())
+            del self.store[s][:int(used[s])]
+            self.n_abs[s] += 36 * count[s]
+        return out

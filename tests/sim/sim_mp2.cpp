@@ -96,6 +96,67 @@ void sim_mp2_ring_frame(const uint8_t *frame, uint32_t n, float *ring, uint32_t 
 	*n_abs += MP2_SUBBLOCKS_PER_FRAME;
 }
 
+// Live mode (C ABI part 6, jsmpeg_amd/csrc/mp2_live.hip): ONE tick's kernels over the pending bytes of n_streams streams the
+// way jsmpeg_hip_mp2_live_tick sequences them -- `cap` frame places per stream (the empty ones leave at once), every stream's
+// vectors in its own ring of `ring` vectors (rings: [n_streams][ring][64] floats, zero before a stream's first tick) at their
+// absolute sub-block numbers n_abs[s] + ..  pcm_out: [n_streams * cap][2][1152]; count_out[s]: frames decoded, used_out[s]: the
+// bytes they took.  The caller keeps the state between ticks (drops used_out[s] bytes, adds 36 * count_out[s] to n_abs[s]).
+void sim_mp2_live_tick(const uint8_t *const *data, const uint32_t *bytes, uint32_t n_streams, uint32_t cap, uint32_t ring,
+                       float *rings, const uint32_t *n_abs, float *pcm_out, uint32_t *count_out, uint32_t *used_out) {
+	std::vector<uint32_t> begin(n_streams), end(n_streams), cap_first(n_streams + 1, 0), count(n_streams, 0xffffffffu);
+	uint64_t at = 0;
+	for (uint32_t s = 0; s < n_streams; s++) {
+		begin[s] = (uint32_t)at; end[s] = (uint32_t)(at + bytes[s]);
+		at = (at + bytes[s] + 3) & ~3ull;
+		cap_first[s + 1] = cap_first[s] + cap;
+	}
+	std::vector<uint8_t> in(at + MP2_PAD, 0);
+	for (uint32_t s = 0; s < n_streams; s++) if (bytes[s]) memcpy(in.data() + begin[s], data[s], bytes[s]);
+	std::vector<uint32_t> frame_pos((size_t)n_streams * cap, 0), frame_hdr((size_t)n_streams * cap, 0);
+	float window[512];
+	mp2_window_expand(window);
+	Mp2Bufs b;
+	memset(&b, 0, sizeof(b));
+	b.in = in.data(); b.begin = begin.data(); b.end = end.data(); b.n_streams = n_streams; b.cap_first = cap_first.data();
+	b.frame_pos = frame_pos.data(); b.frame_hdr = frame_hdr.data(); b.count = count.data(); b.window = window;
+	b.w = rings; b.pcm = pcm_out; b.n_frames = n_streams * cap;
+	b.live_cap = cap; b.live_ring = ring; b.n_abs_ptr = n_abs;
+	for (uint32_t s = 0; s < n_streams; s++) {
+		static Mp2Walk W;
+		for (int t = 0; t < MP2_WALK_WG; t++) mp2_wg_walk_init(b, s, t, W);
+		while (!W.done) {
+			for (int t = 0; t < MP2_WALK_WG; t++) mp2_wg_walk_fill(b, s, t, W);
+			mp2_wg_walk_hop(b, s, W);
+		}
+	}
+	static int samples[72][33];
+	static float staged[MP2_STAGED][MP2_VEC_FLOATS], win[512];
+	static Mp2Frame F;
+	for (uint32_t f = 0; f < n_streams * cap; f++) {
+		if (!mp2_frame_there(b, f)) continue;
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_stage_frame(b, f, t, F);
+		for (int phase = 0; phase < 5; phase++)
+			for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_side(t, phase, F);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples);
+		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, samples);
+	}
+	for (uint32_t f = 0; f < n_streams * cap; f++) {
+		if (!mp2_frame_there(b, f)) continue;
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win);
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, f, t, staged, win);
+	}
+	for (uint32_t s = 0; s < n_streams; s++) {
+		count_out[s] = count[s];
+		used_out[s] = 0;
+		if (count[s] && count[s] <= cap) {
+			Mp2Hdr H;
+			mp2_parse_header_word(frame_hdr[(size_t)s * cap + count[s] - 1], H);
+			used_out[s] = frame_pos[(size_t)s * cap + count[s] - 1] - begin[s] + (uint32_t)H.frame_bytes;
+		}
+	}
+}
+
 // header fields of the frame at `pos` (frame length 0 = the reference would not decode it)
 int sim_mp2_frame_bytes(const uint8_t *p, uint32_t end, uint32_t pos, int *sample_rate) {
 	Mp2Hdr H;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     lib = ctypes.CDLL(hip_lib)
     for n in declared_symbols():
         assert hasattr(lib, n), n
-    for n in batch.BATCH_SYMBOLS + mp2.MP2_BATCH_SYMBOLS + cabi.MP2_ABI_SYMBOLS:
+    for n in batch.BATCH_SYMBOLS + mp2.MP2_BATCH_SYMBOLS + mp2.MP2_LIVE_SYMBOLS + cabi.MP2_ABI_SYMBOLS:
         assert hasattr(lib, n), n
 
 
@@ -47,6 +47,8 @@ def test_no_device_means_loud_failure(hip_lib):
     assert b"no CPU fallback" in L.jsmpeg_hip_last_error()
     with pytest.raises(RuntimeError):
         mp2.Mp2Batch(1, 1 << 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mp2.Mp2Live(4)
 
 
 def test_hot_kernels_use_no_scratch():
