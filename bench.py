@@ -1481,6 +1481,11 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import mp2_bench
             line["audio_stage"] = mp2_bench.measure(cpu_baseline=not args.no_cpu_baseline)
+            try:                                # the same streams LIVE (C ABI part 6): a frame per stream per tick
+                line["audio_stage"]["live_tick"] = mp2_bench.measure_live()
+            except Exception as e:
+                log("live audio tick figure failed: %r" % (e,))
+                line["audio_stage"]["live_tick"] = {"error": repr(e)[:300]}
         except Exception as e:
             log("audio stage figure failed: %r" % (e,))
             line["audio_stage"] = {"error": repr(e)}

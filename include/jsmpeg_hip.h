@@ -614,7 +614,8 @@ typedef struct jsmpeg_hip_mp2_live_frame_t {
 	uint64_t stream_offset;           /* byte offset of that byte in everything ever written to the stream */
 	uint32_t bytes;                   /* the frame's length (what mp2_decoder_decode returns for it) */
 	uint32_t reserved;
-	float *device_pcm;                /* DEVICE pointer: left[1152] | right[1152]; valid until the next tick */
+	float *device_pcm;                /* DEVICE pointer: left[1152] | right[1152]; valid until the next tick.  The tick's frames lie
+	                                     one behind the other: frame i + 1's samples follow frame i's */
 } jsmpeg_hip_mp2_live_frame_t;
 
 typedef struct jsmpeg_hip_mp2_live_stream_info_t {
@@ -658,7 +659,7 @@ int jsmpeg_hip_mp2_live_tick(jsmpeg_hip_mp2_live_t *a, void *hip_stream);
 uint32_t jsmpeg_hip_mp2_live_frame_count(jsmpeg_hip_mp2_live_t *a);
 int jsmpeg_hip_mp2_live_frame(jsmpeg_hip_mp2_live_t *a, uint32_t i, jsmpeg_hip_mp2_live_frame_t *out);
 /* Frames first .. first + count - 1 of the last tick to the host: out[count][2][1152] floats (left, right) -- what
- * destination.play(sampleRate, left, right) takes (mp2-wasm.js:93-103).  One copy per run of frames of a stream, one wait;
+ * destination.play(sampleRate, left, right) takes (mp2-wasm.js:93-103).  ONE copy (the tick's samples lie packed), one wait;
  * at the link's rate when `out` is pinned (jsmpeg_hip_host_alloc / _register). */
 int jsmpeg_hip_mp2_live_read_pcm(jsmpeg_hip_mp2_live_t *a, uint32_t first, uint32_t count, float *out);
 int jsmpeg_hip_mp2_live_stream_info(jsmpeg_hip_mp2_live_t *a, uint32_t stream, jsmpeg_hip_mp2_live_stream_info_t *out);

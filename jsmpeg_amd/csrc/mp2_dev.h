@@ -380,8 +380,10 @@ MP2_HD int mp2_f2i(float a) {
 /* wave-uniform values: on the device they are moved to scalar registers */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MP2_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define MP2_LDS_ADD(word, v) atomicAdd(&(word), (v))
 #else
 #define MP2_UNIFORM(x) (x)
+#define MP2_LDS_ADD(word, v) ((word) += (v))
 #endif
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -595,9 +597,17 @@ MP2_HD void mp2_wg_matrix_store(const Mp2Bufs &b, uint32_t f, int tid, const int
  * wavefront takes sub-blocks p = wave, wave + 4, ..: lane = channel * 32 + output sample.  Everything that depends on
  * the sub-block alone -- the ring position k, which vector a tap reads, where in the window -- is wave-uniform; a
  * lane keeps only where its two V entries (o = i and o = 32 + i) sit in x[] and their signs. */
-MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&xs)[MP2_STAGED][MP2_VEC_FLOATS], float (&win)[512]) {
+/* (live: the tick's samples lie packed in tick order -- stream after stream, frame after frame -- so that a host takes them in one
+ * copy: the frame's place among them is the frames of the streams before it, summed here by all lanes into `pcm_first`, which is
+ * zero when the workgroup comes here and complete after the barrier that follows) */
+MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&xs)[MP2_STAGED][MP2_VEC_FLOATS], float (&win)[512], uint32_t &pcm_first) {
 	uint32_t s, n;
 	mp2_frame_place(b, f, s, n);
+	if (b.live_cap) {
+		uint32_t before = 0;
+		for (uint32_t t = (uint32_t)tid; t < s; t += MP2_WINDOW_WG) before += b.count[t];
+		if (before) MP2_LDS_ADD(pcm_first, before);
+	}
 	const Mp2WPlace w = mp2_frame_w(b, f);
 	const uint32_t n_abs0 = mp2_frame_n_abs0(b, s, n);
 	for (int idx = tid; idx < 512; idx += MP2_WINDOW_WG) win[idx] = b.window[idx];
@@ -613,13 +623,14 @@ MP2_HD void mp2_wg_window_stage(const Mp2Bufs &b, uint32_t f, int tid, float (&x
 	}
 }
 MP2_HD void mp2_wg_window_run(const Mp2Bufs &b, uint32_t f, int tid, const float (&xs)[MP2_STAGED][MP2_VEC_FLOATS],
-                              const float (&win)[512]) {
+                              const float (&win)[512], uint32_t pcm_first) {
 	uint32_t s, n;
 	mp2_frame_place(b, f, s, n);
 	const uint32_t n_abs0 = mp2_frame_n_abs0(b, s, n);
 	const int wave = MP2_UNIFORM(tid >> 6), lane = tid & 63, ch = lane >> 5, i = lane & 31;
 	const Mp2VMap lo = mp2_v_map(i), hi = mp2_v_map(32 + i);
-	float *out = b.pcm + ((size_t)f * 2 + (size_t)ch) * MP2_SAMPLES_PER_FRAME + (size_t)i;
+	const uint32_t pcm_frame = b.live_cap ? pcm_first + n : f;
+	float *out = b.pcm + ((size_t)pcm_frame * 2 + (size_t)ch) * MP2_SAMPLES_PER_FRAME + (size_t)i;
 	for (int p = wave; p < MP2_SUBBLOCKS_PER_FRAME; p += MP2_WINDOW_WG / 64) {
 		const int k = (int)((0u - (n_abs0 + (uint32_t)p + 1u)) & 15u);   /* v_pos = 64 k after this sub-block's shift (mp2.c:445) */
 		const int odd = k & 1;

@@ -13,7 +13,8 @@
  *                          a channel, a frame's first windowing reads the 15 before it -- they are where the last tick's
  *                          k_mp2_matrix left them.  The position in the reference's ring (v_pos, mp2.c:445) is the
  *                          sub-block number mod 16: n_abs, one word per stream, goes over with every tick's tables
- *   d_pcm                  [stream][max_frames_per_tick][2][1152]: a tick's samples, valid until the next tick
+ *   d_pcm                  [frames of the tick, stream after stream][2][1152]: a tick's samples PACKED (k_mp2_window sums the
+ *                          walk's counts of the streams before its own), one copy takes them all; valid until the next tick
  * One tick = one upload (bytes + tables), k_mp2_walk, k_mp2_matrix, k_mp2_window, one download (frame counts, positions,
  * headers), ONE wait.  The launches are sized by the CAPACITY (max_frames_per_tick frame places per stream; a workgroup whose
  * place the walk left empty returns at once), not by the walk's counts: the batch's host turn-around is not here.
@@ -295,7 +296,7 @@ extern "C" int jsmpeg_hip_mp2_live_tick(jsmpeg_hip_mp2_live_t *a, void *hip_stre
 				return alive_fail("internal: stream %s%ld: the frame walk's table does not describe the stream's bytes", "", s);
 			const uint64_t at_stream = S.consumed + off;
 			while (S.stamps.size() > 1 && S.stamps[1].at <= at_stream) S.stamps.pop_front();
-			a->frames.push_back(Mp2LiveFrame{ s, s * cap + n, (uint32_t)H.frame_bytes, H.sample_rate, S.stamps.empty() ? 0.0 : S.stamps.front().pts, at_stream });
+			a->frames.push_back(Mp2LiveFrame{ s, (uint32_t)a->frames.size(), (uint32_t)H.frame_bytes, H.sample_rate, S.stamps.empty() ? 0.0 : S.stamps.front().pts, at_stream });
 			S.sample_rate = H.sample_rate;
 			used = off + (uint32_t)H.frame_bytes;
 		}
@@ -331,15 +332,11 @@ extern "C" int jsmpeg_hip_mp2_live_read_pcm(jsmpeg_hip_mp2_live_t *a, uint32_t f
 	if (!a || (count && !out)) return alive_fail("null live audio argument");
 	if ((uint64_t)first + count > a->frames.size()) return alive_fail("read_pcm: frames %s%ld .. are not in the last tick", "", first);
 	ALIVE_TRY(hipSetDevice(a->device));
-	const size_t frame_floats = 2 * MP2_SAMPLES_PER_FRAME;
-	for (uint32_t i = first; i < first + count;) {                       /* a run of consecutive places = a stream's frames: one copy */
-		uint32_t j = i + 1;
-		while (j < first + count && a->frames[j].place == a->frames[j - 1].place + 1) j++;
-		ALIVE_TRY(hipMemcpyAsync(out + (size_t)(i - first) * frame_floats, a->d_pcm + (size_t)a->frames[i].place * frame_floats,
-		                         sizeof(float) * frame_floats * (j - i), hipMemcpyDeviceToHost, a->own_stream));
-		i = j;
+	const size_t frame_floats = 2 * MP2_SAMPLES_PER_FRAME;           /* (the tick's samples lie packed in tick order: one copy) */
+	if (count) {
+		ALIVE_TRY(hipMemcpyAsync(out, a->d_pcm + (size_t)first * frame_floats, sizeof(float) * frame_floats * count, hipMemcpyDeviceToHost, a->own_stream));
+		ALIVE_TRY(hipStreamSynchronize(a->own_stream));
 	}
-	ALIVE_TRY(hipStreamSynchronize(a->own_stream));
 	return 0;
 }
 

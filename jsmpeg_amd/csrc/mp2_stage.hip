@@ -74,11 +74,16 @@ __global__ void __launch_bounds__(MP2_MATRIX_WG) k_mp2_matrix(Mp2Bufs b) {
 __global__ void __launch_bounds__(MP2_WINDOW_WG) k_mp2_window(Mp2Bufs b) {
 	__shared__ float xs[MP2_STAGED][MP2_VEC_FLOATS];
 	__shared__ float win[512];
+	__shared__ uint32_t pcm_first;       /* live launches: the frame's place among the tick's frames (mp2_wg_window_stage) */
 	const int tid = (int)threadIdx.x;
 	if (!mp2_frame_there(b, blockIdx.x)) return;
-	mp2_wg_window_stage(b, blockIdx.x, tid, xs, win);
+	if (b.live_cap) {
+		if (tid == 0) pcm_first = 0;
+		__syncthreads();
+	}
+	mp2_wg_window_stage(b, blockIdx.x, tid, xs, win, pcm_first);
 	__syncthreads();
-	mp2_wg_window_run(b, blockIdx.x, tid, xs, win);
+	mp2_wg_window_run(b, blockIdx.x, tid, xs, win, b.live_cap ? pcm_first : 0u);
 }
 
 /* ========================================================================================== shared state */

@@ -40,6 +40,7 @@
  *   batchFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures    jsmpeg_hip_batch_frame_hashes (device-side 64-bit plane hashes)
  *
  * Live streams (include/jsmpeg_hip.h part 5): napi_live.c.  Shards across the GPUs of a node (part 4): napi_shard.c.
+ * Live audio streams (part 6): napi_live_audio.c.
  *
  * MP2 audio (include/jsmpeg_hip.h part 3; what module.instance.exports._mp2_decoder_* is for the reference's
  * src/mp2-wasm.js:21-104), used by jsmpeg_amd/js/mp2-hip.js:
@@ -965,6 +966,8 @@ static napi_value fn_mp2_batch_read_pcm(napi_env env, napi_callback_info info) {
 int jm_napi_register_live(napi_env env, napi_value exports);
 /* ... and napi_shard.c (part 4: shards across the GPUs of a node) */
 int jm_napi_register_shard(napi_env env, napi_value exports);
+/* ... and napi_live_audio.c (part 6: live audio streams) */
+int jm_napi_register_live_audio(napi_env env, napi_value exports);
 
 static napi_value init(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
@@ -994,7 +997,7 @@ static napi_value init(napi_env env, napi_value exports) {
 			return NULL;
 		}
 	}
-	if (jm_napi_register_live(env, exports) != 0 || jm_napi_register_shard(env, exports) != 0) {
+	if (jm_napi_register_live(env, exports) != 0 || jm_napi_register_shard(env, exports) != 0 || jm_napi_register_live_audio(env, exports) != 0) {
 		napi_throw_error(env, NULL, "jsmpeg_hip: addon init failed");
 		return NULL;
 	}

@@ -94,9 +94,11 @@ class SimLive:
                                    ctypes.c_void_p(self.n_abs.ctypes.data), ctypes.c_void_p(pcm.ctypes.data),
                                    ctypes.c_void_p(count.ctypes.data), ctypes.c_void_p(used.ctypes.data))
         out = []
+        at = 0
         for s in range(self.n):
             assert count[s] <= self.cap
-            out.append(pcm[s * self.cap:s * self.cap + count[s]].copy())
+            out.append(pcm[at:at + count[s]].copy())          # packed in tick order
+            at += int(count[s])
             del self.store[s][:int(used[s])]
             self.n_abs[s] += 36 * count[s]
         return out

@@ -60,8 +60,9 @@ int sim_mp2_batch(const uint8_t *const *data, const uint64_t *bytes, uint32_t n_
 		for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, f, t, samples);
 	}
 	for (uint32_t f = 0; f < n_frames; f++) {
-		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win);
-		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, f, t, staged, win);
+		uint32_t pcm_first = 0;
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win, pcm_first);
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, f, t, staged, win, pcm_first);
 	}
 	return (int)n_frames;
 }
@@ -91,15 +92,16 @@ void sim_mp2_ring_frame(const uint8_t *frame, uint32_t n, float *ring, uint32_t 
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_read(t, F, samples);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_run(t, samples);
 	for (int t = 0; t < MP2_MATRIX_WG; t++) mp2_wg_matrix_store(b, 0, t, samples);
-	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, 0, t, staged, win);
-	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, 0, t, staged, win);
+	uint32_t pcm_first = 0;
+	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, 0, t, staged, win, pcm_first);
+	for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, 0, t, staged, win, pcm_first);
 	*n_abs += MP2_SUBBLOCKS_PER_FRAME;
 }
 
 // Live mode (C ABI part 6, jsmpeg_amd/csrc/mp2_live.hip): ONE tick's kernels over the pending bytes of n_streams streams the
 // way jsmpeg_hip_mp2_live_tick sequences them -- `cap` frame places per stream (the empty ones leave at once), every stream's
 // vectors in its own ring of `ring` vectors (rings: [n_streams][ring][64] floats, zero before a stream's first tick) at their
-// absolute sub-block numbers n_abs[s] + ..  pcm_out: [n_streams * cap][2][1152]; count_out[s]: frames decoded, used_out[s]: the
+// absolute sub-block numbers n_abs[s] + ..  pcm_out: [frames of the tick, stream after stream][2][1152] (room for n_streams * cap); count_out[s]: frames decoded, used_out[s]: the
 // bytes they took.  The caller keeps the state between ticks (drops used_out[s] bytes, adds 36 * count_out[s] to n_abs[s]).
 void sim_mp2_live_tick(const uint8_t *const *data, const uint32_t *bytes, uint32_t n_streams, uint32_t cap, uint32_t ring,
                        float *rings, const uint32_t *n_abs, float *pcm_out, uint32_t *count_out, uint32_t *used_out) {
@@ -143,8 +145,9 @@ void sim_mp2_live_tick(const uint8_t *const *data, const uint32_t *bytes, uint32
 	}
 	for (uint32_t f = 0; f < n_streams * cap; f++) {
 		if (!mp2_frame_there(b, f)) continue;
-		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win);
-		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, f, t, staged, win);
+		uint32_t pcm_first = 0;
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_stage(b, f, t, staged, win, pcm_first);
+		for (int t = 0; t < MP2_WINDOW_WG; t++) mp2_wg_window_run(b, f, t, staged, win, pcm_first);
 	}
 	for (uint32_t s = 0; s < n_streams; s++) {
 		count_out[s] = count[s];

@@ -74,10 +74,74 @@ def measure(n_streams=64, n_frames=154, reps=5, cpu_baseline=True, device=-1):
     return out
 
 
+def measure_live(n_streams=64, n_frames=60, abi_streams=4, device=-1):
+    """LIVE audio streams (include/jsmpeg_hip.h part 6): the same streams arriving a frame per stream per tick -- a write() per
+    stream, ONE jsmpeg_hip_mp2_live_tick for all of them, the samples brought to the host -- beside the reference's one-frame
+    decoder ABI driven the same way (a decoder per stream: write a frame, decode(), the samples on the host).  Every frame of
+    every tick against the oracle's decode of the whole stream."""
+    from jsmpeg_amd import build, cabi, mp2, synth
+    made = [synth.generate_mp2_config("mp2_stereo_44k_192", n_frames, stream=s) for s in range(n_streams)]
+    oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
+    want = [cabi.decode_mp2_stream(oracle, d)[0] for d, _ in made]
+    bounds = [[int(o) for o in offs] + [len(d)] for d, offs in made]
+    t_tick, t_write, t_read, parts, bad = [], [], [], [], 0
+    with mp2.Mp2Live(n_streams, max_frames_per_tick=2, device=device) as live:
+        for _ in range(n_streams):
+            live.open()
+        for k in range(n_frames):
+            pieces = [made[s][0][bounds[s][k]:bounds[s][k + 1]] for s in range(n_streams)]
+            t0 = time.perf_counter()
+            for s in range(n_streams):
+                live.write(s, k * 1152 / 44100.0, pieces[s])
+            t1 = time.perf_counter()
+            n = live.tick()
+            t2 = time.perf_counter()
+            pcm = live.read_pcm()
+            t3 = time.perf_counter()
+            if n != n_streams:
+                raise RuntimeError("live audio tick %d decoded %d frames, expected %d" % (k, n, n_streams))
+            for s in range(n_streams):                 # the checker, outside the clocks
+                bad += not np.array_equal(pcm[s].view(np.uint32), want[s][k].view(np.uint32))
+            if k >= 3:
+                t_write.append(t1 - t0); t_tick.append(t2 - t1); t_read.append(t3 - t2); parts.append(live.timings())
+    if bad:
+        raise RuntimeError("live audio parity failure: %d frames differ from the oracle" % bad)
+    # the one-frame ABI the same way: abi_streams decoders in turn
+    t_abi = []
+    decs = [cabi.Mp2Decoder(build.LIB_HIP, 128 * 1024, cabi.MODE_EVICT) for _ in range(abi_streams)]
+    try:
+        for k in range(n_frames):
+            for s in range(abi_streams):
+                piece = made[s][0][bounds[s][k]:bounds[s][k + 1]]
+                t0 = time.perf_counter()
+                decs[s].write(piece)
+                if not decs[s].decode():
+                    raise RuntimeError("the one-frame ABI decoded nothing")
+                decs[s].channels()
+                if k >= 3:
+                    t_abi.append(time.perf_counter() - t0)
+    finally:
+        for d in decs:
+            d.close()
+    med = lambda v: float(np.median(v)) * 1e3
+    tick_ms, write_ms, read_ms, abi_ms = med(t_tick), med(t_write), med(t_read), med(t_abi)
+    whole = write_ms + tick_ms + read_ms
+    return {"streams": n_streams, "frames_per_stream_per_tick": 1, "ticks": n_frames, "frames_differing_from_oracle": 0,
+            "ms_per_tick": round(whole, 4), "ms_writes": round(write_ms, 4), "ms_tick_call": round(tick_ms, 4), "ms_samples_to_host": round(read_ms, 4),
+            "parts_ms": {k: round(float(np.median([p[k] for p in parts])), 4) for k in parts[0]},
+            "frames_per_s": round(n_streams / (whole * 1e-3), 1), "realtime_streams": round(n_streams / (whole * 1e-3) * 1152 / 44100, 1),
+            "one_frame_abi": {"ms_per_frame": round(abi_ms, 4), "frames_per_s": round(1e3 / abi_ms, 1),
+                              "note": "mp2_decoder_* of the same library, %d decoders in turn: write a frame, decode(), the samples on the host" % abi_streams},
+            "live_over_one_frame_abi": round((n_streams / whole) / (1.0 / abi_ms), 2),
+            "note": "tools/mp2_bench.py measure_live: every tick = one write() per stream (a whole frame) + ONE jsmpeg_hip_mp2_live_tick + the "
+                    "tick's samples to the host in one call, host clock, median; every frame of every tick == the oracle's"}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--frames", type=int, default=154)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--live", action="store_true", help="the live streams' tick instead (measure_live)")
     a = ap.parse_args()
-    print(json.dumps(measure(a.streams, a.frames, a.reps)))
+    print(json.dumps(measure_live(a.streams, min(a.frames, 60)) if a.live else measure(a.streams, a.frames, a.reps)))
