@@ -254,3 +254,15 @@ def test_ts_in_audio_beside_the_live_video(hip_lib, libs):
                 off += size
             frames, _, _ = cabi.decode_stream(libs["oracle"], es, keep="planes")
             assert pics[s] == [hashing.frame_hash(*f) for f in frames]
+
+
+def test_live_audio_fuzz_short_run(hip_lib, libs):
+    """tools/fuzz_live_audio.py: random generator parameters / feeding (whole frames with small stores that evict and noise that
+    stalls, arbitrary byte pieces, TS in pieces), streams joining and leaving on reused ids -- a short run of the sweep whose long
+    runs are profiles/r06_fuzz_live_audio.txt"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live_audio.py"), "60", "91"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
