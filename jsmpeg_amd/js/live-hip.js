@@ -243,14 +243,28 @@ function install(JSMpeg, options) {
     this.waiting = new Set();          // streams whose size is not known yet
     this.holdBytes = this.opts.holdBytes || 1 << 20;   // what a stream may hold before its header shows (beyond: the oldest writes go)
   }
+  // SEVERAL GPUs behind the same object (options.devices: HIP ordinals, e.g. [0, 1, ..., 7]): streams are independent, so the
+  // path shards by stream with no exchange at all -- one HIPLive per (size, device), a stream joins the device that holds the
+  // fewest streams when its size shows, and tickBegin() puts every handle's pass on ITS device before tickEnd() waits for the
+  // first (tick() = the two halves; the passes of the devices run beside each other, one host thread).
   HIPLiveRouter.prototype.liveFor = function (width, height) {
-    const key = width + 'x' + height;
-    let live = this.lives.get(key);
-    if (!live) {
-      const o = this.opts;
-      live = new HIPLive({ width, height, maxStreams: o.maxStreamsPerSize || 64, picturesPerTick: o.picturesPerTick, videoBufferSize: o.videoBufferSize, device: o.device });
-      this.lives.set(key, live);
-    }
+    const o = this.opts;
+    const devices = o.devices && o.devices.length ? o.devices : [o.device];
+    let best = null, bestKey = null, bestLoad = Infinity, bestDevice = null;
+    devices.forEach((d, i) => {
+      // (keyed by the entry's place in `devices`, not by the ordinal: [0, 0] is two handles on GPU 0 -- how the tests run it on one GPU)
+      const tag = devices.length > 1 ? '#' + i : '';
+      const key = width + 'x' + height + tag;
+      const live = this.lives.get(key) || null;
+      let load = 0;                                              // a device's load: its streams of EVERY size
+      for (const [k, l] of this.lives) if (!tag || k.endsWith(tag)) load += l.streams.size;
+      const full = live && live.streams.size >= live.maxStreams;
+      if (!full && load < bestLoad) { best = live; bestKey = key; bestLoad = load; bestDevice = d; }
+    });
+    if (bestKey === null) throw new Error('HIPLiveRouter: every device holds ' + (o.maxStreamsPerSize || 64) + ' streams of ' + width + ' x ' + height);
+    if (best) return best;
+    const live = new HIPLive({ width, height, maxStreams: o.maxStreamsPerSize || 64, picturesPerTick: o.picturesPerTick, videoBufferSize: o.videoBufferSize, device: bestDevice });
+    this.lives.set(bestKey, live);
     return live;
   };
   HIPLiveRouter.prototype.open = function (options) {
@@ -260,6 +274,7 @@ function install(JSMpeg, options) {
   };
   const routedFrame = (opts) => Object.assign({}, opts, { onFrame: opts.onFrame && ((f) => { f.liveStream = f.stream; f.stream = f.stream.routed || f.stream; opts.onFrame(f); }) });
   HIPLiveRouter.prototype.tick = function (opts) {
+    if (this.opts.devices && this.opts.devices.length > 1) { this.tickBegin(opts); return this.tickEnd(); }   // the devices' passes beside each other
     let n = 0;
     for (const live of this.lives.values()) n += live.tick(routedFrame(opts || {}));
     return n;

@@ -70,6 +70,17 @@ def test_live_router_logic_over_an_injected_binding():
                           ["frame", "c", 32, 16, 5], ["render a"], ["frame", "a", 32, 16, 3], ["frame", "b", 48, 32, 4], ["tick", 3]]
 
 
+def test_live_router_spreads_streams_over_devices():
+    """JSMpeg.HIPLiveRouter({devices: [...]}): streams shard by stream over the GPUs of a node with no exchange -- a handle per
+    (size, device) made on demand, a new stream joins the device that holds the fewest, a full device is passed over, and a tick puts
+    every handle's pass on its device (tickBegin) before it waits for the first (tickEnd)"""
+    out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "live_router_devices_fake.js")]))
+    assert out["where"] == [4, 5, 6, 4, 5, 6, 4] and out["late"] == 6 and out["full"] is True
+    assert out["creates"] == [["liveCreate", 32, 16, 4], ["liveCreate", 32, 16, 5], ["liveCreate", 32, 16, 6], ["liveCreate", 48, 32, 6], ["liveCreate", 48, 32, 4]]
+    assert out["tickCalls"] == ["liveTickBegin"] * 5 + ["liveTickEnd"] * 5
+    assert out["frames"] == [[4, 32], [5, 32], [6, 32], [4, 48]]
+
+
 def _ts_files(n, frames, w, h):
     paths, want, es_all = [], [], []
     oracle = build.LIB_ORACLE if os.path.exists(build.LIB_ORACLE) else build.build_oracle()
@@ -144,7 +155,8 @@ def test_node_live_rgba_frames(hip_lib):
 
 
 @pytest.mark.gpu
-def test_node_live_router_streams_of_several_sizes(hip_lib):
+@pytest.mark.parametrize("devices", [None, "0,0"], ids=["one handle per size", "two handles per size on GPU 0 (the N-GPU form rehearsed)"])
+def test_node_live_router_streams_of_several_sizes(hip_lib, devices):
     """JSMpeg.HIPLiveRouter over the real addon: five TS files of three picture sizes, fed in ragged pieces (ts-demux.js ->
     write() for the even ones, writeTS for the odd ones); the router finds each stream's size in the stream, one HIPLive per
     size; every rendered picture == the oracle's"""
@@ -160,11 +172,19 @@ def test_node_live_router_streams_of_several_sizes(hip_lib):
         paths.append(f.name)
         want.append(cabi.decode_stream(oracle, es)[0])
     try:
-        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_router.js")] + paths, timeout=300))
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_router.js")] + (["--devices", devices] if devices else []) + paths, timeout=300))
     finally:
         for p in paths:
             os.unlink(p)
-    assert out["handles"] == sorted("%dx%d" % wh for wh in set(sizes)) and out["waiting"] == 0
+    if devices:
+        # {devices: [0, 0]}: the streams alternate between the two entries (least loaded first), every handle's pass is on the device
+        # before the first is waited for -- two live handles in flight at once
+        load = {"#0": 0, "#1": 0}
+        for key, n in out["perHandle"]:
+            load[key[-2:]] += n
+        assert sorted(load.values()) == [2, 3] and out["waiting"] == 0 and {k.split("#")[0] for k, _ in out["perHandle"]} == {"%dx%d" % wh for wh in sizes}
+    else:
+        assert out["handles"] == sorted("%dx%d" % wh for wh in set(sizes)) and out["waiting"] == 0
     assert out["pictures"] == 5 * 9 and out["widths"] == [w for w, _ in sizes]
     for s, (w, h) in enumerate(sizes):
         st = out["streams"][s]
