@@ -562,6 +562,15 @@ int jsmpeg_hip_live_read_rgba(jsmpeg_hip_live_t *l, uint32_t i, void *host_rgba)
  * 64 x 1080p pictures in 4.1 ms (49 GB/s) against 7.3-8 ms through 64 jsmpeg_hip_live_read_frame calls into pageable memory.
  * What a host that RENDERS every picture (destination.render(y, cr, cb), mpeg1-wasm.js:109-119) calls once per tick. */
 int jsmpeg_hip_live_read_frames(jsmpeg_hip_live_t *l, uint32_t first, uint32_t count, void *host, uint64_t stride);
+/* The same read in two halves, for a host whose cycle IS the read-out (64 x 1080p pictures are 199 MB: 4.1 ms on the link against
+ * a tick of 0.9): _begin enqueues the copies on a stream of the handle's own and returns; the host writes, and the NEXT tick
+ * decodes, while they run; _end waits for them.  One read-out at a time (a second _begin before _end is an error; _end without
+ * one returns 0).  The frames being read are safe: the tick right behind them writes other slots of the streams' rings when no
+ * stream has more than two pictures among them, and any tick that could write over them (a stream with three or more; the tick
+ * after the next) waits for the copies ON THE DEVICE first -- the host never blocks in a tick because of a read-out.  `host`
+ * must stay valid (and should be pinned) until _end.  Unlike the other calls _end does not end a tick in flight. */
+int jsmpeg_hip_live_read_frames_begin(jsmpeg_hip_live_t *l, uint32_t first, uint32_t count, void *host, uint64_t stride);
+int jsmpeg_hip_live_read_frames_end(jsmpeg_hip_live_t *l);
 /* Pinned host memory (hipHostMalloc / hipHostRegister): what the copy engines read and write at full rate.  register: the
  * caller's own memory (a JS ArrayBuffer's, a numpy array's) for as long as it stays registered; it must not be freed before
  * jsmpeg_hip_host_unregister. */

@@ -71,6 +71,12 @@ struct jsmpeg_hip_live_t {
 	JmStream *h_back;                   /* pinned: the stream table as the pass left it (the headers it found) */
 	std::vector<LivePicture> out;
 	uint32_t *d_slots; uint64_t *d_hashes; uint8_t *d_rgba;
+	/* a tick's pictures on their way to the host BESIDE the next tick (jsmpeg_hip_live_read_frames_begin / _end): the copies run on
+	 * a stream of the handle's own.  The frames they read stay untouched for ONE more tick when no stream has more than two
+	 * pictures among them (a ring holds pictures per tick + 2 frames: the next tick writes the other slots); otherwise, and for
+	 * every tick after the next, the tick's stream waits for ev_read on the device before anything of the pass runs */
+	hipStream_t rd_stream; hipEvent_t ev_read;
+	bool read_in_flight, read_deep; uint32_t read_age;
 	float ms[9];
 };
 
@@ -84,6 +90,8 @@ static void live_free(jsmpeg_hip_live_t *l) {
 	if (l->b) { hipSetDevice(l->b->device); hipDeviceSynchronize(); l->b->live = nullptr; batch_free(l->b); }
 	if (l->up_stream) hipStreamDestroy(l->up_stream);
 	if (l->ev_sent) hipEventDestroy(l->ev_sent);
+	if (l->rd_stream) hipStreamDestroy(l->rd_stream);
+	if (l->ev_read) hipEventDestroy(l->ev_read);
 	if (l->h_stage) hipHostFree(l->h_stage);
 	if (l->h_tab) hipHostFree(l->h_tab);
 	if (l->h_back) hipHostFree(l->h_back);
@@ -96,6 +104,8 @@ static int live_alloc(jsmpeg_hip_live_t *l) {
 	HIP_TRY(hipHostMalloc(&l->h_stage, l->stage_cap, hipHostMallocDefault));
 	HIP_TRY(hipStreamCreateWithFlags(&l->up_stream, hipStreamNonBlocking));
 	HIP_TRY(hipEventCreateWithFlags(&l->ev_sent, hipEventDisableTiming));
+	HIP_TRY(hipStreamCreateWithFlags(&l->rd_stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&l->ev_read, hipEventDisableTiming));
 	HIP_TRY(jm_malloc(&l->d_arena, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
 	HIP_TRY(hipMemset(l->d_arena, 0xff, (size_t)l->stage_cap + 2 * (size_t)l->es_cap));
 	l->tab_cap = 4 * ms + 64;
@@ -135,6 +145,7 @@ extern "C" jsmpeg_hip_live_t *jsmpeg_hip_live_create(const jsmpeg_hip_live_confi
 	l->b = nullptr; l->h_stage = nullptr; l->d_arena = nullptr; l->h_tab = nullptr; l->d_tab = nullptr; l->h_back = nullptr;
 	l->d_slots = nullptr; l->d_hashes = nullptr; l->d_rgba = nullptr; l->stage_used = 0; l->cur = 0; l->tab_cap = 0;
 	l->up_stream = nullptr; l->ev_sent = nullptr; l->stage_sent = 0;
+	l->rd_stream = nullptr; l->ev_read = nullptr; l->read_in_flight = false; l->read_deep = false; l->read_age = 0;
 	l->in_flight = false; l->last_n = 0; l->up_pending = false;
 	{ const char *v = getenv("JSMPEG_HIP_LIVE_UPLOAD_CHUNK"); l->up_chunk = v ? (uint32_t)strtoul(v, nullptr, 0) : (1u << 20); }   /* 0: everything at the tick */
 	for (float &m : l->ms) m = 0.f;
@@ -174,6 +185,8 @@ extern "C" int jsmpeg_hip_live_open(jsmpeg_hip_live_t *l) {
 	g_err[0] = 0;
 	if (!l) return fail("null live handle");
 	if (live_settle(l) < 0) return -1;
+	/* (pictures on their way to the host may lie in the ring of the id handed out next: its first tick would write over them) */
+	if (l->read_in_flight) { HIP_TRY(hipSetDevice(l->b->device)); HIP_TRY(hipEventSynchronize(l->ev_read)); }
 	for (uint32_t s = 0; s < l->streams.size(); s++) {
 		LiveStream &S = l->streams[s];
 		if (S.open) continue;
@@ -431,6 +444,9 @@ static int live_tick_begin_impl(jsmpeg_hip_live_t *l, uint32_t flags, void *hip_
 	const bool flush = (flags & JSMPEG_HIP_LIVE_FLUSH) != 0;
 	l->out.clear();
 	for (float &m : l->ms) m = 0.f;
+	/* pictures of an earlier tick on their way to the host (jsmpeg_hip_live_read_frames_begin): the tick right behind them leaves
+	 * their frames alone unless a stream has more than two among them; any other tick waits for the copies -- on the device */
+	if (l->read_in_flight && (++l->read_age >= 2 || l->read_deep)) HIP_TRY(hipStreamWaitEvent(st, l->ev_read, 0));
 
 	/* ---- 1. the streams of this pass: the open ones with bytes pending ---- */
 	l->pass_stream.clear();
@@ -683,6 +699,39 @@ extern "C" int jsmpeg_hip_live_read_frames(jsmpeg_hip_live_t *l, uint32_t first,
 	for (uint32_t k = 0; k < count; k++)
 		HIP_TRY(hipMemcpyAsync((uint8_t *)host + (uint64_t)k * stride, b->d_pool + (uint64_t)l->out[first + k].slot * b->g.frame_bytes, planes, hipMemcpyDeviceToHost, b->stream));
 	HIP_TRY(hipStreamSynchronize(b->stream));
+	return 0;
+}
+
+/* The same read in two halves: the copies run on a stream of the handle's own while the host writes and the NEXT tick decodes. */
+extern "C" int jsmpeg_hip_live_read_frames_begin(jsmpeg_hip_live_t *l, uint32_t first, uint32_t count, void *host, uint64_t stride) {
+	g_err[0] = 0;
+	if (live_settle(l) < 0) return -1;
+	if (!l || (count && !host) || (uint64_t)first + count > l->out.size()) return fail("bad picture range %u + %u of %u", first, count, l ? (unsigned)l->out.size() : 0u);
+	if (l->read_in_flight) return fail("read_frames_begin: a read-out is in flight (jsmpeg_hip_live_read_frames_end first)");
+	const jsmpeg_hip_batch_t *b = l->b;
+	const size_t planes = (size_t)b->g.luma_bytes + 2 * (size_t)b->g.chroma_bytes;
+	if (count && stride < planes) return fail("stride %llu < the %llu bytes of a picture's planes", (unsigned long long)stride, (unsigned long long)planes);
+	HIP_TRY(hipSetDevice(b->device));
+	/* (the tick that made these pictures has ended: its stream was waited for -- the copies need no event of it) */
+	uint32_t run = 0;
+	l->read_deep = false;
+	for (uint32_t k = 0; k < count; k++) {
+		HIP_TRY(hipMemcpyAsync((uint8_t *)host + (uint64_t)k * stride, b->d_pool + (uint64_t)l->out[first + k].slot * b->g.frame_bytes, planes, hipMemcpyDeviceToHost, l->rd_stream));
+		run = k && l->out[first + k].stream == l->out[first + k - 1].stream ? run + 1 : 1;     /* (a tick's pictures are listed stream by stream) */
+		if (run > 2) l->read_deep = true;
+	}
+	HIP_TRY(hipEventRecord(l->ev_read, l->rd_stream));
+	l->read_in_flight = true; l->read_age = 0;
+	return 0;
+}
+
+extern "C" int jsmpeg_hip_live_read_frames_end(jsmpeg_hip_live_t *l) {
+	g_err[0] = 0;
+	if (!l) return fail("null live handle");
+	if (!l->read_in_flight) return 0;
+	HIP_TRY(hipSetDevice(l->b->device));
+	HIP_TRY(hipEventSynchronize(l->ev_read));
+	l->read_in_flight = false;
 	return 0;
 }
 

@@ -14,6 +14,7 @@
  *   livePicture(handle, i) -> {stream, type, pts, streamOffset}                    jsmpeg_hip_live_picture
  *   liveReadPlanes(handle, i, y, cr, cb) / liveReadRGBA(handle, i, Uint8ClampedArray)
  *   liveReadFrames(handle, first, count, Uint8Array, stride) -> count              jsmpeg_hip_live_read_frames (all of a tick's pictures in one call)
+ *   liveReadFramesBegin(handle, first, count, Uint8Array, stride) / liveReadFramesEnd(handle)   jsmpeg_hip_live_read_frames_begin / _end (beside the next tick)
  *   hostRegister(Uint8Array) / hostUnregister(Uint8Array)                          jsmpeg_hip_host_register / _unregister (pinned: the link's rate)
  *   liveFrameHashes(handle, Uint8Array(8 * pictures)) -> pictures                  jsmpeg_hip_live_frame_hashes
  *   liveStreamInfo(handle, id) -> {hasSequenceHeader, width, height, frameRate, status, pendingBytes, bytesWritten, pictures, evictions}
@@ -272,6 +273,40 @@ static napi_value fn_live_read_frames(napi_env env, napi_callback_info info) {
 	return out;
 }
 
+/* liveReadFramesBegin(handle, first, count, Uint8Array out, stride) / liveReadFramesEnd(handle): the same read in two halves
+ * (jsmpeg_hip_live_read_frames_begin / _end) -- the copies run beside the host's writes and the next tick; `out` must stay
+ * referenced (and should be hostRegister()ed) until the End call */
+static napi_value fn_live_read_frames_begin(napi_env env, napi_callback_info info) {
+	size_t argc = 5;
+	napi_value argv[5], out;
+	uint32_t first = 0, count = 0;
+	double stride = 0;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	if (argc < 5 || napi_get_value_uint32(env, argv[1], &first) != napi_ok || napi_get_value_uint32(env, argv[2], &count) != napi_ok ||
+	    napi_get_value_double(env, argv[4], &stride) != napi_ok || stride < 0) { napi_throw_type_error(env, NULL, "jsmpeg_hip: liveReadFramesBegin(handle, first, count, Uint8Array, stride)"); return NULL; }
+	uint32_t luma = 0, chroma = 0;
+	int32_t cw, ch;
+	jsmpeg_hip_live_geometry(l, &cw, &ch, &luma, &chroma);
+	const double need = count ? (double)(count - 1) * stride + (double)luma + 2.0 * chroma : 0;
+	void *data = u8_arg(env, argv[3], (size_t)need);
+	if (!data && count) { napi_throw_range_error(env, NULL, "jsmpeg_hip: the target must hold (count - 1) * stride + a picture's planes"); return NULL; }
+	if (jsmpeg_hip_live_read_frames_begin(l, first, count, data, (uint64_t)stride) < 0) return throw_last(env);
+	NAPI_OK(napi_create_uint32(env, count, &out));
+	return out;
+}
+static napi_value fn_live_read_frames_end(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], out;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_live_t *l = live_arg(env, argv[0]);
+	if (!l) return NULL;
+	if (jsmpeg_hip_live_read_frames_end(l) < 0) return throw_last(env);
+	NAPI_OK(napi_get_undefined(env, &out));
+	return out;
+}
+
 /* hostRegister(Uint8Array) / hostUnregister(Uint8Array): the array's memory pinned for the copy engines (jsmpeg_hip_host_register);
  * the caller keeps the array alive until it has unregistered it */
 static napi_value fn_host_register(napi_env env, napi_callback_info info) {
@@ -377,7 +412,7 @@ static napi_value fn_live_timings(napi_env env, napi_callback_info info) {
 int jm_napi_register_live(napi_env env, napi_value exports) {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 		{ "liveCreate", fn_live_create }, { "liveDestroy", fn_live_destroy }, { "liveOpen", fn_live_open }, { "liveClose", fn_live_close },
-		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "liveTickBegin", fn_live_tick_begin }, { "liveTickEnd", fn_live_tick_end }, { "livePicture", fn_live_picture }, { "liveReadFrames", fn_live_read_frames }, { "hostRegister", fn_host_register }, { "hostUnregister", fn_host_unregister },
+		{ "liveWrite", fn_live_write }, { "liveWriteTS", fn_live_write_ts }, { "liveTick", fn_live_tick }, { "liveTickBegin", fn_live_tick_begin }, { "liveTickEnd", fn_live_tick_end }, { "livePicture", fn_live_picture }, { "liveReadFrames", fn_live_read_frames }, { "liveReadFramesBegin", fn_live_read_frames_begin }, { "liveReadFramesEnd", fn_live_read_frames_end }, { "hostRegister", fn_host_register }, { "hostUnregister", fn_host_unregister },
 		{ "liveReadPlanes", fn_live_read_planes }, { "liveReadRGBA", fn_live_read_rgba }, { "liveFrameHashes", fn_live_frame_hashes },
 		{ "liveStreamInfo", fn_live_stream_info }, { "liveGeometry", fn_live_geometry }, { "liveTimings", fn_live_timings },
 	};

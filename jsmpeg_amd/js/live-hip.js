@@ -46,11 +46,21 @@ function install(JSMpeg, options) {
     this.pictures = 0;
     this.planes = null; this.rgba = null; this.out = null; this.outPinned = false;
     this.inFlight = false; this.flight = null;
+    // {pipelined: true}: a tick hands out the pictures of the tick BEFORE it -- their planes travelled to the host beside this
+    // tick's pass (jsmpeg_hip_live_read_frames_begin / _end; two pinned arrays in turn) -- and starts its own pictures on their
+    // way.  For a host that renders every picture the cycle is the read-out (64 x 1080p: 4.1 ms) instead of read-out + tick;
+    // the price is one tick of delay.  drain() hands out the last tick's pictures when the ticks stop.
+    this.pipelined = !!opts.pipelined;
+    this.pipe = null;                                              // the read-out in flight: { records, buffer }
+    this.pipeBuffers = [null, null]; this.pipeTurn = 0;
   }
 
   HIPLive.prototype.releaseOut = function () {
     if (this.out && this.outPinned) { try { this.native.hostUnregister(this.out); } catch (e) { /* the device is gone: so is the pinning */ } }
     this.out = null; this.outPinned = false;
+    if (this.pipe) { try { this.native.liveReadFramesEnd(this.handle); } catch (e) { /* nothing to wait for any more */ } this.pipe = null; }
+    for (const b of this.pipeBuffers) if (b && b.pinned) { try { this.native.hostUnregister(b.bytes); } catch (e) { /* as above */ } }
+    this.pipeBuffers = [null, null];
   };
 
   HIPLive.prototype.destroy = function () {
@@ -111,11 +121,67 @@ function install(JSMpeg, options) {
     return new Promise((resolve, reject) => setImmediate(() => { try { resolve(this.tickEnd()); } catch (e) { reject(e); } }));
   };
 
+  // the frames of a read-out that has finished: views into the array they arrived in
+  HIPLive.prototype.handOut = function (p, opts) {
+    const planes = this.lumaBytes + 2 * this.chromaBytes, out = p.buffer.bytes;
+    p.records.forEach((r, i) => {
+      const s = r.stream;
+      if (!s || !s.live) return;                                   // closed meanwhile
+      const at = i * planes;
+      const frame = { stream: s, index: s.pictures, pts: r.pts, type: r.type, streamOffset: r.streamOffset, width: this.width, height: this.height,
+                      codedWidth: this.codedWidth, codedHeight: this.codedHeight,
+                      y: out.subarray(at, at + this.lumaBytes), cr: out.subarray(at + this.lumaBytes, at + this.lumaBytes + this.chromaBytes),
+                      cb: out.subarray(at + this.lumaBytes + this.chromaBytes, at + planes) };
+      // (y, cr, cb, isClampedArray): the decoder classes' render call (reference src/mpeg1-wasm.js:109-119)
+      if (s.destination) s.destination.render(frame.y, frame.cr, frame.cb, false);
+      s.pictures++;
+      s.decodedTime += 1 / s.frameRate;                            // decoder.js:73-104 in streaming mode: no time stamps are collected
+      if (s.onDecodeCallback) s.onDecodeCallback(s, p.elapsed / p.records.length);
+      if (opts.onFrame) opts.onFrame(frame);
+    });
+    return p.records.length;
+  };
+  // when the ticks stop: the pictures of the read-out still in flight
+  HIPLive.prototype.drain = function (opts) {
+    const p = this.pipe;
+    if (!p) return 0;
+    this.pipe = null;
+    this.native.liveReadFramesEnd(this.handle);
+    return this.handOut(p, opts || p.opts);
+  };
+  // pipelined: the read-out of the tick before has had this whole tick to finish -- end it; start this tick's pictures on their
+  // way into the OTHER array; then hand out the tick before's frames (the host renders them beside the new copies)
+  HIPLive.prototype.deliverPipelined = function (n, opts, elapsed) {
+    const planes = this.lumaBytes + 2 * this.chromaBytes;
+    const held = this.pipe;
+    this.pipe = null;
+    if (held) this.native.liveReadFramesEnd(this.handle);
+    if (n) {
+      let b = this.pipeBuffers[this.pipeTurn];
+      if (!b || b.bytes.length < n * planes) {
+        if (b && b.pinned) { try { this.native.hostUnregister(b.bytes); } catch (e) { /* as in releaseOut */ } }
+        b = { bytes: new Uint8Array(Math.max(n, b ? 2 * (b.bytes.length / planes) : 0) * planes), pinned: false };
+        try { this.native.hostRegister(b.bytes); b.pinned = true; } catch (e) { b.pinned = false; }   // (unpinned: the same copies, slower)
+        this.pipeBuffers[this.pipeTurn] = b;
+      }
+      const records = [];
+      for (let i = 0; i < n; i++) {
+        const p = this.native.livePicture(this.handle, i);
+        records.push({ stream: this.streams.get(p.stream) || null, pts: p.pts, type: p.type, streamOffset: p.streamOffset });
+      }
+      this.native.liveReadFramesBegin(this.handle, 0, n, b.bytes, planes);
+      this.pipe = { records, buffer: b, opts, elapsed };
+      this.pipeTurn ^= 1;
+    }
+    return held ? this.handOut(held, opts) : 0;
+  };
+
   HIPLive.prototype.deliver = function (n, opts, elapsed) {
     this.pictures = n;
     for (const s of this.streams.values()) if (!s.hasSequenceHeader && s.bytesWritten) s.pollSequenceHeader();
-    if (!n) return 0;
     const wantPixels = opts.onFrame || Array.from(this.streams.values()).some((s) => s.destination);
+    if (this.pipelined && !opts.rgba && (wantPixels || this.pipe)) return this.deliverPipelined(n, opts, elapsed);
+    if (!n) return 0;
     // the planes of ALL the tick's pictures in one call, into one pinned array (a copy per picture, one wait, the link's rate:
     // 64 x 1080p in 4.1 ms against 7.3-8 through a call per picture into pageable memory); frames are views into it
     const planes = this.lumaBytes + 2 * this.chromaBytes;

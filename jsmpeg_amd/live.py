@@ -11,7 +11,7 @@ FLUSH = 1
 
 LIVE_SYMBOLS = ("jsmpeg_hip_live_create", "jsmpeg_hip_live_destroy", "jsmpeg_hip_live_open", "jsmpeg_hip_live_close",
                 "jsmpeg_hip_live_write", "jsmpeg_hip_live_write_v", "jsmpeg_hip_live_write_ts", "jsmpeg_hip_live_tick", "jsmpeg_hip_live_tick_begin", "jsmpeg_hip_live_tick_end", "jsmpeg_hip_live_picture_count", "jsmpeg_hip_live_picture",
-                "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_frames", "jsmpeg_hip_live_read_rgba",
+                "jsmpeg_hip_live_geometry", "jsmpeg_hip_live_read_frame", "jsmpeg_hip_live_read_frames", "jsmpeg_hip_live_read_frames_begin", "jsmpeg_hip_live_read_frames_end", "jsmpeg_hip_live_read_rgba",
                 "jsmpeg_hip_host_alloc", "jsmpeg_hip_host_free", "jsmpeg_hip_host_register", "jsmpeg_hip_host_unregister",
                 "jsmpeg_hip_live_frame_hashes", "jsmpeg_hip_live_stream_info", "jsmpeg_hip_live_timings")
 
@@ -68,6 +68,10 @@ def lib():
         L.jsmpeg_hip_live_read_frame.argtypes = [vp, u32, vp, vp, vp]
         L.jsmpeg_hip_live_read_frames.restype = ctypes.c_int
         L.jsmpeg_hip_live_read_frames.argtypes = [vp, u32, u32, vp, ctypes.c_uint64]
+        L.jsmpeg_hip_live_read_frames_begin.restype = ctypes.c_int
+        L.jsmpeg_hip_live_read_frames_begin.argtypes = [vp, u32, u32, vp, ctypes.c_uint64]
+        L.jsmpeg_hip_live_read_frames_end.restype = ctypes.c_int
+        L.jsmpeg_hip_live_read_frames_end.argtypes = [vp]
         L.jsmpeg_hip_host_alloc.restype = vp
         L.jsmpeg_hip_host_alloc.argtypes = [ctypes.c_uint64]
         L.jsmpeg_hip_host_free.restype = None
@@ -185,6 +189,39 @@ class Live:
                 raise RuntimeError("jsmpeg_hip_host_alloc: " + _batch.last_error())
         self._ok(self.L.jsmpeg_hip_live_read_frames(self.h, first, n, self._pin, planes))
         return np.ctypeslib.as_array((ctypes.c_uint8 * (n * planes)).from_address(self._pin)).reshape(n, planes)
+
+    def read_frames_begin(self, first=0, count=None):
+        """the read-out in two halves: the last tick's pictures start on their way to pinned memory of the object's own (two
+        buffers in turn) and the call returns; writes and the NEXT tick go on beside the copies; read_frames_end() waits and
+        hands out the array (valid until the read-out after the next one)"""
+        n = self.picture_count - first if count is None else count
+        planes = self.luma_bytes + 2 * self.chroma_bytes
+        if not hasattr(self, "_pins"):
+            self._pins, self._pin_turn, self._pending = [[None, 0], [None, 0]], 0, None
+        if self._pending is not None:
+            raise RuntimeError("read_frames_begin: a read-out is in flight (read_frames_end first)")
+        slot = self._pins[self._pin_turn]
+        if slot[1] < max(1, n) * planes:
+            if slot[0]:
+                self.L.jsmpeg_hip_host_free(slot[0])
+            slot[1] = max(1, 2 * n) * planes
+            slot[0] = self.L.jsmpeg_hip_host_alloc(slot[1])
+            if not slot[0]:
+                slot[1] = 0
+                raise RuntimeError("jsmpeg_hip_host_alloc: " + _batch.last_error())
+        self._ok(self.L.jsmpeg_hip_live_read_frames_begin(self.h, first, max(0, n), slot[0], planes))
+        self._pending = (slot[0], max(0, n), planes)
+        self._pin_turn ^= 1
+
+    def read_frames_end(self):
+        if getattr(self, "_pending", None) is None:
+            return None
+        ptr, n, planes = self._pending
+        self._pending = None
+        self._ok(self.L.jsmpeg_hip_live_read_frames_end(self.h))
+        if n == 0:
+            return np.empty((0, planes), dtype=np.uint8)
+        return np.ctypeslib.as_array((ctypes.c_uint8 * (n * planes)).from_address(ptr)).reshape(n, planes)
 
     def read_rgba(self, i):
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

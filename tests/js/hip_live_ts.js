@@ -1,7 +1,8 @@
 // GPU test helper: N .ts files -> a TS demuxer per stream (the reference's own JSMpeg.Demuxer.TS from its shipped bundle
 // when --bundle is given, else jsmpeg_amd/js/ts-demux.js) -> JSMpeg.HIPLive streams (real addon) -> one tick per round of
 // writes.  Every stream's rendered planes as md5, in order; the last stream joins `--late` rounds after the others.
-//   node hip_live_ts.js <width> <height> [--bundle jsmpeg.min.js] [--late n] [--packets n] [--rgba] [--overlap] a.ts b.ts ...
+//   node hip_live_ts.js <width> <height> [--bundle jsmpeg.min.js] [--late n] [--packets n] [--rgba] [--overlap] [--pipelined] a.ts b.ts ...
+// --pipelined: HIPLive({pipelined: true}) -- a tick hands out the pictures of the tick before (their planes travelled beside its pass); drain() at the end.
 // --overlap: a round's pieces are written WHILE the tick of the round before is on the device (live.tickAsync: tickBegin, one
 // turn of the event loop, tickEnd) -- the same pictures, the same rounds.
 'use strict';
@@ -12,7 +13,7 @@ const { install } = require('../../jsmpeg_amd/js/live-hip.js');
 
 const args = process.argv.slice(2);
 const width = +args.shift(), height = +args.shift();
-let bundle = null, late = 0, packets = 40, rgba = false, nativeTS = false, overlap = false;
+let bundle = null, late = 0, packets = 40, rgba = false, nativeTS = false, overlap = false, pipelined = false;
 while (args.length && args[0].startsWith('--')) {
   const k = args.shift();
   if (k === '--bundle') bundle = args.shift();
@@ -20,6 +21,7 @@ while (args.length && args[0].startsWith('--')) {
   else if (k === '--packets') packets = +args.shift();
   else if (k === '--rgba') rgba = true;
   else if (k === '--overlap') overlap = true;
+  else if (k === '--pipelined') pipelined = true;
   else if (k === '--native-ts') nativeTS = true;     // no JS demuxer at all: HIPLiveStream.writeTS (the library's ts.js restatement, state kept per stream)
 }
 const files = args.map((f) => fs.readFileSync(f));
@@ -43,7 +45,7 @@ if (bundle) {
 }
 
 const { HIPLive } = install();
-const live = new HIPLive({ width, height, maxStreams: files.length, picturesPerTick: 4 });
+const live = new HIPLive({ width, height, maxStreams: files.length, picturesPerTick: 4, pipelined });
 const streams = files.map(() => null);
 const out = files.map(() => ({ planes: [], sizes: [], pts: [], types: [], callbacks: 0, rgba: [] }));
 function join(i) {
@@ -86,11 +88,12 @@ const tickOptions = {
 };
 function ticked(n) {
   pictures += n;
-  if (n) { hashesSeen += live.frameHashes().length; ticks.push(live.timings().totalMs); }
+  if (live.pictures) { hashesSeen += live.frameHashes().length; ticks.push(live.timings().totalMs); }
 }
 function finish() {
+  pictures += live.drain(tickOptions);                 // (pipelined: the last tick's pictures are still on their way)
   const info = streams.map((s) => s.video.info());
-  const result = { demuxer: nativeTS ? 'jsmpeg_hip_live_write_ts' : demuxerName, rounds: round, pictures, hashesSeen, streams: out, overlap,
+  const result = { demuxer: nativeTS ? 'jsmpeg_hip_live_write_ts' : demuxerName, rounds: round, pictures, hashesSeen, streams: out, overlap, pipelined,
                    frameRates: streams.map((s) => s.video.frameRate), decodedTimes: streams.map((s) => +s.video.decodedTime.toFixed(6)),
                    ids: streams.map((s) => s.video.id), pending: info.map((x) => x.pendingBytes), evictions: info.map((x) => x.evictions),
                    bytesWritten: streams.map((s) => s.video.bytesWritten), bytesWrittenInfo: info.map((x) => x.bytesWritten),

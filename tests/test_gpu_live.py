@@ -503,3 +503,59 @@ def test_live_fuzz_short_run(hip_lib, libs, chunk):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live.py"), "30", "77"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_read_out_beside_the_next_ticks(hip_lib, libs):
+    """jsmpeg_hip_live_read_frames_begin / _end: a tick's pictures on their way to the host WHILE the next tick decodes into the
+    same rings.  Four streams, rings of 3 + 2 frames, ticks of 1, 2 and 3 pictures per stream: with at most two pictures per
+    stream in flight the next tick runs beside the copies (it writes the rings' other slots), with three it waits for them on the
+    device -- either way what arrives is what the tick decoded.  Every fifth read-out stays in flight across TWO ticks (the second
+    one waits for it on the device; their own pictures are read the plain way meanwhile).  A second _begin is refused, _end with
+    nothing in flight is nothing."""
+    from jsmpeg_amd import batch as jb
+    n_streams, n_pic = 4, 36
+    cases = [synth.generate_config("cfg1_720p", n_frames=n_pic, width=352, height=288, stream=120 + s) for s in range(n_streams)]
+    want = [cabi.decode_stream(libs["oracle"], es)[0] for es, _ in cases]            # md5(Y | Cr | Cb) per picture
+    writes = [picture_writes(es, [int(o) for o in offs]) for es, offs in cases]
+    rng = random.Random(7)
+    seen = [0] * n_streams
+
+    def check(arr, streams_of):
+        assert len(arr) == len(streams_of)
+        for row, s in zip(arr, streams_of):
+            assert hashlib.md5(row.tobytes()).hexdigest() == want[s][seen[s]], (s, seen[s])
+            seen[s] += 1
+
+    with jl.Live(352, 288, n_streams, pictures_per_tick=3, store_bytes=1 << 20) as lv:
+        assert lv.read_frames_end() is None and lv.L.jsmpeg_hip_live_read_frames_end(lv.h) == 0
+        for _ in range(n_streams):
+            lv.open()
+        at = [0] * n_streams
+        inflight, saved, step, held, deep = None, [], 0, 0, 0
+        while min(at) < n_pic:
+            step += 1
+            k = rng.choice([1, 1, 2, 2, 3])
+            deep += k == 3
+            for s in range(n_streams):
+                for w in writes[s][at[s]:at[s] + k]:
+                    lv.write(s, w)
+                at[s] = min(n_pic, at[s] + k)
+            lv.tick(flush=True)
+            now = [p.stream for p in lv.pictures()]
+            if inflight is not None and inflight["hold"]:
+                inflight["hold"] -= 1
+                saved.append((lv.read_frames().copy(), now))         # this tick's pictures the plain way; the read-out stays in flight
+                continue
+            if inflight is not None:
+                check(lv.read_frames_end(), inflight["streams"])
+                for a in saved:
+                    check(*a)
+                saved = []
+            lv.read_frames_begin()
+            assert lv.L.jsmpeg_hip_live_read_frames_begin(lv.h, 0, 0, None, 0) < 0 and "in flight" in jb.last_error()
+            inflight = {"streams": now, "hold": 1 if step % 5 == 0 else 0}
+            held += inflight["hold"]
+        check(lv.read_frames_end(), inflight["streams"])
+        for a in saved:
+            check(*a)
+        assert seen == [n_pic] * n_streams and held >= 2 and deep >= 2

@@ -135,6 +135,27 @@ def test_node_live_streams_on_gpu(demuxer, overlap, hip_lib):
 
 
 @pytest.mark.gpu
+def test_node_live_pipelined_read_out(hip_lib):
+    """HIPLive({pipelined: true}): a tick hands out the pictures of the tick BEFORE it -- their planes went to the host beside this
+    tick's pass (jsmpeg_hip_live_read_frames_begin / _end, two pinned arrays in turn) -- and drain() the last ones: the same
+    pictures in the same order as the plain form, one tick later"""
+    build.build_addon()
+    paths, want, _ = _ts_files(4, 14, 352, 288)
+    try:
+        out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "hip_live_ts.js"), "352", "288", "--pipelined", "--late", "3",
+                                                  "--packets", "24"] + paths, timeout=300))
+    finally:
+        for p in paths:
+            os.unlink(p)
+    assert out["pipelined"] is True and out["pictures"] == 4 * 14 == out["hashesSeen"]
+    for s in range(4):
+        st = out["streams"][s]
+        assert st["planes"] == want[s], s
+        assert st["sizes"] == [[352, 288]] and st["callbacks"] == 14 and len(st["pts"]) == 14
+        assert abs(out["decodedTimes"][s] - 14 / 30) < 1e-5
+
+
+@pytest.mark.gpu
 def test_node_live_rgba_frames(hip_lib):
     """tick({rgba: true}): frames as Canvas2D-identical RGBA, converted on the device"""
     import numpy as np

@@ -139,10 +139,13 @@ def run(streams=64, pictures=36, config="cfg2_1080p", per_tick=1, check=True, ab
         if "ms_per_tick_p_pictures" in out["via_napi"]:
             say("  the same from Node (JSMpeg.HIPLive over the N-API addon): %.3f ms per tick of P pictures, %.0f pictures/s"
                 % (out["via_napi"]["ms_per_tick_p_pictures"], out["via_napi"]["pictures_per_s"]))
-            for key, what in (("writes_beside_the_tick_in_flight", "writes beside the tick (tickBegin / tickEnd)"), ("with_planes_to_host", "every picture's planes to the host as well (onFrame)")):
+            for key, what in (("writes_beside_the_tick_in_flight", "writes beside the tick (tickBegin / tickEnd)"), ("with_planes_to_host", "every picture's planes to the host as well (onFrame)"),
+                              ("with_planes_to_host_pipelined", "... the planes of tick k travelling beside the pass of tick k + 1 ({pipelined: true})")):
                 r = out["via_napi"].get(key)
                 if r:
                     say("      %s: %.3f ms per tick of P pictures, %.0f pictures/s" % (what, r["ms_per_tick_p_pictures"], r["pictures_per_s"]))
+                    if r.get("wall"):
+                        say("          by the loop's wall clock, nothing between the ticks: %.3f ms per tick, %.0f pictures/s" % (r["wall"]["ms_per_tick"], r["wall"]["pictures_per_s"]))
     return out
 
 
