@@ -124,9 +124,11 @@ function install(JSMpeg, options) {
   // the frames of a read-out that has finished: views into the array they arrived in
   HIPLive.prototype.handOut = function (p, opts) {
     const planes = this.lumaBytes + 2 * this.chromaBytes, out = p.buffer.bytes;
+    let handed = 0;
     p.records.forEach((r, i) => {
       const s = r.stream;
       if (!s || !s.live) return;                                   // closed meanwhile
+      handed++;
       const at = i * planes;
       const frame = { stream: s, index: s.pictures, pts: r.pts, type: r.type, streamOffset: r.streamOffset, width: this.width, height: this.height,
                       codedWidth: this.codedWidth, codedHeight: this.codedHeight,
@@ -139,7 +141,7 @@ function install(JSMpeg, options) {
       if (s.onDecodeCallback) s.onDecodeCallback(s, p.elapsed / p.records.length);
       if (opts.onFrame) opts.onFrame(frame);
     });
-    return p.records.length;
+    return handed;
   };
   // when the ticks stop: the pictures of the read-out still in flight
   HIPLive.prototype.drain = function (opts) {

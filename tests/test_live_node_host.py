@@ -70,6 +70,17 @@ def test_live_router_logic_over_an_injected_binding():
                           ["frame", "c", 32, 16, 5], ["render a"], ["frame", "a", 32, 16, 3], ["frame", "b", 48, 32, 4], ["tick", 3]]
 
 
+def test_live_pipelined_class_logic_over_an_injected_binding():
+    """HIPLive({pipelined: true}): a tick ends the read-out of the tick before, starts its own pictures on their way into the OTHER
+    pinned array, then hands out the tick before's frames; a tick without pictures still hands out the one before; a stream closed
+    meanwhile gets nothing; drain() the last ones; both arrays unpinned at destroy; the plain liveReadFrames is never called"""
+    out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js", "live_pipelined_fake.js")]))
+    assert out["calls"] == [["liveTick"], ["pin", 0], ["begin", 0, 2, 0, 768], ["liveTick"], ["end"], ["pin", 1], ["begin", 0, 1, 1, 768], ["liveClose", 1],
+                            ["liveTick"], ["end"], ["liveTick"], ["begin", 0, 1, 0, 768], ["end"], ["unpin"], ["unpin"], ["liveDestroy"]]
+    assert out["log"] == [["tick", 0], ["frame", 0, 0, 1, 0, 512, 128], ["frame", 1, 0, 1.5, 1, 512, 128], ["tick", 2], ["frame", 0, 1, 2, 10, 512, 128], ["tick", 1],
+                          ["tick", 0], ["drain", 0, 0], ["state", 2, 0.08]]
+
+
 def test_live_router_spreads_streams_over_devices():
     """JSMpeg.HIPLiveRouter({devices: [...]}): streams shard by stream over the GPUs of a node with no exchange -- a handle per
     (size, device) made on demand, a new stream joins the device that holds the fewest, a full device is passed over, and a tick puts
