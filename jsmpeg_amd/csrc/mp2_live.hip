@@ -159,6 +159,9 @@ extern "C" int jsmpeg_hip_mp2_live_open(jsmpeg_hip_mp2_live_t *a) {
 		Mp2LiveStream &S = a->streams[s];
 		if (S.open) continue;
 		S.open = true; S.store.clear(); S.stamps.clear(); S.written = S.consumed = 0; S.n_abs = 0; S.clear_ring = true;
+		/* (diagnostics: JSMPEG_HIP_MP2_LIVE_N_ABS=<sub-blocks, a multiple of 16> starts a stream's count there -- the same samples, and
+		 * the step that keeps the count below 2^31 comes after minutes instead of after 200 hours of sound: tests) */
+		if (const char *v = getenv("JSMPEG_HIP_MP2_LIVE_N_ABS")) S.n_abs = (uint32_t)strtoul(v, nullptr, 0) & ~15u;
 		S.sample_rate = 44100;                                             /* mp2.c:234 */
 		S.frames = S.evictions = 0;
 		delete S.ts; S.ts = nullptr;

@@ -68,7 +68,7 @@ class SimLive:
     """The host side of jsmpeg_hip_mp2_live_* restated in a few lines (stores, cursors, sub-block counts) around the
     simulator's sim_mp2_live_tick -- the kernels' LIVE placement (per-stream rings, frame places) on the CPU.  TEST ONLY."""
 
-    def __init__(self, n_streams, cap):
+    def __init__(self, n_streams, cap, n_abs0=0):
         self.lib = sim_lib()
         self.lib.sim_mp2_live_tick.restype = None
         self.n, self.cap = n_streams, cap
@@ -76,7 +76,7 @@ class SimLive:
         while self.ring < 15 + 36 * cap:
             self.ring *= 2
         self.rings = np.zeros((n_streams, self.ring, 64), np.float32)
-        self.n_abs = np.zeros(n_streams, np.uint32)
+        self.n_abs = np.full(n_streams, n_abs0, np.uint32)
         self.store = [bytearray() for _ in range(n_streams)]
 
     def write(self, s, data):
@@ -101,4 +101,6 @@ class SimLive:
             at += int(count[s])
             del self.store[s][:int(used[s])]
             self.n_abs[s] += 36 * count[s]
+            if self.n_abs[s] >= (1 << 30) + (1 << 29):            # mp2_live.hip: the count stays below 2^31 by steps every ring size divides
+                self.n_abs[s] -= 1 << 29
         return out

@@ -256,6 +256,22 @@ def test_ts_in_audio_beside_the_live_video(hip_lib, libs):
             assert pics[s] == [hashing.frame_hash(*f) for f in frames]
 
 
+def test_the_sub_block_count_near_its_ceiling(hip_lib, monkeypatch):
+    """A stream that has been playing for 200 hours (JSMPEG_HIP_MP2_LIVE_N_ABS starts its count just below the step that keeps it
+    under 2^31): the samples across the step are the golden ones"""
+    fx, data, offs = load_case(FIXTURES[FIXTURE_IDS.index("varying_44k")])
+    monkeypatch.setenv("JSMPEG_HIP_MP2_LIVE_N_ABS", str((1 << 30) + (1 << 29) - 36 * 4 - 16))
+    b = _bounds(data, offs)
+    got = []
+    with mp2.Mp2Live(1, max_frames_per_tick=2) as live:
+        s = live.open()
+        for k in range(fx["n_frames"]):
+            live.write(s, 0.0, data[b[k]:b[k + 1]])
+            assert live.tick() == 1
+            got.append(live.read_pcm()[0])
+    assert frame_md5(got) == fx["frame_md5"]
+
+
 def test_live_audio_fuzz_short_run(hip_lib, libs):
     """tools/fuzz_live_audio.py: random generator parameters / feeding (whole frames with small stores that evict and noise that
     stalls, arbitrary byte pieces, TS in pieces), streams joining and leaving on reused ids -- a short run of the sweep whose long

@@ -62,3 +62,22 @@ def test_a_stream_that_stops_at_a_header_the_reference_refuses(libs):
     assert same_bits(pcm, want[:3])
     (pcm,) = live.tick()
     assert len(pcm) == 0 and len(live.store[0]) == len(bad) - int(offs[3])
+
+
+def test_the_sub_block_count_near_its_ceiling():
+    """A stream that has been playing for 200 hours: the count of sub-blocks synthesised is kept below 2^31 by steps of 2^29 (a
+    multiple of 16 and of every ring size: the same ring slots, the same phase of the reference's v_pos) -- the samples across
+    the step are the golden ones."""
+    fx, data, offs = load_case(FIXTURES[FIXTURE_IDS.index("varying_44k")])
+    start = (1 << 30) + (1 << 29) - 36 * 4 - 16          # (a multiple of 16; the step falls behind the stream's fourth or fifth frame)
+    assert start % 16 == 0
+    live = SimLive(1, 2, n_abs0=start)
+    bounds = list(offs) + [len(data)]
+    got, stepped = [], False
+    for k in range(fx["n_frames"]):
+        before = int(live.n_abs[0])
+        live.write(0, data[int(bounds[k]):int(bounds[k + 1])])
+        (pcm,) = live.tick()
+        stepped = stepped or int(live.n_abs[0]) < before
+        got.append(pcm[0])
+    assert stepped and frame_md5(got) == fx["frame_md5"]
