@@ -17,3 +17,12 @@ def test_device_functions_under_asan_and_ubsan():
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ", 0 stopped by a sanitizer or with the wrong picture count" in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not installed")
+def test_mp2_device_functions_under_asan_and_ubsan():
+    """the MP2 kernels' device functions the same way (tools/sanitize_sim_mp2.py; long run: profiles/r06_sanitize_sim_mp2.txt): every
+    fixture through one batch pass and through live ticks with 1 / 2 / 5 frame places (the same samples from all four), and damaged copies"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize_sim_mp2.py"), "--damaged", "8", "--seed", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ", 0 stopped by a sanitizer or with the wrong frame count" in r.stdout
