@@ -280,7 +280,7 @@ static bool live_may_begin_header(const uint8_t *p, uint32_t n) {
 
 /* buffer.js:37-56: decoded bytes never stand in the way of a write (a tick drops them), so a write that does not fit finds
  * the store full of UNDECODED bytes: the reference's emergency evacuation -- they go, the write starts an empty store.
- * (A sequence header they held is not lost with them: live_header_at_write.) */
+ * (A sequence header they held is not lost with them: it was taken when the write that completed it arrived, live_account_write.) */
 static inline void live_make_room(jsmpeg_hip_live_t *l, uint32_t stream, uint32_t n) {
 	LiveStream &S = l->streams[stream];
 	if ((uint64_t)S.tail_bytes + S.new_bytes + n <= l->cfg.store_bytes) return;
@@ -295,10 +295,33 @@ static inline void live_make_room(jsmpeg_hip_live_t *l, uint32_t stream, uint32_
 static void live_account_write(jsmpeg_hip_live_t *l, uint32_t stream, double pts, uint32_t off, uint32_t n) {
 	LiveStream &S = l->streams[stream];
 	uint32_t skip = 0;
-	/* (only into an EMPTY store: undecoded bytes in front of this write may end with the beginning of a header that a write cut
-	 * short -- a tick that takes only what is complete is holding it, or will -- and then the header in THIS write is not the
-	 * stream's first; the tick's index kernel sorts that out) */
-	if (!S.has_header && S.tail_bytes + S.new_bytes == 0 && (skip = live_header_at_write(l, S, l->h_stage + off, n)) != 0) {
+	/* A header-less stream that HOLDS bytes no tick has seen yet (bytes in which a header may begin: noise that ends in a zero, a
+	 * header a write cut short): what the next tick's index kernel would find in the held bytes + this write is found now, by the
+	 * same function over the same bytes -- the reference finds its header inside write() (mpeg1.c:812-819), so a header that is
+	 * complete with this write must survive an evacuation that comes before any tick (tools/fuzz_live.py, seed 43 case 377: noise
+	 * ending in a zero, the header's write, a write that does not fit -- the header went with the evacuated bytes and the stream
+	 * never decoded anything), and the bytes up to its end must stop counting against the store.  (Bytes a tick has left on the
+	 * device -- tail_bytes -- are not looked at: the tick's index kernel sorts those out.) */
+	uint32_t held = 0;
+	if (!S.has_header && S.tail_bytes == 0 && S.new_bytes != 0) {
+		std::vector<uint8_t> cat;
+		cat.reserve((size_t)S.new_bytes + n);
+		for (const LiveSeg &g : l->segs) if (g.stream == stream && g.bytes) cat.insert(cat.end(), l->h_stage + g.stage_off, l->h_stage + g.stage_off + g.bytes);
+		if (cat.size() == S.new_bytes) {
+			held = S.new_bytes;
+			cat.insert(cat.end(), l->h_stage + off, l->h_stage + off + n);
+			const uint32_t end = live_header_at_write(l, S, cat.data(), (uint32_t)cat.size());
+			if (end > held) {                             /* (a header complete inside the held bytes would have been found by the write that completed it) */
+				skip = end - held;
+				S.tail_bytes = 0; S.new_bytes = 0;
+				live_drop_staged(l, stream);
+			} else if (end) {
+				S.has_header = false; S.status = 0;       /* (cannot happen; left to the tick) */
+			}
+		}
+	}
+	/* (into an EMPTY store the write alone is looked at) */
+	if (skip != 0 || (!S.has_header && S.tail_bytes + S.new_bytes == 0 && (skip = live_header_at_write(l, S, l->h_stage + off, n)) != 0)) {
 		/* the stream's first sequence header: everything in front of it and the header itself are behind the reference's cursor
 		 * now (mpeg1.c:812-819) -- what was pending goes (without a header the reference's cursor was at the end of its data
 		 * after every write), this write's bytes count from the header's end */

@@ -559,3 +559,41 @@ def test_read_out_beside_the_next_ticks(hip_lib, libs):
         for a in saved:
             check(*a)
         assert seen == [n_pic] * n_streams and held >= 2 and deep >= 2
+
+
+@pytest.mark.parametrize("noise_tail", [b"\x00", b"\x00\x00", b"\x00\x00\x01"], ids=["00", "0000", "000001"])
+def test_a_header_behind_held_bytes_survives_an_evacuation_before_any_tick(noise_tail, hip_lib, libs):
+    """Noise that ENDS with what could begin a start code is held (a header may begin in it); the next write brings the sequence
+    header and the first picture; a third write does not fit and evacuates the store -- all before any tick.  The reference found
+    its header inside the second write() (mpeg1.c:812-819), so the stream goes on decoding what is written afterwards
+    (tools/fuzz_live.py seed 43 case 377: the header went with the evacuated bytes, the stream never decoded anything).
+    (Noise that ends with a sequence header's start code and a few bytes is outside this: the reference parses whatever its store
+    holds behind the written bytes as the header's fields.)"""
+    es, offs = synth.generate_config("cfg1_720p", n_frames=5, width=176, height=144, stream=77)
+    ws = picture_writes(es, [int(o) for o in offs])
+    noise = np.frombuffer(bytes(range(7, 250)) + noise_tail, np.uint8)
+    store = len(noise) + len(ws[0]) + len(ws[1]) // 2          # the second picture does not fit beside the first
+    writes = [noise, ws[0], ws[1], ws[2], ws[3], ws[4]]
+    want = []
+    with cabi.Mpeg1Decoder(libs["oracle"], store, cabi.MODE_EVICT) as dec:
+        for w in writes[:3]:
+            dec.write(w)
+        while dec.decode():
+            want.append(md5_planes(dec.planes()))
+        for w in writes[3:]:
+            dec.write(w)
+            while dec.decode():
+                want.append(md5_planes(dec.planes()))
+    got = []
+    with jl.Live(176, 144, 1, pictures_per_tick=4, store_bytes=store) as lv:
+        s = lv.open()
+        for w in writes[:3]:
+            lv.write(s, w)
+        lv.tick(flush=True)
+        drain(lv, got)
+        assert lv.stream_info(s).has_sequence_header and lv.stream_info(s).evictions >= 1
+        for w in writes[3:]:
+            lv.write(s, w)
+            lv.tick(flush=True)
+            drain(lv, got)
+    assert len(want) >= 3 and got == want
