@@ -257,7 +257,32 @@ __global__ __launch_bounds__(JM_WG) void k_place(const uint8_t *src, uint8_t *ds
 		a += n16 << 4;
 		if (a + threadIdx.x < c1) pd[a + threadIdx.x] = ps[a + threadIdx.x];
 	} else {
-		for (uint32_t i = c0 + threadIdx.x; i < c1; i += JM_WG) pd[i] = ps[i];
+		/* Source and destination differ modulo 16 (packed streams of any lengths laid out at 16-byte boundaries: 15 of 16
+		 * streams of jsmpeg_hip_batch_upload_device): 16-byte stores all the same -- a destination piece is put together from the
+		 * two ALIGNED 16-byte source pieces it lies in (r = 1 .. 15 bytes into the first; both pieces hold at least one byte of
+		 * the stream, so neither read leaves the pages the stream is in).  Byte by byte this branch moved cfg2's 495 MB in
+		 * ~2 ms; so it is a copy's time. */
+		uint32_t a = c0;
+		const uint32_t mis = (uint32_t)((16u - ((uintptr_t)(pd + c0) & 15u)) & 15u);
+		const uint32_t head = min(mis, c1 - c0);
+		if (threadIdx.x < head) pd[c0 + threadIdx.x] = ps[c0 + threadIdx.x];
+		a += head;
+		const uint32_t n16 = (c1 - a) >> 4;
+		const uint32_t r = (uint32_t)((uintptr_t)(ps + a) & 15u), sh = r & 3u;
+		const uint4 *base = reinterpret_cast<const uint4 *>(ps + a - r);
+		for (uint32_t i = threadIdx.x; i < n16; i += JM_WG) {
+			const uint4 A = base[i], B = base[i + 1];
+			uint4 o;
+			switch (r >> 2) {      /* (uniform over the workgroup) */
+			case 0: o = make_uint4(jm_alignbyte(A.y, A.x, sh), jm_alignbyte(A.z, A.y, sh), jm_alignbyte(A.w, A.z, sh), jm_alignbyte(B.x, A.w, sh)); break;
+			case 1: o = make_uint4(jm_alignbyte(A.z, A.y, sh), jm_alignbyte(A.w, A.z, sh), jm_alignbyte(B.x, A.w, sh), jm_alignbyte(B.y, B.x, sh)); break;
+			case 2: o = make_uint4(jm_alignbyte(A.w, A.z, sh), jm_alignbyte(B.x, A.w, sh), jm_alignbyte(B.y, B.x, sh), jm_alignbyte(B.z, B.y, sh)); break;
+			default: o = make_uint4(jm_alignbyte(B.x, A.w, sh), jm_alignbyte(B.y, B.x, sh), jm_alignbyte(B.z, B.y, sh), jm_alignbyte(B.w, B.z, sh)); break;
+			}
+			reinterpret_cast<uint4 *>(pd + a)[i] = o;
+		}
+		a += n16 << 4;
+		if (a + threadIdx.x < c1) pd[a + threadIdx.x] = ps[a + threadIdx.x];
 	}
 }
 

@@ -348,3 +348,36 @@ def test_history_resolution_one_rank_per_thread(case, hip_lib):
     for s in range(len(streams)):
         assert per[s] == fx["frame_md5"], (case, s)
     assert max(results[0][1], results[1][1]) >= 1
+
+
+def test_upload_device_places_streams_from_any_residue(hip_lib):
+    """jsmpeg_hip_batch_upload_device lays packed streams out at 16-byte boundaries: k_place's two forms (source and
+    destination congruent modulo 16 / not: 16-byte stores from two aligned source pieces) over every source residue,
+    lengths around the 16-byte and 64 KiB chunk edges, a source that ends at the very end of its allocation and one that
+    begins 1 .. 15 bytes into it; read_es must return exactly the bytes (batches are not decoded: the bytes are noise)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(20260930)
+    lens = [0, 1, 2, 15, 16, 17, 31, 33, 255, 4097, 65535, 65536, 65537, 65536 + 15, 2 * 65536 + 1, 200003]
+    for shift in (0, 1, 7, 15):
+        for rot in range(0, 16, 3):
+            order = [lens[(i * 7 + rot) % len(lens)] for i in range(len(lens))] + [int(rng.integers(1, 70000)) for _ in range(16 - rot % 5)]
+            gaps = [int(rng.integers(0, 3)) * int(rng.integers(0, 20)) for _ in order]
+            begin, end, off = [], [], 0
+            for n, g in zip(order, gaps):
+                off += g
+                begin.append(off)
+                off += n
+                end.append(off)
+            total = off
+            src = rng.integers(0, 256, total, dtype=np.uint8)
+            # the packed buffer sits `shift` bytes into its allocation and ends with the allocation
+            d_all = torch.empty(shift + total, dtype=torch.uint8, device=dev)
+            d_all[shift:] = torch.from_numpy(src).to(dev)
+            torch.cuda.synchronize()
+            with jb.Batch(176, 144, len(order), 64, total + 64 * len(order) + 4096) as b:
+                b.upload_device(ctypes.c_void_p(d_all.data_ptr() + shift), total, np.asarray(begin, np.uint32), np.asarray(end, np.uint32))
+                for s, (b0, e0) in enumerate(zip(begin, end)):
+                    got = np.frombuffer(b.read_es(s), np.uint8) if e0 > b0 else np.zeros(0, np.uint8)
+                    assert got.size == e0 - b0, (shift, rot, s)
+                    assert np.array_equal(got, src[b0:e0]), (shift, rot, s, e0 - b0, b0 & 15)
