@@ -245,8 +245,14 @@ void oracle_predict_block(const uint8_t *src, int stride, int x, int y, int size
 		}
 }
 
+/* checker-side statistic (not part of the reference's ABI): macroblocks predicted from the forward frame since the process
+ * started -- what SURVEY.md 8d's "384 bytes read per predicted macroblock" counts (tools/enc_content_bench.py) */
+static unsigned long long oracle_n_predicted;
+unsigned long long oracle_debug_predicted_macroblocks(void) { return oracle_n_predicted; }
+
 static void copy_macroblock(mpeg1_decoder_t *d, int mvh, int mvv) {
 	uint8_t tmp[256];
+	oracle_n_predicted++;
 	int cw = d->coded_width, hw = cw >> 1;
 	oracle_predict_block(d->forward.y, cw, d->mb_col << 4, d->mb_row << 4, 16, mvh, mvv, tmp);
 	for (int r = 0; r < 16; r++) memcpy(d->current.y + ((d->mb_row << 4) + r) * cw + (d->mb_col << 4), tmp + r * 16, 16);

@@ -43,6 +43,7 @@ void *mpeg1_decoder_get_cb_ptr(mpeg1_decoder_t *self);
 bool mpeg1_decoder_decode(mpeg1_decoder_t *self);
 
 /* Unit-level entry points for kernel tests (not part of the reference ABI). */
+unsigned long long oracle_debug_predicted_macroblocks(void);   /* checker-side statistic: calls of copy_macroblock so far */
 void oracle_idct(int32_t block[64]);                       /* mpeg1.c:1673-1740 */
 int32_t oracle_dequant(int level, int intra, int qscale, int quant, int premult); /* mpeg1.c:1535-1551 */
 void oracle_predict_block(const uint8_t *src, int stride, int x, int y, int size,

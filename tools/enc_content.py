@@ -1,0 +1,35 @@
+"""CPU (minutes): 1080p GOPs from the test-side ENCODER (tests/enc/mpeg1_enc.py: procedural moving pictures, block motion
+search + half-pel refinement, DCT, quantisation, skipped / not-coded macroblocks) for tools/enc_content_bench.py -- coded
+VIDEO statistics (coherent vector fields, zero vectors, skipped runs, sparse high frequencies) at the headline's picture
+size, beside the generator's uniform-random syntax.  Eight GOPs of 12 pictures with different motion, noise and quantiser,
+one process each -> tests/enc/_cache/enc1080_<k>.m1v (git-ignored: ~45 s of Python per picture; they travel to the GPU box
+with the tree like the built libraries).    python tools/enc_content.py [pictures per GOP]"""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "enc"))
+OUT = os.path.join(ROOT, "tests", "enc", "_cache")
+GOPS = (  # seed, pan (pixels per picture), noise (sigma), quantiser scale, f_code
+    (11, 1.5, 1.5, 8, 1), (12, 3.0, 2.5, 6, 2), (13, 0.0, 1.0, 8, 1), (14, 5.0, 3.0, 5, 2),
+    (15, 0.7, 2.0, 10, 1), (16, 7.0, 4.0, 4, 3), (17, 2.0, 0.5, 6, 1), (18, 4.0, 6.0, 3, 2))
+
+
+def one(k):
+    import mpeg1_enc as enc
+    seed, pan, noise, q, f = GOPS[k]
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    t0 = time.time()
+    es, offs = enc.encode(width=1920, height=1080, n_frames=n, gop=n, qscale=q, f_code=f, seed=seed, pan=pan, noise=noise)
+    es.tofile(os.path.join(OUT, "enc1080_%d.m1v" % k))
+    return "GOP %d (seed %d, pan %.1f, noise %.1f, qscale %d, f_code %d): %d pictures, %d bytes (first %d), %.0f s" % (
+        k, seed, pan, noise, q, f, n, len(es), int(offs[1]) if len(offs) > 1 else len(es), time.time() - t0)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    with mp.Pool(min(len(GOPS), os.cpu_count() or 1)) as pool:
+        for line in pool.imap_unordered(one, range(len(GOPS))):
+            print(line, flush=True)
