@@ -1445,6 +1445,22 @@ def main():
         except Exception as e:
             log("other configurations failed: %r" % (e,))
             line["other_configs"] = {"error": repr(e)[:300]}
+    # CODED VIDEO: the same shape (64 streams x 120 pictures of 1920x1080, the headline's bit rate) on content made by the
+    # test-side encoder (tests/golden/enc1080/: four GOPs with golden vectors, reference JS == wasm == C == oracle) -- coherent
+    # vector fields, skipped runs, intra pictures 10-30 x the predicted ones -- one batch at a time and two in flight; every
+    # picture gated against the oracle.  A reported extra, never `value`.
+    if world == 1 and not args.no_other_configs:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import enc_content_bench
+            torch.cuda.empty_cache()
+            cv = enc_content_bench.run(64, 10, 6, None, two=True, device=local_rank, two_fn=two_batches_in_flight)
+            line["coded_video_content"] = cv
+            log("coded video content: %.0f frames/s one batch at a time (parse %.2f ms, reconstruct %.2f ms), %.0f with two batches in flight"
+                % (cv["frames_per_s"], cv["gpu_phases_ms"]["parse_ms"], cv["gpu_phases_ms"]["recon_ms"], (cv.get("two_batches_in_flight") or {}).get("value", 0.0)))
+        except Exception as e:
+            log("coded video content figure failed: %r" % (e,))
+            line["coded_video_content"] = {"error": repr(e)[:300]}
     # LIVE streams (include/jsmpeg_hip.h part 5): the same 64 x 1080p content arriving a picture per stream per tick -- a write()
     # per stream, ONE jsmpeg_hip_live_tick for all of them -- beside the one-picture ABI driven the same way; every picture of
     # every tick gated against the oracle.  A reported extra, never `value`.

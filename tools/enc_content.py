@@ -2,8 +2,10 @@
 search + half-pel refinement, DCT, quantisation, skipped / not-coded macroblocks) for tools/enc_content_bench.py -- coded
 VIDEO statistics (coherent vector fields, zero vectors, skipped runs, sparse high frequencies) at the headline's picture
 size, beside the generator's uniform-random syntax.  Eight GOPs of 12 pictures with different motion, noise and quantiser,
-one process each -> tests/enc/_cache/enc1080_<k>.m1v (git-ignored: ~45 s of Python per picture; they travel to the GPU box
-with the tree like the built libraries).    python tools/enc_content.py [pictures per GOP]"""
+one process each -> tests/enc/_cache/enc1080_<k>.m1v (git-ignored: 15-50 s of Python per picture; they travel to the GPU box
+with the tree like the built libraries).  GOPs 0, 2, 4 and 6 (quantiser 6-10, the short search range: ~16 Mbit/s per stream, the
+headline's bit rate) are COMMITTED as tests/golden/enc1080/ with golden vectors (tests/golden/make_golden_enc1080.py: reference
+JS == wasm == C == oracle): bench.py's `coded_video_content` and tests/test_enc1080_golden.py read those.    python tools/enc_content.py [pictures per GOP]"""
 import multiprocessing as mp
 import os
 import sys
