@@ -487,10 +487,11 @@ class RehearsalPlane:
         pass
 
 
-def via_napi(streams, want_hashes, width, height, frames, steps, warmup, device):
+def via_napi(streams, want_hashes, width, height, frames, steps, warmup, device, two=8):
     """The same batch driven from the host north_star names -- Node.js over the N-API addon (tools/bench_node.js,
     JSMpeg.HIPBatch): inputs uploaded once, `warmup` untimed and `steps` timed decode() calls, every picture's device hash
-    against what the oracle said (want_hashes: {stream: [int]}).  A reported extra, never `value`."""
+    against what the oracle said (want_hashes: {stream: [int]}); then (`two` passes each, 0: not) TWO HIPBatch objects in flight,
+    a chain of decodeAsync() each (`two_batches_in_flight` inside the result).  A reported extra, never `value`."""
     import tempfile
     addon = os.path.join(ROOT, "jsmpeg_amd", "js", "jsmpeg_hip.node")
     if not os.path.exists(addon):
@@ -502,7 +503,7 @@ def via_napi(streams, want_hashes, width, height, frames, steps, warmup, device)
         json.dump({str(k): ["%016x" % h for h in v] for k, v in want_hashes.items()}, open(hp, "w"))
         cmd = ["node", os.path.join(ROOT, "tools", "bench_node.js"), "--dir", td, "--streams", str(len(streams)), "--width", str(width),
                "--height", str(height), "--frames", str(frames), "--steps", str(steps), "--warmup", str(warmup), "--hashes", hp,
-               "--device", str(device)]
+               "--device", str(device)] + (["--two", str(two)] if two else [])
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
         if not lines:
@@ -1454,7 +1455,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import enc_content_bench
             torch.cuda.empty_cache()
-            cv = enc_content_bench.run(64, 10, 6, None, two=True, device=local_rank, two_fn=two_batches_in_flight)
+            cv = enc_content_bench.run(64, 10, 6, None, two=True, device=local_rank, two_fn=two_batches_in_flight, napi_fn=None if args.no_napi else via_napi)
             line["coded_video_content"] = cv
             log("coded video content: %.0f frames/s one batch at a time (parse %.2f ms, reconstruct %.2f ms), %.0f with two batches in flight"
                 % (cv["frames_per_s"], cv["gpu_phases_ms"]["parse_ms"], cv["gpu_phases_ms"]["recon_ms"], (cv.get("two_batches_in_flight") or {}).get("value", 0.0)))

@@ -29,6 +29,7 @@
  *   batchUpload(handle, [Uint8Array ES, ...])                       jsmpeg_hip_batch_upload
  *   batchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xE0)    jsmpeg_hip_batch_upload_ts (device demux, ts.js semantics)
  *   batchDecode(handle) -> pictures                                  jsmpeg_hip_batch_decode + _sync
+ *   batchDecodeAsync(handle) -> Promise<pictures>                    the same on a thread of libuv's pool (two batches in flight)
  *   batchPictureInfo(handle, p) -> {stream, esOffset, type, decoded, level, forward}
  *   batchTsWrites(handle, stream) -> [{pts, offset, length}, ...]   jsmpeg_hip_batch_ts_writes
  *   batchReadPlanes(handle, p, y, cr, cb)   (Uint8Arrays of coded size) jsmpeg_hip_batch_read_frame
@@ -454,6 +455,63 @@ static napi_value fn_batch_decode(napi_env env, napi_callback_info info) {
 	if (n < 0 || jsmpeg_hip_batch_sync(b) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
 	NAPI_OK(napi_create_int32(env, n, &out));
 	return out;
+}
+
+/* batchDecodeAsync(handle) -> Promise<pictures>: the same decode + sync on a thread of libuv's pool (napi_async_work), so that a
+ * Node host can keep TWO batches in flight -- one batch's start-code index, host turn-around and slice parse beside the other's
+ * reconstruct (on coded video, whose parse is as long as its intra slices' serial walk, that is worth
+ * half again: profiles/r06k_enc_content.md).  A batch object belongs to one thread at a time (include/jsmpeg_hip.h part 5): the
+ * JS class refuses any other call on a batch whose promise is pending.  The library's error text is per thread: copied in the job. */
+typedef struct {
+	napi_async_work work;
+	napi_deferred deferred;
+	jsmpeg_hip_batch_t *b;
+	int n;
+	char err[512];
+} DecodeJob;
+static void decode_job_execute(napi_env env, void *data) {
+	(void)env;
+	DecodeJob *j = (DecodeJob *)data;
+	j->n = jsmpeg_hip_batch_decode(j->b, NULL);
+	if (j->n >= 0 && jsmpeg_hip_batch_sync(j->b) < 0) j->n = -1;
+	if (j->n < 0) { strncpy(j->err, jsmpeg_hip_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+}
+static void decode_job_complete(napi_env env, napi_status status, void *data) {
+	DecodeJob *j = (DecodeJob *)data;
+	napi_value v, msg;
+	if (status == napi_ok && j->n >= 0) {
+		if (napi_create_int32(env, j->n, &v) == napi_ok) napi_resolve_deferred(env, j->deferred, v);
+	} else {
+		napi_create_string_utf8(env, j->n < 0 && j->err[0] ? j->err : "jsmpeg_hip: the decode job did not run", NAPI_AUTO_LENGTH, &msg);
+		napi_create_error(env, NULL, msg, &v);
+		napi_reject_deferred(env, j->deferred, v);
+	}
+	napi_delete_async_work(env, j->work);
+	free(j);
+}
+static napi_value fn_batch_decode_async(napi_env env, napi_callback_info info) {
+	size_t argc = 1;
+	napi_value argv[1], promise, name;
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	if (!b) return NULL;
+	DecodeJob *j = (DecodeJob *)calloc(1, sizeof(DecodeJob));
+	if (!j) { napi_throw_error(env, NULL, "jsmpeg_hip: out of memory"); return NULL; }
+	j->b = b;
+	if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+	    napi_create_string_utf8(env, "jsmpeg_hip.batchDecode", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+	    napi_create_async_work(env, NULL, name, decode_job_execute, decode_job_complete, j, &j->work) != napi_ok) {
+		free(j);
+		napi_throw_error(env, NULL, "jsmpeg_hip: could not create the decode job");
+		return NULL;
+	}
+	if (napi_queue_async_work(env, j->work) != napi_ok) {
+		napi_delete_async_work(env, j->work);
+		free(j);
+		napi_throw_error(env, NULL, "jsmpeg_hip: could not queue the decode job");
+		return NULL;
+	}
+	return promise;
 }
 
 static napi_value fn_batch_picture_info(napi_env env, napi_callback_info info) {
@@ -978,7 +1036,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "decode", fn_decode }, { "getPlanes", fn_get_planes }, { "renderRGBA", fn_render_rgba },
 		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error }, { "liveDecoders", fn_live_decoders },
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
-		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchPictureInfo", fn_batch_picture_info },
+		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchDecodeAsync", fn_batch_decode_async }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadFrames", fn_batch_read_frames }, { "batchReadRGBA", fn_batch_read_rgba },
 		{ "batchGeometry", fn_batch_geometry }, { "batchStreamInfo", fn_batch_stream_info }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },

@@ -56,6 +56,7 @@ function install(JSMpeg, options) {
     this.out = null; this.outPinned = false;
   };
   HIPBatch.prototype.destroy = function () {
+    this._idle('destroy');
     this.releaseOut();
     if (this.handle) { this.native.batchDestroy(this.handle); this.handle = null; }
     if (this.audio && this.audio.handle) { this.native.mp2BatchDestroy(this.audio.handle); this.audio.handle = null; }
@@ -110,25 +111,45 @@ function install(JSMpeg, options) {
 
   // MPEG-TS buffers -> device demux with ts.js semantics (resync after garbage, partial last packet left unread) -> decode.  Returns the picture count.
   HIPBatch.prototype.uploadTS = function (buffers, streamId) {
+    this._idle('uploadTS');
     this.native.batchUploadTS(this.handle, buffers, streamId || 0xE0);
     this.writes = buffers.map((_, s) => this.native.batchTsWrites(this.handle, s));
     return this;
   };
   // elementary streams, already demultiplexed
   HIPBatch.prototype.upload = function (buffers) {
+    this._idle('upload');
     this.native.batchUpload(this.handle, buffers);
     this.writes = null;
     return this;
   };
   HIPBatch.prototype.decode = function () {
+    this._idle('decode');
     this.pictures = this.native.batchDecode(this.handle);
     return this.pictures;
+  };
+  // The same decode on a thread of libuv's pool: a Promise of the picture count.  What it is for: TWO batches in flight --
+  //   await Promise.all([a.decodeAsync(), b.decodeAsync()])   (or two chains of them, each with its own uploads)
+  // -- one batch's start-code index, host turn-around and slice parse run beside the other's reconstruct.  On coded video, whose
+  // parse lasts as long as the intra slices' serial walk while most of the GPU is idle, that is worth half again (INTEGRATION.md
+  // section 5, profiles/r06k_enc_content.md).  Until the promise settles the batch belongs to that thread: every other call
+  // on it throws (a batch object is one thread's at a time, include/jsmpeg_hip.h part 5).
+  HIPBatch.prototype.decodeAsync = function () {
+    if (this.decoding) return Promise.reject(new Error('JSMpeg.HIPBatch: a decode of this batch is in flight'));
+    this.decoding = true;
+    return this.native.batchDecodeAsync(this.handle).then(
+      (n) => { this.decoding = false; this.pictures = n; return n; },
+      (e) => { this.decoding = false; throw e; });
+  };
+  HIPBatch.prototype._idle = function (what) {
+    if (this.decoding) throw new Error('JSMpeg.HIPBatch.' + what + ': a decodeAsync() of this batch is in flight');
   };
   HIPBatch.prototype.pictureInfo = function (p) { return this.native.batchPictureInfo(this.handle, p); };
   HIPBatch.prototype.timings = function () { return this.native.batchTimings(this.handle); };
   // the device-computed 64-bit content hash of every picture of the last decode (Y | Cr | Cb planes), as 16 hex digits
   // each, picture after picture: what a host compares instead of reading 3 MB of planes per picture back
   HIPBatch.prototype.frameHashes = function () {
+    this._idle('frameHashes');
     const raw = new Uint8Array(new ArrayBuffer(8 * Math.max(1, this.pictures)));
     this.native.batchFrameHashes(this.handle, raw);
     const out = new Array(this.pictures);
@@ -141,11 +162,13 @@ function install(JSMpeg, options) {
   };
 
   HIPBatch.prototype.readPlanes = function (p, target) {
+    this._idle('readPlanes');
     target = target || { y: new Uint8Array(this.lumaBytes), cr: new Uint8Array(this.chromaBytes), cb: new Uint8Array(this.chromaBytes) };
     this.native.batchReadPlanes(this.handle, p, target.y, target.cr, target.cb);
     return target;
   };
   HIPBatch.prototype.readRGBA = function (p, target) {
+    this._idle('readRGBA');
     const need = this.width * this.height * 4;
     target = target || new Uint8ClampedArray(need);
     if (target.length < need) throw new RangeError('HIPBatch.readRGBA: target smaller than width * height * 4');
@@ -157,6 +180,7 @@ function install(JSMpeg, options) {
   // Picture k of a stream carries the pts of the k-th PES the demuxer completed for it (one picture per PES is what
   // jsmpeg's sources and the reference's own muxing advice produce, README.md "Encoding Video").
   HIPBatch.prototype.forEachFrame = function (opts, cb) {
+    this._idle('forEachFrame');
     if (typeof opts === 'function') { cb = opts; opts = {}; }
     const perStream = new Map();
     for (let p = 0; p < this.pictures; p++) {

@@ -294,3 +294,69 @@ def test_node_router_mixed_geometries_and_the_decoders_clock(hip_lib):
     assert out["esFrames"] == 7 and out["esPlanes"] == want[0]
     assert out["esPts"] == [round(k / 25.0, 6) for k in range(7)]
     assert out["skippedLater"] == [0]
+
+
+def test_decode_async_class_logic_over_an_injected_binding():
+    """JSMpeg.HIPBatch.decodeAsync: the picture count arrives with the promise; while it is pending every other call on the batch
+    throws (a batch object is one thread's at a time) and a second decodeAsync is rejected; afterwards the batch is usable again;
+    a failed decode rejects and frees the batch too.  (The binding is injected: no addon, no GPU.)"""
+    script = r"""
+const { install } = require(%r);
+let resolveDecode, rejectDecode, destroyed = 0;
+const binding = {
+  batchCreate() { return {}; }, batchGeometry() { return { codedWidth: 16, codedHeight: 16, lumaBytes: 256, chromaBytes: 64 }; },
+  batchUpload() {}, batchDecode() { return 3; }, batchDestroy() { destroyed++; },
+  batchDecodeAsync() { return new Promise((res, rej) => { resolveDecode = res; rejectDecode = rej; }); },
+  batchFrameHashes() {}, hostUnregister() {},
+};
+const { HIPBatch } = install({}, { binding });
+const out = {};
+const threw = (f) => { try { f(); return false; } catch (e) { return /in flight/.test(e.message); } };
+(async () => {
+  const b = new HIPBatch({ width: 16, height: 16 });
+  b.upload([new Uint8Array(4)]);
+  const p = b.decodeAsync();
+  out.busy = b.decoding === true;
+  out.guards = [threw(() => b.decode()), threw(() => b.upload([])), threw(() => b.destroy()), threw(() => b.frameHashes()), threw(() => b.readPlanes(0))];
+  out.second = await b.decodeAsync().then(() => 'resolved', (e) => /in flight/.test(e.message) ? 'rejected' : 'other');
+  resolveDecode(7);
+  out.n = await p;
+  out.after = [b.decoding, b.pictures, b.decode()];
+  const q = b.decodeAsync();
+  rejectDecode(new Error('device lost'));
+  out.failed = await q.then(() => 'resolved', (e) => e.message);
+  out.freed = b.decoding === false;
+  b.destroy();
+  out.destroyed = destroyed;
+  console.log(JSON.stringify(out));
+})();
+""" % os.path.join(ROOT, "jsmpeg_amd", "js", "batch-hip.js")
+    out = json.loads(subprocess.check_output([NODE, "-e", script]))
+    assert out == {"busy": True, "guards": [True] * 5, "second": "rejected", "n": 7, "after": [False, 7, 3], "failed": "device lost",
+                   "freed": True, "destroyed": 1}
+
+
+@pytest.mark.gpu
+def test_two_batches_in_flight_from_node(hip_lib):
+    """tools/bench_node.js --two: two HIPBatch objects, a chain of decodeAsync() each (napi_async_work), side by side on one GPU; the
+    pictures of both frame pools against the oracle's hashes"""
+    from jsmpeg_amd import cabi, hashing
+    build.build_addon()
+    lib = build.build_oracle()
+    streams = [synth.generate_config("cfg1_720p", n_frames=12, width=352, height=288, stream=s, gop=6)[0] for s in range(6)]
+    want = {}
+    for s, es in enumerate(streams):
+        frames = cabi.decode_stream(lib, es, keep="planes")[0]
+        want[str(s)] = ["%016x" % hashing.frame_hash(*f) for f in frames]
+    with tempfile.TemporaryDirectory() as td:
+        for i, es in enumerate(streams):
+            es.tofile(os.path.join(td, "s%d.m1v" % i))
+        hp = os.path.join(td, "hashes.json")
+        json.dump(want, open(hp, "w"))
+        out = subprocess.check_output([NODE, os.path.join(ROOT, "tools", "bench_node.js"), "--dir", td, "--streams", "6", "--width", "352", "--height", "288",
+                                       "--frames", "12", "--steps", "3", "--warmup", "1", "--hashes", hp, "--two", "6"], timeout=300)
+    res = json.loads([ln for ln in out.decode().splitlines() if ln.startswith("{")][-1])
+    assert "error" not in res, res
+    two = res["two_batches_in_flight"]
+    assert "error" not in two, two
+    assert two["parity"].startswith("every picture of both frame pools") and two["passes_in_window"] >= 6 and two["value"] > 0

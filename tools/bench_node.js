@@ -3,7 +3,7 @@
 // bytes in, call decode, look at the pictures).  bench.py runs this after its own timed region and attaches the result as
 // `value_via_napi` (an extra key, never `value`):
 //   node tools/bench_node.js --dir <dir with s0.m1v ... s{n-1}.m1v> --streams n --width w --height h --frames f
-//                            --steps K --warmup W [--hashes expected.json] [--device d]
+//                            --steps K --warmup W [--hashes expected.json] [--device d] [--two P]
 // The compressed streams are uploaded ONCE (resident in HBM before the timed region, like bench.py's); W untimed decode()
 // calls, then K timed ones (each returns when the GPU is through: batchDecode = jsmpeg_hip_batch_decode + _sync); then the
 // device-computed plane hashes of every picture against expected.json ({"<stream>": ["<16 hex digits>", ...]}: what
@@ -83,7 +83,62 @@ try {
   }
 } catch (e) {
   out = { error: String(e && e.message || e) };
-} finally {
-  batch.destroy();
 }
-process.stdout.write(JSON.stringify(out) + '\n');
+
+// --two P: TWO batches in flight from Node -- a second HIPBatch with the same streams, each batch a chain of P decodeAsync()
+// calls (a thread of libuv's pool each), the second chain started half a pass behind the first; counted like bench.py's
+// two_batches_in_flight: the passes inside the window in which both chains are between their first and last pass; the
+// pictures of BOTH frame pools against the oracle's hashes when --hashes is given
+function hashesMatch(b, want) {
+  const got = b.frameHashes(), next = {};
+  let bad = 0;
+  for (let p = 0; p < b.pictures; p++) {
+    const info = b.pictureInfo(p);
+    if (!info.decoded) continue;
+    const k = next[info.stream] = (next[info.stream] || 0);
+    next[info.stream] = k + 1;
+    const w = want[String(info.stream)];
+    if (w && w[k] !== got[p]) bad++;
+  }
+  for (const s of Object.keys(want)) if ((next[s] || 0) !== want[s].length) bad++;
+  return bad;
+}
+async function twoInFlight(passes) {
+  const second = new HIPBatch({ width, height, maxStreams: n, maxPictures: n * frames + 8, maxBytes: bytes + 64 * n + 4096,
+                                device: opt.device === undefined ? -1 : parseInt(opt.device, 10) });
+  try {
+    second.upload(streams);
+    if (second.decode() !== n * frames) throw new Error('the second batch decoded ' + second.pictures + ' pictures');
+    const t1 = process.hrtime.bigint();
+    batch.decode();
+    const halfPassMs = Number(process.hrtime.bigint() - t1) / 2e6;
+    const ends = [[], []];
+    const chain = async (b, k, delayMs) => {
+      if (delayMs) await new Promise((r) => setTimeout(r, delayMs));
+      for (let i = 0; i < passes + 1; i++) { await b.decodeAsync(); ends[k].push(Number(process.hrtime.bigint()) / 1e9); }
+    };
+    await Promise.all([chain(batch, 0, 0), chain(second, 1, halfPassMs)]);
+    const lo = Math.max(ends[0][0], ends[1][0]), hi = Math.min(ends[0][passes], ends[1][passes]);
+    const doneAt = (e, t) => { let k = 0; for (let i = 0; i < e.length; i++) if (e[i] <= t) k = i; return k + (k + 1 < e.length ? (t - e[k]) / (e[k + 1] - e[k]) : 0); };
+    const inWindow = doneAt(ends[0], hi) - doneAt(ends[0], lo) + doneAt(ends[1], hi) - doneAt(ends[1], lo);
+    if (!(hi > lo) || inWindow < passes) throw new Error('the two chains did not run side by side');
+    const res = { value: n * frames * inWindow / (hi - lo), unit: 'frames/s', ms_per_pass: (hi - lo) / inWindow * 1e3, passes: 2 * passes, passes_in_window: inWindow,
+                  host: 'two JSMpeg.HIPBatch objects, a chain of decodeAsync() each (napi_async_work: a thread of libuv\'s pool per decode)' };
+    if (opt.hashes) {
+      const want = JSON.parse(fs.readFileSync(opt.hashes, 'utf8'));
+      const bad = hashesMatch(batch, want) + hashesMatch(second, want);
+      if (bad) throw new Error('PARITY FAILURE with two batches in flight: ' + bad + ' pictures differ from the oracle');
+      res.parity = 'every picture of both frame pools: device hash == oracle';
+    }
+    return res;
+  } finally {
+    second.destroy();
+  }
+}
+(async () => {
+  if (!out.error && opt.two) {
+    try { out.two_batches_in_flight = await twoInFlight(parseInt(opt.two, 10) || 8); } catch (e) { out.two_batches_in_flight = { error: String(e && e.message || e) }; }
+  }
+  try { batch.destroy(); } catch (e) { /* reported above */ }
+  process.stdout.write(JSON.stringify(out) + '\n');
+})();

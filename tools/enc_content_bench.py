@@ -5,12 +5,13 @@ pictures: stream s = the GOPs in the rotation that starts at GOP s % n (every GO
 sequence header, of which the decoder reads the first: mpeg1.c:814), so there are n distinct streams, and every one of them is
 held against the oracle picture by picture before a figure is printed.  The same streams lie at 64 different places of the
 batch: nothing is shared between them on the device.
-    python tools/enc_content_bench.py [streams] [GOPs per stream] [reps] [--out file.json] [--gops all | 0,2,4,6] [--two]
+    python tools/enc_content_bench.py [streams] [GOPs per stream] [reps] [--out file.json] [--gops all | 0,2,4,6] [--two] [--node]
 --gops: default = the four committed under tests/golden/enc1080/ (GOPs 0, 2, 4, 6 of tools/enc_content.py: quantiser 6-10, the
         short search range: ~16 Mbit/s per stream, the headline's bit rate; golden vectors beside them); `all`: also those of
         tests/enc/_cache/ (all eight: ~39 Mbit/s, intra pictures of 0.43-0.77 MB)
 --two:  also two batch objects decoded side by side (bench.py two_batches_in_flight: one's slice parse beside the other's
         reconstruct -- on this content the parse is as long as its longest slices' walk, and the other batch fills the GPU meanwhile)
+--node: also the same streams from Node (tools/bench_node.js --two: JSMpeg.HIPBatch, one batch at a time and two in flight by decodeAsync())
 bench.py attaches run() as `coded_video_content`."""
 import ctypes
 import glob
@@ -41,7 +42,7 @@ def gop_files(which=None):
     return {k: out[k] for k in keep}
 
 
-def run(n_streams=64, gops_per_stream=10, reps=8, which=None, two=False, device=-1, two_fn=None):
+def run(n_streams=64, gops_per_stream=10, reps=8, which=None, two=False, device=-1, two_fn=None, napi_fn=None):
     from jsmpeg_amd import batch as jb, build, cabi, hashing
     files = gop_files(which)
     gops, n_pics_gop, intra_bytes = [], [], []
@@ -138,6 +139,19 @@ def run(n_streams=64, gops_per_stream=10, reps=8, which=None, two=False, device=
     }
     if two_res is not None:
         res["two_batches_in_flight"] = two_res
+    if napi_fn is not None:       # the same streams from Node (bench.py via_napi: JSMpeg.HIPBatch over the N-API addon, one batch and two in flight)
+        try:
+            r = napi_fn(streams, {s: want_all[s] for s in range(n_streams)}, W, H, pics_per_stream[0], max(2, reps), 2, max(0, device))
+            for k in ("value", "ms_per_step"):
+                if isinstance(r.get(k), float):
+                    r[k] = round(r[k], 3)
+            t = r.get("two_batches_in_flight") or {}
+            for k in ("value", "ms_per_pass", "passes_in_window"):
+                if isinstance(t.get(k), float):
+                    t[k] = round(t[k], 3)
+            res["via_napi"] = r
+        except Exception as e:   # noqa: BLE001 (an extra of an extra)
+            res["via_napi"] = {"error": repr(e)[:300]}
     return res
 
 
@@ -149,11 +163,18 @@ if __name__ == "__main__":
     two = "--two" in argv
     if two:
         argv.remove("--two")
+    node = "--node" in argv
+    if node:
+        argv.remove("--node")
     for opt in ("--out", "--gops"):
         if opt in argv:
             i = argv.index(opt)
             del argv[i:i + 2]
-    res = run(int(argv[0]) if len(argv) > 0 else 64, int(argv[1]) if len(argv) > 1 else 10, int(argv[2]) if len(argv) > 2 else 8, which, two)
+    napi_fn = None
+    if node:
+        import bench  # noqa: E402  (via_napi only)
+        napi_fn = bench.via_napi
+    res = run(int(argv[0]) if len(argv) > 0 else 64, int(argv[1]) if len(argv) > 1 else 10, int(argv[2]) if len(argv) > 2 else 8, which, two, napi_fn=napi_fn)
     print(json.dumps(res))
     if out_path:
         with open(out_path, "w") as f:
