@@ -197,6 +197,10 @@ int64_t jsmpeg_hip_batch_read_es(jsmpeg_hip_batch_t *b, uint32_t stream, void *o
 int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream);
 /* Waits for the last decode; returns 0 or < 0. */
 int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b);
+/* A HIP stream of the batch's own (created on first use, destroyed with the batch) to pass as `hip_stream`, for hosts that link
+ * no HIP runtime to make one with (the N-API addon's decodeAsync): two batches in flight need a
+ * stream EACH -- on the null stream their passes run one behind the other.  Returns it, or NULL (jsmpeg_hip_last_error). */
+void *jsmpeg_hip_batch_own_stream(jsmpeg_hip_batch_t *b);
 
 uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b);
 int jsmpeg_hip_batch_picture_info(jsmpeg_hip_batch_t *b, uint32_t picture, jsmpeg_hip_picture_info_t *out);

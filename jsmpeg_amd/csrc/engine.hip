@@ -67,6 +67,7 @@ void batch_free(jsmpeg_hip_batch_t *b) {
 	if (b->ev_idx) hipEventDestroy(b->ev_idx);
 	for (auto &e : b->ev) if (e) hipEventDestroy(e);
 	for (auto &e : b->ev_level) if (e) hipEventDestroy(e);
+	if (b->own_stream) hipStreamDestroy(b->own_stream);
 	delete b;
 }
 
@@ -150,7 +151,7 @@ jsmpeg_hip_batch_t *batch_create(const jsmpeg_hip_batch_config_t *config, uint32
 	for (auto &e : b->ev_level) e = nullptr;
 	b->n_level_ev = 0;
 	b->epoch = 0; b->n_streams = 0; b->es_bytes = 0; b->n_sc = b->n_pics = b->n_levels = b->n_decoded = b->n_slices = b->n_slice_codes = 0;
-	b->timed = false; b->stream = nullptr;
+	b->timed = false; b->stream = nullptr; b->own_stream = nullptr;
 	b->pool_frames = pool_frames; b->mb_pictures = mb_pictures; b->live = nullptr;
 	b->pics_first_copy = mb_pictures ? std::min(std::max(1u, config->max_pictures), 4 * mb_pictures + 64) : std::max(1u, config->max_pictures);
 	if (config->device >= 0) {
@@ -191,6 +192,22 @@ static int batch_layout(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint64_
 	return 0;
 }
 
+/* A launch stream of the batch's own (made on first use, destroyed with the batch) for hosts that have no HIP runtime of their
+ * own to make one with -- the N-API addon: two batches in flight need a stream each, on the null stream their passes would run
+ * one behind the other. */
+extern "C" void *jsmpeg_hip_batch_own_stream(jsmpeg_hip_batch_t *b) {
+	g_err[0] = 0;
+	if (!b) { fail("null batch"); return nullptr; }
+	if (!b->own_stream) {
+		if (hipSetDevice(b->device) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
+			b->own_stream = nullptr;
+			fail("could not create a stream for the batch");
+			return nullptr;
+		}
+	}
+	return (void *)b->own_stream;
+}
+
 extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams, const uint8_t *const *es,
                                        const uint64_t *es_bytes) {
 	g_err[0] = 0;
@@ -199,7 +216,7 @@ extern "C" int jsmpeg_hip_batch_upload(jsmpeg_hip_batch_t *b, uint32_t n_streams
 	if (batch_layout(b, n_streams, es_bytes) != 0) return -1;
 	/* gaps (and everything else) 0xff: can never complete a 00 00 01 */
 	HIP_TRY(hipMemset(b->d_es, 0xff, (size_t)b->es_bytes + JM_ES_PAD));
-	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipStreamSynchronize(nullptr));      /* (the fill's stream, not the device: another batch's decode may be in flight on a stream of its own) */
 	for (uint32_t i = 0; i < n_streams; i++)
 		HIP_TRY(hipMemcpy(b->d_es + b->h_streams[i].es_begin, es[i], es_bytes[i], hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(b->d_streams, b->h_streams.data(), sizeof(JmStream) * n_streams, hipMemcpyHostToDevice));

@@ -75,6 +75,7 @@ struct jsmpeg_hip_batch_t {
 	JmGeom g;
 	JmVlcLuts *d_luts;
 	hipStream_t stream;          /* stream of the last decode */
+	hipStream_t own_stream;      /* made by jsmpeg_hip_batch_own_stream for hosts without a HIP runtime of their own; null until asked for */
 
 	uint8_t *d_es; uint64_t es_cap; uint32_t es_bytes;
 	const uint8_t *es_view;      /* what the decode reads: d_es, or the caller's buffer after jsmpeg_hip_batch_attach_device */

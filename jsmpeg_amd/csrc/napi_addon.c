@@ -472,7 +472,8 @@ typedef struct {
 static void decode_job_execute(napi_env env, void *data) {
 	(void)env;
 	DecodeJob *j = (DecodeJob *)data;
-	j->n = jsmpeg_hip_batch_decode(j->b, NULL);
+	void *st = jsmpeg_hip_batch_own_stream(j->b);       /* a stream per batch: on the null stream two batches' passes would not overlap */
+	j->n = st ? jsmpeg_hip_batch_decode(j->b, st) : -1;
 	if (j->n >= 0 && jsmpeg_hip_batch_sync(j->b) < 0) j->n = -1;
 	if (j->n < 0) { strncpy(j->err, jsmpeg_hip_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
 }

@@ -354,9 +354,9 @@ def test_two_batches_in_flight_from_node(hip_lib):
         hp = os.path.join(td, "hashes.json")
         json.dump(want, open(hp, "w"))
         out = subprocess.check_output([NODE, os.path.join(ROOT, "tools", "bench_node.js"), "--dir", td, "--streams", "6", "--width", "352", "--height", "288",
-                                       "--frames", "12", "--steps", "3", "--warmup", "1", "--hashes", hp, "--two", "6"], timeout=300)
+                                       "--frames", "12", "--steps", "3", "--warmup", "1", "--hashes", hp, "--two", "80"], timeout=300)   # (80 passes: the chains are long against the timer that staggers them)
     res = json.loads([ln for ln in out.decode().splitlines() if ln.startswith("{")][-1])
     assert "error" not in res, res
     two = res["two_batches_in_flight"]
     assert "error" not in two, two
-    assert two["parity"].startswith("every picture of both frame pools") and two["passes_in_window"] >= 6 and two["value"] > 0
+    assert two["parity"].startswith("every picture of both frame pools") and two["passes_in_window"] >= 80 and two["value"] > 0
