@@ -654,7 +654,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	 * decoded pictures, their slices, and how many slices are much longer than the mean (the
 	 * intra pictures' in an I + P batch: a picture's bytes / its slices against the batch's -- the slices come longest first,
 	 * jm_launch_parse gives that many fewer lanes per wavefront when the pass is of a size where it pays) */
-	uint64_t long_slices = 0;
+	uint64_t long_slices = 0, crit_bytes = 0, crit_pics = 0;
 	{
 		const uint64_t lanes = std::min(b->h_counters[4], b->sc_cap);
 		for (uint32_t p = 0; p < b->n_pics; p++) {
@@ -665,6 +665,7 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 			const uint32_t end = p + 1 < b->n_pics && b->h_pics[p + 1].stream == pic.stream ? b->h_pics[p + 1].pos : b->h_streams[pic.stream].es_end;
 			const uint64_t bytes = end > pic.pos ? end - pic.pos : 0;
 			if (bytes * 2 * lanes >= (uint64_t)3 * b->es_bytes * pic.n_slices) long_slices += pic.n_slices;   /* >= 1.5 x the mean slice */
+			if (bytes * lanes >= (uint64_t)4 * b->es_bytes * pic.n_slices) { crit_bytes += bytes; crit_pics++; }   /* >= 4 x: coded video's intra pictures */
 		}
 	}
 	if (b->live && live_assign_slots(b->live) < 0) return -1;      /* live streams: which pool slot each picture of this pass is written to */
@@ -688,6 +689,12 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 	{   /* compressed bytes per macroblock of the decoded pictures: what the parse's header-step threshold follows */
 		const uint64_t n_dec = b->n_decoded;
 		if (n_dec) pb.bytes_per_mb_x16 = (uint32_t)std::min<uint64_t>(1u << 20, (uint64_t)b->es_bytes * 16 / (n_dec * (uint64_t)std::max(1, b->g.mb_size)));
+		/* ... unless the pass has pictures whose slices are several times the mean (coded video: an intra picture is 10-30 x a
+		 * predicted one): the pass then lasts as long as THEIR slices' walk, and the figure that sets the threshold and the ring's
+		 * service form is theirs -- encoder-made 1080p at 16 Mbit/s (8 bytes per macroblock over all, 57 in the intra pictures):
+		 * parse 7.04 -> 6.60 ms with the dense settings (profiles/r06l_tcold_enc.txt); the generator's configurations have no such
+		 * pictures (intra ~2 x predicted) and keep theirs */
+		if (crit_pics) pb.bytes_per_mb_x16 = std::max(pb.bytes_per_mb_x16, (uint32_t)std::min<uint64_t>(1u << 20, crit_bytes * 16 / (crit_pics * (uint64_t)std::max(1, b->g.mb_size))));
 	}
 	if (!stream_order) {
 		pb.slice_sc = b->d_slice_order;             /* (ordered above, beside the host's turn-around) */
