@@ -28,7 +28,7 @@ def short(n):
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs --no-napi --no-h2d\n")
     f.write("# (durations in microseconds; 6 decode passes = 1 warm-up + 5 timed)\n")
     f.write("%-28s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in db(d_trace).execute("select * from top_kernels"):
