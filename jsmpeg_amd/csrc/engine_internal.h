@@ -55,8 +55,12 @@ static inline void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g,
  * two streams in lockstep: 0-1000 unfinished first looks in 1.5 M; one stream in lockstep, distance 1: 1.16 M, three times
  * the time; 4K, 816 tiles, one stream: 0.87 M).  Below the residency the per-level launches are the better form (small
  * pictures with few streams per class).
+ * Late in round 6 the distance aimed at went from 200 to 400: on CODED video (encoder-made 1080p, profiles/r06k_enc_content.md)
+ * a predicted picture's tiles are mostly copies and run up against a forward reference only 204 tiles ahead -- two 1080p streams
+ * in lockstep: 339 k waits, the launch 18.9 ms against 10.2 with three (0 waits; four, six, eight the same) -- and the generator's
+ * cfg2 is no slower with three (11.16 against 11.25 ms; 720p goes from four streams in lockstep to six: 5.01 against 5.06).
  * JSMPEG_HIP_RECON_ORDER: 0 = always level by level, n = n streams in lockstep whatever the picture size (tests). */
-#define JM_ORDER_DISTANCE 200u
+#define JM_ORDER_DISTANCE 400u
 #define JM_ORDER_MIN_DISTANCE 160u
 #define JM_ORDER_AUTO 0xffffffffu
 /* pictures the one-picture interface decodes per pass of the batch engine when that many are buffered (mpeg1_decoder_t::ahead) */

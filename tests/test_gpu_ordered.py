@@ -115,10 +115,10 @@ def test_batches_that_do_not_fill_eight_classes_go_level_by_level(hip_lib):
 
 
 def test_the_lockstep_width_follows_the_picture_size(hip_lib):
-    """by itself the engine walks as many streams in lockstep as put the last tile of a picture's forward reference ~200
-    workgroups behind the picture's first tile in its class's dispatch order, and launches level by level where the batch
-    cannot give that (small pictures, few streams per class): 1080p x 16 streams -> two in lockstep (200 tiles each), one
-    launch; 176x144 x 16 -> per level"""
+    """by itself the engine walks as many streams in lockstep as put the last tile of a picture's forward reference ~400
+    workgroups behind the picture's first tile in its class's dispatch order (as many as the class has, if fewer; at least 160
+    workgroups), and launches level by level where the batch cannot give that (small pictures, few streams per class): 1080p x 16
+    streams -> the class's two in lockstep (204 tiles each), one launch; 176x144 x 16 -> per level"""
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "frames_enc_static_1920x1080.json")))
     es, _ = synth.generate_config(fx["config"], n_frames=fx["n_frames"], **fx["overrides"])
     # (the fixture's intra picture is DENSE -- more than 19.4 bytes per macroblock: left to itself such a batch goes level by level
