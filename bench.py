@@ -243,6 +243,8 @@ def two_batches_in_flight(b, make_batch, give_streams, n_pictures, want, passes=
     import torch
     b2 = make_batch()
     try:
+        for bb in (b, b2):          # what a host with two in flight sets: one launch per level shares the GPU better with the other batch's parse
+            bb.set_reconstruct("levels")
         bs, keep, ptrs = [b, b2], [torch.cuda.Stream(), torch.cuda.Stream()], []
         for bb, st in zip(bs, keep):
             ptrs.append(ctypes.c_void_p(st.cuda_stream))
@@ -293,12 +295,16 @@ def two_batches_in_flight(b, make_batch, give_streams, n_pictures, want, passes=
                         raise RuntimeError("PARITY FAILURE against the oracle on stream %d" % s_)
         return {"value": round(n_pictures / dt, 1), "unit": "frames/s", "ms_per_pass": round(dt * 1e3, 3), "passes": 2 * passes, "passes_in_window": round(in_window, 2),
                 "parity": "every picture of both frame pools: device hash == oracle" if want is not None else "not checked (JSMPEG_BENCH_PARITY_STREAMS)",
-                "note": "two batch objects with the same streams, each decoded pass after pass on its own HIP stream by its own host thread (started half a pass apart; "
+                "note": "two batch objects with the same streams (jsmpeg_hip_batch_set_reconstruct 0: level by level), each decoded pass after pass on its own HIP stream by its own host thread (started half a pass apart; "
                         "counted: the passes inside the window in which both threads are between their first and last pass): one batch's "
                         "start-code index, host turn-around and slice parse beside the other's reconstruct (profiles/r04_recon_notes.md: the two kernels "
                         "want the same things of a CU, 3-4 %); a reported extra, never `value`"}
     finally:
         b2.close()
+        try:
+            b.set_reconstruct("auto")
+        except Exception:   # noqa: BLE001 (the batch is gone: so is its setting)
+            pass
 
 
 def other_configs(device, passes=5):

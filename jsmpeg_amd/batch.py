@@ -309,6 +309,13 @@ class Batch:
         k = self._ok(fn(self.h, out, n))
         return [int(out[i]) for i in range(k)]
 
+    def set_reconstruct(self, plan):
+        """0 / "levels": always one launch per dependency level; 1 / "auto": the engine's choice (include/jsmpeg_hip.h)"""
+        fn = self.L.jsmpeg_hip_batch_set_reconstruct
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._ok(fn(self.h, {"levels": 0, "auto": 1}.get(plan, plan)))
+
     def recon_info(self):
         """how the last decode reconstructed: launches (1 = the ordered launch), lockstep group, waits, status"""
         c = (ctypes.c_uint32 * 4)()

@@ -30,6 +30,7 @@
  *   batchUploadTS(handle, [Uint8Array TS, ...], streamId = 0xE0)    jsmpeg_hip_batch_upload_ts (device demux, ts.js semantics)
  *   batchDecode(handle) -> pictures                                  jsmpeg_hip_batch_decode + _sync
  *   batchDecodeAsync(handle) -> Promise<pictures>                    the same on a thread of libuv's pool (two batches in flight)
+ *   batchSetReconstruct(handle, plan)                                jsmpeg_hip_batch_set_reconstruct (0 level by level, 1 the engine's choice)
  *   batchPictureInfo(handle, p) -> {stream, esOffset, type, decoded, level, forward}
  *   batchTsWrites(handle, stream) -> [{pts, offset, length}, ...]   jsmpeg_hip_batch_ts_writes
  *   batchReadPlanes(handle, p, y, cr, cb)   (Uint8Arrays of coded size) jsmpeg_hip_batch_read_frame
@@ -513,6 +514,19 @@ static napi_value fn_batch_decode_async(napi_env env, napi_callback_info info) {
 		return NULL;
 	}
 	return promise;
+}
+
+/* batchSetReconstruct(handle, plan): 0 = level by level, 1 = the engine's choice (jsmpeg_hip_batch_set_reconstruct) */
+static napi_value fn_batch_set_reconstruct(napi_env env, napi_callback_info info) {
+	size_t argc = 2;
+	napi_value argv[2];
+	NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+	jsmpeg_hip_batch_t *b = batch_arg(env, argv[0]);
+	int32_t plan = 1;
+	if (!b) return NULL;
+	if (argc > 1) NAPI_OK(napi_get_value_int32(env, argv[1], &plan));
+	if (jsmpeg_hip_batch_set_reconstruct(b, plan) < 0) { napi_throw_error(env, NULL, jsmpeg_hip_last_error()); return NULL; }
+	return NULL;
 }
 
 static napi_value fn_batch_picture_info(napi_env env, napi_callback_info info) {
@@ -1037,7 +1051,7 @@ static napi_value init(napi_env env, napi_value exports) {
 		{ "decode", fn_decode }, { "getPlanes", fn_get_planes }, { "renderRGBA", fn_render_rgba },
 		{ "deviceCount", fn_device_count }, { "lastError", fn_last_error }, { "liveDecoders", fn_live_decoders },
 		{ "batchCreate", fn_batch_create }, { "batchDestroy", fn_batch_destroy }, { "batchUpload", fn_batch_upload },
-		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchDecodeAsync", fn_batch_decode_async }, { "batchPictureInfo", fn_batch_picture_info },
+		{ "batchUploadTS", fn_batch_upload_ts }, { "batchDecode", fn_batch_decode }, { "batchDecodeAsync", fn_batch_decode_async }, { "batchSetReconstruct", fn_batch_set_reconstruct }, { "batchPictureInfo", fn_batch_picture_info },
 		{ "batchTsWrites", fn_batch_ts_writes }, { "batchReadPlanes", fn_batch_read_planes }, { "batchReadFrames", fn_batch_read_frames }, { "batchReadRGBA", fn_batch_read_rgba },
 		{ "batchGeometry", fn_batch_geometry }, { "batchStreamInfo", fn_batch_stream_info }, { "batchTimings", fn_batch_timings }, { "batchFrameHashes", fn_batch_frame_hashes },
 		{ "mp2Create", fn_mp2_create }, { "mp2Destroy", fn_mp2_destroy }, { "mp2BufferWrite", fn_mp2_buffer_write },

@@ -39,6 +39,9 @@ function install(JSMpeg, options) {
     this.device = opts.device === undefined || opts.device === null ? -1 : (opts.device | 0);   // HIP ordinal: one HIPBatch per GPU of a node; -1 = the current device
     this.native = binding();
     this.handle = this.native.batchCreate(this.width, this.height, this.maxStreams, this.maxPictures, this.maxBytes, this.device);   // throws without a GPU / on a bad ordinal
+    // {reconstruct: 'levels'}: one launch per dependency level instead of the engine's choice -- for a host that keeps two batches in
+    // flight (decodeAsync): short launches share the GPU better with the other batch's parse (include/jsmpeg_hip.h)
+    if (opts.reconstruct === 'levels') this.native.batchSetReconstruct(this.handle, 0);
     const g = this.native.batchGeometry(this.handle);
     this.codedWidth = g.codedWidth; this.codedHeight = g.codedHeight;
     this.lumaBytes = g.lumaBytes; this.chromaBytes = g.chromaBytes;

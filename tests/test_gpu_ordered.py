@@ -212,3 +212,24 @@ print("DONE")
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JSMPEG_HIP_RECON_CHAINS="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_the_plan_is_a_setting_of_the_batch(hip_lib):
+    """jsmpeg_hip_batch_set_reconstruct: 0 = one launch per dependency level, 1 = the engine's choice again; the pictures are the
+    same either way (what a host with two batches in flight sets on wide batches)"""
+    streams = [synth.generate_config("cfg2_1080p", n_frames=13, stream=s)[0] for s in range(16)]
+    with jb.Batch(1920, 1080, 16, 16 * 13 + 4, sum(len(s) for s in streams) + 16 * 64 + 8192) as b:
+        b.upload(streams)
+        assert b.decode() == 16 * 13
+        first, auto = b.frame_hashes().copy(), b.recon_info()
+        assert auto["launches"] == 1 and auto["status"] == 0, auto
+        b.set_reconstruct("levels")
+        assert b.decode() == 16 * 13
+        info = b.recon_info()
+        assert info["launches"] > 1 and info["group"] == 0, info
+        assert np.array_equal(b.frame_hashes(), first)
+        b.set_reconstruct("auto")
+        assert b.decode() == 16 * 13
+        assert b.recon_info()["launches"] == 1 and np.array_equal(b.frame_hashes(), first)
+        with pytest.raises(RuntimeError):
+            b.set_reconstruct(7)

@@ -104,8 +104,9 @@ function hashesMatch(b, want) {
   return bad;
 }
 async function twoInFlight(passes) {
-  const second = new HIPBatch({ width, height, maxStreams: n, maxPictures: n * frames + 8, maxBytes: bytes + 64 * n + 4096,
+  const second = new HIPBatch({ width, height, maxStreams: n, maxPictures: n * frames + 8, maxBytes: bytes + 64 * n + 4096, reconstruct: 'levels',
                                 device: opt.device === undefined ? -1 : parseInt(opt.device, 10) });
+  batch.native.batchSetReconstruct(batch.handle, 0);       // both level by level: what a host with two in flight sets (include/jsmpeg_hip.h)
   try {
     second.upload(streams);
     if (second.decode() !== n * frames) throw new Error('the second batch decoded ' + second.pictures + ' pictures');
@@ -123,7 +124,7 @@ async function twoInFlight(passes) {
     const inWindow = doneAt(ends[0], hi) - doneAt(ends[0], lo) + doneAt(ends[1], hi) - doneAt(ends[1], lo);
     if (!(hi > lo) || inWindow < passes) throw new Error('the two chains did not run side by side');
     const res = { value: n * frames * inWindow / (hi - lo), unit: 'frames/s', ms_per_pass: (hi - lo) / inWindow * 1e3, passes: 2 * passes, passes_in_window: inWindow,
-                  host: 'two JSMpeg.HIPBatch objects, a chain of decodeAsync() each (napi_async_work: a thread of libuv\'s pool per decode)' };
+                  host: 'two JSMpeg.HIPBatch objects ({reconstruct: \'levels\'}), a chain of decodeAsync() each (napi_async_work: a thread of libuv\'s pool per decode)' };
     if (opt.hashes) {
       const want = JSON.parse(fs.readFileSync(opt.hashes, 'utf8'));
       const bad = hashesMatch(batch, want) + hashesMatch(second, want);
