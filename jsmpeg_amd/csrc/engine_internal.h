@@ -58,7 +58,9 @@ static inline void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g,
  * Late in round 6 the distance aimed at went from 200 to 400: on CODED video (encoder-made 1080p, profiles/r06k_enc_content.md)
  * a predicted picture's tiles are mostly copies and run up against a forward reference only 204 tiles ahead -- two 1080p streams
  * in lockstep: 339 k waits, the launch 18.9 ms against 10.2 with three (0 waits; four, six, eight the same) -- and the generator's
- * cfg2 is no slower with three (11.16 against 11.25 ms; 720p goes from four streams in lockstep to six: 5.01 against 5.06).
+ * cfg2 is the same with three within a box's noise (alternating on two boxes, three rounds each: 11.03-11.05 against 11.11-11.16 ms
+ * on one, 11.17-11.22 against 11.14-11.15 on the other: profiles/r06n_order_ab.txt, r06o_order_ab.txt; 720p goes from four streams
+ * in lockstep to six: 5.01 against 5.06).
  * JSMPEG_HIP_RECON_ORDER: 0 = always level by level, n = n streams in lockstep whatever the picture size (tests). */
 #define JM_ORDER_DISTANCE 400u
 #define JM_ORDER_MIN_DISTANCE 160u
