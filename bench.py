@@ -1273,6 +1273,10 @@ def main():
         try:
             pj = json.load(open(prof))
             traffic = pj.get(dom["kernel"])
+            if traffic and dom["launches_per_step"] > 1:      # level by level: the step's traffic / launches (the root level is another kernel)
+                root = next((pj[r] for r in ("k_recon_intra_dense", "k_recon_intra") if pj.get(r)), None)
+                if root:
+                    traffic = int(((dom["launches_per_step"] - 1) * traffic + root) / dom["launches_per_step"])
             traffic_source = "static: profiles/pmc_traffic.json (%s), not measured in this run" % pj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         except Exception:
             traffic = None
@@ -1529,6 +1533,16 @@ def main():
             k = roofline["kernel"]
             if k in cn["fetch_bytes"] and k in cn["write_bytes"]:
                 t_b = cn["fetch_bytes"][k] + cn["write_bytes"][k]
+                L = int(roofline.get("launches_per_step") or 1)
+                if L > 1:
+                    # level by level: the level without a forward reference is another kernel (k_recon_intra / _intra_dense) with its
+                    # own, smaller traffic; `algorithmic_bytes_per_launch` is the step's bytes / launches, so the traffic is the
+                    # step's traffic / launches too (not the predicted levels' average held against every level's mean)
+                    root = next((r for r in ("k_recon_intra_dense", "k_recon_intra") if r in cn["fetch_bytes"] and r in cn["write_bytes"]), None)
+                    if root:
+                        t_b = ((L - 1) * t_b + cn["fetch_bytes"][root] + cn["write_bytes"][root]) / L
+                        roofline["traffic_note"] = ("per launch = (%d x k_recon's + %s's HBM bytes) / %d launches of the step; k_recon alone: %d bytes per launch"
+                                                    % (L - 1, root, L, cn["fetch_bytes"][k] + cn["write_bytes"][k]))
                 roofline["traffic"] = int(t_b)
                 roofline["traffic_source"] = cn["source"]
                 roofline["traffic_rate"] = round(t_b / (roofline["avg_launch_ms"] * 1e-3) / 1e9, 1)

@@ -765,6 +765,19 @@ extern "C" int jsmpeg_hip_batch_decode(jsmpeg_hip_batch_t *b, void *hip_stream) 
 		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) deepest = std::max(deepest, b->h_pics[p].level);
 		dense_roots = deepest < 16;
 	}
+	/* WIDE batches go level by level too (late round 6, profiles/r06n_levels_vs_ordered.txt): from ~2.5 M macroblocks per level up
+	 * -- 32 streams x 120 pictures of 1080p, the headline's 64 x 120 -- a level's launch is long against the gap behind it and the
+	 * two plans take the same time (11.151 against 11.152 ms, 5.745 / 5.734); below that the one launch is 1-12 % faster and stays.
+	 * What the levels have for them where they cost nothing: they share the GPU better with another batch in flight (582.6 k
+	 * against 554.1 k frames/s), and they stand on kernel boundaries, not on the ordered launch's argument about one XCD's L2
+	 * (kernels.hip jm_recon_wait).  JSMPEG_HIP_RECON_WIDE_LEVELS=0: the ordered launch for these too (measurements). */
+	if (!dense_roots && b->order_group == JM_ORDER_AUTO && any_dependency && !force_chains) {
+		static const bool wide_rule = !(getenv("JSMPEG_HIP_RECON_WIDE_LEVELS") && atoi(getenv("JSMPEG_HIP_RECON_WIDE_LEVELS")) == 0);
+		int32_t deepest = 0;
+		for (uint32_t p = 0; p < b->n_pics; p++) if (b->h_pics[p].decoded) deepest = std::max(deepest, b->h_pics[p].level);
+		if (wide_rule && deepest < 16 && (uint64_t)b->n_decoded * (uint64_t)std::max(1, b->g.mb_size) >= (uint64_t)JM_WIDE_LEVEL_MBS * (uint64_t)(deepest + 1))
+			dense_roots = true;     /* (the same consequence: no ordered plan, no chains; recon_by_levels picks each level's kernel form by itself) */
+	}
 	bool planned = any_dependency && !dense_roots && !force_chains && group && jm_plan_ordered(b->h_pics, b->n_pics, b->n_streams, group, 8, plan, b->link_prev.size() == b->n_streams ? b->link_prev.data() : nullptr) &&
 	               (size_t)8 * plan.rows <= b->desc_cap && (b->order_group != JM_ORDER_AUTO || (plan.lockstep - 1) * per_picture >= JM_ORDER_MIN_DISTANCE);
 	std::vector<uint32_t> chain_of;

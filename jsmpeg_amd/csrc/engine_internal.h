@@ -65,6 +65,7 @@ static inline void geom_init(JmGeom &g, int width, int height) { jm_geom_init(g,
 #define JM_ORDER_DISTANCE 400u
 #define JM_ORDER_MIN_DISTANCE 160u
 #define JM_ORDER_AUTO 0xffffffffu
+#define JM_WIDE_LEVEL_MBS 2500000u       /* macroblocks per dependency level from which a batch left to itself goes level by level (engine.hip) */
 /* pictures the one-picture interface decodes per pass of the batch engine when that many are buffered (mpeg1_decoder_t::ahead) */
 #ifndef JM_DECODE_AHEAD
 #define JM_DECODE_AHEAD 48u        /* ... at most, and no more than fit 160 MB of frames (1080p: 48, 2160p: 12): dec_sequence_header */
