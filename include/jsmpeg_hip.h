@@ -202,9 +202,11 @@ int jsmpeg_hip_batch_sync(jsmpeg_hip_batch_t *b);
  * stream EACH -- on the null stream their passes run one behind the other.  Returns it, or NULL (jsmpeg_hip_last_error). */
 void *jsmpeg_hip_batch_own_stream(jsmpeg_hip_batch_t *b);
 /* The reconstruct's plan for this batch's passes: 0 = always one launch per dependency level, 1 = the engine's choice (the
- * default: ONE dependency-ordered launch where the batch's shape suits it).  One batch at a time the choice is the faster or
- * equal everywhere; a host that keeps two batches in flight sets 0 on wide batches (>= 32 streams of 1080p): short launches
- * share the GPU better with the other batch's parse (+5 % on the 64 x 1080p workload, +24 % on coded video).  Returns 0 or < 0. */
+ * default: level by level for dense intra pictures and for WIDE batches -- from 2.5 M macroblocks per level, where both plans take
+ * the same time --, ONE dependency-ordered launch for everything narrower or shorter, 1-12 % faster there).  One batch at a time
+ * the choice is the faster or equal everywhere; a host that keeps two batches in flight sets 0 also on narrower batches: short
+ * launches share the GPU better with the other batch's parse (+5 % on the 64 x 1080p workload, +24 % on coded video).
+ * Returns 0 or < 0. */
 int jsmpeg_hip_batch_set_reconstruct(jsmpeg_hip_batch_t *b, int plan);
 
 uint32_t jsmpeg_hip_batch_picture_count(jsmpeg_hip_batch_t *b);
