@@ -29,7 +29,9 @@ def short(n):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs --no-napi --no-h2d\n")
-    f.write("# (durations in microseconds; 6 decode passes = 1 warm-up + 5 timed)\n")
+    f.write("# (durations in microseconds; 6 decode passes = 1 warm-up + 5 timed; a step that reconstructs level by level -- wide batches, dense\n")
+    f.write("#  intra pictures -- has per pass one k_recon launch per predicted level + one k_recon_intra[_dense] launch for the level without\n")
+    f.write("#  a forward reference: the step's reconstruct = their sum; bench.py's roofline figures are per launch = that / launches)\n")
     f.write("%-28s %8s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, total, avg, pct in db(d_trace).execute("select * from top_kernels"):
         f.write("%-28s %8d %14.1f %12.2f %7.2f%%\n" % (short(name)[:28], calls, total, avg, pct))
